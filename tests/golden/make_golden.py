@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE's own point-cloud library.
+
+Run in the build container only (needs /root/reference, which does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+It imports /root/reference/semantic_depth_lib/pcl.py (the one reference module that imports without
+TensorFlow/OpenCV/Open3D), feeds it inputs produced by the oracle's synthetic ground-plane scene
+ and stores inputs + the reference's outputs:
+
+  pcl_mini.npz        64x128 miniature, full arrays for every pcl function on the road-width path,
+                      plus the fence-side helpers and the edge cases (empty window, MAD == 0).
+  pcl_full.json       512x1024 scene: generator parameters + counts / coefficients / end points /
+                      order-sensitive checksums of the reference's outputs (arrays are regenerated from
+                      the seed by the oracle's scene generator at test time).
+
+Fixtures are data (inputs and expected outputs); no reference source is copied.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+from semantic_depth_lib import pcl as ref  # noqa: E402  (the reference)
+from oracle import fusion, pipeline  # noqa: E402
+
+
+def checksum(a: np.ndarray) -> str:
+    """Order-sensitive digest: sum_i (i+1)*bits(a_i) mod 2^64 over the raw little-endian words."""
+    b = np.ascontiguousarray(a).view(np.uint8).ravel()
+    pad = (-len(b)) % 4
+    if pad:
+        b = np.concatenate([b, np.zeros(pad, np.uint8)])
+    wds = b.view(np.uint32).astype(np.uint64)
+    idx = np.arange(1, len(wds) + 1, dtype=np.uint64)
+    return hex(int((wds * idx).sum(dtype=np.uint64)))
+
+
+def ref_chain(points, colors, depth=10.0):
+    """the road chain of semantic_depth.py:206-219,254-259 with the reference's functions (Open3D absent)."""
+    out = {}
+    p, c = ref.remove_from_to(points, colors, 2, 0.0, 7.0)
+    out["zcut"] = (p, c)
+    p, c = ref.remove_noise_by_mad(p, c, 1, 15.0)
+    out["mad_y"] = (p, c)
+    p, c = ref.remove_noise_by_mad(p, c, 0, 2.0)
+    out["mad_x"] = (p, c)
+    p, c, _, _, coeff = ref.remove_noise_by_fitting_plane(p, c, axis=1, threshold=5.0, plane_color=[200, 200, 200])
+    out["plane"] = (p, c)
+    out["coeff"] = coeff
+    l, r = ref.get_end_points_of_road(p.astype(np.float64), depth - 0.02)
+    out["left"], out["right"] = l, r
+    return out
+
+
+def scene_inputs(h, w, seed, f, fences=False):
+    dp, road, fence, frame, cam = pipeline.synthetic_scene(h, w, seed=seed, f=f, fences=fences)
+    fz = fusion.fuse(dp, road, fence, frame, **cam)
+    return dp, road, fence, frame, cam, fz
+
+
+def main():
+    # ---------------- miniature: full arrays ----------------
+    dp, road, fence, frame, cam, fz = scene_inputs(64, 128, seed=7, f=125.0, fences=True)
+    pts, col = fz["road3d"], fz["road_rgb"]
+    ch = ref_chain(pts, col)
+    z = {
+        "disp_pair": dp, "road_mask": road, "fence_mask": fence, "frame_bgr": frame,
+        "cam": np.array([cam["cx"], cam["cy"], cam["f"], cam["b"], cam["disp_mult"]], np.float64),
+        "road3d": pts, "road_rgb": col, "fence3d": fz["fence3d"], "fence_rgb": fz["fence_rgb"],
+    }
+    for k in ("zcut", "mad_y", "mad_x", "plane"):
+        z[f"{k}_pts"], z[f"{k}_col"] = ch[k]
+    z["plane_coeff"] = np.array([ch["coeff"][k] for k in ("Cx", "Cy", "Cz", "C")], np.float64)
+    z["left_pts"], z["right_pts"] = ch["left"], ch["right"]
+    # MAD with tighter thresholds so that something is actually removed
+    for axis, thr in ((0, 1.0), (1, 2.0), (2, 0.8)):
+        p, c = ref.remove_noise_by_mad(pts, col, axis, thr)
+        z[f"mad_a{axis}_pts"], z[f"mad_a{axis}_col"] = p, c
+    # plane fit on all three axes with a tight threshold (fence planes use axis 0, seq:262-275)
+    for axis, thr in ((0, 0.5), (1, 0.02), (2, 3.0)):
+        p, c, _, _, coeff = ref.remove_noise_by_fitting_plane(pts, col, axis=axis, threshold=thr)
+        z[f"plane_a{axis}_pts"], z[f"plane_a{axis}_col"] = p, c
+        z[f"plane_a{axis}_coeff"] = np.array([coeff[k] for k in ("Cx", "Cy", "Cz", "C")], np.float64)
+    # empty depth window -> (None, None)
+    l, r = ref.get_end_points_of_road(ch["plane"][0].astype(np.float64), 500.0)
+    z["empty_window_is_none"] = np.array([l is None, r is None])
+    # MAD == 0: constant-y cloud -> penalty nan/inf -> everything with |dev|==0 gives nan -> dropped
+    flat = pts.copy()
+    flat[:, 1] = np.float32(-1.5)
+    with np.errstate(all="ignore"):
+        p, c = ref.remove_noise_by_mad(flat, col, 1, 15.0)
+    z["mad0_in"], z["mad0_pts"] = flat, p
+    # fence-side helpers
+    fp, fc = fz["fence3d"], fz["fence_rgb"]
+    p, c = ref.threshold_complete(fp, fc, 2, 35.0)
+    z["thr_pts"], z["thr_col"] = p, c
+    a, ac, b, bc = ref.extract_pcls(p, c)
+    z["split_left"], z["split_left_col"], z["split_right"], z["split_right_col"] = a, ac, b, bc
+    z["dist3d"] = np.float64(ref.compute_distance_in_3D(np.array([[1.0, 2.0, 3.0]]), np.array([[-2.0, 0.5, 7.0]])))
+    lp, rp = ch["left"][:1].copy(), ch["right"][:1].copy()
+    z["line_in_left"], z["line_in_right"] = lp.copy(), rp.copy()
+    line, lcol = ref.create_3Dline_from_3Dpoints(lp, rp, [250, 0, 0])
+    z["line"], z["line_col"], z["line_left_after"], z["line_right_after"] = line, lcol, lp, rp
+    np.savez_compressed(os.path.join(HERE, "pcl_mini.npz"), **z)
+
+    # ---------------- full size: digests ----------------
+    full = {"scene": dict(h=512, w=1024, seed=1234, f=1000.0, fences=False)}
+    dp, road, fence, frame, cam, fz = scene_inputs(512, 1024, seed=1234, f=1000.0)
+    ch = ref_chain(fz["road3d"], fz["road_rgb"])
+    full["n_road"] = int(fz["road3d"].shape[0])
+    full["road3d_checksum"] = checksum(fz["road3d"])
+    full["road_rgb_checksum"] = checksum(fz["road_rgb"])
+    for k in ("zcut", "mad_y", "mad_x", "plane"):
+        full[f"n_{k}"] = int(ch[k][0].shape[0])
+        full[f"{k}_checksum"] = checksum(ch[k][0])
+    full["plane_coeff"] = {k: float(v) for k, v in ch["coeff"].items()}
+    full["x_left"] = float(ch["left"][0][0])
+    full["x_right"] = float(ch["right"][0][0])
+    full["left_pt"] = [float(v) for v in ch["left"][0]]
+    full["right_pt"] = [float(v) for v in ch["right"][0]]
+    full["dist_rw"] = float(abs(ch["left"][0][0] - ch["right"][0][0]))
+    full["numpy"] = np.__version__
+    with open(os.path.join(HERE, "pcl_full.json"), "w") as fh:
+        json.dump(full, fh, indent=1, sort_keys=True)
+    print("wrote pcl_mini.npz, pcl_full.json;", {k: full[k] for k in ("n_road", "n_zcut", "n_plane", "dist_rw")})
+
+
+if __name__ == "__main__":
+    main()
