@@ -1,0 +1,169 @@
+/*
+ * semdepth.h — C ABI of libsemdepth.so, the MI355X (gfx950) implementation of semantic-depth's
+ * per-frame hot path.  Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *
+ * The reference (pablopalafox/semantic-depth) has no FFI: its operator boundary is the Python
+ * duck-type FrameProcessor consumes.  Every entry point below names the reference interface
+ * it replaces (file:line relative to the reference tree; "seq" = semantic_depth_cityscapes_sequence.py).
+ *
+ * Conventions
+ *   - every function returns sd_status (0 = OK, negative = error); sd_last_error() gives the text.
+ *   - all data pointers are DEVICE pointers owned by the caller unless the name ends in _host.
+ *   - every compute call takes a hipStream_t (passed as void*) and is asynchronous w.r.t. the host.
+ *   - a handle is bound to one device, is not thread-safe, and owns no device memory: the caller
+ *     (PyTorch-ROCm in the Python host) allocates the weight and workspace arenas whose sizes
+ *     sd_query_memory() reports and binds them with sd_bind_memory().
+ *   - images are NHWC, row-major, channel order as the caller supplies it (the reference feeds BGR).
+ */
+#ifndef SEMDEPTH_H
+#define SEMDEPTH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int sd_status;
+enum {
+    SD_OK = 0,
+    SD_ERR_INVALID = -1,   /* bad argument */
+    SD_ERR_HIP = -2,       /* HIP runtime error (text in sd_last_error) */
+    SD_ERR_STATE = -3,     /* call order violated (e.g. forward before weights are loaded) */
+    SD_ERR_NOTFOUND = -4   /* unknown weight / tensor name */
+};
+
+typedef enum { SD_ENC_VGG = 0, SD_ENC_RESNET50 = 1 } sd_encoder;      /* semantic_depth.py:721-722 --encoder */
+typedef enum { SD_NET_FCN8S = 0, SD_NET_MONODEPTH = 1 } sd_net;
+typedef enum { SD_PREC_F32 = 0 } sd_precision;                         /* arithmetic of the conv stacks */
+
+typedef struct sd_handle sd_handle;
+
+/* camera of DepthFrame.__init__, semantic_depth.py:592-607 (seq:500-508), plus the disparity
+ * multiplier of semantic_depth.py:109,145 (seq:105,146).  Doubles: the library rounds the Q-matrix
+ * entries to float32 exactly like np.float32([...]) at semantic_depth.py:691-694. */
+typedef struct {
+    double cx, cy, f, b, disp_mult;
+} sd_camera;
+
+/* every literal of the reference's road-width call sites (semantic_depth.py:206-259) */
+typedef struct {
+    double depth;         /* --depth, :754-756 (10.0) */
+    double z_cut;         /* remove_from_to(..., 2, 0.0, 7.0)        :206 */
+    double mad_y;         /* remove_noise_by_mad(..., 1, 15.0)       :209 */
+    double mad_x;         /* remove_noise_by_mad(..., 0, 2.0)        :212 */
+    double plane_thr;     /* remove_noise_by_fitting_plane(axis=1, threshold=5.0) :215-219 */
+    int32_t sor_k;        /* statistical_outlier_removal nb_neighbors=10   :234-235 */
+    double sor_ratio;     /*                              std_ratio=0.5 */
+    int32_t ror_n;        /* radius_outlier_removal nb_points=80           :238-239 */
+    double ror_r;         /*                         radius=0.5 */
+    double window;        /* +-0.05 depth window, pcl.py:283 */
+    double depth_offset;  /* depth-0.02, :254-255 */
+    int32_t use_o3d;      /* 0 skips the two Open3D filters */
+} sd_rw_params;
+
+/* per-frame record: what the reference prints/draws (semantic_depth.py:259; seq:232-238) plus the
+ * kept-point count after every stage.  This is the record the multi-GPU driver all-gathers. */
+typedef struct {
+    double width;          /* |x_left - x_right|, NaN when !found */
+    float x_left, x_right; /* x of the first min-x / max-x point in the depth window */
+    float left_pt[3], right_pt[3];
+    int32_t found;         /* 0: no road point in the window ((None,None) of pcl.py:303-304) */
+    int32_t n_road;        /* projected road points (points3D[road_mask]) */
+    int32_t n_zcut, n_mad_y, n_mad_x, n_plane, n_sor, n_ror;
+    double plane[4];       /* Cx,Cy,Cz,C of pcl.py:168 */
+} sd_rw_result;
+
+/* ---------------------------------------------------------------- lifecycle */
+const char* sd_version(void);
+const char* sd_status_string(sd_status s);
+/* replaces DepthFrame.__init__ + SegmentFrame.__init__ (semantic_depth.py:464-469, :575-624):
+ * fixes H, W, the largest batch a call may carry and the monodepth encoder; builds both layer plans. */
+sd_status sd_create(sd_handle** out, int device, int H, int W, int max_batch, sd_encoder enc, sd_precision prec);
+sd_status sd_destroy(sd_handle* h);
+const char* sd_last_error(const sd_handle* h);
+
+/* ---------------------------------------------------------------- memory + weights
+ * replaces SegmentFrame.restore_model / DepthFrame.restore_model (semantic_depth.py:498-541, :627-653) */
+sd_status sd_query_memory(const sd_handle* h, size_t* fcn_weight_bytes, size_t* mono_weight_bytes, size_t* workspace_bytes);
+sd_status sd_bind_memory(sd_handle* h, void* fcn_weights_dev, void* mono_weights_dev, void* workspace_dev);
+int sd_weight_count(const sd_handle* h, sd_net net);
+/* name_out: >= 64 bytes; shape_out: 4 x int64 in TensorFlow layout (conv HWIO, transposed conv HWOI, bias [C]) */
+sd_status sd_weight_info(const sd_handle* h, sd_net net, int index, char* name_out, int64_t* shape_out, int* rank_out);
+/* data_host: float32, TensorFlow layout; re-laid-out for the kernels and copied into the bound arena (synchronous) */
+sd_status sd_load_weight(sd_handle* h, sd_net net, const char* name, const float* data_host, const int64_t* shape, int rank);
+
+/* ---------------------------------------------------------------- the three operators + fused tail */
+/* SegmentFrame.segment_frame, semantic_depth.py:544-571 (seq:459-485), for B frames at once.
+ * frames: u8 [B,H,W,3].  Outputs (each nullable): logits f32 [B,H,W,3] ('logits:0', fcn8s/fcn.py:241),
+ * road/fence u8 [B,H,W] = softmax > 0.5 (:555-556,:563-564), argmax u8 [B,H,W] (fcn8s/fcn.py:218-224). */
+sd_status sd_fcn8s_forward(sd_handle* h, const uint8_t* frames, int B, float* logits, uint8_t* road_mask,
+                           uint8_t* fence_mask, uint8_t* argmax, void* stream);
+
+/* DepthFrame.compute_disparity, semantic_depth.py:667-678 (seq:568-579), for B frames: /255, (frame, fliplr(frame))
+ * pair through monodepth, disp_left_est[0], post_processing (:656-664).  disp_pp: f32 [B,H,W] in fraction of
+ * image width.  disp_raw (nullable): f32 [B,2,H,W] = the net's channel-0 output for frame and flipped frame. */
+sd_status sd_monodepth_forward(sd_handle* h, const uint8_t* frames, int B, float* disp_pp, float* disp_raw, void* stream);
+
+/* DepthFrame.post_processing alone, semantic_depth.py:656-664: disp_raw f32 [B,2,H,W] -> disp_pp f32 [B,H,W] */
+sd_status sd_post_process(sd_handle* h, const float* disp_raw, int B, float* disp_pp, void* stream);
+
+/* disparity scaling + DepthFrame.compute_3D_points + BGR->RGB + mask gather,
+ * semantic_depth.py:145,160-161,183-187,686-697 (seq:146,152-153,170-174), for B frames.
+ * disp_pp f32 [B,H,W]; masks u8 [B,H,W]; frames u8 [B,H,W,3]; cams[B] (HOST pointer).
+ * points_dense (nullable) f32 [B,H,W,3] = cv2.reprojectImageTo3D(disp_pp*mult, Q).
+ * road_xyz f32 [B,cap,3], road_rgb u8 [B,cap,3] (nullable), n_road i32 [B]; same for fence (all nullable as a group).
+ * cap = per-frame capacity in points (H*W is always enough); order = row-major order of the True pixels. */
+sd_status sd_fuse_backproject(sd_handle* h, const float* disp_pp, const uint8_t* road_mask, const uint8_t* fence_mask,
+                              const uint8_t* frames, const sd_camera* cams_host, int B, int cap, float* points_dense,
+                              float* road_xyz, uint8_t* road_rgb, int32_t* n_road, float* fence_xyz, uint8_t* fence_rgb,
+                              int32_t* n_fence, void* stream);
+
+/* the road chain of FrameProcessor.process_frame, semantic_depth.py:203-259 (seq:180-238):
+ * z-cut -> MAD(y) -> MAD(x) -> plane fit -> [Open3D statistical + radius] -> end points -> width.
+ * road_xyz f32 [B,cap,3], n_road i32 [B] (device).  results: DEVICE array of B sd_rw_result.
+ * final_xyz (nullable) f32 [B,cap,3] receives the denoised cloud, n_final i32 [B] its size. */
+sd_status sd_road_width(sd_handle* h, const float* road_xyz, const int32_t* n_road, int B, int cap,
+                        const sd_rw_params* params_host, sd_rw_result* results, float* final_xyz, int32_t* n_final,
+                        void* stream);
+
+/* ---------------------------------------------------------------- pcl.py, function by function
+ * (semantic_depth_lib/pcl.py; one cloud per call: xyz f32 [n,3], rgb u8 [n,3] nullable, n on the host).
+ * Outputs keep the input row order.  *n_out is a DEVICE int32. */
+/* pcl.remove_from_to, pcl.py:30-43 (keeps coord[axis] < -to_meter) */
+sd_status sd_pcl_remove_from_to(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int axis, double to_meter,
+                                float* xyz_out, uint8_t* rgb_out, int32_t* n_out, void* stream);
+/* pcl.remove_noise_by_mad + mad, pcl.py:46-81.  stats_out (nullable, device f32[2]) = {median, MAD} */
+sd_status sd_pcl_remove_noise_by_mad(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int axis, double threshold,
+                                     float* xyz_out, uint8_t* rgb_out, int32_t* n_out, float* stats_out, void* stream);
+/* pcl.remove_noise_by_fitting_plane, pcl.py:84-209 (without the visualisation grid).  coeff_out: device f64[4] = Cx,Cy,Cz,C */
+sd_status sd_pcl_remove_noise_by_fitting_plane(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int axis,
+                                               double threshold, float* xyz_out, uint8_t* rgb_out, int32_t* n_out,
+                                               double* coeff_out, void* stream);
+/* pcl.threshold_complete, pcl.py:240-250 (keeps |coord[axis]| < threshold) */
+sd_status sd_pcl_threshold_complete(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int axis, double threshold,
+                                    float* xyz_out, uint8_t* rgb_out, int32_t* n_out, void* stream);
+/* pcl.get_end_points_of_road, pcl.py:271-313: first min-x and max-x rows of the depth window.
+ * out: device sd_rw_result (only found, x_left, x_right, left_pt, right_pt, width are written) */
+sd_status sd_pcl_get_end_points_of_road(sd_handle* h, const float* xyz, int n, double depth, double window,
+                                        sd_rw_result* out, void* stream);
+/* Open3D statistical_outlier_removal / radius_outlier_removal as called at semantic_depth.py:234-241 */
+sd_status sd_o3d_statistical_outlier_removal(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int nb_neighbors,
+                                             double std_ratio, float* xyz_out, uint8_t* rgb_out, int32_t* n_out,
+                                             double* mean_dist_out /* nullable, device f64[n] */, void* stream);
+sd_status sd_o3d_radius_outlier_removal(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int nb_points,
+                                        double radius, float* xyz_out, uint8_t* rgb_out, int32_t* n_out, void* stream);
+
+/* ---------------------------------------------------------------- introspection (tests / profiling) */
+/* copy an intermediate activation of the last forward (e.g. "layer3_out", "conv5") to out (device f32);
+ * numel_out receives its element count; shape_out 4 x int64 [N,H,W,C] */
+sd_status sd_net_tensor(sd_handle* h, sd_net net, const char* name, float* out, size_t out_capacity_floats,
+                        int64_t* shape_out, void* stream);
+/* number of conv-engine FLOPs (2*M*N*K over all layers, per image) of a plan — for roofline accounting */
+double sd_net_flops_per_image(const sd_handle* h, sd_net net);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEMDEPTH_H */

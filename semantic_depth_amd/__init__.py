@@ -1,0 +1,26 @@
+"""semantic_depth_amd — MI355X-native implementation of semantic-depth's per-frame hot path.
+
+FCN-8s forward + monodepth forward + per-pixel fusion/back-projection -> class-masked point cloud -> road width
+(BASELINE.json north_star).  All compute is hand-written HIP for gfx950 in libsemdepth.so
+(include/semdepth.h); this package is the Python host side mirroring the reference's operator interface:
+
+    SegmentFrame, DepthFrame, FrameProcessor     (semantic_depth.py:82-96, :464-571, :575-697)
+    pcl                                           (semantic_depth_lib/pcl.py)
+
+There is no CPU fallback: without the built library or without a GPU the operators raise.
+"""
+from .weights import (NUM_CLASSES, fcn8s_weight_shapes, make_fcn8s_weights, make_monodepth_weights,  # noqa: F401
+                      monodepth_weight_shapes)
+
+
+def __getattr__(name):  # lazy: importing the package must not need torch/GPU (weights tables are pure numpy)
+    if name in ("Engine", "RoadWidthParams", "Camera", "RW_DTYPE"):
+        from . import engine
+        return getattr(engine, name)
+    if name in ("SegmentFrame", "DepthFrame", "FrameProcessor"):
+        from . import api
+        return getattr(api, name)
+    if name == "pcl":
+        import importlib
+        return importlib.import_module(".pcl", __name__)
+    raise AttributeError(name)

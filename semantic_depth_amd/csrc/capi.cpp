@@ -1,0 +1,451 @@
+// extern "C" surface of libsemdepth.so (include/semdepth.h).  Owns the layer plans and the launch sequences;
+// owns no device memory (the caller binds arenas it allocated, e.g. torch tensors).
+#include "../../include/semdepth.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "plan.hpp"
+
+using namespace sd;
+
+static_assert(sizeof(RwResultDev) == sizeof(sd_rw_result), "sd_rw_result layout");
+
+struct sd_handle {
+    int device = 0, H = 0, W = 0, max_batch = 0, enc = 0, chunk = 0, cap = 0;
+    NetPlan fcn, mono;
+    bool bound = false;
+    char* wf = nullptr;   // FCN weight arena
+    char* wm = nullptr;   // monodepth weight arena
+    char* ws = nullptr;   // workspace arena
+    // workspace carve (byte offsets)
+    size_t o_fcn = 0, o_mono = 0, o_fuse = 0, o_cams = 0, o_bufA = 0, o_bufB = 0, o_cnt = 0, o_plane = 0, o_o3d = 0, o_misc = 0;
+    size_t ws_bytes = 0;
+    int last_fcn_images = 0, last_mono_images = 0;
+    std::vector<CamDev> cams_stage;
+    std::string err;
+};
+
+namespace {
+
+size_t al(size_t v) { return (v + 255) / 256 * 256; }
+
+sd_status fail(sd_handle* h, sd_status code, const std::string& msg) {
+    if (h) h->err = msg;
+    return code;
+}
+#define HIPCHK(h, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) return fail(h, SD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+NetPlan& plan_of(sd_handle* h, sd_net net) { return net == SD_NET_FCN8S ? h->fcn : h->mono; }
+const NetPlan& plan_of(const sd_handle* h, sd_net net) { return net == SD_NET_FCN8S ? h->fcn : h->mono; }
+char* warena(sd_handle* h, sd_net net) { return net == SD_NET_FCN8S ? h->wf : h->wm; }
+
+void carve_workspace(sd_handle* h) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t r = off; off += al(bytes); return r; };
+    const size_t B = (size_t)h->max_batch, cap = (size_t)h->cap;
+    h->o_fcn = take(h->fcn.act_bytes);
+    h->o_mono = take(h->mono.act_bytes);
+    h->o_fuse = take(fuse_scratch_bytes(h->max_batch, h->H, h->W));
+    h->o_cams = take(sizeof(CamDev) * B);
+    h->o_bufA = take(B * cap * 3 * sizeof(float));
+    h->o_bufB = take(B * cap * 3 * sizeof(float));
+    h->o_cnt = take(B * sizeof(int32_t) * 16);
+    h->o_plane = take(B * sizeof(double) * 4);
+    h->o_o3d = take(o3d_scratch_bytes(h->max_batch, h->cap));
+    h->o_misc = take(4096);
+    h->ws_bytes = off;
+}
+
+sd_status upload_tables(sd_handle* h, sd_net net) {
+    NetPlan& p = plan_of(h, net);
+    char* wbase = warena(h, net);
+    const char* abase = h->ws + (net == SD_NET_FCN8S ? h->o_fcn : h->o_mono);
+    for (const OpDesc& op : p.ops) {
+        if (op.kind != OP_CONV) continue;
+        std::vector<int32_t> ktab;
+        ConvSrc srcs[3];
+        build_conv_tables(p, op, abase, ktab, srcs);
+        HIPCHK(h, hipMemcpy(wbase + op.tab_offset, ktab.data(), ktab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(wbase + op.srcs_offset, srcs, sizeof(ConvSrc) * 3, hipMemcpyHostToDevice));
+    }
+    return SD_OK;
+}
+
+struct HeadOut { float* logits; uint8_t* road; uint8_t* fence; uint8_t* argmax; };
+
+// one chunk through a plan.  frames: u8 [nframes,H,W,3] (device)
+sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes, const HeadOut* head, hipStream_t s) {
+    NetPlan& p = plan_of(h, net);
+    char* wbase = warena(h, net);
+    char* abase = h->ws + (net == SD_NET_FCN8S ? h->o_fcn : h->o_mono);
+    const int N = nframes * (p.images / p.frames);
+    auto T = [&](int t) -> float* { return reinterpret_cast<float*>(abase + p.tensors[t].offset); };
+    auto Wp = [&](int w) -> const float* { return reinterpret_cast<const float*>(wbase + p.weights[w].offset); };
+    for (const WeightSlot& wsl : p.weights)
+        if (!wsl.loaded) return fail(h, SD_ERR_STATE, "weight not loaded: " + wsl.name);
+    for (const OpDesc& op : p.ops) {
+        hipError_t e = hipSuccess;
+        switch (op.kind) {
+            case OP_PRE_VGG:
+                e = launch_pre_vgg(frames, T(op.dst), (long)nframes * h->H * h->W, s);
+                break;
+            case OP_PRE_MONO:
+                e = launch_pre_mono(frames, T(op.dst), nframes, h->H, h->W, s);
+                break;
+            case OP_CONV: {
+                const TensorDesc& d = p.tensors[op.dst];
+                const TensorDesc& s0 = p.tensors[op.src[0]];
+                ConvParams c{};
+                c.srcs = reinterpret_cast<const ConvSrc*>(wbase + op.srcs_offset);
+                c.nsrc = op.nsrc; c.Ctot = op.Ctot;
+                c.N = N; c.Hin = s0.H * (op.up[0] ? 2 : 1); c.Win = s0.W * (op.up[0] ? 2 : 1);
+                c.Hout = d.H; c.Wout = d.W; c.Cout = d.C; c.CoutPad = p.weights[op.w].CoutPad;
+                c.kh = c.kw = op.k; c.stride = op.stride; c.pad = op.pad;
+                c.K = op.K; c.Kpad = op.Kpad;
+                c.wt = Wp(op.w); c.bias = Wp(op.b);
+                c.ktab = reinterpret_cast<const int4*>(wbase + op.tab_offset);
+                c.vec = op.vec;
+                c.residual = op.residual >= 0 ? T(op.residual) : nullptr;
+                c.out = T(op.dst);
+                c.act = op.act; c.m_fastest = op.m_fastest;
+                e = launch_conv_igemm(c, s);
+                break;
+            }
+            case OP_SMALLN: {
+                const TensorDesc& s0 = p.tensors[op.src[0]];
+                SmallNParams c{};
+                c.x = T(op.src[0]); c.N = N; c.H = s0.H; c.W = s0.W; c.C = s0.C; c.k = op.k; c.nout = op.nout;
+                c.wt = Wp(op.w); c.bias = Wp(op.b); c.out = T(op.dst); c.act = op.act;
+                e = launch_conv_smalln(c, s);
+                break;
+            }
+            case OP_POOL2: {
+                const TensorDesc& s0 = p.tensors[op.src[0]];
+                e = launch_maxpool2(T(op.src[0]), T(op.dst), N, s0.H, s0.W, s0.C, s);
+                break;
+            }
+            case OP_POOL3Z: {
+                const TensorDesc& s0 = p.tensors[op.src[0]];
+                e = launch_maxpool3z(T(op.src[0]), T(op.dst), N, s0.H, s0.W, s0.C, s);
+                break;
+            }
+            case OP_DECONV4_ADD: {
+                const TensorDesc& s0 = p.tensors[op.src[0]];
+                e = launch_deconv4s2_add(T(op.src[0]), Wp(op.w), Wp(op.b), T(op.residual), T(op.dst), N, s0.H, s0.W, s);
+                break;
+            }
+            case OP_HEAD16: {
+                const TensorDesc& s0 = p.tensors[op.src[0]];
+                e = launch_deconv16s8_head(T(op.src[0]), Wp(op.w), Wp(op.b), N, s0.H, s0.W, head->logits, head->road, head->fence,
+                                           head->argmax, s);
+                break;
+            }
+        }
+        if (e != hipSuccess) return fail(h, SD_ERR_HIP, "launch " + op.name + ": " + hipGetErrorString(e));
+    }
+    (net == SD_NET_FCN8S ? h->last_fcn_images : h->last_mono_images) = N;
+    return SD_OK;
+}
+
+CamDev make_cam(const sd_camera& c) {
+    // np.float32([[1,0,0,-cx],[0,-1,0,cy],[0,0,0,-f],[0,0,1/b,0]]) then promoted to double by OpenCV
+    CamDev d;
+    const float q[16] = {1.f, 0.f, 0.f, (float)(-c.cx), 0.f, -1.f, 0.f, (float)c.cy, 0.f, 0.f, 0.f, (float)(-c.f), 0.f, 0.f, (float)(1.0 / c.b), 0.f};
+    for (int i = 0; i < 16; ++i) d.q[i] = (double)q[i];
+    d.mult = (float)c.disp_mult;
+    return d;
+}
+
+int32_t* cnt_slot(sd_handle* h, int i) { return reinterpret_cast<int32_t*>(h->ws + h->o_cnt) + (size_t)i * h->max_batch; }
+
+}  // namespace
+
+extern "C" {
+
+const char* sd_version(void) { return "semdepth 0.1 (gfx950, f32 MFMA)"; }
+
+const char* sd_status_string(sd_status s) {
+    switch (s) {
+        case SD_OK: return "ok";
+        case SD_ERR_INVALID: return "invalid argument";
+        case SD_ERR_HIP: return "HIP error";
+        case SD_ERR_STATE: return "invalid state";
+        case SD_ERR_NOTFOUND: return "not found";
+        default: return "unknown";
+    }
+}
+
+sd_status sd_create(sd_handle** out, int device, int H, int W, int max_batch, sd_encoder enc, sd_precision prec) {
+    if (!out || H <= 0 || W <= 0 || max_batch <= 0 || prec != SD_PREC_F32) return SD_ERR_INVALID;
+    sd_handle* h = new sd_handle();
+    h->device = device; h->H = H; h->W = W; h->max_batch = max_batch; h->enc = (int)enc; h->cap = H * W;
+    int chunk = 8;
+    if (const char* e = std::getenv("SEMDEPTH_CHUNK")) chunk = std::max(1, atoi(e));
+    h->chunk = std::min(max_batch, chunk);
+    try {
+        h->fcn = build_fcn8s(h->chunk, H, W);
+        h->mono = build_monodepth(enc == SD_ENC_VGG ? 0 : 1, h->chunk, H, W);
+    } catch (const std::exception& ex) {
+        std::fprintf(stderr, "sd_create: %s\n", ex.what());
+        delete h;
+        return SD_ERR_INVALID;
+    }
+    carve_workspace(h);
+    *out = h;
+    return SD_OK;
+}
+
+sd_status sd_destroy(sd_handle* h) {
+    delete h;
+    return SD_OK;
+}
+
+const char* sd_last_error(const sd_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+sd_status sd_query_memory(const sd_handle* h, size_t* fcn_w, size_t* mono_w, size_t* ws) {
+    if (!h) return SD_ERR_INVALID;
+    if (fcn_w) *fcn_w = h->fcn.weight_bytes;
+    if (mono_w) *mono_w = h->mono.weight_bytes;
+    if (ws) *ws = h->ws_bytes;
+    return SD_OK;
+}
+
+sd_status sd_bind_memory(sd_handle* h, void* wf, void* wm, void* ws) {
+    if (!h || !wf || !wm || !ws) return SD_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    h->wf = (char*)wf; h->wm = (char*)wm; h->ws = (char*)ws;
+    h->bound = true;
+    sd_status st = upload_tables(h, SD_NET_FCN8S);
+    if (st != SD_OK) return st;
+    return upload_tables(h, SD_NET_MONODEPTH);
+}
+
+int sd_weight_count(const sd_handle* h, sd_net net) { return h ? (int)plan_of(h, net).weights.size() : 0; }
+
+sd_status sd_weight_info(const sd_handle* h, sd_net net, int index, char* name_out, int64_t* shape_out, int* rank_out) {
+    if (!h) return SD_ERR_INVALID;
+    const NetPlan& p = plan_of(h, net);
+    if (index < 0 || index >= (int)p.weights.size()) return SD_ERR_INVALID;
+    const WeightSlot& s = p.weights[index];
+    if (name_out) { std::strncpy(name_out, s.name.c_str(), 63); name_out[63] = 0; }
+    if (shape_out) for (int i = 0; i < 4; ++i) shape_out[i] = s.shape[i];
+    if (rank_out) *rank_out = s.rank;
+    return SD_OK;
+}
+
+sd_status sd_load_weight(sd_handle* h, sd_net net, const char* name, const float* data, const int64_t* shape, int rank) {
+    if (!h || !name || !data || !shape) return SD_ERR_INVALID;
+    if (!h->bound) return fail(h, SD_ERR_STATE, "sd_bind_memory first");
+    NetPlan& p = plan_of(h, net);
+    auto it = p.weight_by_name.find(name);
+    if (it == p.weight_by_name.end()) return fail(h, SD_ERR_NOTFOUND, std::string("unknown weight ") + name);
+    WeightSlot& s = p.weights[it->second];
+    if (rank != s.rank) return fail(h, SD_ERR_INVALID, std::string("rank mismatch for ") + name);
+    for (int i = 0; i < rank; ++i)
+        if (shape[i] != s.shape[i]) return fail(h, SD_ERR_INVALID, std::string("shape mismatch for ") + name);
+    std::vector<float> buf;
+    relayout_weight(s, data, buf);
+    HIPCHK(h, hipMemcpy(warena(h, net) + s.offset, buf.data(), s.bytes, hipMemcpyHostToDevice));
+    s.loaded = true;
+    return SD_OK;
+}
+
+sd_status sd_fcn8s_forward(sd_handle* h, const uint8_t* frames, int B, float* logits, uint8_t* road, uint8_t* fence,
+                           uint8_t* argmax, void* stream) {
+    if (!h || !frames || B <= 0 || B > h->max_batch) return fail(h, SD_ERR_INVALID, "sd_fcn8s_forward: bad arguments");
+    if (!h->bound) return fail(h, SD_ERR_STATE, "sd_bind_memory first");
+    const size_t npix = (size_t)h->H * h->W;
+    for (int b0 = 0; b0 < B; b0 += h->chunk) {
+        const int nb = std::min(h->chunk, B - b0);
+        HeadOut ho{logits ? logits + (size_t)b0 * npix * 3 : nullptr, road ? road + (size_t)b0 * npix : nullptr,
+                   fence ? fence + (size_t)b0 * npix : nullptr, argmax ? argmax + (size_t)b0 * npix : nullptr};
+        sd_status st = run_plan(h, SD_NET_FCN8S, frames + (size_t)b0 * npix * 3, nb, &ho, (hipStream_t)stream);
+        if (st != SD_OK) return st;
+    }
+    return SD_OK;
+}
+
+sd_status sd_post_process(sd_handle* h, const float* disp_raw, int B, float* disp_pp, void* stream) {
+    if (!h || !disp_raw || !disp_pp || B <= 0) return fail(h, SD_ERR_INVALID, "sd_post_process: bad arguments");
+    HIPCHK(h, launch_post_process(disp_raw, disp_pp, B, h->H, h->W, (hipStream_t)stream));
+    return SD_OK;
+}
+
+sd_status sd_monodepth_forward(sd_handle* h, const uint8_t* frames, int B, float* disp_pp, float* disp_raw, void* stream) {
+    if (!h || !frames || !disp_pp || B <= 0 || B > h->max_batch) return fail(h, SD_ERR_INVALID, "sd_monodepth_forward: bad arguments");
+    if (!h->bound) return fail(h, SD_ERR_STATE, "sd_bind_memory first");
+    const size_t npix = (size_t)h->H * h->W;
+    hipStream_t s = (hipStream_t)stream;
+    const NetPlan& p = h->mono;
+    const float* raw = reinterpret_cast<const float*>(h->ws + h->o_mono + p.tensors[p.t_output].offset);
+    for (int b0 = 0; b0 < B; b0 += h->chunk) {
+        const int nb = std::min(h->chunk, B - b0);
+        sd_status st = run_plan(h, SD_NET_MONODEPTH, frames + (size_t)b0 * npix * 3, nb, nullptr, s);
+        if (st != SD_OK) return st;
+        HIPCHK(h, launch_post_process(raw, disp_pp + (size_t)b0 * npix, nb, h->H, h->W, s));
+        if (disp_raw)
+            HIPCHK(h, hipMemcpyAsync(disp_raw + (size_t)b0 * 2 * npix, raw, (size_t)nb * 2 * npix * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    return SD_OK;
+}
+
+sd_status sd_fuse_backproject(sd_handle* h, const float* disp_pp, const uint8_t* road, const uint8_t* fence, const uint8_t* frames,
+                              const sd_camera* cams, int B, int cap, float* dense, float* road_xyz, uint8_t* road_rgb,
+                              int32_t* n_road, float* fence_xyz, uint8_t* fence_rgb, int32_t* n_fence, void* stream) {
+    if (!h || !disp_pp || !cams || B <= 0 || B > h->max_batch || cap <= 0) return fail(h, SD_ERR_INVALID, "sd_fuse_backproject: bad arguments");
+    if (!h->bound) return fail(h, SD_ERR_STATE, "sd_bind_memory first");
+    if ((road_xyz && (!road || !n_road)) || (fence_xyz && (!fence || !n_fence)))
+        return fail(h, SD_ERR_INVALID, "sd_fuse_backproject: a cloud output needs its mask and its counter");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<CamDev> cd(B);
+    for (int b = 0; b < B; ++b) cd[b] = make_cam(cams[b]);
+    CamDev* dcams = reinterpret_cast<CamDev*>(h->ws + h->o_cams);
+    if (h->cams_stage.size() != (size_t)B || std::memcmp(h->cams_stage.data(), cd.data(), sizeof(CamDev) * B) != 0) {
+        h->cams_stage = cd;
+        HIPCHK(h, hipMemcpyAsync(dcams, h->cams_stage.data(), sizeof(CamDev) * B, hipMemcpyHostToDevice, s));
+    }
+    FuseParams p{};
+    p.disp_pp = disp_pp; p.road = road_xyz ? road : nullptr; p.fence = fence_xyz ? fence : nullptr; p.frames = frames; p.cams = dcams;
+    p.B = B; p.H = h->H; p.W = h->W; p.cap = cap;
+    p.dense = dense; p.road_xyz = road_xyz; p.road_rgb = frames ? road_rgb : nullptr; p.n_road = n_road;
+    p.fence_xyz = fence_xyz; p.fence_rgb = frames ? fence_rgb : nullptr; p.n_fence = n_fence;
+    const size_t nblk = ((size_t)h->H * h->W + 255) / 256;
+    p.blk_counts = reinterpret_cast<int32_t*>(h->ws + h->o_fuse);
+    p.blk_offsets = p.blk_counts + (size_t)h->max_batch * nblk * 2;
+    HIPCHK(h, launch_fuse(p, s));
+    return SD_OK;
+}
+
+sd_status sd_road_width(sd_handle* h, const float* road_xyz, const int32_t* n_road, int B, int cap, const sd_rw_params* prm,
+                        sd_rw_result* results, float* final_xyz, int32_t* n_final, void* stream) {
+    if (!h || !road_xyz || !n_road || !prm || !results || B <= 0 || B > h->max_batch || cap <= 0 || cap > h->cap)
+        return fail(h, SD_ERR_INVALID, "sd_road_width: bad arguments");
+    if (!h->bound) return fail(h, SD_ERR_STATE, "sd_bind_memory first");
+    hipStream_t s = (hipStream_t)stream;
+    float* A = reinterpret_cast<float*>(h->ws + h->o_bufA);
+    int32_t *n1 = cnt_slot(h, 1), *n2 = cnt_slot(h, 2), *n3 = cnt_slot(h, 3), *n4 = cnt_slot(h, 4), *n5 = cnt_slot(h, 5),
+            *n6 = cnt_slot(h, 6);
+    double* plane = reinterpret_cast<double*>(h->ws + h->o_plane);
+    void* o3d = h->ws + h->o_o3d;
+    RwResultDev* res = reinterpret_cast<RwResultDev*>(results);
+    // every stage compacts in place in arena A (ordered compaction only moves rows toward the front)
+    HIPCHK(h, launch_filter_coord({road_xyz, nullptr, n_road}, {A, nullptr, n1}, B, cap, F_LT_NEG, 2, prm->z_cut, s));
+    HIPCHK(h, launch_mad_filter({A, nullptr, n1}, {A, nullptr, n2}, B, cap, 1, prm->mad_y, nullptr, s));
+    HIPCHK(h, launch_mad_filter({A, nullptr, n2}, {A, nullptr, n3}, B, cap, 0, prm->mad_x, nullptr, s));
+    HIPCHK(h, launch_plane_filter({A, nullptr, n3}, {A, nullptr, n4}, B, cap, 1, prm->plane_thr, plane, s));
+    const int32_t* nlast = n4;
+    if (prm->use_o3d) {
+        HIPCHK(h, launch_sor({A, nullptr, n4}, {A, nullptr, n5}, B, cap, prm->sor_k, prm->sor_ratio, o3d, nullptr, s));
+        HIPCHK(h, launch_ror({A, nullptr, n5}, {A, nullptr, n6}, B, cap, prm->ror_n, prm->ror_r, o3d, s));
+        nlast = n6;
+    } else {
+        n5 = n4; n6 = n4;
+    }
+    HIPCHK(h, launch_end_points({A, nullptr, nlast}, B, cap, prm->depth - prm->depth_offset, prm->window, res, s));
+    HIPCHK(h, launch_record_counts(res, B, n_road, n1, n2, n3, n4, n5, n6, plane, s));
+    if (final_xyz) HIPCHK(h, hipMemcpyAsync(final_xyz, A, (size_t)B * cap * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (n_final) HIPCHK(h, hipMemcpyAsync(n_final, nlast, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    return SD_OK;
+}
+
+// ---------------------------------------------------------------- pcl.py function by function (single cloud)
+static sd_status set_n(sd_handle* h, int n, int32_t** dn, hipStream_t s) {
+    *dn = reinterpret_cast<int32_t*>(h->ws + h->o_misc);
+    HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)*dn, n, 1, s));
+    return SD_OK;
+}
+#define PCL_PROLOGUE()                                                                                         \
+    if (!h || !xyz || !xyz_out || !n_out || n < 0 || (size_t)n > (size_t)h->max_batch * h->cap)                \
+        return fail(h, SD_ERR_INVALID, "pcl: bad arguments");                                                  \
+    if (!h->bound) return fail(h, SD_ERR_STATE, "sd_bind_memory first");                                       \
+    hipStream_t s = (hipStream_t)stream;                                                                       \
+    int32_t* dn = nullptr;                                                                                     \
+    { sd_status st_ = set_n(h, n, &dn, s); if (st_ != SD_OK) return st_; }                                     \
+    const int cap1 = std::max(n, 1);
+
+sd_status sd_pcl_remove_from_to(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int axis, double to_meter,
+                                float* xyz_out, uint8_t* rgb_out, int32_t* n_out, void* stream) {
+    PCL_PROLOGUE();
+    HIPCHK(h, launch_filter_coord({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, F_LT_NEG, axis, to_meter, s));
+    return SD_OK;
+}
+sd_status sd_pcl_threshold_complete(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int axis, double threshold,
+                                    float* xyz_out, uint8_t* rgb_out, int32_t* n_out, void* stream) {
+    PCL_PROLOGUE();
+    HIPCHK(h, launch_filter_coord({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, F_ABS_LT, axis, threshold, s));
+    return SD_OK;
+}
+sd_status sd_pcl_remove_noise_by_mad(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int axis, double threshold,
+                                     float* xyz_out, uint8_t* rgb_out, int32_t* n_out, float* stats_out, void* stream) {
+    PCL_PROLOGUE();
+    HIPCHK(h, launch_mad_filter({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, axis, threshold, stats_out, s));
+    return SD_OK;
+}
+sd_status sd_pcl_remove_noise_by_fitting_plane(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int axis, double threshold,
+                                               float* xyz_out, uint8_t* rgb_out, int32_t* n_out, double* coeff_out, void* stream) {
+    PCL_PROLOGUE();
+    if (axis < 0 || axis > 2) return fail(h, SD_ERR_INVALID, "axis");
+    HIPCHK(h, launch_plane_filter({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, axis, threshold, coeff_out, s));
+    return SD_OK;
+}
+sd_status sd_pcl_get_end_points_of_road(sd_handle* h, const float* xyz, int n, double depth, double window, sd_rw_result* out,
+                                        void* stream) {
+    if (!h || !xyz || !out || n < 0) return fail(h, SD_ERR_INVALID, "pcl: bad arguments");
+    if (!h->bound) return fail(h, SD_ERR_STATE, "sd_bind_memory first");
+    hipStream_t s = (hipStream_t)stream;
+    int32_t* dn = nullptr;
+    sd_status st = set_n(h, n, &dn, s);
+    if (st != SD_OK) return st;
+    HIPCHK(h, launch_end_points({xyz, nullptr, dn}, 1, std::max(n, 1), depth, window, reinterpret_cast<RwResultDev*>(out), s));
+    return SD_OK;
+}
+sd_status sd_o3d_statistical_outlier_removal(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int nb_neighbors,
+                                             double std_ratio, float* xyz_out, uint8_t* rgb_out, int32_t* n_out,
+                                             double* mean_dist_out, void* stream) {
+    PCL_PROLOGUE();
+    if (nb_neighbors < 1 || nb_neighbors > 16) return fail(h, SD_ERR_INVALID, "nb_neighbors must be in 1..16");
+    if (o3d_scratch_bytes(1, cap1) > o3d_scratch_bytes(h->max_batch, h->cap)) return fail(h, SD_ERR_INVALID, "cloud too large");
+    HIPCHK(h, launch_sor({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, nb_neighbors, std_ratio, h->ws + h->o_o3d, mean_dist_out, s));
+    return SD_OK;
+}
+sd_status sd_o3d_radius_outlier_removal(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int nb_points, double radius,
+                                        float* xyz_out, uint8_t* rgb_out, int32_t* n_out, void* stream) {
+    PCL_PROLOGUE();
+    if (o3d_scratch_bytes(1, cap1) > o3d_scratch_bytes(h->max_batch, h->cap)) return fail(h, SD_ERR_INVALID, "cloud too large");
+    HIPCHK(h, launch_ror({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, nb_points, radius, h->ws + h->o_o3d, s));
+    return SD_OK;
+}
+
+// ---------------------------------------------------------------- introspection
+sd_status sd_net_tensor(sd_handle* h, sd_net net, const char* name, float* out, size_t cap_floats, int64_t* shape_out, void* stream) {
+    if (!h || !name) return SD_ERR_INVALID;
+    NetPlan& p = plan_of(h, net);
+    auto it = p.tensor_by_name.find(name);
+    if (it == p.tensor_by_name.end()) return fail(h, SD_ERR_NOTFOUND, std::string("unknown tensor ") + name);
+    const TensorDesc& t = p.tensors[it->second];
+    const int N = net == SD_NET_FCN8S ? h->last_fcn_images : h->last_mono_images;
+    if (shape_out) { shape_out[0] = N; shape_out[1] = t.H; shape_out[2] = t.W; shape_out[3] = t.C; }
+    if (!out) return SD_OK;
+    if (!h->bound) return fail(h, SD_ERR_STATE, "sd_bind_memory first");
+    const size_t numel = (size_t)N * t.H * t.W * t.C;
+    if (numel > cap_floats) return fail(h, SD_ERR_INVALID, "output buffer too small");
+    const char* abase = h->ws + (net == SD_NET_FCN8S ? h->o_fcn : h->o_mono);
+    HIPCHK(h, hipMemcpyAsync(out, abase + t.offset, numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return SD_OK;
+}
+
+double sd_net_flops_per_image(const sd_handle* h, sd_net net) { return h ? plan_of(h, net).flops_per_image : 0.0; }
+
+}  // extern "C"

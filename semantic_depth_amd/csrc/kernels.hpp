@@ -1,0 +1,112 @@
+// Launch interfaces of the HIP kernels (gfx950).  Plain structs; everything is NHWC float32 unless stated.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sd {
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_SIGMOID03 = 3 /* 0.3*sigmoid, monodepth get_disp */ };
+
+// ---------------------------------------------------------------------------------------------
+// implicit-GEMM convolution on the f32 MFMA (conv_igemm.hip)
+// ---------------------------------------------------------------------------------------------
+struct ConvSrc {
+    const float* ptr;  // [N, H, W, C]
+    int C, H, W;       // physical dims of the stored tensor
+    int up;            // 1: read through a x2 nearest-neighbour upsample (logical dims 2H x 2W)
+};
+
+struct ConvParams {
+    const ConvSrc* srcs;  // DEVICE array [nsrc]: channel-concatenated sources (tf.concat order)
+    int nsrc, Ctot;
+    int N, Hin, Win;   // logical input dims (after upsample)
+    int Hout, Wout, Cout, CoutPad;
+    int kh, kw, stride, pad;
+    int K, Kpad;       // K = kh*kw*Ctot ; Kpad = multiple of 32
+    const float* wt;   // re-laid-out weights [Kpad/4][CoutPad][4]
+    const float* bias; // [Cout]
+    const int4* ktab;  // vec path: one entry per 32-wide k-tile {src, dy-pad, dx-pad, c0}
+                       // scalar path: one entry per k {src (-1 = zero), dy-pad, dx-pad, c}
+    int vec;           // 1: every source has C % 32 == 0 (k-tiles never straddle a tap or a source)
+    const float* residual;  // nullable [M][Cout], added before the activation (resnet shortcut)
+    float* out;             // [M][Cout]
+    int act;
+    int m_fastest;     // block order: 1 = consecutive blocks walk M (share a weight panel), 0 = walk N
+};
+hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t s);
+
+// small-N convolution (N <= 4 output channels: score 1x1 convs, monodepth disparity heads)
+struct SmallNParams {
+    const float* x;     // [N,H,W,C]
+    int N, H, W, C;
+    int k;              // 1 or 3 (stride 1, zero pad (k-1)/2)
+    int nout;           // computed output channels (<= 4)
+    const float* wt;    // [k*k*C][4] (zero padded to 4 outputs)
+    const float* bias;  // [4]
+    float* out;         // [N,H,W,nout]
+    int act;
+};
+hipError_t launch_conv_smalln(const SmallNParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// misc network ops (ops_misc.hip)
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_pre_vgg(const uint8_t* frames, float* out, long npix, hipStream_t s);                 // K1
+hipError_t launch_pre_mono(const uint8_t* frames, float* out, int B, int H, int W, hipStream_t s);      // /255 + fliplr pair
+hipError_t launch_maxpool2(const float* x, float* y, int N, int H, int W, int C, hipStream_t s);        // 2x2 s2 (even dims)
+hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C, hipStream_t s);       // zero-pad 1, 3x3 s2
+// y[n,2i+ky-1,2j+kx-1,o] += x[n,i,j,c]*w[ky,kx,o,c]; y += bias + skip   (3->3 channels; fcn8s/fcn.py:186-204)
+hipError_t launch_deconv4s2_add(const float* x, const float* w, const float* bias, const float* skip, float* y,
+                                int N, int H, int W, hipStream_t s);
+// 16x16 s8 transposed conv + softmax + 0.5 thresholds + argmax (fcn8s/fcn.py:207-224, semantic_depth.py:550-564)
+hipError_t launch_deconv16s8_head(const float* x, const float* w, const float* bias, int N, int H, int W,
+                                  float* logits, uint8_t* road, uint8_t* fence, uint8_t* argmax, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// fusion (fuse.hip; compiled with -ffp-contract=off: bit-exact vs numpy / OpenCV arithmetic)
+// ---------------------------------------------------------------------------------------------
+struct CamDev { double q[16]; float mult; };   // Q rounded to f32 then widened; multiplier as f32
+hipError_t launch_post_process(const float* disp_raw, float* disp_pp, int B, int H, int W, hipStream_t s);
+struct FuseParams {
+    const float* disp_pp;      // [B,H,W]
+    const uint8_t* road; const uint8_t* fence; const uint8_t* frames;
+    const CamDev* cams;        // device [B]
+    int B, H, W, cap;
+    float* dense;              // nullable [B,H,W,3]
+    float* road_xyz; uint8_t* road_rgb; int32_t* n_road;
+    float* fence_xyz; uint8_t* fence_rgb; int32_t* n_fence;
+    int32_t* blk_counts;       // scratch [B][nblk][2]
+    int32_t* blk_offsets;      // scratch [B][nblk][2]
+};
+size_t fuse_scratch_bytes(int B, int H, int W);
+hipError_t launch_fuse(const FuseParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// road-width tail (pcl.hip; -ffp-contract=off)
+// ---------------------------------------------------------------------------------------------
+struct RwParamsDev {
+    double depth, z_cut, mad_y, mad_x, plane_thr, sor_ratio, ror_r, window, depth_offset;
+    int sor_k, ror_n, use_o3d;
+};
+struct RwResultDev {   // layout == sd_rw_result
+    double width; float x_left, x_right; float left_pt[3], right_pt[3];
+    int32_t found, n_road, n_zcut, n_mad_y, n_mad_x, n_plane, n_sor, n_ror; double plane[4];
+};
+struct CloudView { const float* xyz; const uint8_t* rgb; const int32_t* n; };   // per-frame stride = cap points
+struct CloudOut { float* xyz; uint8_t* rgb; int32_t* n; };
+
+enum FilterKind { F_LT_NEG = 0 /* coord < -t */, F_ABS_LT = 1 /* |coord| < t */ };
+hipError_t launch_filter_coord(CloudView in, CloudOut out, int B, int cap, int kind, int axis, double t, hipStream_t s);
+hipError_t launch_mad_filter(CloudView in, CloudOut out, int B, int cap, int axis, double thr, float* stats, hipStream_t s);
+hipError_t launch_plane_filter(CloudView in, CloudOut out, int B, int cap, int axis, double thr, double* coeff, hipStream_t s);
+hipError_t launch_end_points(CloudView in, int B, int cap, double depth, double window, RwResultDev* res, hipStream_t s);
+size_t o3d_scratch_bytes(int B, int cap);
+hipError_t launch_sor(CloudView in, CloudOut out, int B, int cap, int k, double ratio, void* scratch, double* mean_out,
+                      hipStream_t s);
+hipError_t launch_ror(CloudView in, CloudOut out, int B, int cap, int nb, double radius, void* scratch, hipStream_t s);
+// writes the count fields of the per-frame records from device-side counters
+hipError_t launch_record_counts(RwResultDev* res, int B, const int32_t* n_road, const int32_t* n_zcut, const int32_t* n_mad_y,
+                                const int32_t* n_mad_x, const int32_t* n_plane, const int32_t* n_sor, const int32_t* n_ror,
+                                const double* plane, hipStream_t s);
+
+}  // namespace sd

@@ -1,0 +1,312 @@
+// HBM-bound network ops around the conv engine (gfx950): input pre-processing, pools, small-N convs
+// (score layers, disparity heads), the FCN-8s transposed-conv ladder and its softmax/threshold/argmax head.
+// SURVEY.md §2.2 rows K1, K3, K6-K9, K11, K15.
+#include "kernels.hpp"
+
+namespace sd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// K1: VGG 'Processing' block [UPSTREAM Udacity vgg]: split (c0,c1,c2), subtract means, concat reversed.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pre_vgg_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, long npix) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const uint8_t* p = in + i * 3;
+    float* o = out + i * 3;
+    o[0] = (float)p[2] - 103.939f;
+    o[1] = (float)p[1] - 116.779f;
+    o[2] = (float)p[0] - 123.68f;
+}
+hipError_t launch_pre_vgg(const uint8_t* frames, float* out, long npix, hipStream_t s) {
+    hipLaunchKernelGGL(pre_vgg_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, frames, out, npix);
+    return hipGetLastError();
+}
+
+// monodepth input: frame.astype(f32)/255 and its fliplr, stacked per frame (semantic_depth.py:671-672)
+__global__ __launch_bounds__(256) void pre_mono_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int B, int H, int W) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    long npix = (long)B * H * W;
+    if (i >= npix) return;
+    int x = (int)(i % W);
+    long row = i / W;               // b*H + y
+    int b = (int)(row / H);
+    int y = (int)(row - (long)b * H);
+    const uint8_t* p = in + i * 3;
+    float v0 = (float)p[0] / 255.0f, v1 = (float)p[1] / 255.0f, v2 = (float)p[2] / 255.0f;
+    float* o = out + (((long)(2 * b) * H + y) * W + x) * 3;
+    o[0] = v0; o[1] = v1; o[2] = v2;
+    float* f = out + (((long)(2 * b + 1) * H + y) * W + (W - 1 - x)) * 3;
+    f[0] = v0; f[1] = v1; f[2] = v2;
+}
+hipError_t launch_pre_mono(const uint8_t* frames, float* out, int B, int H, int W, hipStream_t s) {
+    long npix = (long)B * H * W;
+    hipLaunchKernelGGL(pre_mono_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, frames, out, B, H, W);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: max-pool 2x2 stride 2 (TF SAME on even dims = no padding); K11: zero-pad 1 then 3x3 stride 2 VALID
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool2_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, int N, int H, int W, int C4) {
+    const int Ho = H / 2, Wo = W / 2;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    long total = (long)N * Ho * Wo * C4;
+    if (i >= total) return;
+    int c = (int)(i % C4);
+    long r = i / C4;
+    int ox = (int)(r % Wo); r /= Wo;
+    int oy = (int)(r % Ho);
+    int n = (int)(r / Ho);
+    const f32x4* p = x + (((long)n * H + 2 * oy) * W + 2 * ox) * C4 + c;
+    f32x4 a = p[0], b = p[C4], d = p[(long)W * C4], e = p[(long)W * C4 + C4];
+    f32x4 m;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = fmaxf(fmaxf(a[j], b[j]), fmaxf(d[j], e[j]));
+    y[i] = m;
+}
+hipError_t launch_maxpool2(const float* x, float* y, int N, int H, int W, int C, hipStream_t s) {
+    long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f32x4*)x, (f32x4*)y, N, H, W, C / 4);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void maxpool3z_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, int N, int H, int W, int C4) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    long total = (long)N * Ho * Wo * C4;
+    if (i >= total) return;
+    int c = (int)(i % C4);
+    long r = i / C4;
+    int ox = (int)(r % Wo); r /= Wo;
+    int oy = (int)(r % Ho);
+    int n = (int)(r / Ho);
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            int iy = 2 * oy - 1 + dy, ix = 2 * ox - 1 + dx;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};   // the padding is ZERO and takes part in the max (upstream quirk)
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((long)n * H + iy) * W + ix) * C4 + c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], v[j]);
+        }
+    y[i] = m;
+}
+hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C, hipStream_t s) {
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    long total = (long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool3z_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f32x4*)x, (f32x4*)y, N, H, W, C / 4);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6 / K15: convolution with <= 4 output channels, k in {1,3}, stride 1, zero pad (k-1)/2.
+//   THREAD variant: one thread per output pixel, weights [K][4] staged in LDS (K*16 B <= 64 KiB)
+//   WAVE   variant: one wave per output pixel, lanes stride over the channel quads, shuffle reduction
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float smalln_act(float v, int act) {
+    if (act == ACT_SIGMOID03) return 0.3f * (1.0f / (1.0f + expf(-v)));
+    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == ACT_ELU) return v > 0.f ? v : expm1f(v);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void conv_smalln_thread_kernel(const SmallNParams p) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [K][4]
+    const int K = p.k * p.k * p.C;
+    for (int i = threadIdx.x; i < K; i += 256) reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(p.wt)[i];
+    __syncthreads();
+    long pix = (long)blockIdx.x * 256 + threadIdx.x;
+    long npix = (long)p.N * p.H * p.W;
+    if (pix >= npix) return;
+    int x = (int)(pix % p.W);
+    long r = pix / p.W;
+    int y = (int)(r % p.H);
+    int n = (int)(r / p.H);
+    const int pad = (p.k - 1) / 2;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(p.bias);
+    const int C4 = p.C / 4;
+    for (int ky = 0; ky < p.k; ++ky) {
+        int iy = y + ky - pad;
+        if (iy < 0 || iy >= p.H) continue;
+        for (int kx = 0; kx < p.k; ++kx) {
+            int ix = x + kx - pad;
+            if (ix < 0 || ix >= p.W) continue;
+            const f32x4* xp = reinterpret_cast<const f32x4*>(p.x + (((long)n * p.H + iy) * p.W + ix) * p.C);
+            const f32x4* wp = reinterpret_cast<const f32x4*>(wl) + (ky * p.k + kx) * p.C;
+            for (int c = 0; c < C4; ++c) {
+                f32x4 v = xp[c];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc += v[j] * wp[c * 4 + j];
+            }
+        }
+    }
+    float* o = p.out + pix * p.nout;
+    for (int j = 0; j < p.nout; ++j) o[j] = smalln_act(acc[j], p.act);
+}
+
+__global__ __launch_bounds__(256) void conv_smalln_wave_kernel(const SmallNParams p) {
+    const int lane = threadIdx.x & 63;
+    long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    long npix = (long)p.N * p.H * p.W;
+    if (pix >= npix) return;
+    int x = (int)(pix % p.W);
+    long r = pix / p.W;
+    int y = (int)(r % p.H);
+    int n = (int)(r / p.H);
+    const int pad = (p.k - 1) / 2;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int C4 = p.C / 4;
+    for (int ky = 0; ky < p.k; ++ky) {
+        int iy = y + ky - pad;
+        if (iy < 0 || iy >= p.H) continue;
+        for (int kx = 0; kx < p.k; ++kx) {
+            int ix = x + kx - pad;
+            if (ix < 0 || ix >= p.W) continue;
+            const f32x4* xp = reinterpret_cast<const f32x4*>(p.x + (((long)n * p.H + iy) * p.W + ix) * p.C);
+            const f32x4* wp = reinterpret_cast<const f32x4*>(p.wt) + (long)(ky * p.k + kx) * p.C;
+            for (int c = lane; c < C4; c += 64) {
+                f32x4 v = xp[c];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc += v[j] * wp[c * 4 + j];
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += __shfl_xor(acc[j], off);
+    if (lane == 0) {
+        float* o = p.out + pix * p.nout;
+        for (int j = 0; j < p.nout; ++j) o[j] = smalln_act(acc[j] + p.bias[j], p.act);
+    }
+}
+
+hipError_t launch_conv_smalln(const SmallNParams& p, hipStream_t s) {
+    const long npix = (long)p.N * p.H * p.W;
+    const int K = p.k * p.k * p.C;
+    if (K <= 2048) {
+        hipLaunchKernelGGL(conv_smalln_thread_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), (size_t)K * 16, s, p);
+    } else {
+        hipLaunchKernelGGL(conv_smalln_wave_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, p);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// K7: conv2d_transpose 4x4 stride 2 SAME, 3 -> 3 channels, + bias + skip (fcn8s/fcn.py:186-204)
+//   y[n, 2i+ky-1, 2j+kx-1, o] += x[n,i,j,c] * w[ky,kx,o,c]     (TF kernel layout [kh,kw,out,in])
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void deconv4s2_add_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, const float* __restrict__ skip,
+                                                            float* __restrict__ y, int N, int H, int W) {
+    __shared__ float wl[4 * 4 * 9];
+    if (threadIdx.x < 144) wl[threadIdx.x] = w[threadIdx.x];
+    __syncthreads();
+    const int Ho = 2 * H, Wo = 2 * W;
+    long pix = (long)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= (long)N * Ho * Wo) return;
+    int ox = (int)(pix % Wo);
+    long r = pix / Wo;
+    int oy = (int)(r % Ho);
+    int n = (int)(r / Ho);
+    float acc[3] = {bias[0], bias[1], bias[2]};
+    // oy + 1 = 2*iy + ky, ky in [0,4): iy = (oy+1)>>1 with ky = (oy+1)&1, and iy-1 with ky+2
+    const int iyh = (oy + 1) >> 1, kyh = (oy + 1) & 1;
+    const int ixh = (ox + 1) >> 1, kxh = (ox + 1) & 1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        int iy = iyh - a, ky = kyh + 2 * a;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            int ix = ixh - b, kx = kxh + 2 * b;
+            if (ix < 0 || ix >= W) continue;
+            const float* xp = x + (((long)n * H + iy) * W + ix) * 3;
+            const float* wp = wl + (ky * 4 + kx) * 9;
+#pragma unroll
+            for (int o = 0; o < 3; ++o)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[o] += xp[c] * wp[o * 3 + c];
+        }
+    }
+    const float* sp = skip + pix * 3;
+    float* yp = y + pix * 3;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) yp[o] = acc[o] + sp[o];
+}
+hipError_t launch_deconv4s2_add(const float* x, const float* w, const float* bias, const float* skip, float* y,
+                                int N, int H, int W, hipStream_t s) {
+    long npix = (long)N * 4 * H * W;
+    hipLaunchKernelGGL(deconv4s2_add_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, x, w, bias, skip, y, N, H, W);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8 + K9: conv2d_transpose 16x16 stride 8 SAME (3 -> 3) fused with the reference's consumers of 'logits':
+//   tf.nn.softmax (semantic_depth.py:551), > 0.5 for road (class 0) / fence (class 1) (:555-556, :563-564),
+//   argmax (fcn8s/fcn.py:218-224).  Gather form: each output pixel has 2x2 contributing inputs.
+//   oy + 4 = 8*iy + ky, ky in [0,16).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void deconv16s8_head_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, int N, int H, int W,
+                                                              float* __restrict__ logits, uint8_t* __restrict__ road,
+                                                              uint8_t* __restrict__ fence, uint8_t* __restrict__ amax) {
+    __shared__ float wl[16 * 16 * 9];
+    for (int i = threadIdx.x; i < 2304; i += 256) wl[i] = w[i];
+    __syncthreads();
+    const int Ho = 8 * H, Wo = 8 * W;
+    long pix = (long)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= (long)N * Ho * Wo) return;
+    int ox = (int)(pix % Wo);
+    long r = pix / Wo;
+    int oy = (int)(r % Ho);
+    int n = (int)(r / Ho);
+    float acc[3] = {bias[0], bias[1], bias[2]};
+    const int iyh = (oy + 4) >> 3, kyh = (oy + 4) & 7;
+    const int ixh = (ox + 4) >> 3, kxh = (ox + 4) & 7;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        int iy = iyh - a, ky = kyh + 8 * a;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            int ix = ixh - b, kx = kxh + 8 * b;
+            if (ix < 0 || ix >= W) continue;
+            const float* xp = x + (((long)n * H + iy) * W + ix) * 3;
+            const float* wp = wl + (ky * 16 + kx) * 9;
+#pragma unroll
+            for (int o = 0; o < 3; ++o)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[o] += xp[c] * wp[o * 3 + c];
+        }
+    }
+    if (logits) {
+        float* lp = logits + pix * 3;
+        lp[0] = acc[0]; lp[1] = acc[1]; lp[2] = acc[2];
+    }
+    const float mx = fmaxf(acc[0], fmaxf(acc[1], acc[2]));
+    const float e0 = expf(acc[0] - mx), e1 = expf(acc[1] - mx), e2 = expf(acc[2] - mx);
+    const float sum = e0 + e1 + e2;
+    const float p0 = e0 / sum, p1 = e1 / sum, p2 = e2 / sum;
+    if (road) road[pix] = p0 > 0.5f;
+    if (fence) fence[pix] = p1 > 0.5f;
+    if (amax) {
+        int am = 0; float best = p0;
+        if (p1 > best) { best = p1; am = 1; }
+        if (p2 > best) { am = 2; }
+        amax[pix] = (uint8_t)am;
+    }
+}
+hipError_t launch_deconv16s8_head(const float* x, const float* w, const float* bias, int N, int H, int W,
+                                  float* logits, uint8_t* road, uint8_t* fence, uint8_t* argmax, hipStream_t s) {
+    long npix = (long)N * 64 * H * W;
+    hipLaunchKernelGGL(deconv16s8_head_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, x, w, bias, N, H, W,
+                       logits, road, fence, argmax);
+    return hipGetLastError();
+}
+
+}  // namespace sd

@@ -1,0 +1,665 @@
+// Road-width tail on gfx950 (HBM / latency bound; no MFMA): the reference's "hand-made point cloud library"
+// (semantic_depth_lib/pcl.py) and the two Open3D outlier filters of semantic_depth.py:227-245, for B frames at once.
+// SURVEY.md §2.2 rows K20-K24.  Compiled with -ffp-contract=off: every comparison that selects points must
+// round exactly like numpy / Open3D do on the CPU.
+//
+// Layout: a cloud is xyz f32 [cap][3] (+ optional rgb u8 [cap][3]) with its size in a DEVICE int32; frame b
+// lives at offset b*cap.  The reductions (medians, moments, arg-min/max) run one 1024-thread workgroup per
+// frame with wave ballots / shuffles inside; the Open3D filters run one thread per point over a uniform grid.
+// All filters keep the input row order (ordered compaction), which the reference's "first min / first max"
+// end-point pick depends on (pcl.py:307-311, semantic_depth.py:259).
+#include "kernels.hpp"
+
+namespace sd {
+
+constexpr int TB = 1024;          // threads of a per-frame workgroup
+constexpr int NW = TB / 64;       // waves per workgroup
+
+// ------------------------------------------------------------------------------------------ helpers
+__device__ __forceinline__ unsigned f2key(float v) {       // monotone float -> uint
+    unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+struct Lds {
+    unsigned hist[256];
+    unsigned sh[8];
+    int wsum[NW];
+    int base;
+    double dred[NW];
+    float fred[NW];
+    int ired[NW];
+    unsigned ured[NW];
+};
+
+// rank-th smallest (0-based) of val(0..n-1); 8-bit MSB-first radix select, wave-aggregated LDS histogram
+template <class F>
+__device__ float block_select(F val, int n, unsigned rank, Lds& L) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    unsigned prefix = 0, mask = 0;
+    for (int pass = 3; pass >= 0; --pass) {
+        for (int i = tid; i < 256; i += TB) L.hist[i] = 0;
+        __syncthreads();
+        const int shift = pass * 8;
+        for (int i0 = 0; i0 < n; i0 += TB) {
+            const int i = i0 + tid;
+            bool valid = false;
+            unsigned bin = 0;
+            if (i < n) {
+                const unsigned k = f2key(val(i));
+                valid = (k & mask) == prefix;
+                bin = (k >> shift) & 255u;
+            }
+            // a few rounds of wave aggregation (the top bytes of a coordinate column take only a handful of values)
+            unsigned long long act = __ballot(valid);
+            for (int it = 0; it < 4 && act; ++it) {
+                const int leader = __ffsll((long long)act) - 1;
+                const unsigned b0 = __shfl(bin, leader);
+                const unsigned long long m = __ballot(valid && bin == b0);
+                if (lane == leader) atomicAdd(&L.hist[b0], (unsigned)__popcll(m));
+                if (bin == b0) valid = false;
+                act = __ballot(valid);
+            }
+            if (valid) atomicAdd(&L.hist[bin], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned cum = 0;
+            int b = 0;
+            for (; b < 255; ++b) {
+                const unsigned c = L.hist[b];
+                if (cum + c > rank) break;
+                cum += c;
+            }
+            L.sh[0] = (unsigned)b;
+            L.sh[1] = rank - cum;
+        }
+        __syncthreads();
+        prefix |= L.sh[0] << shift;
+        mask |= 0xFFu << shift;
+        rank = L.sh[1];
+        __syncthreads();
+    }
+    return key2f(prefix);
+}
+
+__device__ __forceinline__ int block_sum_int(int v, Lds& L) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) L.ired[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int s = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += L.ired[w];
+    return s;
+}
+__device__ __forceinline__ double block_sum_f64(double v, Lds& L) {   // fixed order -> deterministic
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) L.dred[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += L.dred[w];
+    return s;
+}
+__device__ __forceinline__ unsigned block_min_u32(unsigned v, Lds& L) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { unsigned t = __shfl_xor(v, o); v = t < v ? t : v; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) L.ured[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned s = 0xFFFFFFFFu;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s = L.ured[w] < s ? L.ured[w] : s;
+    return s;
+}
+
+// np.median of val(0..n-1) (float32 semantics: odd -> middle, even -> (a+b)/2 in f32; any NaN -> NaN)
+template <class F>
+__device__ float block_median(F val, int n, Lds& L) {
+    if (n <= 0) return __uint_as_float(0x7fc00000u);
+    int nan_local = 0;
+    for (int i = threadIdx.x; i < n; i += TB) { float v = val(i); nan_local |= (v != v); }
+    if (block_sum_int(nan_local, L) > 0) return __uint_as_float(0x7fc00000u);
+    if (n & 1) return block_select(val, n, (unsigned)(n / 2), L);
+    const float a = block_select(val, n, (unsigned)(n / 2 - 1), L);
+    // b = element of rank n/2: a again if enough copies <= a, else the smallest element > a
+    int le = 0;
+    unsigned nxt = 0xFFFFFFFFu;
+    const unsigned ka = f2key(a);
+    for (int i = threadIdx.x; i < n; i += TB) {
+        const unsigned k = f2key(val(i));
+        if (k <= ka) ++le; else nxt = k < nxt ? k : nxt;
+    }
+    const int cnt_le = block_sum_int(le, L);
+    const unsigned kmin = block_min_u32(nxt, L);
+    const float b = (cnt_le >= n / 2 + 1) ? a : key2f(kmin);
+    return (a + b) / 2.0f;
+}
+
+// ordered compaction of one frame: keeps rows with pred(i, x, y, z); in and out may alias
+template <class P>
+__device__ void block_compact(const float* __restrict__ xyz, const uint8_t* __restrict__ rgb, int n, float* oxyz,
+                              uint8_t* orgb, int32_t* n_out, int cap, P pred, Lds& L) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) L.base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += TB) {
+        const int i = i0 + tid;
+        float x = 0.f, y = 0.f, z = 0.f;
+        uint8_t c0 = 0, c1 = 0, c2 = 0;
+        bool keep = false;
+        if (i < n) {
+            x = xyz[(size_t)i * 3]; y = xyz[(size_t)i * 3 + 1]; z = xyz[(size_t)i * 3 + 2];
+            if (rgb) { c0 = rgb[(size_t)i * 3]; c1 = rgb[(size_t)i * 3 + 1]; c2 = rgb[(size_t)i * 3 + 2]; }
+            keep = pred(i, x, y, z);
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) L.wsum[wave] = __popcll(m);
+        __syncthreads();           // all rows of this chunk are in registers; wave totals visible
+        int pos = L.base + __popcll(m & ((1ull << lane) - 1ull));
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const int c = L.wsum[w]; if (w < wave) pos += c; tot += c; }
+        if (keep && pos < cap) {
+            oxyz[(size_t)pos * 3] = x; oxyz[(size_t)pos * 3 + 1] = y; oxyz[(size_t)pos * 3 + 2] = z;
+            if (orgb) { orgb[(size_t)pos * 3] = c0; orgb[(size_t)pos * 3 + 1] = c1; orgb[(size_t)pos * 3 + 2] = c2; }
+        }
+        __syncthreads();
+        if (tid == 0) L.base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *n_out = L.base;
+}
+
+#define FRAME_VIEW()                                                                          \
+    const int b = blockIdx.x;                                                                 \
+    const float* xyz = in.xyz + (size_t)b * cap * 3;                                          \
+    const uint8_t* rgb = in.rgb ? in.rgb + (size_t)b * cap * 3 : nullptr;                     \
+    const int n = min(in.n[b], cap);                                                          \
+    float* oxyz = out.xyz + (size_t)b * cap * 3;                                              \
+    uint8_t* orgb = (out.rgb && in.rgb) ? out.rgb + (size_t)b * cap * 3 : nullptr;            \
+    int32_t* on = out.n + b;                                                                  \
+    __shared__ Lds L;
+
+// ------------------------------------------------------------------------------------------ K20 / threshold
+// pcl.remove_from_to (pcl.py:30-43): keep coord < -t.   pcl.threshold_complete (pcl.py:240-250): keep |coord| < t.
+// The comparison is float32 vs the float32-rounded literal, as numpy does for a float32 column.
+__global__ __launch_bounds__(TB) void filter_coord_kernel(CloudView in, CloudOut out, int cap, int kind, int axis, float t) {
+    FRAME_VIEW();
+    block_compact(xyz, rgb, n, oxyz, orgb, on, cap, [=](int, float x, float y, float z) {
+        const float v = axis == 0 ? x : (axis == 1 ? y : z);
+        return kind == F_LT_NEG ? (v < -t) : (fabsf(v) < t);
+    }, L);
+}
+hipError_t launch_filter_coord(CloudView in, CloudOut out, int B, int cap, int kind, int axis, double t, hipStream_t s) {
+    hipLaunchKernelGGL(filter_coord_kernel, dim3(B), dim3(TB), 0, s, in, out, cap, kind, axis, (float)t);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ K21 MAD
+// pcl.remove_noise_by_mad + mad (pcl.py:46-81), all float32 like numpy on a float32 column:
+//   med = median(v); dev = |v - med|; MAD = median(dev); keep 0.6745f*dev/MAD < thr
+__global__ __launch_bounds__(TB) void mad_filter_kernel(CloudView in, CloudOut out, int cap, int axis, float thr, float* stats) {
+    FRAME_VIEW();
+    auto col = [=](int i) { return xyz[(size_t)i * 3 + axis]; };
+    const float med = block_median(col, n, L);
+    auto dev = [=](int i) { return fabsf(xyz[(size_t)i * 3 + axis] - med); };
+    const float madv = block_median(dev, n, L);
+    if (stats && threadIdx.x == 0) { stats[b * 2] = med; stats[b * 2 + 1] = madv; }
+    block_compact(xyz, rgb, n, oxyz, orgb, on, cap, [=](int, float x, float y, float z) {
+        const float v = axis == 0 ? x : (axis == 1 ? y : z);
+        const float pen = 0.6745f * fabsf(v - med) / madv;
+        return pen < thr;
+    }, L);
+}
+hipError_t launch_mad_filter(CloudView in, CloudOut out, int B, int cap, int axis, double thr, float* stats, hipStream_t s) {
+    hipLaunchKernelGGL(mad_filter_kernel, dim3(B), dim3(TB), 0, s, in, out, cap, axis, (float)thr, stats);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ K22 plane fit
+// pcl.remove_noise_by_fitting_plane (pcl.py:84-209): least squares dep = C0*u + C1*v + C2 in float64
+// (the reference calls scipy.linalg.lstsq on float64 columns; here: centred normal equations, float64,
+// deterministic reduction order), then keep |C0*u + C1*v - dep + C2| < thr (float64).
+__global__ __launch_bounds__(TB) void plane_filter_kernel(CloudView in, CloudOut out, int cap, int axis, double thr, double* coeff) {
+    FRAME_VIEW();
+    const int iu = axis == 0 ? 1 : 0, iv = axis == 2 ? 1 : 2, id = axis;
+    double su = 0, sv = 0, sd_ = 0;
+    for (int i = threadIdx.x; i < n; i += TB) {
+        su += (double)xyz[(size_t)i * 3 + iu]; sv += (double)xyz[(size_t)i * 3 + iv]; sd_ += (double)xyz[(size_t)i * 3 + id];
+    }
+    const double inv_n = 1.0 / (double)n;
+    const double mu = block_sum_f64(su, L) * inv_n, mv = block_sum_f64(sv, L) * inv_n, md = block_sum_f64(sd_, L) * inv_n;
+    double suu = 0, suv = 0, svv = 0, sud = 0, svd = 0;
+    for (int i = threadIdx.x; i < n; i += TB) {
+        const double u = (double)xyz[(size_t)i * 3 + iu] - mu, v = (double)xyz[(size_t)i * 3 + iv] - mv;
+        const double d = (double)xyz[(size_t)i * 3 + id] - md;
+        suu += u * u; suv += u * v; svv += v * v; sud += u * d; svd += v * d;
+    }
+    suu = block_sum_f64(suu, L); suv = block_sum_f64(suv, L); svv = block_sum_f64(svv, L);
+    sud = block_sum_f64(sud, L); svd = block_sum_f64(svd, L);
+    const double det = suu * svv - suv * suv;
+    const double C0 = (sud * svv - svd * suv) / det;
+    const double C1 = (svd * suu - sud * suv) / det;
+    const double C2 = md - C0 * mu - C1 * mv;
+    if (coeff && threadIdx.x == 0) {
+        double* c = coeff + (size_t)b * 4;     // Cx, Cy, Cz, C  (pcl.py:130, :168, :204)
+        if (axis == 0)      { c[0] = -1.0; c[1] = C0; c[2] = C1; }
+        else if (axis == 1) { c[0] = C0; c[1] = -1.0; c[2] = C1; }
+        else                { c[0] = C0; c[1] = C1; c[2] = -1.0; }
+        c[3] = C2;
+    }
+    block_compact(xyz, rgb, n, oxyz, orgb, on, cap, [=](int, float x, float y, float z) {
+        const double p[3] = {(double)x, (double)y, (double)z};
+        const double a = ((C0 * p[iu] + C1 * p[iv]) - p[id]) + C2;
+        return fabs(a) < thr;
+    }, L);
+}
+hipError_t launch_plane_filter(CloudView in, CloudOut out, int B, int cap, int axis, double thr, double* coeff, hipStream_t s) {
+    hipLaunchKernelGGL(plane_filter_kernel, dim3(B), dim3(TB), 0, s, in, out, cap, axis, thr, coeff);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ K24 end points
+// pcl.get_end_points_of_road / get_end_points_of_segment (pcl.py:271-313) + width (semantic_depth.py:259):
+// window -(depth+w) < z < -(depth-w) in float64; first row with min x, first row with max x.
+__global__ __launch_bounds__(TB) void end_points_kernel(CloudView in, int cap, double depth, double window, RwResultDev* res) {
+    const int b = blockIdx.x;
+    const float* xyz = in.xyz + (size_t)b * cap * 3;
+    const int n = min(in.n[b], cap);
+    __shared__ unsigned long long smin[NW], smax[NW];
+    const double hi = -(depth - window), lo = -(depth + window);
+    // key = (monotone x key << 32) | index : min picks smallest x then smallest index;
+    // for the max: (~xkey << 32) | index, min of that picks largest x then smallest index
+    unsigned long long kmin = ~0ull, kmax = ~0ull;
+    for (int i = threadIdx.x; i < n; i += TB) {
+        const double z = (double)xyz[(size_t)i * 3 + 2];
+        if (z < hi && z > lo) {
+            const unsigned kx = f2key(xyz[(size_t)i * 3]);
+            const unsigned long long a = ((unsigned long long)kx << 32) | (unsigned)i;
+            const unsigned long long c = ((unsigned long long)(~kx) << 32) | (unsigned)i;
+            kmin = a < kmin ? a : kmin;
+            kmax = c < kmax ? c : kmax;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long t1 = __shfl_xor(kmin, o), t2 = __shfl_xor(kmax, o);
+        kmin = t1 < kmin ? t1 : kmin;
+        kmax = t2 < kmax ? t2 : kmax;
+    }
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = kmin; smax[threadIdx.x >> 6] = kmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 0; w < NW; ++w) { kmin = smin[w] < kmin ? smin[w] : kmin; kmax = smax[w] < kmax ? smax[w] : kmax; }
+        RwResultDev& r = res[b];
+        if (kmin == ~0ull) {
+            r.found = 0;
+            r.width = __longlong_as_double(0x7ff8000000000000ll);
+            r.x_left = r.x_right = __uint_as_float(0x7fc00000u);
+            for (int j = 0; j < 3; ++j) { r.left_pt[j] = r.x_left; r.right_pt[j] = r.x_left; }
+        } else {
+            const unsigned il = (unsigned)(kmin & 0xFFFFFFFFull), ir = (unsigned)(kmax & 0xFFFFFFFFull);
+            r.found = 1;
+            for (int j = 0; j < 3; ++j) { r.left_pt[j] = xyz[(size_t)il * 3 + j]; r.right_pt[j] = xyz[(size_t)ir * 3 + j]; }
+            r.x_left = r.left_pt[0];
+            r.x_right = r.right_pt[0];
+            r.width = fabs((double)r.x_left - (double)r.x_right);
+        }
+    }
+}
+hipError_t launch_end_points(CloudView in, int B, int cap, double depth, double window, RwResultDev* res, hipStream_t s) {
+    hipLaunchKernelGGL(end_points_kernel, dim3(B), dim3(TB), 0, s, in, cap, depth, window, res);
+    return hipGetLastError();
+}
+
+__global__ void record_counts_kernel(RwResultDev* res, int B, const int32_t* n_road, const int32_t* n_zcut, const int32_t* n_mad_y,
+                                     const int32_t* n_mad_x, const int32_t* n_plane, const int32_t* n_sor, const int32_t* n_ror,
+                                     const double* plane) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    RwResultDev& r = res[b];
+    r.n_road = n_road[b]; r.n_zcut = n_zcut[b]; r.n_mad_y = n_mad_y[b]; r.n_mad_x = n_mad_x[b];
+    r.n_plane = n_plane[b]; r.n_sor = n_sor[b]; r.n_ror = n_ror[b];
+    for (int j = 0; j < 4; ++j) r.plane[j] = plane[(size_t)b * 4 + j];
+}
+hipError_t launch_record_counts(RwResultDev* res, int B, const int32_t* n_road, const int32_t* n_zcut, const int32_t* n_mad_y,
+                                const int32_t* n_mad_x, const int32_t* n_plane, const int32_t* n_sor, const int32_t* n_ror,
+                                const double* plane, hipStream_t s) {
+    hipLaunchKernelGGL(record_counts_kernel, dim3((B + 63) / 64), dim3(64), 0, s, res, B, n_road, n_zcut, n_mad_y, n_mad_x,
+                       n_plane, n_sor, n_ror, plane);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ K23 Open3D filters
+// [UPSTREAM Open3D legacy RemoveStatisticalOutliers / RemoveRadiusOutliers, parity unpinned — see oracle/o3d.py]
+// Exact k-NN / radius counts in float64 over a uniform grid: points are binned (clamped at the grid faces,
+// which keeps every lower bound valid), counting-sorted by cell, and every point searches Chebyshev shells
+// of cells until its k-th distance is proven final.  d2 := (dx*dx + dy*dy) + dz*dz, no FMA.
+constexpr int GRID_CELLS = 1 << 19;
+constexpr int KMAX = 16;
+constexpr int SOR_RMAX = 16;       // shells searched before the brute-force fallback
+
+struct GridMeta { double ox, oy, oz, inv; double cell; int gx, gy, gz, pad; };
+
+struct O3dScratch {       // carved from one arena, per-frame strides
+    GridMeta* meta;       // [B]
+    int* cell_cnt;        // [B][GRID_CELLS]      counts, then scatter cursors
+    int* cell_start;      // [B][GRID_CELLS + 1]
+    int* cell_of;         // [B][cap]
+    int* sidx;            // [B][cap]  original index of the j-th sorted point
+    float* sxyz;          // [B][cap][3]
+    double* mean_d;       // [B][cap]  (by original index)
+    uint8_t* keep;        // [B][cap]
+};
+size_t o3d_scratch_bytes(int B, int cap) {
+    size_t per = sizeof(GridMeta) + (size_t)GRID_CELLS * 4 + (size_t)(GRID_CELLS + 1) * 4 + (size_t)cap * (4 + 4 + 12 + 8 + 1);
+    return (size_t)B * per + 4096;
+}
+static O3dScratch carve(void* base, int B, int cap) {
+    O3dScratch s;
+    char* p = (char*)base;
+    auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) / 256 * 256; return r; };
+    s.meta = (GridMeta*)take(sizeof(GridMeta) * B);
+    s.mean_d = (double*)take((size_t)B * cap * 8);
+    s.cell_cnt = (int*)take((size_t)B * GRID_CELLS * 4);
+    s.cell_start = (int*)take((size_t)B * (GRID_CELLS + 1) * 4);
+    s.cell_of = (int*)take((size_t)B * cap * 4);
+    s.sidx = (int*)take((size_t)B * cap * 4);
+    s.sxyz = (float*)take((size_t)B * cap * 12);
+    s.keep = (uint8_t*)take((size_t)B * cap);
+    return s;
+}
+
+__device__ __forceinline__ int cell_coord(double p, double o, double inv, int g) {
+    double t = floor((p - o) * inv);
+    if (!(t >= 0.0)) t = 0.0;                 // also catches NaN
+    if (t > (double)(g - 1)) t = (double)(g - 1);
+    return (int)t;
+}
+
+// bounding box (finite coordinates only) -> grid origin / dims
+__global__ __launch_bounds__(TB) void grid_meta_kernel(CloudView in, int cap, double cell, int gx, int gy, int gz, GridMeta* meta) {
+    const int b = blockIdx.x;
+    const float* xyz = in.xyz + (size_t)b * cap * 3;
+    const int n = min(in.n[b], cap);
+    __shared__ float smin[3][NW];
+    float mn[3] = {INFINITY, INFINITY, INFINITY};
+    for (int i = threadIdx.x; i < n; i += TB)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float v = xyz[(size_t)i * 3 + j];
+            if (v > -INFINITY && v < mn[j]) mn[j] = v;
+        }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mn[j] = fminf(mn[j], __shfl_xor(mn[j], o));
+        if ((threadIdx.x & 63) == 0) smin[j][threadIdx.x >> 6] = mn[j];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int j = 0; j < 3; ++j) {
+            float m = INFINITY;
+            for (int w = 0; w < NW; ++w) m = fminf(m, smin[j][w]);
+            mn[j] = (m == INFINITY) ? 0.f : m;
+        }
+        GridMeta g;
+        g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
+        // z grows toward the camera (scene z is negative, dense near z ~ -z_cut): anchor the z grid at the far
+        // end only if everything fits; otherwise anchor so that the NEAR (dense) end is resolved and the far tail clamps
+        g.cell = cell; g.inv = 1.0 / cell; g.gx = gx; g.gy = gy; g.gz = gz; g.pad = 0;
+        meta[b] = g;
+    }
+}
+
+// max-z anchored variant needs the max too; keep it simple: second pass computes max z and shifts oz so that
+// the top cell holds max z.  (Dense road points sit at the high-z end.)
+__global__ __launch_bounds__(TB) void grid_anchor_kernel(CloudView in, int cap, GridMeta* meta) {
+    const int b = blockIdx.x;
+    const float* xyz = in.xyz + (size_t)b * cap * 3;
+    const int n = min(in.n[b], cap);
+    __shared__ float smax[NW];
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += TB) {
+        const float v = xyz[(size_t)i * 3 + 2];
+        if (v < INFINITY && v > mx) mx = v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 0; w < NW; ++w) mx = fmaxf(mx, smax[w]);
+        if (mx == -INFINITY) mx = 0.f;
+        GridMeta g = meta[b];
+        const double span = g.cell * (double)g.gz;
+        if ((double)mx - g.oz > span) g.oz = (double)mx - span + 0.5 * g.cell;
+        meta[b] = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void grid_count_kernel(CloudView in, int cap, const GridMeta* meta, int* cell_cnt, int* cell_of) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= min(in.n[b], cap)) return;
+    const GridMeta g = meta[b];
+    const float* p = in.xyz + ((size_t)b * cap + i) * 3;
+    const int cx = cell_coord((double)p[0], g.ox, g.inv, g.gx);
+    const int cy = cell_coord((double)p[1], g.oy, g.inv, g.gy);
+    const int cz = cell_coord((double)p[2], g.oz, g.inv, g.gz);
+    const int c = (cz * g.gy + cy) * g.gx + cx;
+    cell_of[(size_t)b * cap + i] = c;
+    atomicAdd(&cell_cnt[(size_t)b * GRID_CELLS + c], 1);
+}
+
+__global__ __launch_bounds__(TB) void grid_scan_kernel(const GridMeta* meta, int* cell_cnt, int* cell_start) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    const GridMeta g = meta[b];
+    const int cells = g.gx * g.gy * g.gz;
+    int* cnt = cell_cnt + (size_t)b * GRID_CELLS;
+    int* st = cell_start + (size_t)b * (GRID_CELLS + 1);
+    const int per = (cells + TB - 1) / TB;
+    int s = 0;
+    for (int j = 0; j < per; ++j) { const int k = t * per + j; if (k < cells) s += cnt[k]; }
+    __shared__ int ps[TB];
+    ps[t] = s;
+    __syncthreads();
+    for (int off = 1; off < TB; off <<= 1) {
+        int a = t >= off ? ps[t - off] : 0;
+        __syncthreads();
+        ps[t] += a;
+        __syncthreads();
+    }
+    int run = ps[t] - s;
+    for (int j = 0; j < per; ++j) {
+        const int k = t * per + j;
+        if (k < cells) { st[k] = run; run += cnt[k]; cnt[k] = 0; }   // counts become scatter cursors
+    }
+    if (t == TB - 1) st[cells] = ps[TB - 1];
+}
+
+__global__ __launch_bounds__(256) void grid_scatter_kernel(CloudView in, int cap, int* cell_cnt, const int* cell_start,
+                                                           const int* cell_of, int* sidx, float* sxyz) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= min(in.n[b], cap)) return;
+    const int c = cell_of[(size_t)b * cap + i];
+    const int pos = cell_start[(size_t)b * (GRID_CELLS + 1) + c] + atomicAdd(&cell_cnt[(size_t)b * GRID_CELLS + c], 1);
+    sidx[(size_t)b * cap + pos] = i;
+    const float* p = in.xyz + ((size_t)b * cap + i) * 3;
+    float* q = sxyz + ((size_t)b * cap + pos) * 3;
+    q[0] = p[0]; q[1] = p[1]; q[2] = p[2];
+}
+
+__device__ __forceinline__ double dist2(double ax, double ay, double az, const float* p) {
+    const double dx = ax - (double)p[0], dy = ay - (double)p[1], dz = az - (double)p[2];
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+struct TopK {
+    double v[KMAX];
+    double kth;      // v[k-1]
+    int k;
+    __device__ __forceinline__ void init(int k_) {
+        k = k_;
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) v[t] = INFINITY;
+        kth = INFINITY;
+    }
+    __device__ __forceinline__ void push(double d) {
+        if (!(d < kth)) return;
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) {      // bubble the new value into the ascending array
+            const double lo = d < v[t] ? d : v[t];
+            const double hi = d < v[t] ? v[t] : d;
+            v[t] = lo; d = hi;
+        }
+        double kv = v[0];
+#pragma unroll
+        for (int t = 1; t < KMAX; ++t) kv = (t == k - 1) ? v[t] : kv;
+        kth = kv;
+    }
+};
+
+__global__ __launch_bounds__(256) void sor_knn_kernel(CloudView in, int cap, const GridMeta* meta, const int* cell_start,
+                                                      const int* sidx, const float* sxyz, int k, double* mean_d) {
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int n = min(in.n[b], cap);
+    if (j >= n) return;
+    const GridMeta g = meta[b];
+    const int* st = cell_start + (size_t)b * (GRID_CELLS + 1);
+    const float* pts = sxyz + (size_t)b * cap * 3;
+    const float* q = pts + (size_t)j * 3;
+    const double qx = q[0], qy = q[1], qz = q[2];
+    const int cx = cell_coord(qx, g.ox, g.inv, g.gx), cy = cell_coord(qy, g.oy, g.inv, g.gy), cz = cell_coord(qz, g.oz, g.inv, g.gz);
+    const int kk = k < n ? k : n;
+    TopK top;
+    top.init(kk);
+    const int rall = max(g.gx, max(g.gy, g.gz));
+    bool done = false;
+    for (int r = 0; r <= SOR_RMAX && !done; ++r) {
+        for (int dz = -r; dz <= r; ++dz) {
+            const int z = cz + dz;
+            if (z < 0 || z >= g.gz) continue;
+            for (int dy = -r; dy <= r; ++dy) {
+                const int y = cy + dy;
+                if (y < 0 || y >= g.gy) continue;
+                const bool face = (dz == -r || dz == r || dy == -r || dy == r);
+                const int step = face ? 1 : (r == 0 ? 1 : 2 * r);    // interior rows: only dx = -r and dx = +r
+                for (int dx = -r; dx <= r; dx += step) {
+                    const int x = cx + dx;
+                    if (x < 0 || x >= g.gx) continue;
+                    const int c = (z * g.gy + y) * g.gx + x;
+                    const int e = st[c + 1];
+                    for (int t = st[c]; t < e; ++t) top.push(dist2(qx, qy, qz, pts + (size_t)t * 3));
+                }
+            }
+        }
+        const double bound = (double)r * g.cell * (1.0 - 1e-9);
+        if (top.kth <= bound * bound) done = true;    // nothing unvisited can be closer than r cells
+        if (r >= rall) done = true;                    // whole grid visited
+    }
+    if (!done) {                                       // isolated point: exact brute force over the frame
+        top.init(kk);
+        for (int t = 0; t < n; ++t) top.push(dist2(qx, qy, qz, pts + (size_t)t * 3));
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t) if (t < kk) acc = acc + sqrt(top.v[t]);   // ascending, sequential adds
+    mean_d[(size_t)b * cap + sidx[(size_t)b * cap + j]] = acc / (double)kk;
+}
+
+__global__ __launch_bounds__(TB) void sor_select_kernel(CloudView in, CloudOut out, int cap, double ratio, const double* mean_d) {
+    FRAME_VIEW();
+    const double* md = mean_d + (size_t)b * cap;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += TB) { const double v = md[i]; if (v > 0.0) s += v; }
+    const double cloud_mean = block_sum_f64(s, L) / (double)n;
+    double q = 0.0;
+    for (int i = threadIdx.x; i < n; i += TB) { const double v = md[i]; if (v > 0.0) q += (v - cloud_mean) * (v - cloud_mean); }
+    const double sq = block_sum_f64(q, L);
+    const double stdv = sqrt(sq / (double)(n - 1));
+    const double thr = cloud_mean + ratio * stdv;
+    block_compact(xyz, rgb, n, oxyz, orgb, on, cap, [=](int i, float, float, float) {
+        const double v = md[i];
+        return v > 0.0 && v < thr;
+    }, L);
+}
+
+__global__ __launch_bounds__(256) void ror_count_kernel(CloudView in, int cap, const GridMeta* meta, const int* cell_start,
+                                                        const int* sidx, const float* sxyz, int nb, double r2, uint8_t* keep) {
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int n = min(in.n[b], cap);
+    if (j >= n) return;
+    const GridMeta g = meta[b];
+    const int* st = cell_start + (size_t)b * (GRID_CELLS + 1);
+    const float* pts = sxyz + (size_t)b * cap * 3;
+    const float* q = pts + (size_t)j * 3;
+    const double qx = q[0], qy = q[1], qz = q[2];
+    const int cx = cell_coord(qx, g.ox, g.inv, g.gx), cy = cell_coord(qy, g.oy, g.inv, g.gy), cz = cell_coord(qz, g.oz, g.inv, g.gz);
+    int cnt = 0;
+    for (int dz = -1; dz <= 1 && cnt <= nb; ++dz) {
+        const int z = cz + dz;
+        if (z < 0 || z >= g.gz) continue;
+        for (int dy = -1; dy <= 1 && cnt <= nb; ++dy) {
+            const int y = cy + dy;
+            if (y < 0 || y >= g.gy) continue;
+            for (int dx = -1; dx <= 1 && cnt <= nb; ++dx) {
+                const int x = cx + dx;
+                if (x < 0 || x >= g.gx) continue;
+                const int c = (z * g.gy + y) * g.gx + x;
+                const int e = st[c + 1];
+                for (int t = st[c]; t < e && cnt <= nb; ++t) cnt += dist2(qx, qy, qz, pts + (size_t)t * 3) < r2;
+            }
+        }
+    }
+    keep[(size_t)b * cap + sidx[(size_t)b * cap + j]] = cnt > nb;    // self included, strict '<' on d2 (FLANN radius search)
+}
+
+__global__ __launch_bounds__(TB) void keep_select_kernel(CloudView in, CloudOut out, int cap, const uint8_t* keep) {
+    FRAME_VIEW();
+    const uint8_t* kp = keep + (size_t)b * cap;
+    block_compact(xyz, rgb, n, oxyz, orgb, on, cap, [=](int i, float, float, float) { return kp[i] != 0; }, L);
+}
+
+static void build_grid(CloudView in, int B, int cap, double cell, int gx, int gy, int gz, const O3dScratch& sc, hipStream_t s) {
+    hipMemsetAsync(sc.cell_cnt, 0, (size_t)B * GRID_CELLS * 4, s);
+    hipLaunchKernelGGL(grid_meta_kernel, dim3(B), dim3(TB), 0, s, in, cap, cell, gx, gy, gz, sc.meta);
+    hipLaunchKernelGGL(grid_anchor_kernel, dim3(B), dim3(TB), 0, s, in, cap, sc.meta);
+    dim3 grid((cap + 255) / 256, B);
+    hipLaunchKernelGGL(grid_count_kernel, grid, dim3(256), 0, s, in, cap, sc.meta, sc.cell_cnt, sc.cell_of);
+    hipLaunchKernelGGL(grid_scan_kernel, dim3(B), dim3(TB), 0, s, sc.meta, sc.cell_cnt, sc.cell_start);
+    hipLaunchKernelGGL(grid_scatter_kernel, grid, dim3(256), 0, s, in, cap, sc.cell_cnt, sc.cell_start, sc.cell_of, sc.sidx, sc.sxyz);
+}
+
+hipError_t launch_sor(CloudView in, CloudOut out, int B, int cap, int k, double ratio, void* scratch, double* mean_out, hipStream_t s) {
+    if (k > KMAX) return hipErrorInvalidValue;
+    O3dScratch sc = carve(scratch, B, cap);
+    build_grid(in, B, cap, 0.1, 128, 8, 512, sc, s);
+    double* md = mean_out ? mean_out : sc.mean_d;
+    hipLaunchKernelGGL(sor_knn_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx, sc.sxyz, k, md);
+    hipLaunchKernelGGL(sor_select_kernel, dim3(B), dim3(TB), 0, s, in, out, cap, ratio, md);
+    return hipGetLastError();
+}
+
+hipError_t launch_ror(CloudView in, CloudOut out, int B, int cap, int nb, double radius, void* scratch, hipStream_t s) {
+    O3dScratch sc = carve(scratch, B, cap);
+    build_grid(in, B, cap, radius * (1.0 + 1e-6), 64, 16, 512, sc, s);
+    hipLaunchKernelGGL(ror_count_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx,
+                       sc.sxyz, nb, radius * radius, sc.keep);
+    hipLaunchKernelGGL(keep_select_kernel, dim3(B), dim3(TB), 0, s, in, out, cap, sc.keep);
+    return hipGetLastError();
+}
+
+}  // namespace sd

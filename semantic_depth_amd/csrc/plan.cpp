@@ -1,0 +1,350 @@
+// Layer plans: FCN-8s (VGG16 encoder + fcn8s/fcn.py:159-215 decoder) and monodepth (vgg / resnet50).
+// Architectures per SURVEY.md Appendix A/B.  Host-only code.
+#include "plan.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+namespace sd {
+
+namespace {
+
+constexpr size_t ALIGN = 256;
+size_t align_up(size_t v) { return (v + ALIGN - 1) / ALIGN * ALIGN; }
+
+struct Src { int t; int up; };
+
+struct Builder {
+    NetPlan p;
+
+    int tensor(const std::string& name, int N, int H, int W, int C) {
+        TensorDesc t;
+        t.name = name; t.N = N; t.H = H; t.W = W; t.C = C;
+        t.bytes = (size_t)N * H * W * C * sizeof(float);
+        p.tensors.push_back(t);
+        p.tensor_by_name[name] = (int)p.tensors.size() - 1;
+        return (int)p.tensors.size() - 1;
+    }
+    void alias(const std::string& name, int t) { p.tensor_by_name[name] = t; }
+
+    int wslot(const std::string& name, std::initializer_list<int64_t> shape, int layout, int Kpad = 0, int CoutPad = 0, int nout = 0) {
+        WeightSlot s;
+        s.name = name; s.rank = (int)shape.size(); s.layout = layout; s.Kpad = Kpad; s.CoutPad = CoutPad; s.nout = nout;
+        int i = 0;
+        for (auto v : shape) s.shape[i++] = v;
+        size_t n = 0;
+        switch (layout) {
+            case WL_IGEMM: n = (size_t)Kpad * CoutPad; break;
+            case WL_SMALLN: n = (size_t)s.shape[0] * s.shape[1] * s.shape[2] * 4; break;
+            case WL_BIAS4: n = 4; break;
+            default: n = 1; for (int j = 0; j < s.rank; ++j) n *= (size_t)s.shape[j];
+        }
+        s.bytes = n * sizeof(float);
+        p.weights.push_back(s);
+        p.weight_by_name[name] = (int)p.weights.size() - 1;
+        return (int)p.weights.size() - 1;
+    }
+
+    void push(OpDesc& op) { p.ops.push_back(op); }
+
+    // dense conv on the MFMA engine
+    int conv(const std::string& name, std::vector<Src> srcs, int Cout, int k, int stride, int act, const std::string& wname,
+             const std::string& bname, int residual = -1) {
+        OpDesc op;
+        op.kind = OP_CONV; op.name = name; op.nsrc = (int)srcs.size();
+        int Ctot = 0, Hin = 0, Win = 0, N = 0;
+        bool vec = true;
+        for (int i = 0; i < op.nsrc; ++i) {
+            const TensorDesc& t = p.tensors[srcs[i].t];
+            op.src[i] = srcs[i].t; op.up[i] = srcs[i].up;
+            const int h = t.H * (srcs[i].up ? 2 : 1), w = t.W * (srcs[i].up ? 2 : 1);
+            if (i == 0) { Hin = h; Win = w; N = t.N; }
+            else if (h != Hin || w != Win || t.N != N) throw std::runtime_error("conv " + name + ": source dims disagree");
+            Ctot += t.C;
+            if (t.C % 32) vec = false;
+        }
+        op.k = k; op.stride = stride; op.pad = (k - 1) / 2; op.act = act; op.residual = residual;
+        const int Hout = (Hin + 2 * op.pad - k) / stride + 1, Wout = (Win + 2 * op.pad - k) / stride + 1;
+        op.Ctot = Ctot; op.K = k * k * Ctot; op.Kpad = (op.K + 31) / 32 * 32; op.vec = vec ? 1 : 0;
+        const int bn = conv_tile_n(Cout);
+        const int CoutPad = (Cout + bn - 1) / bn * bn;
+        op.w = wslot(wname, {k, k, Ctot, Cout}, WL_IGEMM, op.Kpad, CoutPad);
+        op.b = wslot(bname, {Cout}, WL_RAW);
+        op.dst = tensor(name, N, Hout, Wout, Cout);
+        op.tab_bytes = vec ? (size_t)(op.Kpad / 32) * 16 : (size_t)op.Kpad * 16;
+        const double M = (double)N * Hout * Wout;
+        op.flops = 2.0 * M * Cout * op.K;
+        // block order: walk M first when the weight matrix is the larger operand (it then stays L2-resident per N panel)
+        op.m_fastest = ((double)op.K * Cout > M * Ctot) ? 1 : 0;
+        push(op);
+        return op.dst;
+    }
+
+    int smalln(const std::string& name, int src, int nout, int k, int act, const std::string& wname, const std::string& bname, int cout_tf) {
+        OpDesc op;
+        op.kind = OP_SMALLN; op.name = name; op.nsrc = 1; op.src[0] = src; op.k = k; op.pad = (k - 1) / 2; op.act = act; op.nout = nout;
+        const TensorDesc& t = p.tensors[src];
+        op.w = wslot(wname, {k, k, t.C, cout_tf}, WL_SMALLN, 0, 0, nout);
+        op.b = wslot(bname, {cout_tf}, WL_BIAS4, 0, 0, nout);
+        op.dst = tensor(name, t.N, t.H, t.W, nout);
+        op.flops = 2.0 * t.N * t.H * t.W * nout * k * k * t.C;
+        push(op);
+        return op.dst;
+    }
+
+    int pool(const std::string& name, int src, bool zero3) {
+        OpDesc op;
+        op.kind = zero3 ? OP_POOL3Z : OP_POOL2; op.name = name; op.nsrc = 1; op.src[0] = src;
+        const TensorDesc& t = p.tensors[src];
+        const int Ho = zero3 ? (t.H - 1) / 2 + 1 : t.H / 2, Wo = zero3 ? (t.W - 1) / 2 + 1 : t.W / 2;
+        op.dst = tensor(name, t.N, Ho, Wo, t.C);
+        push(op);
+        return op.dst;
+    }
+
+    void finish() {
+        // liveness
+        for (size_t i = 0; i < p.ops.size(); ++i) {
+            const OpDesc& op = p.ops[i];
+            auto touch = [&](int t) {
+                if (t < 0) return;
+                if (p.tensors[t].first < 0) p.tensors[t].first = (int)i;
+                p.tensors[t].last = (int)i;
+            };
+            touch(op.dst);
+            for (int j = 0; j < op.nsrc; ++j) touch(op.src[j]);
+            touch(op.residual);
+        }
+        // weight arena: slots, then per-op tables
+        size_t off = 0;
+        for (auto& s : p.weights) { s.offset = off; off += align_up(s.bytes); }
+        for (auto& op : p.ops)
+            if (op.kind == OP_CONV) {
+                op.tab_offset = off; off += align_up(op.tab_bytes);
+                op.srcs_offset = off; off += align_up(sizeof(ConvSrc) * 3);
+            }
+        p.weight_bytes = off;
+        // activation arena: first-fit over lifetimes (SEMDEPTH_KEEP_ACTIVATIONS=1: no reuse, for layer-by-layer tests)
+        const char* keep = std::getenv("SEMDEPTH_KEEP_ACTIVATIONS");
+        const bool no_reuse = keep && keep[0] == '1';
+        std::vector<int> order;
+        for (size_t i = 0; i < p.tensors.size(); ++i) if (p.tensors[i].first >= 0) order.push_back((int)i);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return p.tensors[a].first < p.tensors[b].first; });
+        std::vector<int> placed;
+        size_t top = 0;
+        for (int ti : order) {
+            TensorDesc& t = p.tensors[ti];
+            const size_t sz = align_up(t.bytes);
+            std::vector<std::pair<size_t, size_t>> busy;
+            for (int pj : placed) {
+                const TensorDesc& o = p.tensors[pj];
+                if (no_reuse || o.last >= t.first) busy.push_back({o.offset, o.offset + align_up(o.bytes)});
+            }
+            std::sort(busy.begin(), busy.end());
+            size_t pos = 0;
+            for (auto& b : busy) {
+                if (pos + sz <= b.first) break;
+                pos = std::max(pos, b.second);
+            }
+            t.offset = pos;
+            top = std::max(top, pos + sz);
+            placed.push_back(ti);
+        }
+        p.act_bytes = top;
+        double fl = 0;
+        for (auto& op : p.ops) fl += op.flops;
+        p.flops_per_image = fl / std::max(1, p.images);
+    }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+NetPlan build_fcn8s(int frames, int H, int W) {
+    if (H % 32 || W % 32) throw std::runtime_error("FCN-8s needs H, W multiples of 32");
+    Builder b;
+    b.p.net = "fcn8s"; b.p.frames = frames; b.p.images = frames; b.p.H = H; b.p.W = W;
+    int x = b.tensor("input_pre", frames, H, W, 3);
+    { OpDesc op; op.kind = OP_PRE_VGG; op.name = "pre"; op.dst = x; b.push(op); }
+    b.p.t_input = x;
+    const char* blocks[5][3] = {{"conv1_1", "conv1_2", nullptr}, {"conv2_1", "conv2_2", nullptr}, {"conv3_1", "conv3_2", "conv3_3"},
+                                {"conv4_1", "conv4_2", "conv4_3"}, {"conv5_1", "conv5_2", "conv5_3"}};
+    const int ch[5] = {64, 128, 256, 512, 512};
+    int pools[5];
+    for (int s = 0; s < 5; ++s) {
+        for (int j = 0; j < 3 && blocks[s][j]; ++j) {
+            std::string n = blocks[s][j];
+            x = b.conv(n, {{x, 0}}, ch[s], 3, 1, ACT_RELU, "vgg/" + n + "/filter", "vgg/" + n + "/biases");
+        }
+        x = b.pool("pool" + std::to_string(s + 1), x, false);
+        pools[s] = x;
+    }
+    b.alias("layer3_out", pools[2]);
+    b.alias("layer4_out", pools[3]);
+    x = b.conv("fc6", {{pools[4], 0}}, 4096, 7, 1, ACT_RELU, "vgg/fc6/filter", "vgg/fc6/biases");
+    x = b.conv("fc7", {{x, 0}}, 4096, 1, 1, ACT_RELU, "vgg/fc7/filter", "vgg/fc7/biases");
+    b.alias("layer7_out", x);
+    const int s7 = b.smalln("score7", x, 3, 1, ACT_NONE, "dec/score7/kernel", "dec/score7/bias", 3);
+    const int s4 = b.smalln("score4", pools[3], 3, 1, ACT_NONE, "dec/score4/kernel", "dec/score4/bias", 3);
+    const int s3 = b.smalln("score3", pools[2], 3, 1, ACT_NONE, "dec/score3/kernel", "dec/score3/bias", 3);
+    auto deconv4 = [&](const std::string& name, int src, int skip, const std::string& wn) {
+        OpDesc op;
+        op.kind = OP_DECONV4_ADD; op.name = name; op.nsrc = 1; op.src[0] = src; op.residual = skip;
+        op.w = b.wslot("dec/" + wn + "/kernel", {4, 4, 3, 3}, WL_RAW);
+        op.b = b.wslot("dec/" + wn + "/bias", {3}, WL_RAW);
+        const TensorDesc& t = b.p.tensors[src];
+        op.dst = b.tensor(name, t.N, t.H * 2, t.W * 2, 3);
+        b.push(op);
+        return op.dst;
+    };
+    const int first_skip = deconv4("first_skip", s7, s4, "deconv1");
+    const int second_skip = deconv4("second_skip", first_skip, s3, "deconv2");
+    {
+        OpDesc op;
+        op.kind = OP_HEAD16; op.name = "head"; op.nsrc = 1; op.src[0] = second_skip;
+        op.w = b.wslot("dec/deconv3/kernel", {16, 16, 3, 3}, WL_RAW);
+        op.b = b.wslot("dec/deconv3/bias", {3}, WL_RAW);
+        b.push(op);
+    }
+    b.p.t_output = second_skip;
+    b.finish();
+    return b.p;
+}
+
+// ---------------------------------------------------------------------------------------------
+NetPlan build_monodepth(int encoder, int frames, int H, int W) {
+    const int mult = encoder == 0 ? 128 : 64;
+    if (H % mult || W % mult) throw std::runtime_error("monodepth needs H, W multiples of 128 (vgg) / 64 (resnet50)");
+    Builder b;
+    b.p.net = encoder == 0 ? "monodepth-vgg" : "monodepth-resnet50";
+    b.p.frames = frames; b.p.images = 2 * frames; b.p.H = H; b.p.W = W;
+    const int N = 2 * frames;
+    int x = b.tensor("input_pre", N, H, W, 3);
+    { OpDesc op; op.kind = OP_PRE_MONO; op.name = "pre"; op.dst = x; b.push(op); }
+    b.p.t_input = x;
+    auto cv = [&](const std::string& name, std::vector<Src> srcs, int C, int k, int s, int act = ACT_ELU, int res = -1) {
+        return b.conv(name, srcs, C, k, s, act, name + "/weights", name + "/biases", res);
+    };
+    std::map<int, int> skips;   // decoder level -> skip tensor
+    int top, enc_out;
+    if (encoder == 0) {
+        const int spec[7][2] = {{32, 7}, {64, 5}, {128, 3}, {256, 3}, {512, 3}, {512, 3}, {512, 3}};
+        int feats[7];
+        for (int i = 0; i < 7; ++i) {
+            const std::string n = "enc/conv" + std::to_string(i + 1);
+            x = cv(n + "a", {{x, 0}}, spec[i][0], spec[i][1], 1);
+            x = cv(n + "b", {{x, 0}}, spec[i][0], spec[i][1], 2);
+            feats[i] = x;
+        }
+        for (int lvl = 2; lvl <= 7; ++lvl) skips[lvl] = feats[lvl - 2];
+        top = 7; enc_out = feats[6];
+    } else {
+        const int conv1 = cv("enc/conv1", {{x, 0}}, 64, 7, 2);
+        const int pool1 = b.pool("enc/pool1", conv1, true);
+        x = pool1;
+        const int stage_n[4] = {64, 128, 256, 512}, stage_blocks[4] = {3, 4, 6, 3};
+        int stage_out[4];
+        for (int s = 0; s < 4; ++s) {
+            for (int blk = 1; blk <= stage_blocks[s]; ++blk) {
+                const std::string pfx = "enc/res" + std::to_string(s + 2) + "_" + std::to_string(blk);
+                const int stride = blk == stage_blocks[s] ? 2 : 1;     // the LAST block of a stage strides
+                const int n = stage_n[s];
+                const int c1 = cv(pfx + "/conv1", {{x, 0}}, n, 1, 1);
+                const int c2 = cv(pfx + "/conv2", {{c1, 0}}, n, 3, stride);
+                const int sc = cv(pfx + "/proj", {{x, 0}}, 4 * n, 1, stride, ACT_NONE);     // always projected (upstream quirk)
+                x = cv(pfx + "/conv3", {{c2, 0}}, 4 * n, 1, 1, ACT_ELU, sc);                // elu(conv3 + shortcut)
+            }
+            stage_out[s] = x;
+        }
+        b.alias("enc/conv2", stage_out[0]); b.alias("enc/conv3", stage_out[1]);
+        b.alias("enc/conv4", stage_out[2]); b.alias("enc/conv5", stage_out[3]);
+        skips[6] = stage_out[2]; skips[5] = stage_out[1]; skips[4] = stage_out[0]; skips[3] = pool1; skips[2] = conv1;
+        top = 6; enc_out = stage_out[3];
+    }
+    const int dec_ch[8] = {0, 16, 32, 64, 128, 256, 512, 512};
+    x = enc_out;
+    int disp_prev = -1;
+    for (int lvl = top; lvl >= 1; --lvl) {
+        const std::string L = std::to_string(lvl);
+        const int u = cv("dec/upconv" + L, {{x, 1}}, dec_ch[lvl], 3, 1);
+        std::vector<Src> cat = {{u, 0}};
+        if (skips.count(lvl)) cat.push_back({skips[lvl], 0});
+        if (lvl <= 3) cat.push_back({disp_prev, 1});
+        x = cv("dec/iconv" + L, cat, dec_ch[lvl], 3, 1);
+        if (lvl <= 4) {
+            // scales 4..2 feed udisp (both channels); at scale 1 only channel 0 = disp_left_est[0] is fetched (semantic_depth.py:675)
+            const int nout = lvl == 1 ? 1 : 2;
+            disp_prev = b.smalln("dec/disp" + L, x, nout, 3, ACT_SIGMOID03, "dec/disp" + L + "/weights", "dec/disp" + L + "/biases", 2);
+        }
+    }
+    b.p.t_output = disp_prev;
+    b.finish();
+    return b.p;
+}
+
+// ---------------------------------------------------------------------------------------------
+void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& out) {
+    out.assign(s.bytes / sizeof(float), 0.f);
+    if (s.layout == WL_IGEMM) {
+        const int64_t K = s.shape[0] * s.shape[1] * s.shape[2], Cout = s.shape[3];
+        for (int64_t k = 0; k < K; ++k) {
+            float* dst = out.data() + (size_t)(k / 4) * s.CoutPad * 4 + (k % 4);
+            const float* src = w + k * Cout;
+            for (int64_t n = 0; n < Cout; ++n) dst[n * 4] = src[n];
+        }
+    } else if (s.layout == WL_SMALLN) {
+        const int64_t K = s.shape[0] * s.shape[1] * s.shape[2], Cout = s.shape[3];
+        for (int64_t k = 0; k < K; ++k)
+            for (int j = 0; j < s.nout; ++j) out[(size_t)k * 4 + j] = w[k * Cout + j];
+    } else if (s.layout == WL_BIAS4) {
+        for (int j = 0; j < s.nout; ++j) out[j] = w[j];
+    } else {
+        std::memcpy(out.data(), w, s.bytes);
+    }
+}
+
+void build_conv_tables(const NetPlan& p, const OpDesc& op, const char* act_base, std::vector<int32_t>& ktab, ConvSrc srcs[3]) {
+    int cbase[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 3; ++i) {
+        srcs[i] = ConvSrc{nullptr, 0, 0, 0, 0};
+        if (i < op.nsrc) {
+            const TensorDesc& t = p.tensors[op.src[i]];
+            srcs[i].ptr = reinterpret_cast<const float*>(act_base + t.offset);
+            srcs[i].C = t.C; srcs[i].H = t.H; srcs[i].W = t.W; srcs[i].up = op.up[i];
+            cbase[i + 1] = cbase[i] + t.C;
+        }
+    }
+    auto locate = [&](int c, int& s, int& cl) {
+        for (s = 0; s < op.nsrc; ++s)
+            if (c < cbase[s + 1]) { cl = c - cbase[s]; return; }
+        s = -1; cl = 0;
+    };
+    if (op.vec) {
+        const int tiles = op.Kpad / 32;
+        ktab.resize((size_t)tiles * 4);
+        for (int kt = 0; kt < tiles; ++kt) {
+            const int k0 = kt * 32, tap = k0 / op.Ctot, c = k0 % op.Ctot;
+            int s, cl;
+            locate(c, s, cl);
+            ktab[kt * 4 + 0] = s;
+            ktab[kt * 4 + 1] = tap / op.k - op.pad;
+            ktab[kt * 4 + 2] = tap % op.k - op.pad;
+            ktab[kt * 4 + 3] = cl;
+        }
+    } else {
+        ktab.resize((size_t)op.Kpad * 4);
+        for (int k = 0; k < op.Kpad; ++k) {
+            int s = -1, cl = 0, dy = 0, dx = 0;
+            if (k < op.K) {
+                const int tap = k / op.Ctot;
+                locate(k % op.Ctot, s, cl);
+                dy = tap / op.k - op.pad; dx = tap % op.k - op.pad;
+            }
+            ktab[k * 4 + 0] = s; ktab[k * 4 + 1] = dy; ktab[k * 4 + 2] = dx; ktab[k * 4 + 3] = cl;
+        }
+    }
+}
+
+}  // namespace sd

@@ -1,0 +1,77 @@
+// Layer plans of the two networks: tensors, ops, weight slots, activation-arena layout.
+// Host-side only.  The C++ statement of the architectures (the Python statement is semantic_depth_amd/weights.py;
+// tests/test_abi.py checks that the two agree).
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace sd {
+
+struct TensorDesc {
+    std::string name;
+    int N = 0, H = 0, W = 0, C = 0;
+    size_t bytes = 0;
+    size_t offset = 0;      // byte offset in the activation arena
+    int first = -1, last = -1;   // op indices (liveness)
+};
+
+enum OpKind { OP_PRE_VGG, OP_PRE_MONO, OP_CONV, OP_SMALLN, OP_POOL2, OP_POOL3Z, OP_DECONV4_ADD, OP_HEAD16 };
+enum WLayout { WL_RAW = 0, WL_IGEMM = 1, WL_SMALLN = 2, WL_BIAS4 = 3 };
+
+struct WeightSlot {
+    std::string name;
+    int64_t shape[4] = {0, 0, 0, 0};
+    int rank = 0;
+    int layout = WL_RAW;
+    int Kpad = 0, CoutPad = 0, nout = 0;
+    size_t offset = 0, bytes = 0;   // in the weight arena (re-laid-out form)
+    bool loaded = false;
+};
+
+struct OpDesc {
+    OpKind kind;
+    std::string name;
+    int nsrc = 0;
+    int src[3] = {-1, -1, -1};
+    int up[3] = {0, 0, 0};
+    int dst = -1;
+    int residual = -1;     // OP_CONV: tensor added before the activation; OP_DECONV4_ADD: the skip tensor
+    int k = 1, stride = 1, pad = 0, act = ACT_NONE, nout = 0;
+    int w = -1, b = -1;    // weight slots
+    // conv engine
+    int Ctot = 0, K = 0, Kpad = 0, vec = 0, m_fastest = 0;
+    size_t tab_offset = 0, tab_bytes = 0;    // k-table, in the weight arena
+    size_t srcs_offset = 0;                  // ConvSrc[3], in the weight arena
+    double flops = 0;                        // 2*M*N*K for the whole chunk
+};
+
+struct NetPlan {
+    std::string net;
+    int frames = 0;        // frames per chunk
+    int images = 0;        // images per chunk (monodepth: 2 per frame)
+    int H = 0, W = 0;
+    std::vector<TensorDesc> tensors;
+    std::vector<OpDesc> ops;
+    std::vector<WeightSlot> weights;
+    std::map<std::string, int> tensor_by_name, weight_by_name;
+    size_t weight_bytes = 0;   // weights + tables
+    size_t act_bytes = 0;
+    double flops_per_image = 0;
+    int t_input = -1, t_output = -1;
+};
+
+NetPlan build_fcn8s(int frames, int H, int W);
+NetPlan build_monodepth(int encoder /*0 vgg, 1 resnet50*/, int frames, int H, int W);
+
+// host-side re-layout of one TensorFlow-layout weight into its slot's kernel layout
+void relayout_weight(const WeightSlot& s, const float* tf_data, std::vector<float>& out);
+// k-table + source descriptors of one conv op, given the bound activation arena
+void build_conv_tables(const NetPlan& p, const OpDesc& op, const char* act_base, std::vector<int32_t>& ktab, ConvSrc srcs[3]);
+
+int conv_tile_n(int Cout);   // conv_igemm.hip
+
+}  // namespace sd

@@ -1,0 +1,207 @@
+"""Engine: one libsemdepth handle + the torch-allocated device arenas it runs in.
+
+PyTorch-ROCm is plumbing here (device memory, streams); every op on the hot path is a HIP kernel behind the
+C ABI of include/semdepth.h.  One Engine per process / per GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, asdict
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+RW_DTYPE = np.dtype([("width", "<f8"), ("x_left", "<f4"), ("x_right", "<f4"), ("left_pt", "<f4", 3), ("right_pt", "<f4", 3),
+                     ("found", "<i4"), ("n_road", "<i4"), ("n_zcut", "<i4"), ("n_mad_y", "<i4"), ("n_mad_x", "<i4"),
+                     ("n_plane", "<i4"), ("n_sor", "<i4"), ("n_ror", "<i4"), ("plane", "<f8", 4)])
+assert RW_DTYPE.itemsize == C.sizeof(L.sd_rw_result)
+
+
+@dataclass
+class RoadWidthParams:
+    """literals of the reference's road chain, semantic_depth.py:206-259 (defaults = the reference's)."""
+    depth: float = 10.0
+    z_cut: float = 7.0
+    mad_y: float = 15.0
+    mad_x: float = 2.0
+    plane_thr: float = 5.0
+    sor_k: int = 10
+    sor_ratio: float = 0.5
+    ror_n: int = 80
+    ror_r: float = 0.5
+    window: float = 0.05
+    depth_offset: float = 0.02
+    use_o3d: bool = True
+
+    def to_c(self) -> L.sd_rw_params:
+        d = asdict(self)
+        d["use_o3d"] = int(d["use_o3d"])
+        return L.sd_rw_params(**d)
+
+
+@dataclass
+class Camera:
+    """DepthFrame intrinsics (semantic_depth.py:592-607) + disparity multiplier (:109,:145 / seq:105)."""
+    cx: float
+    cy: float
+    f: float
+    b: float
+    disp_mult: float
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    def __init__(self, H: int, W: int, max_batch: int = 1, encoder: str = "resnet50", device: int = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("semantic_depth_amd.Engine needs a GPU (MI355X); there is no CPU fallback")
+        self.lib = L.load()
+        self.H, self.W, self.max_batch, self.encoder = H, W, max_batch, encoder
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        enc = {"vgg": L.SD_ENC_VGG, "resnet50": L.SD_ENC_RESNET50}[encoder]
+        st = self.lib.sd_create(C.byref(h), device, H, W, max_batch, enc, L.SD_PREC_F32)
+        L.check(self.lib, None, st, f"sd_create(H={H}, W={W}, max_batch={max_batch}, {encoder})")
+        self.h = h
+        fw, mw, ws = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        L.check(self.lib, h, self.lib.sd_query_memory(h, C.byref(fw), C.byref(mw), C.byref(ws)), "sd_query_memory")
+        self.bytes = dict(fcn_weights=fw.value, mono_weights=mw.value, workspace=ws.value)
+        # arenas: torch owns the memory; zero-filled so that never-written padding is finite
+        self._wf = torch.zeros(fw.value, dtype=torch.uint8, device=self.device)
+        self._wm = torch.zeros(mw.value, dtype=torch.uint8, device=self.device)
+        self._ws = torch.zeros(ws.value, dtype=torch.uint8, device=self.device)
+        L.check(self.lib, h, self.lib.sd_bind_memory(h, _ptr(self._wf), _ptr(self._wm), _ptr(self._ws)), "sd_bind_memory")
+        self.cap = H * W
+
+    def close(self):
+        if getattr(self, "h", None):
+            torch.cuda.synchronize(self.device)
+            self.lib.sd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def weight_table(self, net: int):
+        out = {}
+        name = C.create_string_buffer(64)
+        shape = (C.c_int64 * 4)()
+        rank = C.c_int()
+        for i in range(self.lib.sd_weight_count(self.h, net)):
+            L.check(self.lib, self.h, self.lib.sd_weight_info(self.h, net, i, name, shape, C.byref(rank)), "sd_weight_info")
+            out[name.value.decode()] = tuple(shape[j] for j in range(rank.value))
+        return out
+
+    def load_weights(self, net: int, weights: dict):
+        for name, arr in weights.items():
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            shape = (C.c_int64 * 4)(*a.shape)
+            st = self.lib.sd_load_weight(self.h, net, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim)
+            L.check(self.lib, self.h, st, f"sd_load_weight({name})")
+
+    # ------------------------------------------------------------------ operators
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _frames(self, frames):
+        assert frames.dtype == torch.uint8 and frames.is_cuda and frames.is_contiguous()
+        assert tuple(frames.shape[1:]) == (self.H, self.W, 3), frames.shape
+        return frames.shape[0]
+
+    def fcn8s_forward(self, frames: torch.Tensor, want_logits: bool = False):
+        B = self._frames(frames)
+        dev = self.device
+        logits = torch.empty((B, self.H, self.W, 3), dtype=torch.float32, device=dev) if want_logits else None
+        road = torch.empty((B, self.H, self.W), dtype=torch.uint8, device=dev)
+        fence = torch.empty_like(road)
+        amax = torch.empty_like(road)
+        st = self.lib.sd_fcn8s_forward(self.h, _ptr(frames), B, _ptr(logits), _ptr(road), _ptr(fence), _ptr(amax), self._stream())
+        L.check(self.lib, self.h, st, "sd_fcn8s_forward")
+        return dict(logits=logits, road=road, fence=fence, argmax=amax)
+
+    def monodepth_forward(self, frames: torch.Tensor, want_raw: bool = False):
+        B = self._frames(frames)
+        pp = torch.empty((B, self.H, self.W), dtype=torch.float32, device=self.device)
+        raw = torch.empty((B, 2, self.H, self.W), dtype=torch.float32, device=self.device) if want_raw else None
+        st = self.lib.sd_monodepth_forward(self.h, _ptr(frames), B, _ptr(pp), _ptr(raw), self._stream())
+        L.check(self.lib, self.h, st, "sd_monodepth_forward")
+        return (pp, raw) if want_raw else pp
+
+    def post_process(self, disp_raw: torch.Tensor):
+        B = disp_raw.shape[0]
+        assert disp_raw.dtype == torch.float32 and tuple(disp_raw.shape[1:]) == (2, self.H, self.W) and disp_raw.is_contiguous()
+        pp = torch.empty((B, self.H, self.W), dtype=torch.float32, device=self.device)
+        L.check(self.lib, self.h, self.lib.sd_post_process(self.h, _ptr(disp_raw), B, _ptr(pp), self._stream()), "sd_post_process")
+        return pp
+
+    def fuse_backproject(self, disp_pp, road, fence, frames, cams, dense: bool = False, cap: int | None = None,
+                         want_rgb: bool = True, want_fence: bool = True):
+        B = disp_pp.shape[0]
+        cap = cap or self.cap
+        dev = self.device
+        carr = (L.sd_camera * B)(*[L.sd_camera(c.cx, c.cy, c.f, c.b, c.disp_mult) for c in cams])
+        out = {}
+        out["dense"] = torch.empty((B, self.H, self.W, 3), dtype=torch.float32, device=dev) if dense else None
+        if road is not None:
+            out["road_xyz"] = torch.empty((B, cap, 3), dtype=torch.float32, device=dev)
+            out["road_rgb"] = torch.empty((B, cap, 3), dtype=torch.uint8, device=dev) if (want_rgb and frames is not None) else None
+            out["n_road"] = torch.empty((B,), dtype=torch.int32, device=dev)
+        else:
+            out["road_xyz"] = out["road_rgb"] = out["n_road"] = None
+        if want_fence and fence is not None:
+            out["fence_xyz"] = torch.empty((B, cap, 3), dtype=torch.float32, device=dev)
+            out["fence_rgb"] = torch.empty((B, cap, 3), dtype=torch.uint8, device=dev) if (want_rgb and frames is not None) else None
+            out["n_fence"] = torch.empty((B,), dtype=torch.int32, device=dev)
+        else:
+            out["fence_xyz"] = out["fence_rgb"] = out["n_fence"] = None
+        st = self.lib.sd_fuse_backproject(self.h, _ptr(disp_pp), _ptr(road), _ptr(fence), _ptr(frames), carr, B, cap,
+                                          _ptr(out["dense"]), _ptr(out["road_xyz"]), _ptr(out["road_rgb"]), _ptr(out["n_road"]),
+                                          _ptr(out["fence_xyz"]), _ptr(out["fence_rgb"]), _ptr(out["n_fence"]), self._stream())
+        L.check(self.lib, self.h, st, "sd_fuse_backproject")
+        return out
+
+    def road_width(self, road_xyz, n_road, params: RoadWidthParams = RoadWidthParams(), want_final: bool = False):
+        B, cap = road_xyz.shape[0], road_xyz.shape[1]
+        res = torch.zeros((B, RW_DTYPE.itemsize), dtype=torch.uint8, device=self.device)
+        fin = torch.empty_like(road_xyz) if want_final else None
+        nfin = torch.empty((B,), dtype=torch.int32, device=self.device) if want_final else None
+        prm = params.to_c()
+        st = self.lib.sd_road_width(self.h, _ptr(road_xyz), _ptr(n_road), B, cap, C.byref(prm), _ptr(res), _ptr(fin), _ptr(nfin),
+                                    self._stream())
+        L.check(self.lib, self.h, st, "sd_road_width")
+        return (res, fin, nfin) if want_final else res
+
+    @staticmethod
+    def records(res: torch.Tensor) -> np.ndarray:
+        """device record buffer -> numpy structured array (synchronises)."""
+        return res.cpu().numpy().view(RW_DTYPE).reshape(-1)
+
+    # ------------------------------------------------------------------ whole path
+    def process_batch(self, frames: torch.Tensor, cams, params: RoadWidthParams = RoadWidthParams()):
+        """seg + depth + fusion + road width for B frames (steps 3-12 of SURVEY §3.2).  Returns device tensors."""
+        seg = self.fcn8s_forward(frames)
+        disp_pp = self.monodepth_forward(frames)
+        fz = self.fuse_backproject(disp_pp, seg["road"], seg["fence"], frames, cams)
+        rec = self.road_width(fz["road_xyz"], fz["n_road"], params)
+        return dict(seg=seg, disp_pp=disp_pp, fuse=fz, records=rec)
+
+    # ------------------------------------------------------------------ introspection
+    def net_tensor(self, net: int, name: str) -> torch.Tensor:
+        shape = (C.c_int64 * 4)()
+        L.check(self.lib, self.h, self.lib.sd_net_tensor(self.h, net, name.encode(), None, 0, shape, None), "sd_net_tensor")
+        out = torch.empty(tuple(shape), dtype=torch.float32, device=self.device)
+        L.check(self.lib, self.h, self.lib.sd_net_tensor(self.h, net, name.encode(), _ptr(out), out.numel(), shape, self._stream()),
+                "sd_net_tensor")
+        return out
+
+    def flops_per_image(self, net: int) -> float:
+        return float(self.lib.sd_net_flops_per_image(self.h, net))

@@ -1,0 +1,85 @@
+"""CPU: the C-ABI library loads, exports every symbol include/semdepth.h declares, and its layer plans agree with
+the Python weight tables.  No compute call is made (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import __graft_entry__ as graft
+from semantic_depth_amd import _lib as L
+from semantic_depth_amd import weights as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    graft.build()
+    return L.load()
+
+
+def _header_functions():
+    txt = open(os.path.join(ROOT, "include", "semdepth.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sd_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    declared = _header_functions()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in semdepth.h but not exported"
+    assert sorted(L.SIGNATURES) == declared, "ctypes signature table and header disagree"
+
+
+def test_struct_sizes_match_header_layout():
+    assert C.sizeof(L.sd_camera) == 40
+    assert C.sizeof(L.sd_rw_result) == 8 + 4 * 2 + 12 * 2 + 4 * 8 + 32
+    assert lib_version(L.load()).startswith("semdepth")
+
+
+def lib_version(lib):
+    return lib.sd_version().decode()
+
+
+def _table(lib, h, net):
+    out = {}
+    name = C.create_string_buffer(64)
+    shape = (C.c_int64 * 4)()
+    rank = C.c_int()
+    for i in range(lib.sd_weight_count(h, net)):
+        assert lib.sd_weight_info(h, net, i, name, shape, C.byref(rank)) == 0
+        out[name.value.decode()] = tuple(shape[j] for j in range(rank.value))
+    return out
+
+
+@pytest.mark.parametrize("enc,encname", [(L.SD_ENC_VGG, "vgg"), (L.SD_ENC_RESNET50, "resnet50")])
+def test_plans_agree_with_python_weight_tables(lib, enc, encname):
+    h = C.c_void_p()
+    assert lib.sd_create(C.byref(h), 0, 256, 512, 2, enc, L.SD_PREC_F32) == 0
+    try:
+        assert _table(lib, h, L.SD_NET_FCN8S) == dict(W.fcn8s_weight_shapes())
+        assert _table(lib, h, L.SD_NET_MONODEPTH) == dict(W.monodepth_weight_shapes(encname))
+        fw, mw, ws = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        assert lib.sd_query_memory(h, C.byref(fw), C.byref(mw), C.byref(ws)) == 0
+        assert fw.value >= 4 * W.count_params(W.fcn8s_weight_shapes())
+        assert mw.value >= 4 * W.count_params(W.monodepth_weight_shapes(encname))
+        # conv-engine FLOPs per image at 256x512 (110.80 G FCN, 29.95 G vgg, 44.98 G resnet50)
+        f_fcn = lib.sd_net_flops_per_image(h, L.SD_NET_FCN8S) / 1e9
+        f_mono = lib.sd_net_flops_per_image(h, L.SD_NET_MONODEPTH) / 1e9
+        assert abs(f_fcn - 110.80) < 0.15, f_fcn
+        assert abs(f_mono - (29.95 if encname == "vgg" else 44.98)) < 0.15, f_mono
+    finally:
+        lib.sd_destroy(h)
+
+
+def test_bad_arguments_are_rejected(lib):
+    h = C.c_void_p()
+    assert lib.sd_create(C.byref(h), 0, 100, 512, 1, L.SD_ENC_VGG, L.SD_PREC_F32) != 0      # H not a multiple of 128
+    assert lib.sd_create(C.byref(h), 0, 256, 512, 0, L.SD_ENC_VGG, L.SD_PREC_F32) != 0      # max_batch 0
+    assert lib.sd_create(C.byref(h), 0, 256, 512, 1, L.SD_ENC_VGG, L.SD_PREC_F32) == 0
+    # forward before bind -> state error, not a crash
+    assert lib.sd_fcn8s_forward(h, C.c_void_p(16), 1, None, None, None, None, None) == -3
+    assert b"bind" in lib.sd_last_error(h)
+    lib.sd_destroy(h)

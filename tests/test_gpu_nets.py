@@ -1,0 +1,105 @@
+"""GPU parity: FCN-8s and monodepth forward passes (conv engine + ops_misc kernels) vs the torch-CPU oracle on the
+same seeded weights and frames.  Tolerance: 1e-3 relative (BASELINE.json north_star); the f32 MFMA path lands ~1e-6."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fusion, nets
+from semantic_depth_amd import _lib as L
+from gpu_common import dev, engine, relerr
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3          # north_star: "within 1e-3 relative fp32 tolerance"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def keep_activations():
+    os.environ["SEMDEPTH_KEEP_ACTIVATIONS"] = "1"      # layer taps stay intact after a forward
+    yield
+    os.environ.pop("SEMDEPTH_KEEP_ACTIVATIONS", None)
+
+
+def _frames(B, H, W, seed=0):
+    return np.random.default_rng(seed).integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+
+
+def test_fcn8s_matches_oracle():
+    H, W, B = 64, 128, 2
+    eng, wf, _ = engine(H, W, B, "resnet50", fcn_kw=dict(decoder_std=0.05, bias_std=0.1), load=("fcn",))
+    fr = _frames(B, H, W)
+    out = eng.fcn8s_forward(dev(fr), want_logits=True)
+    ref, taps = nets.fcn8s_forward(fr, wf, return_taps=True)
+    for name, key in (("layer3_out", "layer3"), ("layer4_out", "layer4"), ("layer7_out", "layer7"), ("first_skip", "first_skip"),
+                      ("second_skip", "second_skip")):
+        got = eng.net_tensor(L.SD_NET_FCN8S, name).cpu().numpy()
+        assert got.shape == taps[key].shape
+        assert relerr(got, taps[key]) < TOL, (name, relerr(got, taps[key]))
+    lg = out["logits"].cpu().numpy()
+    e = relerr(lg, ref)
+    print("fcn8s logits rel err", e)
+    assert e < TOL
+    # the head's softmax / thresholds / argmax are exact functions of its own logits ...
+    _, road, fence, am = nets.softmax_masks(lg)
+    mism = lambda a, b: float((a != b).mean())
+    assert mism(out["road"].cpu().numpy().astype(bool), road) < 1e-4
+    assert mism(out["fence"].cpu().numpy().astype(bool), fence) < 1e-4
+    assert mism(out["argmax"].cpu().numpy(), am) < 1e-4
+    # ... and agree with the oracle's masks up to boundary pixels (compared as a mismatch fraction)
+    _, road_r, fence_r, am_r = nets.softmax_masks(ref)
+    assert mism(out["road"].cpu().numpy().astype(bool), road_r) < 2e-3
+    assert mism(out["argmax"].cpu().numpy(), am_r) < 2e-3
+    assert 0.02 < road_r.mean() < 0.98          # the masks are not trivial
+
+
+@pytest.mark.parametrize("encoder,H,W", [("vgg", 128, 256), ("resnet50", 64, 128), ("resnet50", 128, 256)])
+def test_monodepth_matches_oracle(encoder, H, W):
+    B = 2
+    eng, _, wm = engine(H, W, B, encoder, mono_kw=dict(gain=1.5, bias_std=0.05), load=("mono",))
+    fr = _frames(B, H, W, seed=3)
+    pp, raw = eng.monodepth_forward(dev(fr), want_raw=True)
+    pp, raw = pp.cpu().numpy(), raw.cpu().numpy()
+    for b in range(B):
+        f = fr[b].astype(np.float32) / 255
+        pair = np.stack((f, np.fliplr(f)), 0)
+        scales = nets.monodepth_forward(pair, wm, encoder, all_scales=True)
+        ref_raw = scales[1][..., 0]
+        e = relerr(raw[b], ref_raw)
+        print(encoder, H, W, "disp rel err", e, "range", ref_raw.min(), ref_raw.max())
+        assert e < TOL
+        assert ref_raw.std() > 1e-3                                  # not a constant map
+        ref_pp = fusion.post_processing(ref_raw.astype(np.float32)).astype(np.float32)
+        assert relerr(pp[b], ref_pp) < TOL
+        # post-processing of the GPU's own raw disparities is bit-exact
+        assert np.array_equal(pp[b], fusion.post_processing(raw[b]).astype(np.float32))
+        if b == B - 1:
+            for lvl in (4, 3, 2):
+                got = eng.net_tensor(L.SD_NET_MONODEPTH, f"dec/disp{lvl}").cpu().numpy()
+                assert relerr(got[2 * b:2 * b + 2], scales[lvl]) < TOL, lvl
+
+
+def test_batch_and_chunk_independence():
+    """B=9 > chunk(8): two chunks; every frame's outputs equal the solo run bit for bit (kernels are deterministic)."""
+    H, W, B = 128, 256, 9
+    eng, _, _ = engine(H, W, B, "resnet50", fcn_kw=dict(decoder_std=0.05), load=("fcn", "mono"))
+    fr = dev(_frames(B, H, W, seed=8))
+    seg = eng.fcn8s_forward(fr, want_logits=True)
+    pp = eng.monodepth_forward(fr)
+    for b in (0, 7, 8):
+        s1 = eng.fcn8s_forward(fr[b:b + 1].contiguous(), want_logits=True)
+        p1 = eng.monodepth_forward(fr[b:b + 1].contiguous())
+        assert torch.equal(s1["logits"][0], seg["logits"][b])
+        assert torch.equal(s1["road"][0], seg["road"][b])
+        assert torch.equal(p1[0], pp[b])
+
+
+def test_flipped_frame_symmetry_of_post_processing():
+    """compute_disparity(fliplr(frame)) == fliplr(compute_disparity(frame)) up to rounding: the pair (f, flip f) is
+    just swapped, and post_processing is symmetric under that swap + flip."""
+    H, W = 128, 256
+    eng, _, _ = engine(H, W, 9, "resnet50", fcn_kw=dict(decoder_std=0.05), load=("fcn", "mono"))
+    fr = _frames(1, H, W, seed=12)
+    a = eng.monodepth_forward(dev(fr))[0].cpu().numpy()
+    b = eng.monodepth_forward(dev(fr[:, :, ::-1].copy()))[0].cpu().numpy()
+    assert relerr(b[:, ::-1], a) < 1e-5

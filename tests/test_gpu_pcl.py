@@ -1,0 +1,185 @@
+"""GPU parity: the pcl.py mirror and the road-width tail (csrc/pcl.hip) vs golden vectors captured from the
+reference's pcl.py, and vs the oracle for the Open3D filters.  Bit-exact selections."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import o3d as oracle_o3d
+from oracle import pipeline
+from oracle import pcl as oracle_pcl
+from helpers import checksum
+from gpu_common import Camera, RoadWidthParams, dev, engine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pcl():
+    eng = engine(512, 1024, 2, "resnet50", load=())[0]
+    from semantic_depth_amd import pcl as m
+    m.set_engine(eng)
+    return m
+
+
+@pytest.fixture(scope="module")
+def mini(golden_dir):
+    return np.load(os.path.join(golden_dir, "pcl_mini.npz"))
+
+
+def _eq(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert a.dtype == b.dtype, (a.dtype, b.dtype)
+    assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_road_chain_golden(pcl, mini):
+    p, c = pcl.remove_from_to(mini["road3d"], mini["road_rgb"], 2, 0.0, 7.0)
+    _eq(p, mini["zcut_pts"]); _eq(c, mini["zcut_col"])
+    p, c = pcl.remove_noise_by_mad(p, c, 1, 15.0)
+    _eq(p, mini["mad_y_pts"]); _eq(c, mini["mad_y_col"])
+    p, c = pcl.remove_noise_by_mad(p, c, 0, 2.0)
+    _eq(p, mini["mad_x_pts"]); _eq(c, mini["mad_x_col"])
+    p, c, _, _, coeff = pcl.remove_noise_by_fitting_plane(p, c, axis=1, threshold=5.0)
+    _eq(p, mini["plane_pts"]); _eq(c, mini["plane_col"])
+    got = np.array([coeff[k] for k in ("Cx", "Cy", "Cz", "C")])
+    assert np.allclose(got, mini["plane_coeff"], rtol=1e-9, atol=1e-12), (got, mini["plane_coeff"])
+    l, r = pcl.get_end_points_of_road(p.astype(np.float64), 10.0 - 0.02)
+    _eq(l[0], mini["left_pts"][0]); _eq(r[0], mini["right_pts"][0])
+
+
+@pytest.mark.parametrize("axis,thr", [(0, 1.0), (1, 2.0), (2, 0.8)])
+def test_mad_tight_golden(pcl, mini, axis, thr):
+    p, c = pcl.remove_noise_by_mad(mini["road3d"], mini["road_rgb"], axis, thr)
+    _eq(p, mini[f"mad_a{axis}_pts"]); _eq(c, mini[f"mad_a{axis}_col"])
+
+
+@pytest.mark.parametrize("axis,thr", [(0, 0.5), (1, 0.02), (2, 3.0)])
+def test_plane_all_axes_golden(pcl, mini, axis, thr):
+    p, c, _, _, coeff = pcl.remove_noise_by_fitting_plane(mini["road3d"], mini["road_rgb"], axis=axis, threshold=thr)
+    _eq(p, mini[f"plane_a{axis}_pts"]); _eq(c, mini[f"plane_a{axis}_col"])
+    got = np.array([coeff[k] for k in ("Cx", "Cy", "Cz", "C")])
+    assert np.allclose(got, mini[f"plane_a{axis}_coeff"], rtol=1e-8, atol=1e-10)
+
+
+def test_edge_cases_golden(pcl, mini):
+    l, r = pcl.get_end_points_of_road(mini["plane_pts"].astype(np.float64), 500.0)
+    assert l is None and r is None                      # empty depth window
+    p, _ = pcl.remove_noise_by_mad(mini["mad0_in"], mini["road_rgb"], 1, 15.0)
+    _eq(p, mini["mad0_pts"])                            # MAD == 0 -> nothing survives
+    with pytest.raises(ValueError):
+        pcl.remove_from_to(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint8), 2, 0.0, 7.0)
+    p, c = pcl.threshold_complete(mini["fence3d"], mini["fence_rgb"], 2, 35.0)
+    _eq(p, mini["thr_pts"]); _eq(c, mini["thr_col"])
+    # host-side O(1) helpers
+    assert np.float64(pcl.compute_distance_in_3D(np.array([[1.0, 2.0, 3.0]]), np.array([[-2.0, 0.5, 7.0]]))) == mini["dist3d"]
+    lp, rp = mini["line_in_left"].copy(), mini["line_in_right"].copy()
+    line, lcol = pcl.create_3Dline_from_3Dpoints(lp, rp, [250, 0, 0])
+    _eq(line, mini["line"]); _eq(lp, mini["line_left_after"])
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 64, 65, 1000, 1023, 1024, 1025, 4096, 100001])
+def test_median_matches_numpy(pcl, n):
+    rng = np.random.default_rng(n)
+    v = (rng.standard_normal(n) * 10 ** rng.integers(-3, 4)).astype(np.float32)
+    if n > 10:
+        v[rng.integers(0, n, n // 3)] = v[0]            # heavy ties
+        v[1] = np.inf; v[2] = -np.inf
+    dev_, m = pcl.mad(v)
+    ref_dev, ref_m = oracle_pcl.mad(v)
+    with np.errstate(invalid="ignore"):
+        assert np.array_equal(dev_, ref_dev, equal_nan=True)
+    assert np.float32(m) == np.float32(ref_m) or (np.isnan(m) and np.isnan(ref_m))
+
+
+def test_median_with_nan_is_nan(pcl):
+    v = np.arange(100, dtype=np.float32)
+    v[17] = np.nan
+    _, m = pcl.mad(v)
+    assert np.isnan(m)
+
+
+def _o3d_compare(pcl, pts, col, k=10, ratio=0.5, nb=80, radius=0.5):
+    keep, mean_d, _, _ = oracle_o3d.statistical_outlier_mask(pts, k, ratio)
+    p, c = pcl.statistical_outlier_removal(pts, col, k, ratio)
+    assert len(p) == int(keep.sum())
+    _eq(p, pts[keep]); _eq(c, col[keep])
+    keep2 = oracle_o3d.radius_outlier_mask(p, nb, radius)
+    p2, c2 = pcl.radius_outlier_removal(p, c, nb, radius)
+    assert len(p2) == int(keep2.sum())
+    _eq(p2, p[keep2]); _eq(c2, c[keep2])
+    return len(p), len(p2)
+
+
+def test_o3d_filters_mini(pcl, mini):
+    n1, n2 = _o3d_compare(pcl, mini["zcut_pts"], mini["zcut_col"], nb=8)
+    assert 0 < n2 < n1 < len(mini["zcut_pts"])
+    # duplicates (mean distance 0 -> dropped by the statistical filter) and an isolated far outlier (brute-force path)
+    pts = np.concatenate([mini["zcut_pts"][:300], mini["zcut_pts"][:12], np.float32([[50, 40, -900]])])
+    col = np.concatenate([mini["zcut_col"][:300], mini["zcut_col"][:12], np.uint8([[1, 2, 3]])])
+    _o3d_compare(pcl, pts, col, nb=5)
+    # fewer points than k
+    _o3d_compare(pcl, mini["zcut_pts"][:7], mini["zcut_col"][:7], nb=2)
+
+
+def test_o3d_knn_mean_distance_exact(pcl, mini):
+    """the per-point mean kNN distance itself is bit-exact vs the oracle's canonical float64 definition."""
+    from semantic_depth_amd.engine import _ptr
+    from semantic_depth_amd import _lib as L
+    e = pcl._eng()
+    pts = mini["zcut_pts"]
+    n = len(pts)
+    d_pts = dev(pts)
+    o = torch.empty_like(d_pts)
+    n_out = torch.zeros(1, dtype=torch.int32, device="cuda")
+    md = torch.empty(n, dtype=torch.float64, device="cuda")
+    st = e.lib.sd_o3d_statistical_outlier_removal(e.h, _ptr(d_pts), None, n, 10, 0.5, _ptr(o), None, _ptr(n_out), _ptr(md), e._stream())
+    L.check(e.lib, e.h, st, "sor")
+    assert np.array_equal(md.cpu().numpy(), oracle_o3d.knn_mean_distance(pts, 10))
+
+
+def test_tail_full_size_golden_and_oracle(pcl, golden_dir):
+    """512x1024 Appendix-F scene through Engine.road_width: digests captured from the reference's pcl (no Open3D),
+    then the full chain incl. the Open3D filters vs the oracle."""
+    g = json.load(open(os.path.join(golden_dir, "pcl_full.json")))
+    sc = g["scene"]
+    dp, road, fence, frame, cam = pipeline.synthetic_scene(sc["h"], sc["w"], seed=sc["seed"], f=sc["f"])
+    e = pcl._eng()
+    pp = e.post_process(dev(dp[None]))
+    fz = e.fuse_backproject(pp, dev(road[None].astype(np.uint8)), dev(fence[None].astype(np.uint8)), dev(frame[None]), [Camera(**cam)])
+    res, fin, nfin = e.road_width(fz["road_xyz"], fz["n_road"], RoadWidthParams(use_o3d=False), want_final=True)
+    rec = e.records(res)[0]
+    assert (rec["n_road"], rec["n_zcut"], rec["n_mad_y"], rec["n_mad_x"], rec["n_plane"]) == \
+        (g["n_road"], g["n_zcut"], g["n_mad_y"], g["n_mad_x"], g["n_plane"])
+    assert checksum(fin[0, :int(nfin[0])].cpu().numpy()) == g["plane_checksum"]
+    assert rec["found"] == 1 and float(rec["x_left"]) == g["x_left"] and float(rec["x_right"]) == g["x_right"]
+    assert float(rec["width"]) == g["dist_rw"]
+    assert [float(v) for v in rec["left_pt"]] == g["left_pt"] and [float(v) for v in rec["right_pt"]] == g["right_pt"]
+    for i, k in enumerate(("Cx", "Cy", "Cz", "C")):
+        assert abs(rec["plane"][i] - g["plane_coeff"][k]) <= 1e-9 * max(1.0, abs(g["plane_coeff"][k]))
+    # full chain with the Open3D filters vs the oracle
+    ref = pipeline.frame_tail(dp, road, fence, frame, cam)["rw"]
+    res, fin, nfin = e.road_width(fz["road_xyz"], fz["n_road"], RoadWidthParams(), want_final=True)
+    rec = e.records(res)[0]
+    assert (rec["n_sor"], rec["n_ror"]) == (ref["n_sor"], ref["n_ror"])
+    assert np.array_equal(fin[0, :int(nfin[0])].cpu().numpy().astype(np.float64), ref["points"])
+    assert float(rec["width"]) == ref["width"] and float(rec["x_left"]) == ref["x_left"]
+
+
+def test_tail_batch_and_degenerate_frames(pcl):
+    """B=2: one normal frame and one frame with an empty road mask -> found=0, counts 0, no crash; and a frame whose
+    depth window is empty."""
+    e = pcl._eng()
+    dp, road, fence, frame, cam = pipeline.synthetic_scene(512, 1024, seed=21, f=1000.0)
+    pp = e.post_process(dev(np.stack([dp, dp])))
+    masks = np.stack([road, np.zeros_like(road)]).astype(np.uint8)
+    fz = e.fuse_backproject(pp, dev(masks), dev(masks), dev(np.stack([frame, frame])), [Camera(**cam)] * 2)
+    rec = e.records(e.road_width(fz["road_xyz"], fz["n_road"], RoadWidthParams()))
+    ref = pipeline.frame_tail(dp, road, fence, frame, cam)["rw"]
+    assert rec[0]["found"] == 1 and float(rec[0]["width"]) == ref["width"] and rec[0]["n_ror"] == ref["n_ror"]
+    assert rec[1]["found"] == 0 and rec[1]["n_road"] == 0 and rec[1]["n_ror"] == 0 and np.isnan(rec[1]["width"])
+    rec = e.records(e.road_width(fz["road_xyz"], fz["n_road"], RoadWidthParams(depth=500.0)))
+    assert rec[0]["found"] == 0 and rec[0]["n_ror"] == ref["n_ror"]
