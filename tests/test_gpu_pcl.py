@@ -84,7 +84,7 @@ def test_edge_cases_golden(pcl, mini):
 @pytest.mark.parametrize("n", [1, 2, 3, 64, 65, 1000, 1023, 1024, 1025, 4096, 100001])
 def test_median_matches_numpy(pcl, n):
     rng = np.random.default_rng(n)
-    v = (rng.standard_normal(n) * 10 ** rng.integers(-3, 4)).astype(np.float32)
+    v = (rng.standard_normal(n) * 10.0 ** rng.integers(-3, 4)).astype(np.float32)
     if n > 10:
         v[rng.integers(0, n, n // 3)] = v[0]            # heavy ties
         v[1] = np.inf; v[2] = -np.inf
