@@ -160,6 +160,19 @@ sd_status sd_o3d_radius_outlier_removal(sd_handle* h, const float* xyz, const ui
  * numel_out receives its element count; shape_out 4 x int64 [N,H,W,C] */
 sd_status sd_net_tensor(sd_handle* h, sd_net net, const char* name, float* out, size_t out_capacity_floats,
                         int64_t* shape_out, void* stream);
+/* per-kernel timing of the conv engine with HIP events on the launch stream (bench.py roofline).
+ * sd_profile(h,1) starts recording an event pair around every conv launch; sd_profile_read synchronises the
+ * device, sums elapsed time / algorithmic FLOPs (2*M*N*K) / launches per kernel instantiation into out[0..*n),
+ * and clears the recording.  out: HOST array of capacity cap_buckets. */
+typedef struct {
+    char kernel[64];
+    int64_t launches;
+    double ms;
+    double flops;
+} sd_profile_bucket;
+sd_status sd_profile(sd_handle* h, int enable);
+sd_status sd_profile_read(sd_handle* h, sd_profile_bucket* out_host, int cap_buckets, int* n_out);
+
 /* number of conv-engine FLOPs (2*M*N*K over all layers, per image) of a plan — for roofline accounting */
 double sd_net_flops_per_image(const sd_handle* h, sd_net net);
 

@@ -34,6 +34,10 @@ class sd_rw_result(C.Structure):
                 ("n_ror", C.c_int32), ("plane", C.c_double * 4)]
 
 
+class sd_profile_bucket(C.Structure):
+    _fields_ = [("kernel", C.c_char * 64), ("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double)]
+
+
 # every symbol include/semdepth.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 _H = C.c_void_p
@@ -61,6 +65,8 @@ SIGNATURES = {
     "sd_o3d_statistical_outlier_removal": (C.c_int, [_H, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P, _P]),
     "sd_o3d_radius_outlier_removal": (C.c_int, [_H, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P]),
     "sd_net_tensor": (C.c_int, [_H, C.c_int, C.c_char_p, _P, C.c_size_t, C.POINTER(C.c_int64), _P]),
+    "sd_profile": (C.c_int, [_H, C.c_int]),
+    "sd_profile_read": (C.c_int, [_H, C.POINTER(sd_profile_bucket), C.c_int, C.POINTER(C.c_int)]),
     "sd_net_flops_per_image": (C.c_double, [_H, C.c_int]),
 }
 

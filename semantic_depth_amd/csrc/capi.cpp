@@ -31,6 +31,12 @@ struct sd_handle {
     int last_fcn_images = 0, last_mono_images = 0;
     std::vector<CamDev> cams_stage;
     std::string err;
+    // profiling (sd_profile): event pairs around conv launches
+    bool prof = false;
+    struct ProfRec { int bucket; double flops; hipEvent_t a, b; const char* op; int M, N, K; };
+    std::vector<ProfRec> prof_recs;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
+    size_t prof_used = 0;
 };
 
 namespace {
@@ -74,11 +80,9 @@ sd_status upload_tables(sd_handle* h, sd_net net) {
     const char* abase = h->ws + (net == SD_NET_FCN8S ? h->o_fcn : h->o_mono);
     for (const OpDesc& op : p.ops) {
         if (op.kind != OP_CONV) continue;
-        std::vector<int32_t> ktab;
-        ConvSrc srcs[3];
-        build_conv_tables(p, op, abase, ktab, srcs);
-        HIPCHK(h, hipMemcpy(wbase + op.tab_offset, ktab.data(), ktab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        HIPCHK(h, hipMemcpy(wbase + op.srcs_offset, srcs, sizeof(ConvSrc) * 3, hipMemcpyHostToDevice));
+        std::vector<KEntry> ktab;
+        build_conv_tables(p, op, abase, ktab);
+        HIPCHK(h, hipMemcpy(wbase + op.tab_offset, ktab.data(), ktab.size() * sizeof(KEntry), hipMemcpyHostToDevice));
     }
     return SD_OK;
 }
@@ -108,19 +112,33 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 const TensorDesc& d = p.tensors[op.dst];
                 const TensorDesc& s0 = p.tensors[op.src[0]];
                 ConvParams c{};
-                c.srcs = reinterpret_cast<const ConvSrc*>(wbase + op.srcs_offset);
                 c.nsrc = op.nsrc; c.Ctot = op.Ctot;
                 c.N = N; c.Hin = s0.H * (op.up[0] ? 2 : 1); c.Win = s0.W * (op.up[0] ? 2 : 1);
                 c.Hout = d.H; c.Wout = d.W; c.Cout = d.C; c.CoutPad = p.weights[op.w].CoutPad;
                 c.kh = c.kw = op.k; c.stride = op.stride; c.pad = op.pad;
                 c.K = op.K; c.Kpad = op.Kpad;
                 c.wt = Wp(op.w); c.bias = Wp(op.b);
-                c.ktab = reinterpret_cast<const int4*>(wbase + op.tab_offset);
+                c.ktab = reinterpret_cast<const KEntry*>(wbase + op.tab_offset);
                 c.vec = op.vec;
                 c.residual = op.residual >= 0 ? T(op.residual) : nullptr;
                 c.out = T(op.dst);
                 c.act = op.act; c.m_fastest = op.m_fastest;
-                e = launch_conv_igemm(c, s);
+                if (h->prof) {
+                    if (h->prof_used == h->prof_pool.size()) {
+                        hipEvent_t a, b;
+                        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return fail(h, SD_ERR_HIP, "hipEventCreate");
+                        h->prof_pool.push_back({a, b});
+                    }
+                    auto ev = h->prof_pool[h->prof_used++];
+                    const int tn = conv_tile_n(c.Cout);
+                    const int bucket = (tn == 128 ? 0 : tn == 64 ? 1 : tn == 32 ? 2 : 3) * 2 + (c.vec ? 0 : 1);
+                    hipEventRecord(ev.first, s);
+                    e = launch_conv_igemm(c, s);
+                    hipEventRecord(ev.second, s);
+                    h->prof_recs.push_back({bucket, op.flops * N / p.images, ev.first, ev.second, op.name.c_str(), N * d.H * d.W, d.C, op.K});
+                } else {
+                    e = launch_conv_igemm(c, s);
+                }
                 break;
             }
             case OP_SMALLN: {
@@ -443,6 +461,41 @@ sd_status sd_net_tensor(sd_handle* h, sd_net net, const char* name, float* out, 
     if (numel > cap_floats) return fail(h, SD_ERR_INVALID, "output buffer too small");
     const char* abase = h->ws + (net == SD_NET_FCN8S ? h->o_fcn : h->o_mono);
     HIPCHK(h, hipMemcpyAsync(out, abase + t.offset, numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return SD_OK;
+}
+
+sd_status sd_profile(sd_handle* h, int enable) {
+    if (!h) return SD_ERR_INVALID;
+    h->prof = enable != 0;
+    if (!h->prof) { h->prof_recs.clear(); h->prof_used = 0; }
+    return SD_OK;
+}
+
+sd_status sd_profile_read(sd_handle* h, sd_profile_bucket* out, int cap_buckets, int* n_out) {
+    if (!h || !out || !n_out || cap_buckets < 8) return SD_ERR_INVALID;
+    HIPCHK(h, hipDeviceSynchronize());
+    static const char* names[8] = {"conv_igemm_kernel<2,2,4,4,true>", "conv_igemm_kernel<2,2,4,4,false>",
+                                   "conv_igemm_kernel<4,1,4,4,true>", "conv_igemm_kernel<4,1,4,4,false>",
+                                   "conv_igemm_kernel<4,1,4,2,true>", "conv_igemm_kernel<4,1,4,2,false>",
+                                   "conv_igemm_kernel<4,1,4,1,true>", "conv_igemm_kernel<4,1,4,1,false>"};
+    for (int i = 0; i < 8; ++i) {
+        std::memset(&out[i], 0, sizeof(out[i]));
+        std::strncpy(out[i].kernel, names[i], 63);
+    }
+    const char* verbose = std::getenv("SEMDEPTH_PROFILE_VERBOSE");
+    for (auto& r : h->prof_recs) {
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, r.a, r.b));
+        if (verbose && verbose[0] == '1')
+            std::fprintf(stderr, "[sd_profile] %-28s M=%-8d N=%-5d K=%-6d %8.3f ms %7.2f TF/s  %s\n", r.op, r.M, r.N, r.K, ms,
+                         r.flops / (ms * 1e-3) / 1e12, names[r.bucket]);
+        out[r.bucket].launches += 1;
+        out[r.bucket].ms += ms;
+        out[r.bucket].flops += r.flops;
+    }
+    *n_out = 8;
+    h->prof_recs.clear();
+    h->prof_used = 0;
     return SD_OK;
 }
 

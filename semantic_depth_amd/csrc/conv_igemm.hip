@@ -74,10 +74,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p, int
     }
     const int iy0 = oy * p.stride, ix0 = ox * p.stride;
 
-    // source descriptors live in device memory: indexing a by-value kernarg array dynamically would go through scratch
-    const ConvSrc* __restrict__ const srcs = p.srcs;
     const float* const wt = p.wt;
-    const int4* const ktab = p.ktab;
+    const KEntry* __restrict__ const ktab = p.ktab;
     const int Hin = p.Hin, Win = p.Win, CoutPad = p.CoutPad;
 
     f32x4 ra[T::A_LD];
@@ -95,12 +93,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p, int
         }
         // ---- activations: im2col gather ----
         if (VEC) {
-            const int4 e = ktab[kt];   // uniform: {src, dy, dx, c0}
-            const ConvSrc sc = srcs[e.x];
-            int iy = iy0 + e.y, ix = ix0 + e.z;
-            bool ok = m_ok && iy >= 0 && ix >= 0 && iy < Hin && ix < Win;
-            if (sc.up) { iy >>= 1; ix >>= 1; }
-            const float* base = sc.ptr + ((size_t)(img * sc.H + iy) * sc.W + ix) * sc.C + e.w;
+            const KEntry e = ktab[kt];   // wave-uniform -> one s_load_dwordx8
+            int iy = iy0 + e.dy, ix = ix0 + e.dx;
+            const bool ok = m_ok && iy >= 0 && ix >= 0 && iy < Hin && ix < Win;
+            if (e.flags & 1) { iy >>= 1; ix >>= 1; }
+            const float* base = e.base + ((size_t)(img * e.H + iy) * e.W + ix) * e.C;
 #pragma unroll
             for (int i = 0; i < T::A_LD; ++i) {
                 const int kq = kq0 + KQ_STEP * i;
@@ -109,22 +106,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p, int
                 ra[i] = v;
             }
         } else {
+            // quad path: each k-quad is <= 4 consecutive channels of one (tap, source); kq is wave-uniform, so each
+            // descriptor is one scalar load and the A_LD descriptors of a tile are independent of each other
 #pragma unroll
             for (int i = 0; i < T::A_LD; ++i) {
-                const int kq = kq0 + KQ_STEP * i;
-                f32x4 v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int4 e = ktab[kt * 32 + kq * 4 + j];
-                    float x = 0.f;
-                    if (e.x >= 0) {
-                        const ConvSrc sc = srcs[e.x];
-                        int iy = iy0 + e.y, ix = ix0 + e.z;
-                        const bool ok = m_ok && iy >= 0 && ix >= 0 && iy < Hin && ix < Win;
-                        if (sc.up) { iy >>= 1; ix >>= 1; }
-                        if (ok) x = sc.ptr[((size_t)(img * sc.H + iy) * sc.W + ix) * sc.C + e.w];
-                    }
-                    v[j] = x;
+                const int kq = __builtin_amdgcn_readfirstlane(kq0 + KQ_STEP * i);
+                const KEntry e = ktab[kt * 8 + kq];
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                int iy = iy0 + e.dy, ix = ix0 + e.dx;
+                const bool ok = (e.flags & 0x10000) && m_ok && iy >= 0 && ix >= 0 && iy < Hin && ix < Win;
+                if (e.flags & 1) { iy >>= 1; ix >>= 1; }
+                const int nv = (e.flags >> 8) & 7;
+                const float* q = e.base + ((size_t)(img * e.H + iy) * e.W + ix) * e.C;
+                if (ok) {
+                    if (nv == 4) v = *reinterpret_cast<const f32x4*>(q);
+                    else if (nv == 2) { const float2 t2 = *reinterpret_cast<const float2*>(q); v[0] = t2.x; v[1] = t2.y; }
+                    else { for (int j = 0; j < nv; ++j) v[j] = q[j]; }
                 }
                 ra[i] = v;
             }

@@ -10,23 +10,27 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_SIGMOID03 = 3 /* 0.3*sig
 // ---------------------------------------------------------------------------------------------
 // implicit-GEMM convolution on the f32 MFMA (conv_igemm.hip)
 // ---------------------------------------------------------------------------------------------
-struct ConvSrc {
-    const float* ptr;  // [N, H, W, C]
-    int C, H, W;       // physical dims of the stored tensor
-    int up;            // 1: read through a x2 nearest-neighbour upsample (logical dims 2H x 2W)
+// one gather descriptor = 32 bytes, fetched with a single scalar load:
+//   vec path : one per 32-wide k-tile  (32 consecutive channels of one tap of one source)
+//   quad path: one per channel quad    (<= 4 consecutive channels of one tap of one source)
+struct KEntry {
+    const float* base;  // source tensor + first channel of this entry
+    int H, W, C;        // physical dims of the source tensor
+    int dy, dx;         // tap offset minus pad (in logical, i.e. post-upsample, input coordinates)
+    int flags;          // bit 0: read through a x2 nearest-neighbour upsample; bits 8..10: valid floats (quad path);
+                        // bit 16: entry is live (0 = zero padding of the K axis)
 };
+static_assert(sizeof(KEntry) == 32, "KEntry must be 32 bytes");
 
 struct ConvParams {
-    const ConvSrc* srcs;  // DEVICE array [nsrc]: channel-concatenated sources (tf.concat order)
-    int nsrc, Ctot;
+    int nsrc, Ctot;    // channel-concatenated sources (tf.concat order), described by ktab
     int N, Hin, Win;   // logical input dims (after upsample)
     int Hout, Wout, Cout, CoutPad;
     int kh, kw, stride, pad;
-    int K, Kpad;       // K = kh*kw*Ctot ; Kpad = multiple of 32
+    int K, Kpad;       // K = kh*kw*Ctot (Ctot = sum of sources rounded up to quads) ; Kpad = multiple of 32
     const float* wt;   // re-laid-out weights [Kpad/4][CoutPad][4]
     const float* bias; // [Cout]
-    const int4* ktab;  // vec path: one entry per 32-wide k-tile {src, dy-pad, dx-pad, c0}
-                       // scalar path: one entry per k {src (-1 = zero), dy-pad, dx-pad, c}
+    const KEntry* ktab;  // DEVICE: vec path [Kpad/32], quad path [Kpad/4]
     int vec;           // 1: every source has C % 32 == 0 (k-tiles never straddle a tap or a source)
     const float* residual;  // nullable [M][Cout], added before the activation (resnet shortcut)
     float* out;             // [M][Cout]

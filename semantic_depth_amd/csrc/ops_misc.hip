@@ -14,10 +14,8 @@ __global__ __launch_bounds__(256) void pre_vgg_kernel(const uint8_t* __restrict_
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= npix) return;
     const uint8_t* p = in + i * 3;
-    float* o = out + i * 3;
-    o[0] = (float)p[2] - 103.939f;
-    o[1] = (float)p[1] - 116.779f;
-    o[2] = (float)p[0] - 123.68f;
+    // 4 stored channels (the 4th is zero and meets zero weight rows): conv1_1 gathers whole float4 quads
+    reinterpret_cast<f32x4*>(out)[i] = (f32x4){(float)p[2] - 103.939f, (float)p[1] - 116.779f, (float)p[0] - 123.68f, 0.f};
 }
 hipError_t launch_pre_vgg(const uint8_t* frames, float* out, long npix, hipStream_t s) {
     hipLaunchKernelGGL(pre_vgg_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, frames, out, npix);
@@ -35,10 +33,9 @@ __global__ __launch_bounds__(256) void pre_mono_kernel(const uint8_t* __restrict
     int y = (int)(row - (long)b * H);
     const uint8_t* p = in + i * 3;
     float v0 = (float)p[0] / 255.0f, v1 = (float)p[1] / 255.0f, v2 = (float)p[2] / 255.0f;
-    float* o = out + (((long)(2 * b) * H + y) * W + x) * 3;
-    o[0] = v0; o[1] = v1; o[2] = v2;
-    float* f = out + (((long)(2 * b + 1) * H + y) * W + (W - 1 - x)) * 3;
-    f[0] = v0; f[1] = v1; f[2] = v2;
+    const f32x4 v = {v0, v1, v2, 0.f};       // 4 stored channels, see pre_vgg_kernel
+    reinterpret_cast<f32x4*>(out)[((long)(2 * b) * H + y) * W + x] = v;
+    reinterpret_cast<f32x4*>(out)[((long)(2 * b + 1) * H + y) * W + (W - 1 - x)] = v;
 }
 hipError_t launch_pre_mono(const uint8_t* frames, float* out, int B, int H, int W, hipStream_t s) {
     long npix = (long)B * H * W;

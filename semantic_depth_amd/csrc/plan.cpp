@@ -21,7 +21,7 @@ struct Builder {
 
     int tensor(const std::string& name, int N, int H, int W, int C) {
         TensorDesc t;
-        t.name = name; t.N = N; t.H = H; t.W = W; t.C = C;
+        t.name = name; t.N = N; t.H = H; t.W = W; t.C = C; t.Ctf = C;
         t.bytes = (size_t)N * H * W * C * sizeof(float);
         p.tensors.push_back(t);
         p.tensor_by_name[name] = (int)p.tensors.size() - 1;
@@ -54,15 +54,17 @@ struct Builder {
              const std::string& bname, int residual = -1) {
         OpDesc op;
         op.kind = OP_CONV; op.name = name; op.nsrc = (int)srcs.size();
-        int Ctot = 0, Hin = 0, Win = 0, N = 0;
+        int Ctot = 0, Ctf = 0, Hin = 0, Win = 0, N = 0;
         bool vec = true;
+        int srcCtf[3] = {0, 0, 0}, srcCpad[3] = {0, 0, 0};
         for (int i = 0; i < op.nsrc; ++i) {
             const TensorDesc& t = p.tensors[srcs[i].t];
             op.src[i] = srcs[i].t; op.up[i] = srcs[i].up;
             const int h = t.H * (srcs[i].up ? 2 : 1), w = t.W * (srcs[i].up ? 2 : 1);
             if (i == 0) { Hin = h; Win = w; N = t.N; }
             else if (h != Hin || w != Win || t.N != N) throw std::runtime_error("conv " + name + ": source dims disagree");
-            Ctot += t.C;
+            srcCtf[i] = t.Ctf; srcCpad[i] = (t.C + 3) / 4 * 4;     // the K axis holds whole channel quads per source
+            Ctot += srcCpad[i]; Ctf += t.Ctf;
             if (t.C % 32) vec = false;
         }
         op.k = k; op.stride = stride; op.pad = (k - 1) / 2; op.act = act; op.residual = residual;
@@ -70,14 +72,20 @@ struct Builder {
         op.Ctot = Ctot; op.K = k * k * Ctot; op.Kpad = (op.K + 31) / 32 * 32; op.vec = vec ? 1 : 0;
         const int bn = conv_tile_n(Cout);
         const int CoutPad = (Cout + bn - 1) / bn * bn;
-        op.w = wslot(wname, {k, k, Ctot, Cout}, WL_IGEMM, op.Kpad, CoutPad);
+        op.w = wslot(wname, {k, k, Ctf, Cout}, WL_IGEMM, op.Kpad, CoutPad);
+        {
+            WeightSlot& ws = p.weights[op.w];
+            ws.nsrc = op.nsrc;
+            for (int i = 0; i < 3; ++i) { ws.srcCtf[i] = srcCtf[i]; ws.srcCpad[i] = srcCpad[i]; }
+        }
         op.b = wslot(bname, {Cout}, WL_RAW);
         op.dst = tensor(name, N, Hout, Wout, Cout);
-        op.tab_bytes = vec ? (size_t)(op.Kpad / 32) * 16 : (size_t)op.Kpad * 16;
+        op.tab_bytes = (vec ? (size_t)(op.Kpad / 32) : (size_t)(op.Kpad / 4)) * sizeof(KEntry);
         const double M = (double)N * Hout * Wout;
-        op.flops = 2.0 * M * Cout * op.K;
+        op.flops = 2.0 * M * Cout * (double)(k * k * Ctf);      // algorithmic (TF) K, not the padded one
         // block order: walk M first when the weight matrix is the larger operand (it then stays L2-resident per N panel)
         op.m_fastest = ((double)op.K * Cout > M * Ctot) ? 1 : 0;
+        (void)Ctf;
         push(op);
         return op.dst;
     }
@@ -123,7 +131,6 @@ struct Builder {
         for (auto& op : p.ops)
             if (op.kind == OP_CONV) {
                 op.tab_offset = off; off += align_up(op.tab_bytes);
-                op.srcs_offset = off; off += align_up(sizeof(ConvSrc) * 3);
             }
         p.weight_bytes = off;
         // activation arena: first-fit over lifetimes (SEMDEPTH_KEEP_ACTIVATIONS=1: no reuse, for layer-by-layer tests)
@@ -166,7 +173,8 @@ NetPlan build_fcn8s(int frames, int H, int W) {
     if (H % 32 || W % 32) throw std::runtime_error("FCN-8s needs H, W multiples of 32");
     Builder b;
     b.p.net = "fcn8s"; b.p.frames = frames; b.p.images = frames; b.p.H = H; b.p.W = W;
-    int x = b.tensor("input_pre", frames, H, W, 3);
+    int x = b.tensor("input_pre", frames, H, W, 4);      // 4th channel is zero: float4 gathers in conv1_1
+    b.p.tensors[x].Ctf = 3;
     { OpDesc op; op.kind = OP_PRE_VGG; op.name = "pre"; op.dst = x; b.push(op); }
     b.p.t_input = x;
     const char* blocks[5][3] = {{"conv1_1", "conv1_2", nullptr}, {"conv2_1", "conv2_2", nullptr}, {"conv3_1", "conv3_2", "conv3_3"},
@@ -221,7 +229,8 @@ NetPlan build_monodepth(int encoder, int frames, int H, int W) {
     b.p.net = encoder == 0 ? "monodepth-vgg" : "monodepth-resnet50";
     b.p.frames = frames; b.p.images = 2 * frames; b.p.H = H; b.p.W = W;
     const int N = 2 * frames;
-    int x = b.tensor("input_pre", N, H, W, 3);
+    int x = b.tensor("input_pre", N, H, W, 4);
+    b.p.tensors[x].Ctf = 3;
     { OpDesc op; op.kind = OP_PRE_MONO; op.name = "pre"; op.dst = x; b.push(op); }
     b.p.t_input = x;
     auto cv = [&](const std::string& name, std::vector<Src> srcs, int C, int k, int s, int act = ACT_ELU, int res = -1) {
@@ -288,11 +297,20 @@ NetPlan build_monodepth(int encoder, int frames, int H, int W) {
 void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& out) {
     out.assign(s.bytes / sizeof(float), 0.f);
     if (s.layout == WL_IGEMM) {
-        const int64_t K = s.shape[0] * s.shape[1] * s.shape[2], Cout = s.shape[3];
-        for (int64_t k = 0; k < K; ++k) {
-            float* dst = out.data() + (size_t)(k / 4) * s.CoutPad * 4 + (k % 4);
-            const float* src = w + k * Cout;
-            for (int64_t n = 0; n < Cout; ++n) dst[n * 4] = src[n];
+        const int64_t taps = s.shape[0] * s.shape[1], Ctf = s.shape[2], Cout = s.shape[3];
+        int CtotPad = 0;
+        for (int i = 0; i < s.nsrc; ++i) CtotPad += s.srcCpad[i];
+        for (int64_t tap = 0; tap < taps; ++tap) {
+            int cb_tf = 0, cb_pad = 0;
+            for (int i = 0; i < s.nsrc; ++i) {
+                for (int c = 0; c < s.srcCtf[i]; ++c) {
+                    const int64_t k = tap * CtotPad + cb_pad + c;
+                    float* dst = out.data() + (size_t)(k / 4) * s.CoutPad * 4 + (k % 4);
+                    const float* src = w + (tap * Ctf + cb_tf + c) * Cout;
+                    for (int64_t n = 0; n < Cout; ++n) dst[n * 4] = src[n];
+                }
+                cb_tf += s.srcCtf[i]; cb_pad += s.srcCpad[i];
+            }
         }
     } else if (s.layout == WL_SMALLN) {
         const int64_t K = s.shape[0] * s.shape[1] * s.shape[2], Cout = s.shape[3];
@@ -305,46 +323,28 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
     }
 }
 
-void build_conv_tables(const NetPlan& p, const OpDesc& op, const char* act_base, std::vector<int32_t>& ktab, ConvSrc srcs[3]) {
-    int cbase[4] = {0, 0, 0, 0};
-    for (int i = 0; i < 3; ++i) {
-        srcs[i] = ConvSrc{nullptr, 0, 0, 0, 0};
-        if (i < op.nsrc) {
-            const TensorDesc& t = p.tensors[op.src[i]];
-            srcs[i].ptr = reinterpret_cast<const float*>(act_base + t.offset);
-            srcs[i].C = t.C; srcs[i].H = t.H; srcs[i].W = t.W; srcs[i].up = op.up[i];
-            cbase[i + 1] = cbase[i] + t.C;
-        }
-    }
-    auto locate = [&](int c, int& s, int& cl) {
-        for (s = 0; s < op.nsrc; ++s)
-            if (c < cbase[s + 1]) { cl = c - cbase[s]; return; }
-        s = -1; cl = 0;
+void build_conv_tables(const NetPlan& p, const OpDesc& op, const char* act_base, std::vector<KEntry>& ktab) {
+    int cbase[4] = {0, 0, 0, 0};     // padded channel offsets of the sources inside one tap
+    for (int i = 0; i < op.nsrc; ++i) cbase[i + 1] = cbase[i] + (p.tensors[op.src[i]].C + 3) / 4 * 4;
+    auto entry = [&](int k) {        // descriptor of the channel run starting at padded index k
+        KEntry e{nullptr, 1, 1, 1, 0, 0, 0};
+        if (k >= op.K) return e;
+        const int tap = k / op.Ctot, c = k % op.Ctot;
+        int s = 0;
+        while (s + 1 < op.nsrc && c >= cbase[s + 1]) ++s;
+        const TensorDesc& t = p.tensors[op.src[s]];
+        const int cl = c - cbase[s];
+        e.base = reinterpret_cast<const float*>(act_base + t.offset) + cl;
+        e.H = t.H; e.W = t.W; e.C = t.C;
+        e.dy = tap / op.k - op.pad; e.dx = tap % op.k - op.pad;
+        const int nv = std::max(0, std::min(4, t.C - cl));
+        e.flags = (op.up[s] ? 1 : 0) | (nv << 8) | (nv > 0 ? 0x10000 : 0);
+        return e;
     };
-    if (op.vec) {
-        const int tiles = op.Kpad / 32;
-        ktab.resize((size_t)tiles * 4);
-        for (int kt = 0; kt < tiles; ++kt) {
-            const int k0 = kt * 32, tap = k0 / op.Ctot, c = k0 % op.Ctot;
-            int s, cl;
-            locate(c, s, cl);
-            ktab[kt * 4 + 0] = s;
-            ktab[kt * 4 + 1] = tap / op.k - op.pad;
-            ktab[kt * 4 + 2] = tap % op.k - op.pad;
-            ktab[kt * 4 + 3] = cl;
-        }
-    } else {
-        ktab.resize((size_t)op.Kpad * 4);
-        for (int k = 0; k < op.Kpad; ++k) {
-            int s = -1, cl = 0, dy = 0, dx = 0;
-            if (k < op.K) {
-                const int tap = k / op.Ctot;
-                locate(k % op.Ctot, s, cl);
-                dy = tap / op.k - op.pad; dx = tap % op.k - op.pad;
-            }
-            ktab[k * 4 + 0] = s; ktab[k * 4 + 1] = dy; ktab[k * 4 + 2] = dx; ktab[k * 4 + 3] = cl;
-        }
-    }
+    const int n = op.vec ? op.Kpad / 32 : op.Kpad / 4;
+    const int stepk = op.vec ? 32 : 4;
+    ktab.resize(n);
+    for (int i = 0; i < n; ++i) ktab[i] = entry(i * stepk);
 }
 
 }  // namespace sd

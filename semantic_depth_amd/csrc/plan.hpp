@@ -13,7 +13,8 @@ namespace sd {
 
 struct TensorDesc {
     std::string name;
-    int N = 0, H = 0, W = 0, C = 0;
+    int N = 0, H = 0, W = 0, C = 0;   // C = stored channels
+    int Ctf = 0;                      // channels the TensorFlow graph sees (input_pre stores 4, TF sees 3)
     size_t bytes = 0;
     size_t offset = 0;      // byte offset in the activation arena
     int first = -1, last = -1;   // op indices (liveness)
@@ -28,6 +29,7 @@ struct WeightSlot {
     int rank = 0;
     int layout = WL_RAW;
     int Kpad = 0, CoutPad = 0, nout = 0;
+    int nsrc = 1, srcCtf[3] = {0, 0, 0}, srcCpad[3] = {0, 0, 0};   // WL_IGEMM: channel structure of the K axis
     size_t offset = 0, bytes = 0;   // in the weight arena (re-laid-out form)
     bool loaded = false;
 };
@@ -43,9 +45,9 @@ struct OpDesc {
     int k = 1, stride = 1, pad = 0, act = ACT_NONE, nout = 0;
     int w = -1, b = -1;    // weight slots
     // conv engine
-    int Ctot = 0, K = 0, Kpad = 0, vec = 0, m_fastest = 0;
-    size_t tab_offset = 0, tab_bytes = 0;    // k-table, in the weight arena
-    size_t srcs_offset = 0;                  // ConvSrc[3], in the weight arena
+    int Ctot = 0;          // padded channels per tap (every source rounded up to a multiple of 4)
+    int K = 0, Kpad = 0, vec = 0, m_fastest = 0;
+    size_t tab_offset = 0, tab_bytes = 0;    // KEntry table, in the weight arena
     double flops = 0;                        // 2*M*N*K for the whole chunk
 };
 
@@ -69,8 +71,8 @@ NetPlan build_monodepth(int encoder /*0 vgg, 1 resnet50*/, int frames, int H, in
 
 // host-side re-layout of one TensorFlow-layout weight into its slot's kernel layout
 void relayout_weight(const WeightSlot& s, const float* tf_data, std::vector<float>& out);
-// k-table + source descriptors of one conv op, given the bound activation arena
-void build_conv_tables(const NetPlan& p, const OpDesc& op, const char* act_base, std::vector<int32_t>& ktab, ConvSrc srcs[3]);
+// gather-descriptor table of one conv op, given the bound activation arena
+void build_conv_tables(const NetPlan& p, const OpDesc& op, const char* act_base, std::vector<KEntry>& ktab);
 
 int conv_tile_n(int Cout);   // conv_igemm.hip
 

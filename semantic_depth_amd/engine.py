@@ -203,5 +203,15 @@ class Engine:
                 "sd_net_tensor")
         return out
 
+    def profile(self, enable: bool):
+        L.check(self.lib, self.h, self.lib.sd_profile(self.h, int(enable)), "sd_profile")
+
+    def profile_read(self):
+        """[{kernel, launches, ms, flops}] per conv-engine instantiation since the last read (synchronises)."""
+        buf = (L.sd_profile_bucket * 8)()
+        n = C.c_int()
+        L.check(self.lib, self.h, self.lib.sd_profile_read(self.h, buf, 8, C.byref(n)), "sd_profile_read")
+        return [dict(kernel=b.kernel.decode(), launches=int(b.launches), ms=float(b.ms), flops=float(b.flops)) for b in buf[:n.value]]
+
     def flops_per_image(self, net: int) -> float:
         return float(self.lib.sd_net_flops_per_image(self.h, net))

@@ -1,0 +1,68 @@
+"""CPU, world_size 2, gloo: the N>1 path — frame sharding and the all_gather of per-frame road-width records."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from semantic_depth_amd.distributed import RECORD_BYTES, gather_records, shard_range
+
+
+def test_shard_range_partitions_every_frame_once():
+    for n in (0, 1, 7, 32, 33, 255):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                lo, hi = shard_range(n, r, world)
+                assert 0 <= lo <= hi <= n and hi - lo in (n // world, n // world + 1)
+                seen += list(range(lo, hi))
+            assert seen == list(range(n))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_frames, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from semantic_depth_amd.engine import RW_DTYPE
+        lo, hi = shard_range(n_frames, rank, world)
+        rec = np.zeros(hi - lo, RW_DTYPE)
+        rec["width"] = np.arange(lo, hi) * 0.5
+        rec["n_road"] = np.arange(lo, hi) + 1000
+        rec["found"] = 1
+        local = torch.from_numpy(rec.view(np.uint8).reshape(hi - lo, RECORD_BYTES).copy())
+        allr = gather_records(local, n_frames)
+        got = allr.numpy().view(RW_DTYPE).reshape(-1)
+        ok = (len(got) == n_frames and np.array_equal(got["width"], np.arange(n_frames) * 0.5)
+              and np.array_equal(got["n_road"], np.arange(n_frames) + 1000) and bool(got["found"].all()))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [8, 7])      # even and ragged shards
+def test_gather_records_world2_gloo(n_frames):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_single_process_is_identity():
+    x = torch.zeros((3, RECORD_BYTES), dtype=torch.uint8)
+    assert gather_records(x) is x
