@@ -25,7 +25,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 H, W = 512, 1024
-F32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+# MI355X_MICROARCH.md peaks.  f32: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz.
+# bf16x2: every algorithmic product costs three dense-bf16 MFMA products (hi*hi + hi*lo + lo*hi), so the ceiling for
+# ALGORITHMIC flops is the dense bf16 peak / 3 (frac is then also executed-MFMA-flops / dense bf16 peak).
+PEAK_TFLOPS = {"f32": 157.3, "bf16x2": 2500.0 / 3.0}
+DTYPE = {"f32": "f32", "bf16x2": "bf16x2 split operands (hi+lo, 16 mantissa bits), 3 bf16 MFMA products per product, f32 accumulate"}
 
 
 def log(*a):
@@ -39,6 +43,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step (configs[3]: 32)")
     ap.add_argument("--encoder", default="resnet50")
+    ap.add_argument("--precision", default="bf16x2", choices=["f32", "bf16x2"],
+                    help="conv arithmetic: exact f32 MFMA, or split-bf16 (3 bf16 MFMA products per product, f32 accumulate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -67,7 +73,7 @@ def main():
 
     # ------------------------------------------------------------------ setup (untimed)
     t_setup = time.time()
-    eng = Engine(H, W, B, args.encoder, local_rank)
+    eng = Engine(H, W, B, args.encoder, local_rank, precision=args.precision)
     # seeded synthetic weights.  decoder_std is raised from the reference's 0.01 so that the
     # softmax > 0.5 masks of a random-weight net are non-trivial and the road chain has real work.
     wf = Wt.make_fcn8s_weights(1, decoder_std=float(os.environ.get("SD_BENCH_DECODER_STD", "0.05")))
@@ -153,9 +159,11 @@ def main():
     dom = max(buckets, key=lambda b: b["ms"])
     achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
     roofline = {
-        "bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-        "kernel": "conv_igemm_kernel (all instantiations)", "launches": tot_n,
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": round(PEAK_TFLOPS[args.precision], 1), "unit": "TFLOP/s",
+        "frac": round(achieved / PEAK_TFLOPS[args.precision], 4), "traffic": None,
+        "peak_note": ("f32 MFMA dense peak" if args.precision == "f32" else
+                      "dense bf16 MFMA peak 2500 TF/s / 3 MFMA products per algorithmic product; achieved counts algorithmic flops"),
+        "kernel": ("conv_igemm_kernel" if args.precision == "f32" else "conv_split_kernel") + " (all instantiations)", "launches": tot_n,
         "avg_launch_us": round(tot_ms * 1e3 / max(tot_n, 1), 2),
         "algorithmic_gflop_per_launch": round(tot_fl / max(tot_n, 1) / 1e9, 3),
         "conv_time_share_of_step": round(tot_ms * 1e-3 / dt, 4),
@@ -174,7 +182,7 @@ def main():
     line = {
         "metric": "fused frames/sec (FCN-8s+monodepth+pcl fusion) at 512x1024", "value": round(value, 3), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[3]: full fused pipeline (seg + depth + pcl back-projection + road width), "
                                f"batch {B} per GPU, 512x1024, monodepth-{args.encoder} on frame+flip, seeded synthetic weights",
                    "frames_per_step": world * B, "gflop_per_frame": round(flops_frame / 1e9, 2),

@@ -36,7 +36,9 @@ enum {
 
 typedef enum { SD_ENC_VGG = 0, SD_ENC_RESNET50 = 1 } sd_encoder;      /* semantic_depth.py:721-722 --encoder */
 typedef enum { SD_NET_FCN8S = 0, SD_NET_MONODEPTH = 1 } sd_net;
-typedef enum { SD_PREC_F32 = 0 } sd_precision;                         /* arithmetic of the conv stacks */
+/* arithmetic of the conv stacks: SD_PREC_F32 = exact f32 MFMA; SD_PREC_BF16X2 = every f32 operand split into two bf16
+ * (hi + lo), three bf16 MFMA products per product, f32 accumulate (~1e-5 relative; gfx950 has no TF32) */
+typedef enum { SD_PREC_F32 = 0, SD_PREC_BF16X2 = 1 } sd_precision;
 
 typedef struct sd_handle sd_handle;
 

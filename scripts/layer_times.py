@@ -7,8 +7,9 @@ from semantic_depth_amd import _lib as L, weights as Wt
 from semantic_depth_amd.engine import Engine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 enc = sys.argv[2] if len(sys.argv) > 2 else "resnet50"
+prec = sys.argv[3] if len(sys.argv) > 3 else "f32"
 H, W = 512, 1024
-eng = Engine(H, W, B, enc)
+eng = Engine(H, W, B, enc, precision=prec)
 eng.load_weights(L.SD_NET_FCN8S, Wt.make_fcn8s_weights(1, decoder_std=0.05))
 eng.load_weights(L.SD_NET_MONODEPTH, Wt.make_monodepth_weights(enc, 2))
 fr = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (B, H, W, 3), dtype=np.uint8)).cuda()

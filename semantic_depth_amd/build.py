@@ -18,6 +18,7 @@ ARCH = "gfx950"
 
 SOURCES = [
     ("conv_igemm.hip", []),
+    ("conv_split.hip", []),
     ("ops_misc.hip", []),
     ("fuse.hip", ["-ffp-contract=off"]),
     ("pcl.hip", ["-ffp-contract=off"]),

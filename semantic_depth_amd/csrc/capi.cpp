@@ -19,7 +19,7 @@ using namespace sd;
 static_assert(sizeof(RwResultDev) == sizeof(sd_rw_result), "sd_rw_result layout");
 
 struct sd_handle {
-    int device = 0, H = 0, W = 0, max_batch = 0, enc = 0, chunk = 0, cap = 0;
+    int device = 0, H = 0, W = 0, max_batch = 0, enc = 0, chunk = 0, cap = 0, prec = 0;
     NetPlan fcn, mono;
     bool bound = false;
     char* wf = nullptr;   // FCN weight arena
@@ -33,7 +33,7 @@ struct sd_handle {
     std::string err;
     // profiling (sd_profile): event pairs around conv launches
     bool prof = false;
-    struct ProfRec { int bucket; double flops; hipEvent_t a, b; const char* op; int M, N, K; };
+    struct ProfRec { const char* kernel; double flops; hipEvent_t a, b; const char* op; int M, N, K; };
     std::vector<ProfRec> prof_recs;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
     size_t prof_used = 0;
@@ -123,21 +123,23 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.residual = op.residual >= 0 ? T(op.residual) : nullptr;
                 c.out = T(op.dst);
                 c.act = op.act; c.m_fastest = op.m_fastest;
+                const bool split = h->prec == SD_PREC_BF16X2;
+                hipEvent_t ea = nullptr, eb = nullptr;
                 if (h->prof) {
                     if (h->prof_used == h->prof_pool.size()) {
                         hipEvent_t a, b;
                         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return fail(h, SD_ERR_HIP, "hipEventCreate");
                         h->prof_pool.push_back({a, b});
                     }
-                    auto ev = h->prof_pool[h->prof_used++];
-                    const int tn = conv_tile_n(c.Cout);
-                    const int bucket = (tn == 128 ? 0 : tn == 64 ? 1 : tn == 32 ? 2 : 3) * 2 + (c.vec ? 0 : 1);
-                    hipEventRecord(ev.first, s);
-                    e = launch_conv_igemm(c, s);
-                    hipEventRecord(ev.second, s);
-                    h->prof_recs.push_back({bucket, op.flops * N / p.images, ev.first, ev.second, op.name.c_str(), N * d.H * d.W, d.C, op.K});
-                } else {
-                    e = launch_conv_igemm(c, s);
+                    ea = h->prof_pool[h->prof_used].first; eb = h->prof_pool[h->prof_used].second;
+                    ++h->prof_used;
+                    hipEventRecord(ea, s);
+                }
+                e = split ? launch_conv_split(c, s) : launch_conv_igemm(c, s);
+                if (h->prof) {
+                    hipEventRecord(eb, s);
+                    h->prof_recs.push_back({split ? conv_split_kernel_name(c) : conv_igemm_kernel_name(c), op.flops * N / p.images, ea, eb,
+                                            op.name.c_str(), N * d.H * d.W, d.C, op.K});
                 }
                 break;
             }
@@ -192,7 +194,7 @@ int32_t* cnt_slot(sd_handle* h, int i) { return reinterpret_cast<int32_t*>(h->ws
 
 extern "C" {
 
-const char* sd_version(void) { return "semdepth 0.1 (gfx950, f32 MFMA)"; }
+const char* sd_version(void) { return "semdepth 0.2 (gfx950; f32 MFMA, split-bf16 MFMA)"; }
 
 const char* sd_status_string(sd_status s) {
     switch (s) {
@@ -206,15 +208,15 @@ const char* sd_status_string(sd_status s) {
 }
 
 sd_status sd_create(sd_handle** out, int device, int H, int W, int max_batch, sd_encoder enc, sd_precision prec) {
-    if (!out || H <= 0 || W <= 0 || max_batch <= 0 || prec != SD_PREC_F32) return SD_ERR_INVALID;
+    if (!out || H <= 0 || W <= 0 || max_batch <= 0 || (prec != SD_PREC_F32 && prec != SD_PREC_BF16X2)) return SD_ERR_INVALID;
     sd_handle* h = new sd_handle();
-    h->device = device; h->H = H; h->W = W; h->max_batch = max_batch; h->enc = (int)enc; h->cap = H * W;
+    h->device = device; h->H = H; h->W = W; h->max_batch = max_batch; h->enc = (int)enc; h->cap = H * W; h->prec = (int)prec;
     int chunk = 8;
     if (const char* e = std::getenv("SEMDEPTH_CHUNK")) chunk = std::max(1, atoi(e));
     h->chunk = std::min(max_batch, chunk);
     try {
-        h->fcn = build_fcn8s(h->chunk, H, W);
-        h->mono = build_monodepth(enc == SD_ENC_VGG ? 0 : 1, h->chunk, H, W);
+        h->fcn = build_fcn8s(h->chunk, H, W, h->prec);
+        h->mono = build_monodepth(enc == SD_ENC_VGG ? 0 : 1, h->chunk, H, W, h->prec);
     } catch (const std::exception& ex) {
         std::fprintf(stderr, "sd_create: %s\n", ex.what());
         delete h;
@@ -472,28 +474,29 @@ sd_status sd_profile(sd_handle* h, int enable) {
 }
 
 sd_status sd_profile_read(sd_handle* h, sd_profile_bucket* out, int cap_buckets, int* n_out) {
-    if (!h || !out || !n_out || cap_buckets < 8) return SD_ERR_INVALID;
+    if (!h || !out || !n_out || cap_buckets < 1) return SD_ERR_INVALID;
     HIPCHK(h, hipDeviceSynchronize());
-    static const char* names[8] = {"conv_igemm_kernel<2,2,4,4,true>", "conv_igemm_kernel<2,2,4,4,false>",
-                                   "conv_igemm_kernel<4,1,4,4,true>", "conv_igemm_kernel<4,1,4,4,false>",
-                                   "conv_igemm_kernel<4,1,4,2,true>", "conv_igemm_kernel<4,1,4,2,false>",
-                                   "conv_igemm_kernel<4,1,4,1,true>", "conv_igemm_kernel<4,1,4,1,false>"};
-    for (int i = 0; i < 8; ++i) {
-        std::memset(&out[i], 0, sizeof(out[i]));
-        std::strncpy(out[i].kernel, names[i], 63);
-    }
     const char* verbose = std::getenv("SEMDEPTH_PROFILE_VERBOSE");
+    int n = 0;
     for (auto& r : h->prof_recs) {
         float ms = 0.f;
         HIPCHK(h, hipEventElapsedTime(&ms, r.a, r.b));
         if (verbose && verbose[0] == '1')
             std::fprintf(stderr, "[sd_profile] %-28s M=%-8d N=%-5d K=%-6d %8.3f ms %7.2f TF/s  %s\n", r.op, r.M, r.N, r.K, ms,
-                         r.flops / (ms * 1e-3) / 1e12, names[r.bucket]);
-        out[r.bucket].launches += 1;
-        out[r.bucket].ms += ms;
-        out[r.bucket].flops += r.flops;
+                         r.flops / (ms * 1e-3) / 1e12, r.kernel);
+        int b = 0;
+        while (b < n && std::strcmp(out[b].kernel, r.kernel) != 0) ++b;
+        if (b == n) {
+            if (n == cap_buckets) continue;
+            std::memset(&out[n], 0, sizeof(out[n]));
+            std::strncpy(out[n].kernel, r.kernel, 63);
+            ++n;
+        }
+        out[b].launches += 1;
+        out[b].ms += ms;
+        out[b].flops += r.flops;
     }
-    *n_out = 8;
+    *n_out = n;
     h->prof_recs.clear();
     h->prof_used = 0;
     return SD_OK;

@@ -220,4 +220,13 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t s) {
     }
 }
 
+const char* conv_igemm_kernel_name(const ConvParams& p) {
+    switch (conv_tile_n(p.Cout)) {
+        case 128: return p.vec ? "conv_igemm_kernel<2,2,4,4,true>" : "conv_igemm_kernel<2,2,4,4,false>";
+        case 64:  return p.vec ? "conv_igemm_kernel<4,1,4,4,true>" : "conv_igemm_kernel<4,1,4,4,false>";
+        case 32:  return p.vec ? "conv_igemm_kernel<4,1,4,2,true>" : "conv_igemm_kernel<4,1,4,2,false>";
+        default:  return p.vec ? "conv_igemm_kernel<4,1,4,1,true>" : "conv_igemm_kernel<4,1,4,1,false>";
+    }
+}
+
 }  // namespace sd

@@ -38,6 +38,11 @@ struct ConvParams {
     int m_fastest;     // block order: 1 = consecutive blocks walk M (share a weight panel), 0 = walk N
 };
 hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t s);
+const char* conv_igemm_kernel_name(const ConvParams& p);
+// split-bf16 engine (conv_split.hip): wt = two bf16 planes [Kpad/8][CoutPad][8] (hi, then lo)
+hipError_t launch_conv_split(const ConvParams& p, hipStream_t s);
+const char* conv_split_kernel_name(const ConvParams& p);
+int conv_split_tile_n(int Cout);
 
 // small-N convolution (N <= 4 output channels: score 1x1 convs, monodepth disparity heads)
 struct SmallNParams {

@@ -36,7 +36,7 @@ struct Builder {
         for (auto v : shape) s.shape[i++] = v;
         size_t n = 0;
         switch (layout) {
-            case WL_IGEMM: n = (size_t)Kpad * CoutPad; break;
+            case WL_IGEMM: case WL_IGEMM_SPLIT: n = (size_t)Kpad * CoutPad; break;
             case WL_SMALLN: n = (size_t)s.shape[0] * s.shape[1] * s.shape[2] * 4; break;
             case WL_BIAS4: n = 4; break;
             default: n = 1; for (int j = 0; j < s.rank; ++j) n *= (size_t)s.shape[j];
@@ -70,9 +70,9 @@ struct Builder {
         op.k = k; op.stride = stride; op.pad = (k - 1) / 2; op.act = act; op.residual = residual;
         const int Hout = (Hin + 2 * op.pad - k) / stride + 1, Wout = (Win + 2 * op.pad - k) / stride + 1;
         op.Ctot = Ctot; op.K = k * k * Ctot; op.Kpad = (op.K + 31) / 32 * 32; op.vec = vec ? 1 : 0;
-        const int bn = conv_tile_n(Cout);
+        const int bn = p.prec ? conv_split_tile_n(Cout) : conv_tile_n(Cout);
         const int CoutPad = (Cout + bn - 1) / bn * bn;
-        op.w = wslot(wname, {k, k, Ctf, Cout}, WL_IGEMM, op.Kpad, CoutPad);
+        op.w = wslot(wname, {k, k, Ctf, Cout}, p.prec ? WL_IGEMM_SPLIT : WL_IGEMM, op.Kpad, CoutPad);
         {
             WeightSlot& ws = p.weights[op.w];
             ws.nsrc = op.nsrc;
@@ -169,9 +169,10 @@ struct Builder {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
-NetPlan build_fcn8s(int frames, int H, int W) {
+NetPlan build_fcn8s(int frames, int H, int W, int prec) {
     if (H % 32 || W % 32) throw std::runtime_error("FCN-8s needs H, W multiples of 32");
     Builder b;
+    b.p.prec = prec;
     b.p.net = "fcn8s"; b.p.frames = frames; b.p.images = frames; b.p.H = H; b.p.W = W;
     int x = b.tensor("input_pre", frames, H, W, 4);      // 4th channel is zero: float4 gathers in conv1_1
     b.p.tensors[x].Ctf = 3;
@@ -222,10 +223,11 @@ NetPlan build_fcn8s(int frames, int H, int W) {
 }
 
 // ---------------------------------------------------------------------------------------------
-NetPlan build_monodepth(int encoder, int frames, int H, int W) {
+NetPlan build_monodepth(int encoder, int frames, int H, int W, int prec) {
     const int mult = encoder == 0 ? 128 : 64;
     if (H % mult || W % mult) throw std::runtime_error("monodepth needs H, W multiples of 128 (vgg) / 64 (resnet50)");
     Builder b;
+    b.p.prec = prec;
     b.p.net = encoder == 0 ? "monodepth-vgg" : "monodepth-resnet50";
     b.p.frames = frames; b.p.images = 2 * frames; b.p.H = H; b.p.W = W;
     const int N = 2 * frames;
@@ -296,7 +298,16 @@ NetPlan build_monodepth(int encoder, int frames, int H, int W) {
 // ---------------------------------------------------------------------------------------------
 void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& out) {
     out.assign(s.bytes / sizeof(float), 0.f);
-    if (s.layout == WL_IGEMM) {
+    if (s.layout == WL_IGEMM || s.layout == WL_IGEMM_SPLIT) {
+        const bool split = s.layout == WL_IGEMM_SPLIT;
+        uint16_t* hi = reinterpret_cast<uint16_t*>(out.data());
+        uint16_t* lo = hi + (size_t)s.Kpad * s.CoutPad;
+        auto bf16 = [](float v) -> uint16_t {          // round to nearest even, like v_cvt_pk_bf16_f32
+            uint32_t u; std::memcpy(&u, &v, 4);
+            u += 0x7FFFu + ((u >> 16) & 1u);
+            return (uint16_t)(u >> 16);
+        };
+        auto bf16_to_f = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; };
         const int64_t taps = s.shape[0] * s.shape[1], Ctf = s.shape[2], Cout = s.shape[3];
         int CtotPad = 0;
         for (int i = 0; i < s.nsrc; ++i) CtotPad += s.srcCpad[i];
@@ -305,9 +316,18 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
             for (int i = 0; i < s.nsrc; ++i) {
                 for (int c = 0; c < s.srcCtf[i]; ++c) {
                     const int64_t k = tap * CtotPad + cb_pad + c;
-                    float* dst = out.data() + (size_t)(k / 4) * s.CoutPad * 4 + (k % 4);
                     const float* src = w + (tap * Ctf + cb_tf + c) * Cout;
-                    for (int64_t n = 0; n < Cout; ++n) dst[n * 4] = src[n];
+                    if (!split) {
+                        float* dst = out.data() + (size_t)(k / 4) * s.CoutPad * 4 + (k % 4);
+                        for (int64_t n = 0; n < Cout; ++n) dst[n * 4] = src[n];
+                    } else {                          // two bf16 planes [k/8][n][8]
+                        const size_t base = (size_t)(k / 8) * s.CoutPad * 8 + (k % 8);
+                        for (int64_t n = 0; n < Cout; ++n) {
+                            const uint16_t h = bf16(src[n]);
+                            hi[base + n * 8] = h;
+                            lo[base + n * 8] = bf16(src[n] - bf16_to_f(h));
+                        }
+                    }
                 }
                 cb_tf += s.srcCtf[i]; cb_pad += s.srcCpad[i];
             }

@@ -21,7 +21,7 @@ struct TensorDesc {
 };
 
 enum OpKind { OP_PRE_VGG, OP_PRE_MONO, OP_CONV, OP_SMALLN, OP_POOL2, OP_POOL3Z, OP_DECONV4_ADD, OP_HEAD16 };
-enum WLayout { WL_RAW = 0, WL_IGEMM = 1, WL_SMALLN = 2, WL_BIAS4 = 3 };
+enum WLayout { WL_RAW = 0, WL_IGEMM = 1, WL_SMALLN = 2, WL_BIAS4 = 3, WL_IGEMM_SPLIT = 4 };
 
 struct WeightSlot {
     std::string name;
@@ -56,6 +56,7 @@ struct NetPlan {
     int frames = 0;        // frames per chunk
     int images = 0;        // images per chunk (monodepth: 2 per frame)
     int H = 0, W = 0;
+    int prec = 0;          // 0: exact f32 MFMA, 1: split-bf16 (3 bf16 MFMA products per f32 product)
     std::vector<TensorDesc> tensors;
     std::vector<OpDesc> ops;
     std::vector<WeightSlot> weights;
@@ -66,8 +67,8 @@ struct NetPlan {
     int t_input = -1, t_output = -1;
 };
 
-NetPlan build_fcn8s(int frames, int H, int W);
-NetPlan build_monodepth(int encoder /*0 vgg, 1 resnet50*/, int frames, int H, int W);
+NetPlan build_fcn8s(int frames, int H, int W, int prec);
+NetPlan build_monodepth(int encoder /*0 vgg, 1 resnet50*/, int frames, int H, int W, int prec);
 
 // host-side re-layout of one TensorFlow-layout weight into its slot's kernel layout
 void relayout_weight(const WeightSlot& s, const float* tf_data, std::vector<float>& out);

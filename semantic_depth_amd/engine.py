@@ -56,7 +56,7 @@ def _ptr(t):
 
 
 class Engine:
-    def __init__(self, H: int, W: int, max_batch: int = 1, encoder: str = "resnet50", device: int = 0):
+    def __init__(self, H: int, W: int, max_batch: int = 1, encoder: str = "resnet50", device: int = 0, precision: str = "f32"):
         if not torch.cuda.is_available():
             raise RuntimeError("semantic_depth_amd.Engine needs a GPU (MI355X); there is no CPU fallback")
         self.lib = L.load()
@@ -65,7 +65,9 @@ class Engine:
         torch.cuda.set_device(self.device)
         h = C.c_void_p()
         enc = {"vgg": L.SD_ENC_VGG, "resnet50": L.SD_ENC_RESNET50}[encoder]
-        st = self.lib.sd_create(C.byref(h), device, H, W, max_batch, enc, L.SD_PREC_F32)
+        self.precision = precision
+        prec = {"f32": L.SD_PREC_F32, "bf16x2": L.SD_PREC_BF16X2}[precision]
+        st = self.lib.sd_create(C.byref(h), device, H, W, max_batch, enc, prec)
         L.check(self.lib, None, st, f"sd_create(H={H}, W={W}, max_batch={max_batch}, {encoder})")
         self.h = h
         fw, mw, ws = C.c_size_t(), C.c_size_t(), C.c_size_t()
@@ -208,9 +210,9 @@ class Engine:
 
     def profile_read(self):
         """[{kernel, launches, ms, flops}] per conv-engine instantiation since the last read (synchronises)."""
-        buf = (L.sd_profile_bucket * 8)()
+        buf = (L.sd_profile_bucket * 16)()
         n = C.c_int()
-        L.check(self.lib, self.h, self.lib.sd_profile_read(self.h, buf, 8, C.byref(n)), "sd_profile_read")
+        L.check(self.lib, self.h, self.lib.sd_profile_read(self.h, buf, 16, C.byref(n)), "sd_profile_read")
         return [dict(kernel=b.kernel.decode(), launches=int(b.launches), ms=float(b.ms), flops=float(b.flops)) for b in buf[:n.value]]
 
     def flops_per_image(self, net: int) -> float:

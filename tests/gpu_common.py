@@ -9,12 +9,12 @@ from semantic_depth_amd.engine import Camera, Engine, RoadWidthParams  # noqa: F
 _cache = {}
 
 
-def engine(H, W_, max_batch=1, encoder="resnet50", fcn_kw=None, mono_kw=None, load=("fcn", "mono")):
+def engine(H, W_, max_batch=1, encoder="resnet50", fcn_kw=None, mono_kw=None, load=("fcn", "mono"), precision="f32"):
     """engines are cached per configuration; weights are seeded (seed 1 FCN, seed 2 monodepth)."""
-    key = (H, W_, max_batch, encoder, tuple(sorted((fcn_kw or {}).items())), tuple(sorted((mono_kw or {}).items())), load)
+    key = (H, W_, max_batch, encoder, tuple(sorted((fcn_kw or {}).items())), tuple(sorted((mono_kw or {}).items())), load, precision)
     if key in _cache:
         return _cache[key]
-    eng = Engine(H, W_, max_batch, encoder)
+    eng = Engine(H, W_, max_batch, encoder, precision=precision)
     wf = wm = None
     if "fcn" in load:
         wf = W.make_fcn8s_weights(1, **(fcn_kw or {}))

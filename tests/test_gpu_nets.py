@@ -25,9 +25,13 @@ def _frames(B, H, W, seed=0):
     return np.random.default_rng(seed).integers(0, 256, (B, H, W, 3), dtype=np.uint8)
 
 
-def test_fcn8s_matches_oracle():
+PRECISIONS = ["f32", "bf16x2"]      # exact f32 MFMA / split-bf16 MFMA (3 bf16 products per product)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_fcn8s_matches_oracle(precision):
     H, W, B = 64, 128, 2
-    eng, wf, _ = engine(H, W, B, "resnet50", fcn_kw=dict(decoder_std=0.05, bias_std=0.1), load=("fcn",))
+    eng, wf, _ = engine(H, W, B, "resnet50", fcn_kw=dict(decoder_std=0.05, bias_std=0.1), load=("fcn",), precision=precision)
     fr = _frames(B, H, W)
     out = eng.fcn8s_forward(dev(fr), want_logits=True)
     ref, taps = nets.fcn8s_forward(fr, wf, return_taps=True)
@@ -38,7 +42,7 @@ def test_fcn8s_matches_oracle():
         assert relerr(got, taps[key]) < TOL, (name, relerr(got, taps[key]))
     lg = out["logits"].cpu().numpy()
     e = relerr(lg, ref)
-    print("fcn8s logits rel err", e)
+    print("fcn8s logits rel err", precision, e)
     assert e < TOL
     # the head's softmax / thresholds / argmax are exact functions of its own logits ...
     _, road, fence, am = nets.softmax_masks(lg)
@@ -53,10 +57,12 @@ def test_fcn8s_matches_oracle():
     assert 0.02 < road_r.mean() < 0.98          # the masks are not trivial
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("encoder,H,W", [("vgg", 128, 256), ("resnet50", 64, 128), ("resnet50", 128, 256)])
-def test_monodepth_matches_oracle(encoder, H, W):
+def test_monodepth_matches_oracle(encoder, H, W, precision):
     B = 2
-    eng, _, wm = engine(H, W, B, encoder, mono_kw=dict(gain=1.5 if encoder == "vgg" else 1.0, bias_std=0.05), load=("mono",))
+    eng, _, wm = engine(H, W, B, encoder, mono_kw=dict(gain=1.5 if encoder == "vgg" else 1.0, bias_std=0.05), load=("mono",),
+                        precision=precision)
     fr = _frames(B, H, W, seed=3)
     pp, raw = eng.monodepth_forward(dev(fr), want_raw=True)
     pp, raw = pp.cpu().numpy(), raw.cpu().numpy()
@@ -66,7 +72,7 @@ def test_monodepth_matches_oracle(encoder, H, W):
         scales = nets.monodepth_forward(pair, wm, encoder, all_scales=True)
         ref_raw = scales[1][..., 0]
         e = relerr(raw[b], ref_raw)
-        print(encoder, H, W, "disp rel err", e, "range", ref_raw.min(), ref_raw.max())
+        print(encoder, precision, H, W, "disp rel err", e, "range", ref_raw.min(), ref_raw.max())
         assert e < TOL
         assert ref_raw.std() > 1e-3                                  # not a constant map
         ref_pp = fusion.post_processing(ref_raw.astype(np.float32)).astype(np.float32)
@@ -79,10 +85,11 @@ def test_monodepth_matches_oracle(encoder, H, W):
                 assert relerr(got[2 * b:2 * b + 2], scales[lvl]) < TOL, lvl
 
 
-def test_batch_and_chunk_independence():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_batch_and_chunk_independence(precision):
     """B=9 > chunk(8): two chunks; every frame's outputs equal the solo run bit for bit (kernels are deterministic)."""
     H, W, B = 128, 256, 9
-    eng, _, _ = engine(H, W, B, "resnet50", fcn_kw=dict(decoder_std=0.05), load=("fcn", "mono"))
+    eng, _, _ = engine(H, W, B, "resnet50", fcn_kw=dict(decoder_std=0.05), load=("fcn", "mono"), precision=precision)
     fr = dev(_frames(B, H, W, seed=8))
     seg = eng.fcn8s_forward(fr, want_logits=True)
     pp = eng.monodepth_forward(fr)
