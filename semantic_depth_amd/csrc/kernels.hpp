@@ -50,7 +50,7 @@ struct SmallNParams {
     int N, H, W, C;
     int k;              // 1 or 3 (stride 1, zero pad (k-1)/2)
     int nout;           // computed output channels (<= 4)
-    const float* wt;    // [k*k*C][4] (zero padded to 4 outputs)
+    const float* wt;    // [nout][k*k*C]
     const float* bias;  // [4]
     float* out;         // [N,H,W,nout]
     int act;

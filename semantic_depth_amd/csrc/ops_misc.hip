@@ -101,7 +101,7 @@ hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C
 
 // ---------------------------------------------------------------------------------------------
 // K6 / K15: convolution with <= 4 output channels, k in {1,3}, stride 1, zero pad (k-1)/2.
-//   THREAD variant: one thread per output pixel, weights [K][4] staged in LDS (K*16 B <= 64 KiB)
+//   THREAD variant: one thread per output pixel, weights [nout][K] staged in LDS
 //   WAVE   variant: one wave per output pixel, lanes stride over the channel quads, shuffle reduction
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float smalln_act(float v, int act) {
@@ -111,10 +111,12 @@ __device__ __forceinline__ float smalln_act(float v, int act) {
     return v;
 }
 
+// weights are laid out [nout][K] (K = k*k*C): one broadcast ds_read_b128 + 4 FMAs per output channel and input quad
+template <int NOUT>
 __global__ __launch_bounds__(256) void conv_smalln_thread_kernel(const SmallNParams p) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];   // [K][4]
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [NOUT][K]
     const int K = p.k * p.k * p.C;
-    for (int i = threadIdx.x; i < K; i += 256) reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(p.wt)[i];
+    for (int i = threadIdx.x; i < NOUT * K / 4; i += 256) reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(p.wt)[i];
     __syncthreads();
     long pix = (long)blockIdx.x * 256 + threadIdx.x;
     long npix = (long)p.N * p.H * p.W;
@@ -124,7 +126,9 @@ __global__ __launch_bounds__(256) void conv_smalln_thread_kernel(const SmallNPar
     int y = (int)(r % p.H);
     int n = (int)(r / p.H);
     const int pad = (p.k - 1) / 2;
-    f32x4 acc = *reinterpret_cast<const f32x4*>(p.bias);
+    float acc[NOUT];
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) acc[j] = p.bias[j];
     const int C4 = p.C / 4;
     for (int ky = 0; ky < p.k; ++ky) {
         int iy = y + ky - pad;
@@ -133,16 +137,21 @@ __global__ __launch_bounds__(256) void conv_smalln_thread_kernel(const SmallNPar
             int ix = x + kx - pad;
             if (ix < 0 || ix >= p.W) continue;
             const f32x4* xp = reinterpret_cast<const f32x4*>(p.x + (((long)n * p.H + iy) * p.W + ix) * p.C);
-            const f32x4* wp = reinterpret_cast<const f32x4*>(wl) + (ky * p.k + kx) * p.C;
+            const f32x4* wp = reinterpret_cast<const f32x4*>(wl) + (ky * p.k + kx) * C4;
+#pragma unroll 4
             for (int c = 0; c < C4; ++c) {
-                f32x4 v = xp[c];
+                const f32x4 v = xp[c];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc += v[j] * wp[c * 4 + j];
+                for (int j = 0; j < NOUT; ++j) {
+                    const f32x4 w = wp[j * (K / 4) + c];
+                    acc[j] += v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+                }
             }
         }
     }
-    float* o = p.out + pix * p.nout;
-    for (int j = 0; j < p.nout; ++j) o[j] = smalln_act(acc[j], p.act);
+    float* o = p.out + pix * NOUT;
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) o[j] = smalln_act(acc[j], p.act);
 }
 
 __global__ __launch_bounds__(256) void conv_smalln_wave_kernel(const SmallNParams p) {
@@ -164,11 +173,16 @@ __global__ __launch_bounds__(256) void conv_smalln_wave_kernel(const SmallNParam
             int ix = x + kx - pad;
             if (ix < 0 || ix >= p.W) continue;
             const f32x4* xp = reinterpret_cast<const f32x4*>(p.x + (((long)n * p.H + iy) * p.W + ix) * p.C);
-            const f32x4* wp = reinterpret_cast<const f32x4*>(p.wt) + (long)(ky * p.k + kx) * p.C;
+            const f32x4* wp = reinterpret_cast<const f32x4*>(p.wt) + (long)(ky * p.k + kx) * C4;
+            const int K4 = p.k * p.k * C4;
             for (int c = lane; c < C4; c += 64) {
-                f32x4 v = xp[c];
+                const f32x4 v = xp[c];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc += v[j] * wp[c * 4 + j];
+                for (int j = 0; j < 4; ++j)
+                    if (j < p.nout) {
+                        const f32x4 w = wp[(long)j * K4 + c];
+                        acc[j] += v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+                    }
             }
         }
     }
@@ -186,7 +200,14 @@ hipError_t launch_conv_smalln(const SmallNParams& p, hipStream_t s) {
     const long npix = (long)p.N * p.H * p.W;
     const int K = p.k * p.k * p.C;
     if (K <= 2048) {
-        hipLaunchKernelGGL(conv_smalln_thread_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), (size_t)K * 16, s, p);
+        const dim3 grid((unsigned)((npix + 255) / 256));
+        const size_t lds = (size_t)K * 4 * p.nout;
+        switch (p.nout) {
+            case 1: hipLaunchKernelGGL(conv_smalln_thread_kernel<1>, grid, dim3(256), lds, s, p); break;
+            case 2: hipLaunchKernelGGL(conv_smalln_thread_kernel<2>, grid, dim3(256), lds, s, p); break;
+            case 3: hipLaunchKernelGGL(conv_smalln_thread_kernel<3>, grid, dim3(256), lds, s, p); break;
+            default: hipLaunchKernelGGL(conv_smalln_thread_kernel<4>, grid, dim3(256), lds, s, p); break;
+        }
     } else {
         hipLaunchKernelGGL(conv_smalln_wave_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, p);
     }

@@ -343,10 +343,15 @@ hipError_t launch_record_counts(RwResultDev* res, int B, const int32_t* n_road, 
 // [UPSTREAM Open3D legacy RemoveStatisticalOutliers / RemoveRadiusOutliers, parity unpinned — see oracle/o3d.py]
 // Exact k-NN / radius counts in float64 over a uniform grid: points are binned (clamped at the grid faces,
 // which keeps every lower bound valid), counting-sorted by cell, and every point searches Chebyshev shells
-// of cells until its k-th distance is proven final.  d2 := (dx*dx + dy*dy) + dz*dz, no FMA.
+// of cells until its result is proven final.  d2 := (dx*dx + dy*dy) + dz*dz, no FMA.
+//   statistical filter: cell size adapts to the cloud (~6 points per cell), shells until kth d2 <= (shell*cell)^2
+//   radius filter     : cell = radius/4; cells entirely inside the ball are counted without touching their points,
+//                       cells entirely outside are skipped, the search stops as soon as the count exceeds nb_points
 constexpr int GRID_CELLS = 1 << 19;
 constexpr int KMAX = 16;
 constexpr int SOR_RMAX = 16;       // shells searched before the brute-force fallback
+constexpr int SCAN_SEG = 2048;     // cells per scan segment
+constexpr int SCAN_NSEG = GRID_CELLS / SCAN_SEG;
 
 struct GridMeta { double ox, oy, oz, inv; double cell; int gx, gy, gz, pad; };
 
@@ -354,6 +359,7 @@ struct O3dScratch {       // carved from one arena, per-frame strides
     GridMeta* meta;       // [B]
     int* cell_cnt;        // [B][GRID_CELLS]      counts, then scatter cursors
     int* cell_start;      // [B][GRID_CELLS + 1]
+    int* seg_sum;         // [B][SCAN_NSEG]
     int* cell_of;         // [B][cap]
     int* sidx;            // [B][cap]  original index of the j-th sorted point
     float* sxyz;          // [B][cap][3]
@@ -361,8 +367,8 @@ struct O3dScratch {       // carved from one arena, per-frame strides
     uint8_t* keep;        // [B][cap]
 };
 size_t o3d_scratch_bytes(int B, int cap) {
-    size_t per = sizeof(GridMeta) + (size_t)GRID_CELLS * 4 + (size_t)(GRID_CELLS + 1) * 4 + (size_t)cap * (4 + 4 + 12 + 8 + 1);
-    return (size_t)B * per + 4096;
+    size_t per = sizeof(GridMeta) + (size_t)GRID_CELLS * 4 + (size_t)(GRID_CELLS + 1) * 4 + SCAN_NSEG * 4 + (size_t)cap * (4 + 4 + 12 + 8 + 1);
+    return (size_t)B * per + 8192;
 }
 static O3dScratch carve(void* base, int B, int cap) {
     O3dScratch s;
@@ -372,6 +378,7 @@ static O3dScratch carve(void* base, int B, int cap) {
     s.mean_d = (double*)take((size_t)B * cap * 8);
     s.cell_cnt = (int*)take((size_t)B * GRID_CELLS * 4);
     s.cell_start = (int*)take((size_t)B * (GRID_CELLS + 1) * 4);
+    s.seg_sum = (int*)take((size_t)B * SCAN_NSEG * 4);
     s.cell_of = (int*)take((size_t)B * cap * 4);
     s.sidx = (int*)take((size_t)B * cap * 4);
     s.sxyz = (float*)take((size_t)B * cap * 12);
@@ -385,64 +392,54 @@ __device__ __forceinline__ int cell_coord(double p, double o, double inv, int g)
     if (t > (double)(g - 1)) t = (double)(g - 1);
     return (int)t;
 }
+__device__ __forceinline__ int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
-// bounding box (finite coordinates only) -> grid origin / dims
-__global__ __launch_bounds__(TB) void grid_meta_kernel(CloudView in, int cap, double cell, int gx, int gy, int gz, GridMeta* meta) {
+// bounding box (finite coordinates only) -> cell size, grid dims, origin.  fixed_cell > 0: use it; else adapt to ~6 points/cell
+__global__ __launch_bounds__(TB) void grid_meta_kernel(CloudView in, int cap, double fixed_cell, GridMeta* meta) {
     const int b = blockIdx.x;
     const float* xyz = in.xyz + (size_t)b * cap * 3;
     const int n = min(in.n[b], cap);
-    __shared__ float smin[3][NW];
-    float mn[3] = {INFINITY, INFINITY, INFINITY};
+    __shared__ float smin[3][NW], smax[3][NW];
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = threadIdx.x; i < n; i += TB)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const float v = xyz[(size_t)i * 3 + j];
-            if (v > -INFINITY && v < mn[j]) mn[j] = v;
+            if (v > -INFINITY && v < INFINITY) { mn[j] = fminf(mn[j], v); mx[j] = fmaxf(mx[j], v); }
         }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mn[j] = fminf(mn[j], __shfl_xor(mn[j], o));
-        if ((threadIdx.x & 63) == 0) smin[j][threadIdx.x >> 6] = mn[j];
+        for (int o = 32; o > 0; o >>= 1) { mn[j] = fminf(mn[j], __shfl_xor(mn[j], o)); mx[j] = fmaxf(mx[j], __shfl_xor(mx[j], o)); }
+        if ((threadIdx.x & 63) == 0) { smin[j][threadIdx.x >> 6] = mn[j]; smax[j][threadIdx.x >> 6] = mx[j]; }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        double ext[3];
         for (int j = 0; j < 3; ++j) {
-            float m = INFINITY;
-            for (int w = 0; w < NW; ++w) m = fminf(m, smin[j][w]);
-            mn[j] = (m == INFINITY) ? 0.f : m;
+            float a = INFINITY, c = -INFINITY;
+            for (int w = 0; w < NW; ++w) { a = fminf(a, smin[j][w]); c = fmaxf(c, smax[j][w]); }
+            if (a == INFINITY) { a = 0.f; c = 0.f; }
+            mn[j] = a; mx[j] = c;
+            ext[j] = (double)c - (double)a;
+        }
+        double cell = fixed_cell;
+        if (!(cell > 0.0)) {
+            const double vol = fmax(ext[0], 0.05) * fmax(ext[1], 0.05) * fmax(ext[2], 0.05);
+            cell = cbrt(6.0 * vol / (double)max(n, 1));
+            cell = fmin(fmax(cell, 0.01), 4.0);
         }
         GridMeta g;
+        g.cell = cell; g.inv = 1.0 / cell; g.pad = 0;
+        // dims: powers of two with gx*gy*gz == GRID_CELLS; x and y sized to the box (clamped), z takes the rest
+        const int gy = min(pow2ceil((int)fmin(ext[1] / cell + 2.0, 4096.0)), 64);
+        const int gx = min(pow2ceil((int)fmin(ext[0] / cell + 2.0, 4096.0)), 256);
+        g.gx = gx; g.gy = gy; g.gz = GRID_CELLS / (gx * gy);
         g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
-        // z grows toward the camera (scene z is negative, dense near z ~ -z_cut): anchor the z grid at the far
-        // end only if everything fits; otherwise anchor so that the NEAR (dense) end is resolved and the far tail clamps
-        g.cell = cell; g.inv = 1.0 / cell; g.gx = gx; g.gy = gy; g.gz = gz; g.pad = 0;
-        meta[b] = g;
-    }
-}
-
-// max-z anchored variant needs the max too; keep it simple: second pass computes max z and shifts oz so that
-// the top cell holds max z.  (Dense road points sit at the high-z end.)
-__global__ __launch_bounds__(TB) void grid_anchor_kernel(CloudView in, int cap, GridMeta* meta) {
-    const int b = blockIdx.x;
-    const float* xyz = in.xyz + (size_t)b * cap * 3;
-    const int n = min(in.n[b], cap);
-    __shared__ float smax[NW];
-    float mx = -INFINITY;
-    for (int i = threadIdx.x; i < n; i += TB) {
-        const float v = xyz[(size_t)i * 3 + 2];
-        if (v < INFINITY && v > mx) mx = v;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 0; w < NW; ++w) mx = fmaxf(mx, smax[w]);
-        if (mx == -INFINITY) mx = 0.f;
-        GridMeta g = meta[b];
-        const double span = g.cell * (double)g.gz;
-        if ((double)mx - g.oz > span) g.oz = (double)mx - span + 0.5 * g.cell;
+        // scene z is negative and dense near the camera (large z): if the z range does not fit, anchor the grid at the
+        // near end so the dense part is resolved and the far tail clamps into the first layer
+        const double span = cell * (double)g.gz;
+        if (ext[2] > span) g.oz = (double)mx[2] - span + 0.5 * cell;
         meta[b] = g;
     }
 }
@@ -461,30 +458,57 @@ __global__ __launch_bounds__(256) void grid_count_kernel(CloudView in, int cap, 
     atomicAdd(&cell_cnt[(size_t)b * GRID_CELLS + c], 1);
 }
 
-__global__ __launch_bounds__(TB) void grid_scan_kernel(const GridMeta* meta, int* cell_cnt, int* cell_start) {
-    const int b = blockIdx.x, t = threadIdx.x;
-    const GridMeta g = meta[b];
-    const int cells = g.gx * g.gy * g.gz;
-    int* cnt = cell_cnt + (size_t)b * GRID_CELLS;
-    int* st = cell_start + (size_t)b * (GRID_CELLS + 1);
-    const int per = (cells + TB - 1) / TB;
-    int s = 0;
-    for (int j = 0; j < per; ++j) { const int k = t * per + j; if (k < cells) s += cnt[k]; }
-    __shared__ int ps[TB];
-    ps[t] = s;
+// exclusive scan of the per-frame cell counts in three parallel passes (segment sums, scan of sums, write-back)
+__global__ __launch_bounds__(256) void grid_scan_a_kernel(const int* cell_cnt, int* seg_sum) {
+    const int b = blockIdx.y, seg = blockIdx.x, t = threadIdx.x;
+    const int4* c = reinterpret_cast<const int4*>(cell_cnt + (size_t)b * GRID_CELLS + (size_t)seg * SCAN_SEG) + t * 2;
+    const int4 a = c[0], d = c[1];
+    int s = a.x + a.y + a.z + a.w + d.x + d.y + d.z + d.w;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    __shared__ int ws[4];
+    if ((t & 63) == 0) ws[t >> 6] = s;
     __syncthreads();
-    for (int off = 1; off < TB; off <<= 1) {
-        int a = t >= off ? ps[t - off] : 0;
+    if (t == 0) seg_sum[(size_t)b * SCAN_NSEG + seg] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+__global__ __launch_bounds__(SCAN_NSEG) void grid_scan_b_kernel(int* seg_sum, int* cell_start) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    __shared__ int ps[SCAN_NSEG];
+    const int v = seg_sum[(size_t)b * SCAN_NSEG + t];
+    ps[t] = v;
+    __syncthreads();
+    for (int off = 1; off < SCAN_NSEG; off <<= 1) {
+        const int a = t >= off ? ps[t - off] : 0;
         __syncthreads();
         ps[t] += a;
         __syncthreads();
     }
-    int run = ps[t] - s;
-    for (int j = 0; j < per; ++j) {
-        const int k = t * per + j;
-        if (k < cells) { st[k] = run; run += cnt[k]; cnt[k] = 0; }   // counts become scatter cursors
+    seg_sum[(size_t)b * SCAN_NSEG + t] = ps[t] - v;          // exclusive
+    if (t == SCAN_NSEG - 1) cell_start[(size_t)b * (GRID_CELLS + 1) + GRID_CELLS] = ps[t];
+}
+__global__ __launch_bounds__(256) void grid_scan_c_kernel(int* cell_cnt, const int* seg_sum, int* cell_start) {
+    const int b = blockIdx.y, seg = blockIdx.x, t = threadIdx.x;
+    int4* c = reinterpret_cast<int4*>(cell_cnt + (size_t)b * GRID_CELLS + (size_t)seg * SCAN_SEG) + t * 2;
+    const int4 a = c[0], d = c[1];
+    const int v[8] = {a.x, a.y, a.z, a.w, d.x, d.y, d.z, d.w};
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+    __shared__ int ps[256];
+    ps[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int x = t >= off ? ps[t - off] : 0;
+        __syncthreads();
+        ps[t] += x;
+        __syncthreads();
     }
-    if (t == TB - 1) st[cells] = ps[TB - 1];
+    int run = seg_sum[(size_t)b * SCAN_NSEG + seg] + ps[t] - s;
+    int* st = cell_start + (size_t)b * (GRID_CELLS + 1) + (size_t)seg * SCAN_SEG + t * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { st[j] = run; run += v[j]; }
+    c[0] = make_int4(0, 0, 0, 0);       // counts become scatter cursors
+    c[1] = make_int4(0, 0, 0, 0);
 }
 
 __global__ __launch_bounds__(256) void grid_scatter_kernel(CloudView in, int cap, int* cell_cnt, const int* cell_start,
@@ -556,12 +580,18 @@ __global__ __launch_bounds__(256) void sor_knn_kernel(CloudView in, int cap, con
                 if (y < 0 || y >= g.gy) continue;
                 const bool face = (dz == -r || dz == r || dy == -r || dy == r);
                 const int step = face ? 1 : (r == 0 ? 1 : 2 * r);    // interior rows: only dx = -r and dx = +r
-                for (int dx = -r; dx <= r; dx += step) {
-                    const int x = cx + dx;
-                    if (x < 0 || x >= g.gx) continue;
-                    const int c = (z * g.gy + y) * g.gx + x;
-                    const int e = st[c + 1];
-                    for (int t = st[c]; t < e; ++t) top.push(dist2(qx, qy, qz, pts + (size_t)t * 3));
+                const int rowbase = (z * g.gy + y) * g.gx;
+                if (face) {                                           // a full row of cells is one contiguous point range
+                    const int x0 = max(cx - r, 0), x1 = min(cx + r, g.gx - 1);
+                    const int e = st[rowbase + x1 + 1];
+                    for (int t = st[rowbase + x0]; t < e; ++t) top.push(dist2(qx, qy, qz, pts + (size_t)t * 3));
+                } else {
+                    for (int dx = -r; dx <= r; dx += step) {
+                        const int x = cx + dx;
+                        if (x < 0 || x >= g.gx) continue;
+                        const int e = st[rowbase + x + 1];
+                        for (int t = st[rowbase + x]; t < e; ++t) top.push(dist2(qx, qy, qz, pts + (size_t)t * 3));
+                    }
                 }
             }
         }
@@ -596,6 +626,20 @@ __global__ __launch_bounds__(TB) void sor_select_kernel(CloudView in, CloudOut o
     }, L);
 }
 
+// per-axis squared distance bounds from coordinate q to grid layer idx (box slightly inflated: a point may sit an ulp
+// outside its nominal cell).  Clamped face layers are unbounded outward.
+__device__ __forceinline__ void axis_bounds(double q, double o, double cell, int idx, int g, double& dmin, double& dmax) {
+    const double eps = 1e-9 * cell;
+    const double lo = o + (double)idx * cell - eps, hi = o + (double)(idx + 1) * cell + eps;
+    const bool open_lo = idx == 0, open_hi = idx == g - 1;
+    double a = 0.0;
+    if (!open_lo && q < lo) a = lo - q;
+    if (!open_hi && q > hi) a = q - hi;
+    dmin = a;
+    dmax = (open_lo || open_hi) ? INFINITY : fmax(q - lo, hi - q);
+}
+
+constexpr int ROR_RINGS = 4;       // cell = radius / 4
 __global__ __launch_bounds__(256) void ror_count_kernel(CloudView in, int cap, const GridMeta* meta, const int* cell_start,
                                                         const int* sidx, const float* sxyz, int nb, double r2, uint8_t* keep) {
     const int b = blockIdx.y;
@@ -609,18 +653,35 @@ __global__ __launch_bounds__(256) void ror_count_kernel(CloudView in, int cap, c
     const double qx = q[0], qy = q[1], qz = q[2];
     const int cx = cell_coord(qx, g.ox, g.inv, g.gx), cy = cell_coord(qy, g.oy, g.inv, g.gy), cz = cell_coord(qz, g.oz, g.inv, g.gz);
     int cnt = 0;
-    for (int dz = -1; dz <= 1 && cnt <= nb; ++dz) {
-        const int z = cz + dz;
-        if (z < 0 || z >= g.gz) continue;
-        for (int dy = -1; dy <= 1 && cnt <= nb; ++dy) {
-            const int y = cy + dy;
-            if (y < 0 || y >= g.gy) continue;
-            for (int dx = -1; dx <= 1 && cnt <= nb; ++dx) {
-                const int x = cx + dx;
-                if (x < 0 || x >= g.gx) continue;
-                const int c = (z * g.gy + y) * g.gx + x;
-                const int e = st[c + 1];
-                for (int t = st[c]; t < e && cnt <= nb; ++t) cnt += dist2(qx, qy, qz, pts + (size_t)t * 3) < r2;
+    for (int r = 0; r <= ROR_RINGS && cnt <= nb; ++r) {
+        for (int dz = -r; dz <= r && cnt <= nb; ++dz) {
+            const int z = cz + dz;
+            if (z < 0 || z >= g.gz) continue;
+            double zmin, zmax;
+            axis_bounds(qz, g.oz, g.cell, z, g.gz, zmin, zmax);
+            if (zmin * zmin > r2) continue;
+            for (int dy = -r; dy <= r && cnt <= nb; ++dy) {
+                const int y = cy + dy;
+                if (y < 0 || y >= g.gy) continue;
+                double ymin, ymax;
+                axis_bounds(qy, g.oy, g.cell, y, g.gy, ymin, ymax);
+                const double yzmin = ymin * ymin + zmin * zmin;
+                if (yzmin > r2) continue;
+                const double yzmax = ymax * ymax + zmax * zmax;
+                const bool face = (dz == -r || dz == r || dy == -r || dy == r);
+                const int step = face ? 1 : (r == 0 ? 1 : 2 * r);
+                for (int dx = -r; dx <= r && cnt <= nb; dx += step) {
+                    const int x = cx + dx;
+                    if (x < 0 || x >= g.gx) continue;
+                    const int c = (z * g.gy + y) * g.gx + x;
+                    const int s0 = st[c], e = st[c + 1];
+                    if (s0 == e) continue;
+                    double xmin, xmax;
+                    axis_bounds(qx, g.ox, g.cell, x, g.gx, xmin, xmax);
+                    if (xmin * xmin + yzmin > r2) continue;            // the whole cell is outside the ball
+                    if (xmax * xmax + yzmax < r2) { cnt += e - s0; continue; }   // the whole cell is inside
+                    for (int t = s0; t < e && cnt <= nb; ++t) cnt += dist2(qx, qy, qz, pts + (size_t)t * 3) < r2;
+                }
             }
         }
     }
@@ -633,20 +694,21 @@ __global__ __launch_bounds__(TB) void keep_select_kernel(CloudView in, CloudOut 
     block_compact(xyz, rgb, n, oxyz, orgb, on, cap, [=](int i, float, float, float) { return kp[i] != 0; }, L);
 }
 
-static void build_grid(CloudView in, int B, int cap, double cell, int gx, int gy, int gz, const O3dScratch& sc, hipStream_t s) {
+static void build_grid(CloudView in, int B, int cap, double fixed_cell, const O3dScratch& sc, hipStream_t s) {
     hipMemsetAsync(sc.cell_cnt, 0, (size_t)B * GRID_CELLS * 4, s);
-    hipLaunchKernelGGL(grid_meta_kernel, dim3(B), dim3(TB), 0, s, in, cap, cell, gx, gy, gz, sc.meta);
-    hipLaunchKernelGGL(grid_anchor_kernel, dim3(B), dim3(TB), 0, s, in, cap, sc.meta);
+    hipLaunchKernelGGL(grid_meta_kernel, dim3(B), dim3(TB), 0, s, in, cap, fixed_cell, sc.meta);
     dim3 grid((cap + 255) / 256, B);
     hipLaunchKernelGGL(grid_count_kernel, grid, dim3(256), 0, s, in, cap, sc.meta, sc.cell_cnt, sc.cell_of);
-    hipLaunchKernelGGL(grid_scan_kernel, dim3(B), dim3(TB), 0, s, sc.meta, sc.cell_cnt, sc.cell_start);
+    hipLaunchKernelGGL(grid_scan_a_kernel, dim3(SCAN_NSEG, B), dim3(256), 0, s, sc.cell_cnt, sc.seg_sum);
+    hipLaunchKernelGGL(grid_scan_b_kernel, dim3(B), dim3(SCAN_NSEG), 0, s, sc.seg_sum, sc.cell_start);
+    hipLaunchKernelGGL(grid_scan_c_kernel, dim3(SCAN_NSEG, B), dim3(256), 0, s, sc.cell_cnt, sc.seg_sum, sc.cell_start);
     hipLaunchKernelGGL(grid_scatter_kernel, grid, dim3(256), 0, s, in, cap, sc.cell_cnt, sc.cell_start, sc.cell_of, sc.sidx, sc.sxyz);
 }
 
 hipError_t launch_sor(CloudView in, CloudOut out, int B, int cap, int k, double ratio, void* scratch, double* mean_out, hipStream_t s) {
     if (k > KMAX) return hipErrorInvalidValue;
     O3dScratch sc = carve(scratch, B, cap);
-    build_grid(in, B, cap, 0.1, 128, 8, 512, sc, s);
+    build_grid(in, B, cap, 0.0, sc, s);
     double* md = mean_out ? mean_out : sc.mean_d;
     hipLaunchKernelGGL(sor_knn_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx, sc.sxyz, k, md);
     hipLaunchKernelGGL(sor_select_kernel, dim3(B), dim3(TB), 0, s, in, out, cap, ratio, md);
@@ -655,7 +717,7 @@ hipError_t launch_sor(CloudView in, CloudOut out, int B, int cap, int k, double 
 
 hipError_t launch_ror(CloudView in, CloudOut out, int B, int cap, int nb, double radius, void* scratch, hipStream_t s) {
     O3dScratch sc = carve(scratch, B, cap);
-    build_grid(in, B, cap, radius * (1.0 + 1e-6), 64, 16, 512, sc, s);
+    build_grid(in, B, cap, radius / ROR_RINGS * (1.0 + 1e-6), sc, s);
     hipLaunchKernelGGL(ror_count_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx,
                        sc.sxyz, nb, radius * radius, sc.keep);
     hipLaunchKernelGGL(keep_select_kernel, dim3(B), dim3(TB), 0, s, in, out, cap, sc.keep);

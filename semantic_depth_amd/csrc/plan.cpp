@@ -335,7 +335,7 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
     } else if (s.layout == WL_SMALLN) {
         const int64_t K = s.shape[0] * s.shape[1] * s.shape[2], Cout = s.shape[3];
         for (int64_t k = 0; k < K; ++k)
-            for (int j = 0; j < s.nout; ++j) out[(size_t)k * 4 + j] = w[k * Cout + j];
+            for (int j = 0; j < s.nout; ++j) out[(size_t)j * K + k] = w[k * Cout + j];     // [nout][K]
     } else if (s.layout == WL_BIAS4) {
         for (int j = 0; j < s.nout; ++j) out[j] = w[j];
     } else {
