@@ -69,9 +69,16 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const ConvParams p, int
     const int wm0 = (wave % WAVES_M) * (MT * 32);
     const int wn0 = (wave / WAVES_M) * (NT * 32);
 
+    // XCD-aware tile order: hardware places block b on XCD b % 8; give every XCD a contiguous run of tile ids so that
+    // neighbouring pixel tiles (shared halo rows) and the blocks sharing a weight panel meet in the same L2
+    int tid_;
+    {
+        const int nwg = tilesM * tilesN, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        tid_ = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
     int tm, tn;
-    if (p.m_fastest) { tm = blockIdx.x % tilesM; tn = blockIdx.x / tilesM; }
-    else             { tn = blockIdx.x % tilesN; tm = blockIdx.x / tilesN; }
+    if (p.m_fastest) { tm = tid_ % tilesM; tn = tid_ / tilesM; }
+    else             { tn = tid_ % tilesN; tm = tid_ / tilesN; }
     const int bm0 = tm * BM, bn0 = tn * BN;
 
     const int m_l = t % BM;

@@ -75,7 +75,7 @@ struct Builder {
         op.w = wslot(wname, {k, k, Ctf, Cout}, p.prec ? WL_IGEMM_SPLIT : WL_IGEMM, op.Kpad, CoutPad);
         {
             WeightSlot& ws = p.weights[op.w];
-            ws.nsrc = op.nsrc;
+            ws.nsrc = op.nsrc; ws.vec = op.vec;
             for (int i = 0; i < 3; ++i) { ws.srcCtf[i] = srcCtf[i]; ws.srcCpad[i] = srcCpad[i]; }
         }
         op.b = wslot(bname, {Cout}, WL_RAW);
@@ -84,7 +84,8 @@ struct Builder {
         const double M = (double)N * Hout * Wout;
         op.flops = 2.0 * M * Cout * (double)(k * k * Ctf);      // algorithmic (TF) K, not the padded one
         // block order: walk M first when the weight matrix is the larger operand (it then stays L2-resident per N panel)
-        op.m_fastest = ((double)op.K * Cout > M * Ctot) ? 1 : 0;
+        // concurrent blocks walk M for one weight panel: the panel streams through L2 once per XCD and is shared by all of them
+        op.m_fastest = 1;
         (void)Ctf;
         push(op);
         return op.dst;
@@ -315,7 +316,10 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
             int cb_tf = 0, cb_pad = 0;
             for (int i = 0; i < s.nsrc; ++i) {
                 for (int c = 0; c < s.srcCtf[i]; ++c) {
-                    const int64_t k = tap * CtotPad + cb_pad + c;
+                    // vec layers walk K as (32-channel block, tap, channel): the 9 taps of one channel block are adjacent
+                    // k-tiles, so a block re-reads the same input rows from L1/L2 instead of streaming the whole tensor per tap
+                    const int64_t cp = cb_pad + c;
+                    const int64_t k = s.vec ? ((cp / 32) * taps + tap) * 32 + cp % 32 : tap * CtotPad + cb_pad + c;
                     const float* src = w + (tap * Ctf + cb_tf + c) * Cout;
                     if (!split) {
                         float* dst = out.data() + (size_t)(k / 4) * s.CoutPad * 4 + (k % 4);
@@ -361,10 +365,19 @@ void build_conv_tables(const NetPlan& p, const OpDesc& op, const char* act_base,
         e.flags = (op.up[s] ? 1 : 0) | (nv << 8) | (nv > 0 ? 0x10000 : 0);
         return e;
     };
-    const int n = op.vec ? op.Kpad / 32 : op.Kpad / 4;
-    const int stepk = op.vec ? 32 : 4;
-    ktab.resize(n);
-    for (int i = 0; i < n; ++i) ktab[i] = entry(i * stepk);
+    const int taps = op.k * op.k;
+    if (op.vec) {        // k-tile kt = (channel block cb, tap): see relayout_weight
+        const int n = op.Kpad / 32;
+        ktab.resize(n);
+        for (int kt = 0; kt < n; ++kt) {
+            const int cb = kt / taps, tap = kt % taps;
+            ktab[kt] = entry(tap * op.Ctot + cb * 32);
+        }
+    } else {
+        const int n = op.Kpad / 4;
+        ktab.resize(n);
+        for (int i = 0; i < n; ++i) ktab[i] = entry(i * 4);
+    }
 }
 
 }  // namespace sd

@@ -30,6 +30,7 @@ struct WeightSlot {
     int layout = WL_RAW;
     int Kpad = 0, CoutPad = 0, nout = 0;
     int nsrc = 1, srcCtf[3] = {0, 0, 0}, srcCpad[3] = {0, 0, 0};   // WL_IGEMM: channel structure of the K axis
+    int vec = 0;           // 1: K axis is ordered (32-channel block, tap, channel) instead of (tap, channel)
     size_t offset = 0, bytes = 0;   // in the weight arena (re-laid-out form)
     bool loaded = false;
 };
