@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -30,6 +31,7 @@ struct sd_handle {
     size_t ws_bytes = 0;
     int last_fcn_images = 0, last_mono_images = 0;
     std::vector<CamDev> cams_stage;
+    std::map<std::pair<int, int>, std::vector<float>> bias_host;   // (net, slot) -> host copy, for bias slots that are summed
     std::string err;
     // profiling (sd_profile): event pairs around conv launches
     bool prof = false;
@@ -115,7 +117,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.nsrc = op.nsrc; c.Ctot = op.Ctot;
                 c.N = N; c.Hin = s0.H * (op.up[0] ? 2 : 1); c.Win = s0.W * (op.up[0] ? 2 : 1);
                 c.Hout = d.H; c.Wout = d.W; c.Cout = d.C; c.CoutPad = p.weights[op.w].CoutPad;
-                c.kh = c.kw = op.k; c.stride = op.stride; c.pad = op.pad;
+                c.kh = c.kw = op.k; c.stride = op.sstride[0]; c.pad = op.pad;
                 c.K = op.K; c.Kpad = op.Kpad;
                 c.wt = Wp(op.w); c.bias = Wp(op.b);
                 c.ktab = reinterpret_cast<const KEntry*>(wbase + op.tab_offset);
@@ -277,7 +279,30 @@ sd_status sd_load_weight(sd_handle* h, sd_net net, const char* name, const float
         if (shape[i] != s.shape[i]) return fail(h, SD_ERR_INVALID, std::string("shape mismatch for ") + name);
     std::vector<float> buf;
     relayout_weight(s, data, buf);
-    HIPCHK(h, hipMemcpy(warena(h, net) + s.offset, buf.data(), s.bytes, hipMemcpyHostToDevice));
+    char* base = warena(h, net) + s.offset;
+    if (s.layout == WL_IGEMM) {                     // rows [k_off, k_off+Kpad) of a [Ktotal/4][CoutPad][4] matrix
+        HIPCHK(h, hipMemcpy(base + (size_t)s.k_off * s.CoutPad * 4, buf.data(), s.bytes, hipMemcpyHostToDevice));
+    } else if (s.layout == WL_IGEMM_SPLIT) {        // the same rows in the hi plane and in the lo plane
+        const size_t plane = (size_t)s.Ktotal * s.CoutPad * 2, rows = (size_t)s.Kpad * s.CoutPad * 2, ro = (size_t)s.k_off * s.CoutPad * 2;
+        HIPCHK(h, hipMemcpy(base + ro, buf.data(), rows, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(base + plane + ro, reinterpret_cast<char*>(buf.data()) + rows, rows, hipMemcpyHostToDevice));
+    } else {
+        const int root = s.owner >= 0 ? s.owner : it->second;
+        bool grouped = s.owner >= 0;
+        for (const WeightSlot& o : p.weights) grouped = grouped || (o.owner == root && o.layout == WL_RAW && &o != &s);
+        if (grouped && s.layout == WL_RAW && s.rank == 1) {      // summed bias group (ResNet conv3 + projection)
+            h->bias_host[{(int)net, it->second}] = buf;
+            std::vector<float> sum(buf.size(), 0.f);
+            for (int j = 0; j < (int)p.weights.size(); ++j)
+                if (j == root || p.weights[j].owner == root) {
+                    auto f = h->bias_host.find({(int)net, j});
+                    if (f != h->bias_host.end()) for (size_t i = 0; i < sum.size(); ++i) sum[i] += f->second[i];
+                }
+            HIPCHK(h, hipMemcpy(base, sum.data(), s.bytes, hipMemcpyHostToDevice));
+        } else {
+            HIPCHK(h, hipMemcpy(base, buf.data(), s.bytes, hipMemcpyHostToDevice));
+        }
+    }
     s.loaded = true;
     return SD_OK;
 }

@@ -79,11 +79,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p, int
         oy = r / p.Wout;
         ox = r - oy * p.Wout;
     }
-    const int iy0 = oy * p.stride, ix0 = ox * p.stride;
 
     const float* const wt = p.wt;
     const KEntry* __restrict__ const ktab = p.ktab;
-    const int Hin = p.Hin, Win = p.Win, CoutPad = p.CoutPad;
+    const int CoutPad = p.CoutPad;
 
     f32x4 ra[T::A_LD];
     f32x4 rb[T::B_LD];
@@ -101,9 +100,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p, int
         // ---- activations: im2col gather ----
         if (VEC) {
             const KEntry e = ktab[kt];   // wave-uniform -> one s_load_dwordx8
-            int iy = iy0 + e.dy, ix = ix0 + e.dx;
-            const bool ok = m_ok && iy >= 0 && ix >= 0 && iy < Hin && ix < Win;
-            if (e.flags & 1) { iy >>= 1; ix >>= 1; }
+            const int st = (e.flags >> 4) & 3, up = e.flags & 1;       // per-source stride / x2 upsample
+            int iy = oy * st + e.dy, ix = ox * st + e.dx;
+            const bool ok = m_ok && iy >= 0 && ix >= 0 && iy < (e.H << up) && ix < (e.W << up);
+            iy >>= up; ix >>= up;
             const float* base = e.base + ((size_t)(img * e.H + iy) * e.W + ix) * e.C;
 #pragma unroll
             for (int i = 0; i < T::A_LD; ++i) {
@@ -120,9 +120,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p, int
                 const int kq = __builtin_amdgcn_readfirstlane(kq0 + KQ_STEP * i);
                 const KEntry e = ktab[kt * 8 + kq];
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                int iy = iy0 + e.dy, ix = ix0 + e.dx;
-                const bool ok = (e.flags & 0x10000) && m_ok && iy >= 0 && ix >= 0 && iy < Hin && ix < Win;
-                if (e.flags & 1) { iy >>= 1; ix >>= 1; }
+                const int st = (e.flags >> 4) & 3, up = e.flags & 1;
+                int iy = oy * st + e.dy, ix = ox * st + e.dx;
+                const bool ok = (e.flags & 0x10000) && m_ok && iy >= 0 && ix >= 0 && iy < (e.H << up) && ix < (e.W << up);
+                iy >>= up; ix >>= up;
                 const int nv = (e.flags >> 8) & 7;
                 const float* q = e.base + ((size_t)(img * e.H + iy) * e.W + ix) * e.C;
                 if (ok) {

@@ -95,9 +95,8 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const ConvParams p, int
         oy = r / p.Wout;
         ox = r - oy * p.Wout;
     }
-    const int iy0 = oy * p.stride, ix0 = ox * p.stride;
     const KEntry* __restrict__ const ktab = p.ktab;
-    const int Hin = p.Hin, Win = p.Win, CoutPad = p.CoutPad;
+    const int CoutPad = p.CoutPad;
     const u32x4* __restrict__ const wt_hi = reinterpret_cast<const u32x4*>(p.wt);
     const u32x4* __restrict__ const wt_lo = wt_hi + (size_t)(p.Kpad / 8) * CoutPad;
 
@@ -118,9 +117,10 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const ConvParams p, int
         }
         if (VEC) {
             const KEntry e = ktab[kt];
-            int iy = iy0 + e.dy, ix = ix0 + e.dx;
-            const bool ok = m_ok && iy >= 0 && ix >= 0 && iy < Hin && ix < Win;
-            if (e.flags & 1) { iy >>= 1; ix >>= 1; }
+            const int st = (e.flags >> 4) & 3, up = e.flags & 1;       // per-source stride / x2 upsample
+            int iy = oy * st + e.dy, ix = ox * st + e.dx;
+            const bool ok = m_ok && iy >= 0 && ix >= 0 && iy < (e.H << up) && ix < (e.W << up);
+            iy >>= up; ix >>= up;
             const float* base = e.base + ((size_t)(img * e.H + iy) * e.W + ix) * e.C;
 #pragma unroll
             for (int i = 0; i < T::A_IT; ++i) {
@@ -140,9 +140,10 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const ConvParams p, int
                 for (int hq = 0; hq < 2; ++hq) {
                     const KEntry e = ktab[kt * 8 + kg * 2 + hq];
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    int iy = iy0 + e.dy, ix = ix0 + e.dx;
-                    const bool ok = (e.flags & 0x10000) && m_ok && iy >= 0 && ix >= 0 && iy < Hin && ix < Win;
-                    if (e.flags & 1) { iy >>= 1; ix >>= 1; }
+                    const int st = (e.flags >> 4) & 3, up = e.flags & 1;
+                    int iy = oy * st + e.dy, ix = ox * st + e.dx;
+                    const bool ok = (e.flags & 0x10000) && m_ok && iy >= 0 && ix >= 0 && iy < (e.H << up) && ix < (e.W << up);
+                    iy >>= up; ix >>= up;
                     const int nv = (e.flags >> 8) & 7;
                     const float* q = e.base + ((size_t)(img * e.H + iy) * e.W + ix) * e.C;
                     if (ok) {

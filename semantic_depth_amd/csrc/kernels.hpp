@@ -17,7 +17,8 @@ struct KEntry {
     const float* base;  // source tensor + first channel of this entry
     int H, W, C;        // physical dims of the source tensor
     int dy, dx;         // tap offset minus pad (in logical, i.e. post-upsample, input coordinates)
-    int flags;          // bit 0: read through a x2 nearest-neighbour upsample; bits 8..10: valid floats (quad path);
+    int flags;          // bit 0: read through a x2 nearest-neighbour upsample; bits 4..5: stride of this source (1 or 2);
+                        // bits 8..10: valid floats (quad path);
                         // bit 16: entry is live (0 = zero padding of the K axis)
 };
 static_assert(sizeof(KEntry) == 32, "KEntry must be 32 bytes");

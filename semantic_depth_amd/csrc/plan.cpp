@@ -14,7 +14,7 @@ namespace {
 constexpr size_t ALIGN = 256;
 size_t align_up(size_t v) { return (v + ALIGN - 1) / ALIGN * ALIGN; }
 
-struct Src { int t; int up; };
+struct Src { int t; int up; int stride = 0; /* 0: the op's stride */ };
 
 struct Builder {
     NetPlan p;
@@ -61,21 +61,27 @@ struct Builder {
             const TensorDesc& t = p.tensors[srcs[i].t];
             op.src[i] = srcs[i].t; op.up[i] = srcs[i].up;
             const int h = t.H * (srcs[i].up ? 2 : 1), w = t.W * (srcs[i].up ? 2 : 1);
+            op.sstride[i] = srcs[i].stride ? srcs[i].stride : stride;
+            const int pad_ = (k - 1) / 2;
+            const int ho = (h + 2 * pad_ - k) / op.sstride[i] + 1, wo = (w + 2 * pad_ - k) / op.sstride[i] + 1;
             if (i == 0) { Hin = h; Win = w; N = t.N; }
-            else if (h != Hin || w != Win || t.N != N) throw std::runtime_error("conv " + name + ": source dims disagree");
+            else {
+                const int ho0 = (Hin + 2 * pad_ - k) / op.sstride[0] + 1, wo0 = (Win + 2 * pad_ - k) / op.sstride[0] + 1;
+                if (ho != ho0 || wo != wo0 || t.N != N) throw std::runtime_error("conv " + name + ": source dims disagree");
+            }
             srcCtf[i] = t.Ctf; srcCpad[i] = (t.C + 3) / 4 * 4;     // the K axis holds whole channel quads per source
             Ctot += srcCpad[i]; Ctf += t.Ctf;
             if (t.C % 32) vec = false;
         }
         op.k = k; op.stride = stride; op.pad = (k - 1) / 2; op.act = act; op.residual = residual;
-        const int Hout = (Hin + 2 * op.pad - k) / stride + 1, Wout = (Win + 2 * op.pad - k) / stride + 1;
+        const int Hout = (Hin + 2 * op.pad - k) / op.sstride[0] + 1, Wout = (Win + 2 * op.pad - k) / op.sstride[0] + 1;
         op.Ctot = Ctot; op.K = k * k * Ctot; op.Kpad = (op.K + 31) / 32 * 32; op.vec = vec ? 1 : 0;
         const int bn = p.prec ? conv_split_tile_n(Cout) : conv_tile_n(Cout);
         const int CoutPad = (Cout + bn - 1) / bn * bn;
         op.w = wslot(wname, {k, k, Ctf, Cout}, p.prec ? WL_IGEMM_SPLIT : WL_IGEMM, op.Kpad, CoutPad);
         {
             WeightSlot& ws = p.weights[op.w];
-            ws.nsrc = op.nsrc; ws.vec = op.vec;
+            ws.nsrc = op.nsrc; ws.vec = op.vec; ws.Ktotal = op.Kpad;
             for (int i = 0; i < 3; ++i) { ws.srcCtf[i] = srcCtf[i]; ws.srcCpad[i] = srcCpad[i]; }
         }
         op.b = wslot(bname, {Cout}, WL_RAW);
@@ -87,6 +93,41 @@ struct Builder {
         // concurrent blocks walk M for one weight panel: the panel streams through L2 once per XCD and is shared by all of them
         op.m_fastest = 1;
         (void)Ctf;
+        push(op);
+        return op.dst;
+    }
+
+    // ResNet bottleneck tail: act( conv1x1(a; wA) + conv1x1_stride_s(b; wB) + biasA + biasB ) as ONE GEMM over K = Ca + Cb
+    int conv_pair_1x1(const std::string& name, int a, int b, int stride_b, int Cout, int act, const std::string& wA,
+                      const std::string& bA, const std::string& wB, const std::string& bB) {
+        OpDesc op;
+        op.kind = OP_CONV; op.name = name; op.nsrc = 2;
+        const TensorDesc& ta = p.tensors[a];
+        const TensorDesc& tb = p.tensors[b];
+        if (ta.C % 32 || tb.C % 32) throw std::runtime_error("conv_pair_1x1 " + name + ": channels must be multiples of 32");
+        if ((tb.H - 1) / stride_b + 1 != ta.H || (tb.W - 1) / stride_b + 1 != ta.W || ta.N != tb.N)
+            throw std::runtime_error("conv_pair_1x1 " + name + ": source dims disagree");
+        op.src[0] = a; op.src[1] = b; op.sstride[0] = 1; op.sstride[1] = stride_b;
+        op.k = 1; op.stride = 1; op.pad = 0; op.act = act;
+        op.Ctot = ta.C + tb.C; op.K = op.Ctot; op.Kpad = op.K; op.vec = 1;
+        const int bn = p.prec ? conv_split_tile_n(Cout) : conv_tile_n(Cout);
+        const int CoutPad = (Cout + bn - 1) / bn * bn;
+        const int lay = p.prec ? WL_IGEMM_SPLIT : WL_IGEMM;
+        op.w = wslot(wA, {1, 1, ta.C, Cout}, lay, ta.C, CoutPad);
+        const int w2 = wslot(wB, {1, 1, tb.C, Cout}, lay, tb.C, CoutPad);
+        {
+            WeightSlot& s0 = p.weights[op.w];
+            s0.nsrc = 1; s0.srcCtf[0] = s0.srcCpad[0] = ta.C; s0.vec = 1; s0.Ktotal = op.Kpad; s0.k_off = 0;
+            WeightSlot& s1 = p.weights[w2];
+            s1.nsrc = 1; s1.srcCtf[0] = s1.srcCpad[0] = tb.C; s1.vec = 1; s1.Ktotal = op.Kpad; s1.k_off = ta.C; s1.owner = op.w;
+        }
+        op.b = wslot(bA, {Cout}, WL_RAW);
+        const int b2 = wslot(bB, {Cout}, WL_RAW);
+        p.weights[b2].owner = op.b;
+        op.dst = tensor(name, ta.N, ta.H, ta.W, Cout);
+        op.tab_bytes = (size_t)(op.Kpad / 32) * sizeof(KEntry);
+        op.flops = 2.0 * ta.N * ta.H * ta.W * Cout * (double)op.K;
+        op.m_fastest = 1;
         push(op);
         return op.dst;
     }
@@ -128,7 +169,13 @@ struct Builder {
         }
         // weight arena: slots, then per-op tables
         size_t off = 0;
-        for (auto& s : p.weights) { s.offset = off; off += align_up(s.bytes); }
+        for (auto& s : p.weights) {
+            if (s.owner >= 0) continue;
+            s.offset = off;
+            const bool ig = s.layout == WL_IGEMM || s.layout == WL_IGEMM_SPLIT;
+            off += align_up(ig ? (size_t)s.Ktotal * s.CoutPad * sizeof(float) : s.bytes);
+        }
+        for (auto& s : p.weights) if (s.owner >= 0) s.offset = p.weights[s.owner].offset;
         for (auto& op : p.ops)
             if (op.kind == OP_CONV) {
                 op.tab_offset = off; off += align_up(op.tab_bytes);
@@ -265,8 +312,10 @@ NetPlan build_monodepth(int encoder, int frames, int H, int W, int prec) {
                 const int n = stage_n[s];
                 const int c1 = cv(pfx + "/conv1", {{x, 0}}, n, 1, 1);
                 const int c2 = cv(pfx + "/conv2", {{c1, 0}}, n, 3, stride);
-                const int sc = cv(pfx + "/proj", {{x, 0}}, 4 * n, 1, stride, ACT_NONE);     // always projected (upstream quirk)
-                x = cv(pfx + "/conv3", {{c2, 0}}, 4 * n, 1, 1, ACT_ELU, sc);                // elu(conv3 + shortcut)
+                // elu(conv3(c2) + proj(x)): the shortcut is always a 1x1 projection (upstream quirk), so both 1x1 convs
+                // are one GEMM over the concatenated K axis; the shortcut source is read at the block's stride
+                x = b.conv_pair_1x1(pfx + "/conv3", c2, x, stride, 4 * n, ACT_ELU, pfx + "/conv3/weights", pfx + "/conv3/biases",
+                                    pfx + "/proj/weights", pfx + "/proj/biases");
             }
             stage_out[s] = x;
         }
@@ -362,7 +411,7 @@ void build_conv_tables(const NetPlan& p, const OpDesc& op, const char* act_base,
         e.H = t.H; e.W = t.W; e.C = t.C;
         e.dy = tap / op.k - op.pad; e.dx = tap % op.k - op.pad;
         const int nv = std::max(0, std::min(4, t.C - cl));
-        e.flags = (op.up[s] ? 1 : 0) | (nv << 8) | (nv > 0 ? 0x10000 : 0);
+        e.flags = (op.up[s] ? 1 : 0) | (op.sstride[s] << 4) | (nv << 8) | (nv > 0 ? 0x10000 : 0);
         return e;
     };
     const int taps = op.k * op.k;

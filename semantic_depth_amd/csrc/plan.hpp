@@ -31,6 +31,10 @@ struct WeightSlot {
     int Kpad = 0, CoutPad = 0, nout = 0;
     int nsrc = 1, srcCtf[3] = {0, 0, 0}, srcCpad[3] = {0, 0, 0};   // WL_IGEMM: channel structure of the K axis
     int vec = 0;           // 1: K axis is ordered (32-channel block, tap, channel) instead of (tap, channel)
+    // a slot may be a VIEW of rows [k_off, k_off+Kpad) of a larger device matrix of Ktotal rows owned by slot `owner`
+    // (ResNet block: conv3 and the projection shortcut are one GEMM over the concatenated K axis); a bias view is ADDED
+    // to its owner's bias
+    int owner = -1, k_off = 0, Ktotal = 0;
     size_t offset = 0, bytes = 0;   // in the weight arena (re-laid-out form)
     bool loaded = false;
 };
@@ -41,6 +45,7 @@ struct OpDesc {
     int nsrc = 0;
     int src[3] = {-1, -1, -1};
     int up[3] = {0, 0, 0};
+    int sstride[3] = {1, 1, 1};   // per-source stride (a fused ResNet shortcut reads its source at stride 2)
     int dst = -1;
     int residual = -1;     // OP_CONV: tensor added before the activation; OP_DECONV4_ADD: the skip tensor
     int k = 1, stride = 1, pad = 0, act = ACT_NONE, nout = 0;
