@@ -83,7 +83,7 @@ sd_status upload_tables(sd_handle* h, sd_net net) {
     for (const OpDesc& op : p.ops) {
         if (op.kind != OP_CONV) continue;
         std::vector<KEntry> ktab;
-        build_conv_tables(p, op, abase, ktab);
+        build_conv_tables(p, op, abase, wbase + op.tab_offset, ktab);
         HIPCHK(h, hipMemcpy(wbase + op.tab_offset, ktab.data(), ktab.size() * sizeof(KEntry), hipMemcpyHostToDevice));
     }
     return SD_OK;
@@ -121,7 +121,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.K = op.K; c.Kpad = op.Kpad;
                 c.wt = Wp(op.w); c.bias = Wp(op.b);
                 c.ktab = reinterpret_cast<const KEntry*>(wbase + op.tab_offset);
-                c.vec = op.vec;
+                c.vec = op.vec; c.vtiles = op.Kvec / 32;
                 c.residual = op.residual >= 0 ? T(op.residual) : nullptr;
                 c.out = T(op.dst);
                 c.act = op.act; c.m_fastest = op.m_fastest;

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const ConvParams p, int
 
     f32x4 ra[T::A_IT][2];
     u32x4 rwh[T::B_LD], rwl[T::B_LD];
-    const int ktiles = p.Kpad / 32;
+    const int ktiles = p.Kpad / 32, vtiles = p.vtiles;
 
     auto load_tile = [&](int kt) {
 #pragma unroll
@@ -115,11 +115,11 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const ConvParams p, int
                 rwl[i] = wt_lo[o];
             }
         }
-        if (VEC) {
-            const KEntry e = ktab[kt];
+        if (VEC || kt < vtiles) {
+            const KEntry e = ktab[kt];   // wave-uniform -> one s_load_dwordx8
             const int st = (e.flags >> 4) & 3, up = e.flags & 1;       // per-source stride / x2 upsample
             int iy = oy * st + e.dy, ix = ox * st + e.dx;
-            const bool ok = m_ok && iy >= 0 && ix >= 0 && iy < (e.H << up) && ix < (e.W << up);
+            const bool ok = (e.flags & 0x10000) && m_ok && iy >= 0 && ix >= 0 && iy < (e.H << up) && ix < (e.W << up);
             iy >>= up; ix >>= up;
             const float* base = e.base + ((size_t)(img * e.H + iy) * e.W + ix) * e.C;
 #pragma unroll
@@ -133,19 +133,20 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const ConvParams p, int
                 ra[i][0] = v0; ra[i][1] = v1;
             }
         } else {
+            const KEntry* __restrict__ const qtab = ktab + ktiles + (kt - vtiles) * 8;   // this tile's 8 quad descriptors
 #pragma unroll
             for (int i = 0; i < T::A_IT; ++i) {
                 const int kg = __builtin_amdgcn_readfirstlane(kg0 + KG_STEP * i);
 #pragma unroll
                 for (int hq = 0; hq < 2; ++hq) {
-                    const KEntry e = ktab[kt * 8 + kg * 2 + hq];
+                    const KEntry q4 = qtab[kg * 2 + hq];
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    const int st = (e.flags >> 4) & 3, up = e.flags & 1;
-                    int iy = oy * st + e.dy, ix = ox * st + e.dx;
-                    const bool ok = (e.flags & 0x10000) && m_ok && iy >= 0 && ix >= 0 && iy < (e.H << up) && ix < (e.W << up);
+                    const int st = (q4.flags >> 4) & 3, up = q4.flags & 1;
+                    int iy = oy * st + q4.dy, ix = ox * st + q4.dx;
+                    const bool ok = (q4.flags & 0x10000) && m_ok && iy >= 0 && ix >= 0 && iy < (q4.H << up) && ix < (q4.W << up);
                     iy >>= up; ix >>= up;
-                    const int nv = (e.flags >> 8) & 7;
-                    const float* q = e.base + ((size_t)(img * e.H + iy) * e.W + ix) * e.C;
+                    const int nv = (q4.flags >> 8) & 7;
+                    const float* q = q4.base + ((size_t)(img * q4.H + iy) * q4.W + ix) * q4.C;
                     if (ok) {
                         if (nv == 4) v = *reinterpret_cast<const f32x4*>(q);
                         else if (nv == 2) { const float2 t2 = *reinterpret_cast<const float2*>(q); v[0] = t2.x; v[1] = t2.y; }

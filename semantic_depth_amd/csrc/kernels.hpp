@@ -19,7 +19,8 @@ struct KEntry {
     int dy, dx;         // tap offset minus pad (in logical, i.e. post-upsample, input coordinates)
     int flags;          // bit 0: read through a x2 nearest-neighbour upsample; bits 4..5: stride of this source (1 or 2);
                         // bits 8..10: valid floats (quad path);
-                        // bit 16: entry is live (0 = zero padding of the K axis)
+                        // bit 16: entry is live (0 = zero padding of the K axis); bit 17: k-tile head of a QUAD tile
+                        // (base then points at the tile's 8 quad descriptors)
 };
 static_assert(sizeof(KEntry) == 32, "KEntry must be 32 bytes");
 
@@ -31,8 +32,9 @@ struct ConvParams {
     int K, Kpad;       // K = kh*kw*Ctot (Ctot = sum of sources rounded up to quads) ; Kpad = multiple of 32
     const float* wt;   // re-laid-out weights [Kpad/4][CoutPad][4]
     const float* bias; // [Cout]
-    const KEntry* ktab;  // DEVICE: vec path [Kpad/32], quad path [Kpad/4]
-    int vec;           // 1: every source has C % 32 == 0 (k-tiles never straddle a tap or a source)
+    const KEntry* ktab;  // DEVICE: [Kpad/32] k-tile descriptors, followed by 8 quad descriptors per quad tile
+    int vtiles;        // leading k-tiles that are vec tiles (the rest are quad tiles)
+    int vec;           // 1: every source has C % 32 == 0 (all k-tiles are vec tiles); 0: the K axis ends in quad tiles
     const float* residual;  // nullable [M][Cout], added before the activation (resnet shortcut)
     float* out;             // [M][Cout]
     int act;

@@ -56,7 +56,8 @@ struct Builder {
         op.kind = OP_CONV; op.name = name; op.nsrc = (int)srcs.size();
         int Ctot = 0, Ctf = 0, Hin = 0, Win = 0, N = 0;
         bool vec = true;
-        int srcCtf[3] = {0, 0, 0}, srcCpad[3] = {0, 0, 0};
+        int srcCtf[3] = {0, 0, 0}, srcCpad[3] = {0, 0, 0}, srcVec[3] = {0, 0, 0};
+        int Cvec = 0, CqPad = 0;
         for (int i = 0; i < op.nsrc; ++i) {
             const TensorDesc& t = p.tensors[srcs[i].t];
             op.src[i] = srcs[i].t; op.up[i] = srcs[i].up;
@@ -71,22 +72,26 @@ struct Builder {
             }
             srcCtf[i] = t.Ctf; srcCpad[i] = (t.C + 3) / 4 * 4;     // the K axis holds whole channel quads per source
             Ctot += srcCpad[i]; Ctf += t.Ctf;
-            if (t.C % 32) vec = false;
+            srcVec[i] = (t.C % 32 == 0) ? 1 : 0;
+            if (srcVec[i]) Cvec += t.C; else { CqPad += srcCpad[i]; vec = false; }
         }
         op.k = k; op.stride = stride; op.pad = (k - 1) / 2; op.act = act; op.residual = residual;
         const int Hout = (Hin + 2 * op.pad - k) / op.sstride[0] + 1, Wout = (Win + 2 * op.pad - k) / op.sstride[0] + 1;
-        op.Ctot = Ctot; op.K = k * k * Ctot; op.Kpad = (op.K + 31) / 32 * 32; op.vec = vec ? 1 : 0;
+        op.Ctot = Ctot; op.K = k * k * Ctot; op.vec = vec ? 1 : 0;
+        op.Kvec = k * k * Cvec; op.CqPad = CqPad;
+        op.Kpad = op.Kvec + (k * k * CqPad + 31) / 32 * 32;
         const int bn = p.prec ? conv_split_tile_n(Cout) : conv_tile_n(Cout);
         const int CoutPad = (Cout + bn - 1) / bn * bn;
         op.w = wslot(wname, {k, k, Ctf, Cout}, p.prec ? WL_IGEMM_SPLIT : WL_IGEMM, op.Kpad, CoutPad);
         {
             WeightSlot& ws = p.weights[op.w];
             ws.nsrc = op.nsrc; ws.vec = op.vec; ws.Ktotal = op.Kpad;
-            for (int i = 0; i < 3; ++i) { ws.srcCtf[i] = srcCtf[i]; ws.srcCpad[i] = srcCpad[i]; }
+            for (int i = 0; i < 3; ++i) { ws.srcCtf[i] = srcCtf[i]; ws.srcCpad[i] = srcCpad[i]; ws.srcVec[i] = srcVec[i]; }
         }
         op.b = wslot(bname, {Cout}, WL_RAW);
         op.dst = tensor(name, N, Hout, Wout, Cout);
-        op.tab_bytes = (vec ? (size_t)(op.Kpad / 32) : (size_t)(op.Kpad / 4)) * sizeof(KEntry);
+        // one descriptor per k-tile, plus 8 quad descriptors for every k-tile of the quad tail
+        op.tab_bytes = ((size_t)(op.Kpad / 32) + (size_t)((op.Kpad - op.Kvec) / 32) * 8) * sizeof(KEntry);
         const double M = (double)N * Hout * Wout;
         op.flops = 2.0 * M * Cout * (double)(k * k * Ctf);      // algorithmic (TF) K, not the padded one
         // block order: walk M first when the weight matrix is the larger operand (it then stays L2-resident per N panel)
@@ -109,7 +114,7 @@ struct Builder {
             throw std::runtime_error("conv_pair_1x1 " + name + ": source dims disagree");
         op.src[0] = a; op.src[1] = b; op.sstride[0] = 1; op.sstride[1] = stride_b;
         op.k = 1; op.stride = 1; op.pad = 0; op.act = act;
-        op.Ctot = ta.C + tb.C; op.K = op.Ctot; op.Kpad = op.K; op.vec = 1;
+        op.Ctot = ta.C + tb.C; op.K = op.Ctot; op.Kpad = op.K; op.Kvec = op.K; op.vec = 1;
         const int bn = p.prec ? conv_split_tile_n(Cout) : conv_tile_n(Cout);
         const int CoutPad = (Cout + bn - 1) / bn * bn;
         const int lay = p.prec ? WL_IGEMM_SPLIT : WL_IGEMM;
@@ -117,9 +122,9 @@ struct Builder {
         const int w2 = wslot(wB, {1, 1, tb.C, Cout}, lay, tb.C, CoutPad);
         {
             WeightSlot& s0 = p.weights[op.w];
-            s0.nsrc = 1; s0.srcCtf[0] = s0.srcCpad[0] = ta.C; s0.vec = 1; s0.Ktotal = op.Kpad; s0.k_off = 0;
+            s0.nsrc = 1; s0.srcCtf[0] = s0.srcCpad[0] = ta.C; s0.srcVec[0] = 1; s0.vec = 1; s0.Ktotal = op.Kpad; s0.k_off = 0;
             WeightSlot& s1 = p.weights[w2];
-            s1.nsrc = 1; s1.srcCtf[0] = s1.srcCpad[0] = tb.C; s1.vec = 1; s1.Ktotal = op.Kpad; s1.k_off = ta.C; s1.owner = op.w;
+            s1.nsrc = 1; s1.srcCtf[0] = s1.srcCpad[0] = tb.C; s1.srcVec[0] = 1; s1.vec = 1; s1.Ktotal = op.Kpad; s1.k_off = ta.C; s1.owner = op.w;
         }
         op.b = wslot(bA, {Cout}, WL_RAW);
         const int b2 = wslot(bB, {Cout}, WL_RAW);
@@ -361,14 +366,19 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
         const int64_t taps = s.shape[0] * s.shape[1], Ctf = s.shape[2], Cout = s.shape[3];
         int CtotPad = 0;
         for (int i = 0; i < s.nsrc; ++i) CtotPad += s.srcCpad[i];
+        int Cvec = 0, CqPad = 0;
+        for (int i = 0; i < s.nsrc; ++i) { if (s.srcVec[i]) Cvec += s.srcCpad[i]; else CqPad += s.srcCpad[i]; }
+        const int64_t Kvec = taps * Cvec;
+        (void)CtotPad;
         for (int64_t tap = 0; tap < taps; ++tap) {
-            int cb_tf = 0, cb_pad = 0;
+            int cb_tf = 0, cv = 0, cq = 0;
             for (int i = 0; i < s.nsrc; ++i) {
                 for (int c = 0; c < s.srcCtf[i]; ++c) {
-                    // vec layers walk K as (32-channel block, tap, channel): the 9 taps of one channel block are adjacent
-                    // k-tiles, so a block re-reads the same input rows from L1/L2 instead of streaming the whole tensor per tap
-                    const int64_t cp = cb_pad + c;
-                    const int64_t k = s.vec ? ((cp / 32) * taps + tap) * 32 + cp % 32 : tap * CtotPad + cb_pad + c;
+                    // vec sources walk K as (32-channel block, tap, channel): the taps of one channel block are adjacent
+                    // k-tiles, so a block re-reads the same input rows from L1/L2; the other sources form a (tap, quad) tail
+                    int64_t k;
+                    if (s.srcVec[i]) { const int64_t cp = cv + c; k = ((cp / 32) * taps + tap) * 32 + cp % 32; }
+                    else k = Kvec + tap * CqPad + cq + c;
                     const float* src = w + (tap * Ctf + cb_tf + c) * Cout;
                     if (!split) {
                         float* dst = out.data() + (size_t)(k / 4) * s.CoutPad * 4 + (k % 4);
@@ -382,7 +392,8 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
                         }
                     }
                 }
-                cb_tf += s.srcCtf[i]; cb_pad += s.srcCpad[i];
+                cb_tf += s.srcCtf[i];
+                if (s.srcVec[i]) cv += s.srcCpad[i]; else cq += s.srcCpad[i];
             }
         }
     } else if (s.layout == WL_SMALLN) {
@@ -396,17 +407,13 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
     }
 }
 
-void build_conv_tables(const NetPlan& p, const OpDesc& op, const char* act_base, std::vector<KEntry>& ktab) {
-    int cbase[4] = {0, 0, 0, 0};     // padded channel offsets of the sources inside one tap
-    for (int i = 0; i < op.nsrc; ++i) cbase[i + 1] = cbase[i] + (p.tensors[op.src[i]].C + 3) / 4 * 4;
-    auto entry = [&](int k) {        // descriptor of the channel run starting at padded index k
-        KEntry e{nullptr, 1, 1, 1, 0, 0, 0};
-        if (k >= op.K) return e;
-        const int tap = k / op.Ctot, c = k % op.Ctot;
-        int s = 0;
-        while (s + 1 < op.nsrc && c >= cbase[s + 1]) ++s;
+void build_conv_tables(const NetPlan& p, const OpDesc& op, const char* act_base, const char* tab_dev, std::vector<KEntry>& ktab) {
+    const int taps = op.k * op.k;
+    // channel runs: vec sources concatenated (cv), the other sources concatenated with quad padding (cq)
+    struct Run { int src, c0; };
+    auto describe = [&](int s, int cl, int tap) {
         const TensorDesc& t = p.tensors[op.src[s]];
-        const int cl = c - cbase[s];
+        KEntry e{nullptr, 1, 1, 1, 0, 0, 0};
         e.base = reinterpret_cast<const float*>(act_base + t.offset) + cl;
         e.H = t.H; e.W = t.W; e.C = t.C;
         e.dy = tap / op.k - op.pad; e.dx = tap % op.k - op.pad;
@@ -414,18 +421,36 @@ void build_conv_tables(const NetPlan& p, const OpDesc& op, const char* act_base,
         e.flags = (op.up[s] ? 1 : 0) | (op.sstride[s] << 4) | (nv << 8) | (nv > 0 ? 0x10000 : 0);
         return e;
     };
-    const int taps = op.k * op.k;
-    if (op.vec) {        // k-tile kt = (channel block cb, tap): see relayout_weight
-        const int n = op.Kpad / 32;
-        ktab.resize(n);
-        for (int kt = 0; kt < n; ++kt) {
-            const int cb = kt / taps, tap = kt % taps;
-            ktab[kt] = entry(tap * op.Ctot + cb * 32);
+    auto locate = [&](int c, bool vecpart, int& s, int& cl) {     // c indexes the vec (or quad) concatenation
+        int base = 0;
+        for (s = 0; s < op.nsrc; ++s) {
+            const TensorDesc& t = p.tensors[op.src[s]];
+            const bool v = t.C % 32 == 0;
+            if (v != vecpart) continue;
+            const int cpad = (t.C + 3) / 4 * 4;
+            if (c < base + cpad) { cl = c - base; return true; }
+            base += cpad;
         }
-    } else {
-        const int n = op.Kpad / 4;
-        ktab.resize(n);
-        for (int i = 0; i < n; ++i) ktab[i] = entry(i * 4);
+        return false;
+    };
+    const int ktiles = op.Kpad / 32, vtiles = op.Kvec / 32, qtiles = ktiles - vtiles;
+    ktab.assign((size_t)ktiles + (size_t)qtiles * 8, KEntry{nullptr, 1, 1, 1, 0, 0, 0});
+    for (int kt = 0; kt < vtiles; ++kt) {            // vec region: k-tile = (channel block cb, tap)
+        const int cb = kt / taps, tap = kt % taps;
+        int s, cl;
+        if (locate(cb * 32, true, s, cl)) ktab[kt] = describe(s, cl, tap);
+    }
+    for (int qt = 0; qt < qtiles; ++qt) {            // quad tail: (tap, channel quad) order, 8 quads per k-tile
+        KEntry& head = ktab[vtiles + qt];
+        head.flags = 0x20000;                        // "quad tile": base points at its 8 quad descriptors
+        head.base = reinterpret_cast<const float*>(tab_dev + ((size_t)ktiles + (size_t)qt * 8) * sizeof(KEntry));
+        for (int j = 0; j < 8; ++j) {
+            const int kq = (qt * 8 + j) * 4;         // offset inside the quad tail
+            if (op.CqPad == 0 || kq >= taps * op.CqPad) continue;
+            const int tap = kq / op.CqPad, c = kq % op.CqPad;
+            int s, cl;
+            if (locate(c, false, s, cl)) ktab[(size_t)ktiles + (size_t)qt * 8 + j] = describe(s, cl, tap);
+        }
     }
 }
 

@@ -35,6 +35,7 @@ struct WeightSlot {
     // (ResNet block: conv3 and the projection shortcut are one GEMM over the concatenated K axis); a bias view is ADDED
     // to its owner's bias
     int owner = -1, k_off = 0, Ktotal = 0;
+    int srcVec[3] = {0, 0, 0};   // mixed layers: sources with C % 32 == 0 live in the vec region of K, the others in the quad tail
     size_t offset = 0, bytes = 0;   // in the weight arena (re-laid-out form)
     bool loaded = false;
 };
@@ -53,6 +54,7 @@ struct OpDesc {
     // conv engine
     int Ctot = 0;          // padded channels per tap (every source rounded up to a multiple of 4)
     int K = 0, Kpad = 0, vec = 0, m_fastest = 0;
+    int Kvec = 0, CqPad = 0;     // mixed layers: K = [vec region: (32-channel block, tap, channel)] + [quad tail: (tap, channel quads)]
     size_t tab_offset = 0, tab_bytes = 0;    // KEntry table, in the weight arena
     double flops = 0;                        // 2*M*N*K for the whole chunk
 };
@@ -79,7 +81,7 @@ NetPlan build_monodepth(int encoder /*0 vgg, 1 resnet50*/, int frames, int H, in
 // host-side re-layout of one TensorFlow-layout weight into its slot's kernel layout
 void relayout_weight(const WeightSlot& s, const float* tf_data, std::vector<float>& out);
 // gather-descriptor table of one conv op, given the bound activation arena
-void build_conv_tables(const NetPlan& p, const OpDesc& op, const char* act_base, std::vector<KEntry>& ktab);
+void build_conv_tables(const NetPlan& p, const OpDesc& op, const char* act_base, const char* tab_dev, std::vector<KEntry>& ktab);
 
 int conv_tile_n(int Cout);   // conv_igemm.hip
 
