@@ -1,5 +1,5 @@
 import sys, os, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from semantic_depth_amd import _lib as L, weights as Wt
 from semantic_depth_amd.engine import Camera, Engine, RoadWidthParams

@@ -1,6 +1,6 @@
 """per-layer conv timings (dev tool): SEMDEPTH_PROFILE_VERBOSE=1 python scripts/layer_times.py [B]"""
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["SEMDEPTH_PROFILE_VERBOSE"] = "1"
 import numpy as np, torch
 from semantic_depth_amd import _lib as L, weights as Wt

@@ -48,15 +48,16 @@ template <int WAVES_M, int WAVES_N, int MT, int NT>
 struct STile {
     static constexpr int BM = WAVES_M * MT * 32;
     static constexpr int BN = WAVES_N * NT * 32;
-    static constexpr int A_IT = BM * 4 / 256;                 // (pixel, k-octet) items per thread per k-tile
-    static constexpr int B_LD = (BN * 4 + 255) / 256;         // 16-B loads per thread per k-tile and plane
+    static constexpr int NTHR = WAVES_M * WAVES_N * 64;
+    static constexpr int A_IT = BM * 4 / NTHR;                // (pixel, k-octet) items per thread per k-tile
+    static constexpr int B_LD = (BN * 4 + NTHR - 1) / NTHR;   // 16-B loads per thread per k-tile and plane
     static constexpr int LDS_BYTES = (BM + BN) * 32 * 2 * 2;  // hi + lo, bf16
 };
 
 template <int WAVES_M, int WAVES_N, int MT, int NT, bool VEC>
-__global__ __launch_bounds__(256) void conv_split_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_split_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
     using T = STile<WAVES_M, WAVES_N, MT, NT>;
-    constexpr int BM = T::BM, BN = T::BN;
+    constexpr int BM = T::BM, BN = T::BN, NTHR = T::NTHR;
     __shared__ __attribute__((aligned(16))) unsigned char lds[T::LDS_BYTES];
     u32x4* Xh = reinterpret_cast<u32x4*>(lds);             // [4][BM] 16-B units
     u32x4* Xl = Xh + 4 * BM;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const ConvParams p, int
 
     const int m_l = t % BM;
     const int kg0 = t / BM;                 // 0 (BM=256) or 0/1 (BM=128)
-    constexpr int KG_STEP = 256 / BM;       // 1 or 2
+    constexpr int KG_STEP = NTHR / BM;      // 1, 2 or 4
     const int m = bm0 + m_l;
     const bool m_ok = m < M;
     int img, oy, ox;
@@ -107,9 +108,9 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const ConvParams p, int
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < T::B_LD; ++i) {
-            const int idx = t + 256 * i;
+            const int idx = t + NTHR * i;
             const int n_l = idx % BN, kg = idx / BN;
-            if (BN * 4 >= 256 || idx < BN * 4) {
+            if (BN * 4 >= NTHR || idx < BN * 4) {
                 const size_t o = (size_t)(kt * 4 + kg) * CoutPad + bn0 + n_l;
                 rwh[i] = wt_hi[o];
                 rwl[i] = wt_lo[o];
@@ -180,8 +181,8 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const ConvParams p, int
         }
 #pragma unroll
         for (int i = 0; i < T::B_LD; ++i) {
-            const int idx = t + 256 * i;
-            if (BN * 4 >= 256 || idx < BN * 4) { Wh[idx] = rwh[i]; Wl[idx] = rwl[i]; }
+            const int idx = t + NTHR * i;
+            if (BN * 4 >= NTHR || idx < BN * 4) { Wh[idx] = rwh[i]; Wl[idx] = rwl[i]; }
         }
         __syncthreads();
         if (kt + 1 < ktiles) load_tile(kt + 1);
@@ -199,14 +200,15 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const ConvParams p, int
                 xh[a] = __builtin_bit_cast(bf16x8, Xh[kg * BM + wm0 + a * 32 + frow]);
                 xl[a] = __builtin_bit_cast(bf16x8, Xl[kg * BM + wm0 + a * 32 + frow]);
             }
+            // the three products of one accumulator are issued MT*NT MFMAs apart (no back-to-back dependent MFMAs).
+            // (s_setprio(1) around this cluster was measured: -25 %, the co-resident blocks' staging starves)
 #pragma unroll
-            for (int b = 0; b < NT; ++b)
+            for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
-                for (int a = 0; a < MT; ++a) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[b], xh[a], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[b], xl[a], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[b], xh[a], acc[a][b], 0, 0, 0);
-                }
+                for (int b = 0; b < NT; ++b)
+#pragma unroll
+                    for (int a = 0; a < MT; ++a)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 0 ? wl[b] : wh[b], pr == 1 ? xl[a] : xh[a], acc[a][b], 0, 0, 0);
         }
     }
 
@@ -240,9 +242,9 @@ static hipError_t launch_scfg(const ConvParams& p, hipStream_t s) {
     const int tilesN = (p.Cout + T::BN - 1) / T::BN;
     dim3 grid((unsigned)(tilesM * tilesN));
     if (p.vec)
-        hipLaunchKernelGGL((conv_split_kernel<WAVES_M, WAVES_N, MT, NT, true>), grid, dim3(256), 0, s, p, (int)M, tilesM, tilesN);
+        hipLaunchKernelGGL((conv_split_kernel<WAVES_M, WAVES_N, MT, NT, true>), grid, dim3(T::NTHR), 0, s, p, (int)M, tilesM, tilesN);
     else
-        hipLaunchKernelGGL((conv_split_kernel<WAVES_M, WAVES_N, MT, NT, false>), grid, dim3(256), 0, s, p, (int)M, tilesM, tilesN);
+        hipLaunchKernelGGL((conv_split_kernel<WAVES_M, WAVES_N, MT, NT, false>), grid, dim3(T::NTHR), 0, s, p, (int)M, tilesM, tilesN);
     return hipGetLastError();
 }
 
@@ -252,19 +254,35 @@ int conv_split_tile_n(int Cout) {
     return 32;
 }
 
+// big tiles (8 waves) when there are enough of them to fill the chip: a 128x256 / 256x128 tile moves 25 % fewer bytes
+// from L2 per flop than 128x128 and halves the per-thread staging work on the wider side
+static int split_variant(const ConvParams& p) {
+    const long M = (long)p.N * p.Hout * p.Wout;
+    const int tn = conv_split_tile_n(p.Cout);
+    if (tn == 128) {
+        if (p.Cout % 256 == 0 && ((M + 127) / 128) * (p.Cout / 256) >= 512) return 0;    // 128 x 256
+        return 2;                                                                          // 128 x 128
+    }
+    return tn == 64 ? 3 : 4;
+}
+
 hipError_t launch_conv_split(const ConvParams& p, hipStream_t s) {
-    switch (conv_split_tile_n(p.Cout)) {
-        case 128: return launch_scfg<2, 2, 2, 2>(p, s);   // 128 x 128
-        case 64:  return launch_scfg<4, 1, 2, 2>(p, s);   // 256 x 64
-        default:  return launch_scfg<4, 1, 2, 1>(p, s);   // 256 x 32 (Cout = 16 is padded to 32)
+    switch (split_variant(p)) {
+        case 0:  return launch_scfg<2, 4, 2, 2>(p, s);   // 128 x 256, 8 waves
+        case 1:  return launch_scfg<4, 2, 2, 2>(p, s);   // 256 x 128, 8 waves
+        case 2:  return launch_scfg<2, 2, 2, 2>(p, s);   // 128 x 128
+        case 3:  return launch_scfg<4, 1, 2, 2>(p, s);   // 256 x 64
+        default: return launch_scfg<4, 1, 2, 1>(p, s);   // 256 x 32 (Cout = 16 is padded to 32)
     }
 }
 
 const char* conv_split_kernel_name(const ConvParams& p) {
-    switch (conv_split_tile_n(p.Cout)) {
-        case 128: return p.vec ? "conv_split_kernel<2,2,2,2,true>" : "conv_split_kernel<2,2,2,2,false>";
-        case 64:  return p.vec ? "conv_split_kernel<4,1,2,2,true>" : "conv_split_kernel<4,1,2,2,false>";
-        default:  return p.vec ? "conv_split_kernel<4,1,2,1,true>" : "conv_split_kernel<4,1,2,1,false>";
+    switch (split_variant(p)) {
+        case 0:  return p.vec ? "conv_split_kernel<2,4,2,2,true>" : "conv_split_kernel<2,4,2,2,false>";
+        case 1:  return p.vec ? "conv_split_kernel<4,2,2,2,true>" : "conv_split_kernel<4,2,2,2,false>";
+        case 2:  return p.vec ? "conv_split_kernel<2,2,2,2,true>" : "conv_split_kernel<2,2,2,2,false>";
+        case 3:  return p.vec ? "conv_split_kernel<4,1,2,2,true>" : "conv_split_kernel<4,1,2,2,false>";
+        default: return p.vec ? "conv_split_kernel<4,1,2,1,true>" : "conv_split_kernel<4,1,2,1,false>";
     }
 }
 
