@@ -158,9 +158,18 @@ def main():
     tot_n = sum(b["launches"] for b in buckets)
     dom = max(buckets, key=lambda b: b["ms"])
     achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    # HBM bytes per conv launch from the committed PMC profile of this same command (rocprofv3 FETCH_SIZE / WRITE_SIZE passes)
+    traffic = None
+    try:
+        import glob
+        pf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_conv_traffic.json")))
+        if pf and args.precision == "bf16x2":
+            traffic = round(json.load(open(pf[-1]))["all_conv"]["hbm_bytes_per_launch"])
+    except Exception:
+        traffic = None
     roofline = {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": round(PEAK_TFLOPS[args.precision], 1), "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_TFLOPS[args.precision], 4), "traffic": None,
+        "frac": round(achieved / PEAK_TFLOPS[args.precision], 4), "traffic": traffic,
         "peak_note": ("f32 MFMA dense peak" if args.precision == "f32" else
                       "dense bf16 MFMA peak 2500 TF/s / 3 MFMA products per algorithmic product; achieved counts algorithmic flops"),
         "kernel": ("conv_igemm_kernel" if args.precision == "f32" else "conv_split_kernel") + " (all instantiations)", "launches": tot_n,

@@ -130,6 +130,28 @@ sd_status sd_road_width(sd_handle* h, const float* road_xyz, const int32_t* n_ro
                         const sd_rw_params* params_host, sd_rw_result* results, float* final_xyz, int32_t* n_final,
                         void* stream);
 
+/* fence chain + fence-to-fence distance, semantic_depth.py:273-334 (seq:245-298), for B frames:
+ * MAD(y, mad_y) -> |z| < z_max -> extract_pcls at mean x -> left: MAD(x, mad_left) + plane(axis 0, plane_thr);
+ * right: MAD(x, mad_right) + plane(axis 0, plane_thr) -> both planes intersected with the road plane at z = -depth
+ * -> Euclidean distance.  road: DEVICE array of B sd_rw_result (their .plane is the road plane, from sd_road_width). */
+typedef struct {
+    double depth;        /* :325 z=self.depth (10.0) */
+    double mad_y;        /* remove_noise_by_mad(fence, 1, 5.0)      :279-280 */
+    double z_max;        /* threshold_complete(fence, 2, 35.0)      :283-284 */
+    double mad_left;     /* remove_noise_by_mad(left, 0, 5.0)       :291 */
+    double mad_right;    /* remove_noise_by_mad(right, 0, 1.0)      :302 */
+    double plane_thr;    /* remove_noise_by_fitting_plane(axis=0, threshold=1.0) :294-298, :305-309 */
+} sd_f2f_params;
+typedef struct {
+    double dist;                       /* dist_f2f, :327 */
+    double left_pt[3], right_pt[3];    /* plane intersections at z = -depth, :321-326 */
+    double plane_left[4], plane_right[4];
+    int32_t counts[7];                 /* n_fence, after MAD(y), after |z| cut, left, right, left final, right final */
+    int32_t ok;                        /* 0 when a side is empty / the planes are degenerate (dist is NaN) */
+} sd_f2f_result;
+sd_status sd_fence_to_fence(sd_handle* h, const float* fence_xyz, const int32_t* n_fence, int B, int cap,
+                            const sd_rw_result* road, const sd_f2f_params* params_host, sd_f2f_result* results, void* stream);
+
 /* ---------------------------------------------------------------- pcl.py, function by function
  * (semantic_depth_lib/pcl.py; one cloud per call: xyz f32 [n,3], rgb u8 [n,3] nullable, n on the host).
  * Outputs keep the input row order.  *n_out is a DEVICE int32. */
@@ -146,6 +168,11 @@ sd_status sd_pcl_remove_noise_by_fitting_plane(sd_handle* h, const float* xyz, c
 /* pcl.threshold_complete, pcl.py:240-250 (keeps |coord[axis]| < threshold) */
 sd_status sd_pcl_threshold_complete(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int axis, double threshold,
                                     float* xyz_out, uint8_t* rgb_out, int32_t* n_out, void* stream);
+/* pcl.extract_pcls, pcl.py:253-268: split at np.mean(coord[axis]) (reproduced bit for bit): left = coord < mean,
+ * right = coord > mean.  mean_out (nullable): device f32[1] */
+sd_status sd_pcl_extract_pcls(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int axis, float* left_xyz,
+                              uint8_t* left_rgb, int32_t* n_left, float* right_xyz, uint8_t* right_rgb, int32_t* n_right,
+                              float* mean_out, void* stream);
 /* pcl.get_end_points_of_road, pcl.py:271-313: first min-x and max-x rows of the depth window.
  * out: device sd_rw_result (only found, x_left, x_right, left_pt, right_pt, width are written) */
 sd_status sd_pcl_get_end_points_of_road(sd_handle* h, const float* xyz, int n, double depth, double window,

@@ -69,6 +69,37 @@ def road_width_tail(road3d: np.ndarray, road_rgb: np.ndarray, p: RoadWidthParams
     return out
 
 
+@dataclass
+class FenceParams:
+    """literals of semantic_depth.py:273-334"""
+    depth: float = 10.0
+    mad_y: float = 5.0
+    z_max: float = 35.0
+    mad_left: float = 5.0
+    mad_right: float = 1.0
+    plane_thr: float = 1.0
+
+
+def fence_tail(fence3d: np.ndarray, fence_rgb: np.ndarray, road_plane: dict, p: FenceParams = FenceParams()):
+    """semantic_depth.py:273-334 (seq:245-298): fence chain + fence-to-fence distance."""
+    out = dict(n_fence=len(fence3d))
+    pts, col = pcl.remove_noise_by_mad(fence3d, fence_rgb, 1, p.mad_y)
+    out["n_mad_y"] = len(pts)
+    pts, col = pcl.threshold_complete(pts, col, 2, p.z_max)
+    out["n_thr"] = len(pts)
+    l, lc, r, rc = pcl.extract_pcls(pts, col)
+    out["n_left"], out["n_right"] = len(l), len(r)
+    l, lc = pcl.remove_noise_by_mad(l, lc, 0, p.mad_left)
+    l, lc, cl = pcl.remove_noise_by_fitting_plane(l, lc, axis=0, threshold=p.plane_thr)
+    r, rc = pcl.remove_noise_by_mad(r, rc, 0, p.mad_right)
+    r, rc, cr = pcl.remove_noise_by_fitting_plane(r, rc, axis=0, threshold=p.plane_thr)
+    out.update(n_left_final=len(l), n_right_final=len(r), plane_left=cl, plane_right=cr, left=l, right=r)
+    lp = pcl.planes_intersection_at_certain_depth(road_plane, cl, p.depth)
+    rp = pcl.planes_intersection_at_certain_depth(road_plane, cr, p.depth)
+    out.update(left_pt=lp[0], right_pt=rp[0], dist=float(pcl.compute_distance_in_3D(lp, rp)))
+    return out
+
+
 def frame_tail(disp_pair, road, fence, frame_bgr, cam, p: RoadWidthParams = RoadWidthParams()):
     """fusion + road-width tail for one frame. cam = dict(cx, cy, f, b, disp_mult)."""
     fz = fusion.fuse(disp_pair, road, fence, frame_bgr, **cam)

@@ -34,6 +34,16 @@ class sd_rw_result(C.Structure):
                 ("n_ror", C.c_int32), ("plane", C.c_double * 4)]
 
 
+class sd_f2f_params(C.Structure):
+    _fields_ = [("depth", C.c_double), ("mad_y", C.c_double), ("z_max", C.c_double), ("mad_left", C.c_double),
+                ("mad_right", C.c_double), ("plane_thr", C.c_double)]
+
+
+class sd_f2f_result(C.Structure):
+    _fields_ = [("dist", C.c_double), ("left_pt", C.c_double * 3), ("right_pt", C.c_double * 3), ("plane_left", C.c_double * 4),
+                ("plane_right", C.c_double * 4), ("counts", C.c_int32 * 7), ("ok", C.c_int32)]
+
+
 class sd_profile_bucket(C.Structure):
     _fields_ = [("kernel", C.c_char * 64), ("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double)]
 
@@ -57,6 +67,8 @@ SIGNATURES = {
     "sd_post_process": (C.c_int, [_H, _P, C.c_int, _P, _P]),
     "sd_fuse_backproject": (C.c_int, [_H, _P, _P, _P, _P, C.POINTER(sd_camera), C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sd_road_width": (C.c_int, [_H, _P, _P, C.c_int, C.c_int, C.POINTER(sd_rw_params), _P, _P, _P, _P]),
+    "sd_fence_to_fence": (C.c_int, [_H, _P, _P, C.c_int, C.c_int, _P, C.POINTER(sd_f2f_params), _P, _P]),
+    "sd_pcl_extract_pcls": (C.c_int, [_H, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sd_pcl_remove_from_to": (C.c_int, [_H, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P]),
     "sd_pcl_remove_noise_by_mad": (C.c_int, [_H, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P, _P]),
     "sd_pcl_remove_noise_by_fitting_plane": (C.c_int, [_H, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P, _P]),

@@ -18,6 +18,7 @@
 using namespace sd;
 
 static_assert(sizeof(RwResultDev) == sizeof(sd_rw_result), "sd_rw_result layout");
+static_assert(sizeof(F2fResultDev) == sizeof(sd_f2f_result), "sd_f2f_result layout");
 
 struct sd_handle {
     int device = 0, H = 0, W = 0, max_batch = 0, enc = 0, chunk = 0, cap = 0, prec = 0;
@@ -69,10 +70,10 @@ void carve_workspace(sd_handle* h) {
     h->o_cams = take(sizeof(CamDev) * B);
     h->o_bufA = take(B * cap * 3 * sizeof(float));
     h->o_bufB = take(B * cap * 3 * sizeof(float));
-    h->o_cnt = take(B * sizeof(int32_t) * 16);
+    h->o_cnt = take(B * sizeof(int32_t) * 24);
     h->o_plane = take(B * sizeof(double) * 4);
     h->o_o3d = take(o3d_scratch_bytes(h->max_batch, h->cap));
-    h->o_misc = take(4096);
+    h->o_misc = take(4096 + al(B * 7 * sizeof(int32_t)) + al(B * 12 * sizeof(double)));   // scalars | f2f counts | f2f planes
     h->ws_bytes = off;
 }
 
@@ -405,6 +406,36 @@ sd_status sd_road_width(sd_handle* h, const float* road_xyz, const int32_t* n_ro
     return SD_OK;
 }
 
+sd_status sd_fence_to_fence(sd_handle* h, const float* fence_xyz, const int32_t* n_fence, int B, int cap, const sd_rw_result* road,
+                            const sd_f2f_params* prm, sd_f2f_result* results, void* stream) {
+    if (!h || !fence_xyz || !n_fence || !road || !prm || !results || B <= 0 || B > h->max_batch || cap <= 0 || cap > h->cap)
+        return fail(h, SD_ERR_INVALID, "sd_fence_to_fence: bad arguments");
+    if (!h->bound) return fail(h, SD_ERR_STATE, "sd_bind_memory first");
+    hipStream_t s = (hipStream_t)stream;
+    float* A = reinterpret_cast<float*>(h->ws + h->o_bufA);     // fence, then left fence
+    float* Rb = reinterpret_cast<float*>(h->ws + h->o_bufB);    // right fence
+    float* Lb = reinterpret_cast<float*>(h->ws + h->o_o3d);     // left fence (the Open3D scratch is idle here)
+    int32_t* cnt = cnt_slot(h, 8);                              // [7][max_batch]: slots 8..14
+    auto C = [&](int j) { return cnt + (size_t)j * h->max_batch; };
+    int32_t* packed = reinterpret_cast<int32_t*>(h->ws + h->o_misc + 4096);
+    double* planes = reinterpret_cast<double*>(h->ws + h->o_misc + 4096 + al((size_t)h->max_batch * 7 * sizeof(int32_t)));   // road | left | right, [B][4] each
+    double *p_road = planes, *p_left = planes + (size_t)B * 4, *p_right = planes + (size_t)B * 8;
+    HIPCHK(h, hipMemcpyAsync(C(0), n_fence, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, launch_gather_planes(reinterpret_cast<const RwResultDev*>(road), B, p_road, s));
+    HIPCHK(h, launch_mad_filter({fence_xyz, nullptr, n_fence}, {A, nullptr, C(1)}, B, cap, 1, prm->mad_y, nullptr, s));
+    HIPCHK(h, launch_filter_coord({A, nullptr, C(1)}, {A, nullptr, C(2)}, B, cap, F_ABS_LT, 2, prm->z_max, s));
+    HIPCHK(h, launch_extract_pcls({A, nullptr, C(2)}, {Lb, nullptr, C(3)}, {Rb, nullptr, C(4)}, B, cap, 0, nullptr, s));
+    HIPCHK(h, launch_mad_filter({Lb, nullptr, C(3)}, {Lb, nullptr, C(5)}, B, cap, 0, prm->mad_left, nullptr, s));
+    HIPCHK(h, launch_plane_filter({Lb, nullptr, C(5)}, {Lb, nullptr, C(5)}, B, cap, 0, prm->plane_thr, p_left, s));
+    HIPCHK(h, launch_mad_filter({Rb, nullptr, C(4)}, {Rb, nullptr, C(6)}, B, cap, 0, prm->mad_right, nullptr, s));
+    HIPCHK(h, launch_plane_filter({Rb, nullptr, C(6)}, {Rb, nullptr, C(6)}, B, cap, 0, prm->plane_thr, p_right, s));
+    // counts array for the kernel is [7][B] contiguous: compact the strided slots
+    for (int j = 0; j < 7; ++j)
+        HIPCHK(h, hipMemcpyAsync(packed + (size_t)j * B, C(j), (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, launch_f2f(p_road, p_left, p_right, B, prm->depth, packed, reinterpret_cast<F2fResultDev*>(results), s));
+    return SD_OK;
+}
+
 // ---------------------------------------------------------------- pcl.py function by function (single cloud)
 static sd_status set_n(sd_handle* h, int n, int32_t** dn, hipStream_t s) {
     *dn = reinterpret_cast<int32_t*>(h->ws + h->o_misc);
@@ -443,6 +474,15 @@ sd_status sd_pcl_remove_noise_by_fitting_plane(sd_handle* h, const float* xyz, c
     PCL_PROLOGUE();
     if (axis < 0 || axis > 2) return fail(h, SD_ERR_INVALID, "axis");
     HIPCHK(h, launch_plane_filter({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, axis, threshold, coeff_out, s));
+    return SD_OK;
+}
+sd_status sd_pcl_extract_pcls(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int axis, float* left_xyz, uint8_t* left_rgb,
+                              int32_t* n_left, float* right_xyz, uint8_t* right_rgb, int32_t* n_right, float* mean_out, void* stream) {
+    float* xyz_out = left_xyz;
+    int32_t* n_out = n_left;
+    PCL_PROLOGUE();
+    if (!right_xyz || !n_right || axis < 0 || axis > 2) return fail(h, SD_ERR_INVALID, "pcl: bad arguments");
+    HIPCHK(h, launch_extract_pcls({xyz, rgb, dn}, {left_xyz, left_rgb, n_left}, {right_xyz, right_rgb, n_right}, 1, cap1, axis, mean_out, s));
     return SD_OK;
 }
 sd_status sd_pcl_get_end_points_of_road(sd_handle* h, const float* xyz, int n, double depth, double window, sd_rw_result* out,

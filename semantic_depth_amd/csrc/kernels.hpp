@@ -111,6 +111,16 @@ enum FilterKind { F_LT_NEG = 0 /* coord < -t */, F_ABS_LT = 1 /* |coord| < t */ 
 hipError_t launch_filter_coord(CloudView in, CloudOut out, int B, int cap, int kind, int axis, double t, hipStream_t s);
 hipError_t launch_mad_filter(CloudView in, CloudOut out, int B, int cap, int axis, double thr, float* stats, hipStream_t s);
 hipError_t launch_plane_filter(CloudView in, CloudOut out, int B, int cap, int axis, double thr, double* coeff, hipStream_t s);
+// fence chain
+struct F2fResultDev {   // layout == sd_f2f_result
+    double dist; double left_pt[3], right_pt[3]; double plane_left[4], plane_right[4];
+    int32_t counts[7];   // n_fence, after MAD(y), after |z| threshold, left, right, left final, right final
+    int32_t ok;
+};
+hipError_t launch_extract_pcls(CloudView in, CloudOut outl, CloudOut outr, int B, int cap, int axis, float* mean_out, hipStream_t s);
+hipError_t launch_f2f(const double* road_plane, const double* left_plane, const double* right_plane, int B, double depth,
+                      const int32_t* cnt /* [7][B] */, F2fResultDev* out, hipStream_t s);
+hipError_t launch_gather_planes(const RwResultDev* res, int B, double* planes, hipStream_t s);
 hipError_t launch_end_points(CloudView in, int B, int cap, double depth, double window, RwResultDev* res, hipStream_t s);
 size_t o3d_scratch_bytes(int B, int cap);
 hipError_t launch_sor(CloudView in, CloudOut out, int B, int cap, int k, double ratio, void* scratch, double* mean_out,

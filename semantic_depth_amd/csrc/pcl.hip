@@ -339,6 +339,130 @@ hipError_t launch_record_counts(RwResultDev* res, int B, const int32_t* n_road, 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------ extract_pcls (fence chain)
+// pcl.extract_pcls (pcl.py:253-268): split at np.mean of a float32 coordinate column: left = coord < mean, right = coord > mean.
+// The mean is reproduced bit for bit: numpy's add.reduce walks the column in chunks of 8192 elements (the ufunc buffer
+// size), sums each chunk with its pairwise routine (8 interleaved accumulators on blocks of <= 128 elements, halves
+// rounded down to a multiple of 8 above that), adds the chunk sums in order, and np.mean divides by n in float32.
+struct ColF32 {
+    const float* p;    // first element
+    int stride;        // in floats
+    __device__ __forceinline__ float operator[](int i) const { return p[(size_t)i * stride]; }
+};
+__device__ float np_pairwise(ColF32 a, int off, int n) {
+    if (n < 8) {
+        float r = 0.f;
+        for (int i = 0; i < n; ++i) r += a[off + i];
+        return r;
+    }
+    if (n <= 128) {
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = a[off + j];
+        int i = 8;
+        for (; i < n - (n % 8); i += 8)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] += a[off + i + j];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[off + i];
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise(a, off, n2) + np_pairwise(a, off + n2, n - n2);
+}
+// np.mean(column) for a float32 column, by one workgroup
+__device__ float block_np_mean(ColF32 a, int n, Lds& L) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int full = n / 8192, rem = n % 8192;
+    __shared__ float csum[NW];
+    __shared__ float total;
+    if (tid == 0) total = 0.f;
+    __syncthreads();
+    for (int c0 = 0; c0 < full; c0 += NW) {
+        const int c = c0 + wave;
+        if (c < full) {           // one wave per 8192-chunk: lane j sums leaf j (128 elements), butterfly = the balanced recursion
+            float v = np_pairwise(a, c * 8192 + lane * 128, 128);
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+            if (lane == 0) csum[wave] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 0; w < NW && c0 + w < full; ++w) total = (c0 + w == 0) ? csum[w] : total + csum[w];
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && rem > 0) {
+        const float v = np_pairwise(a, full * 8192, rem);
+        total = full == 0 ? v : total + v;
+    }
+    __syncthreads();
+    (void)L;
+    return total / (float)n;
+}
+
+__global__ __launch_bounds__(TB) void extract_pcls_kernel(CloudView in, CloudOut outl, CloudOut outr, int cap, int axis, float* mean_out) {
+    const int b = blockIdx.x;
+    const float* xyz = in.xyz + (size_t)b * cap * 3;
+    const uint8_t* rgb = in.rgb ? in.rgb + (size_t)b * cap * 3 : nullptr;
+    const int n = min(in.n[b], cap);
+    __shared__ Lds L;
+    const float mean = n > 0 ? block_np_mean(ColF32{xyz + axis, 3}, n, L) : __uint_as_float(0x7fc00000u);
+    if (mean_out && threadIdx.x == 0) mean_out[b] = mean;
+    block_compact(xyz, rgb, n, outl.xyz + (size_t)b * cap * 3, (outl.rgb && rgb) ? outl.rgb + (size_t)b * cap * 3 : nullptr, outl.n + b, cap,
+                  [=](int, float x, float y, float z) { return (axis == 0 ? x : (axis == 1 ? y : z)) < mean; }, L);
+    block_compact(xyz, rgb, n, outr.xyz + (size_t)b * cap * 3, (outr.rgb && rgb) ? outr.rgb + (size_t)b * cap * 3 : nullptr, outr.n + b, cap,
+                  [=](int, float x, float y, float z) { return (axis == 0 ? x : (axis == 1 ? y : z)) > mean; }, L);
+}
+hipError_t launch_extract_pcls(CloudView in, CloudOut outl, CloudOut outr, int B, int cap, int axis, float* mean_out, hipStream_t s) {
+    hipLaunchKernelGGL(extract_pcls_kernel, dim3(B), dim3(TB), 0, s, in, outl, outr, cap, axis, mean_out);
+    return hipGetLastError();
+}
+
+// pcl.planes_intersection_at_certain_depth (pcl.py:212-237) for the two fence planes against the road plane, and the
+// fence-to-fence distance (semantic_depth.py:321-328).  Cramer's rule in float64 (the reference inverts the 2x2 with LAPACK).
+__global__ void f2f_kernel(const double* road_plane, const double* left_plane, const double* right_plane, int B, double depth,
+                           const int32_t* cnt, F2fResultDev* out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    F2fResultDev r;
+    const double z = -depth;
+    const double* rp = road_plane + (size_t)b * 4;
+    const double* pl[2] = {left_plane + (size_t)b * 4, right_plane + (size_t)b * 4};
+    double pt[2][3];
+    for (int s = 0; s < 2; ++s) {
+        const double a = rp[0], bb = rp[1], c = pl[s][0], d = pl[s][1];
+        const double e = -(rp[2] * z + rp[3]), f = -(pl[s][2] * z + pl[s][3]);
+        const double det = a * d - bb * c;
+        pt[s][0] = (e * d - bb * f) / det;
+        pt[s][1] = (a * f - e * c) / det;
+        pt[s][2] = z;
+    }
+    const double dx = pt[0][0] - pt[1][0], dy = pt[0][1] - pt[1][1], dz = pt[0][2] - pt[1][2];
+    r.dist = sqrt(dx * dx + dy * dy + dz * dz);
+    for (int j = 0; j < 3; ++j) { r.left_pt[j] = pt[0][j]; r.right_pt[j] = pt[1][j]; }
+    for (int j = 0; j < 4; ++j) { r.plane_left[j] = pl[0][j]; r.plane_right[j] = pl[1][j]; }
+    for (int j = 0; j < 7; ++j) r.counts[j] = cnt[(size_t)j * B + b];
+    r.ok = (r.dist == r.dist) && r.counts[5] > 0 && r.counts[6] > 0;
+    out[b] = r;
+}
+hipError_t launch_f2f(const double* road_plane, const double* left_plane, const double* right_plane, int B, double depth,
+                      const int32_t* cnt, F2fResultDev* out, hipStream_t s) {
+    hipLaunchKernelGGL(f2f_kernel, dim3((B + 63) / 64), dim3(64), 0, s, road_plane, left_plane, right_plane, B, depth, cnt, out);
+    return hipGetLastError();
+}
+
+__global__ void gather_planes_kernel(const RwResultDev* res, int B, double* planes) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    for (int j = 0; j < 4; ++j) planes[(size_t)b * 4 + j] = res[b].plane[j];
+}
+hipError_t launch_gather_planes(const RwResultDev* res, int B, double* planes, hipStream_t s) {
+    hipLaunchKernelGGL(gather_planes_kernel, dim3((B + 63) / 64), dim3(64), 0, s, res, B, planes);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------ K23 Open3D filters
 // [UPSTREAM Open3D legacy RemoveStatisticalOutliers / RemoveRadiusOutliers, parity unpinned — see oracle/o3d.py]
 // Exact k-NN / radius counts in float64 over a uniform grid: points are binned (clamped at the grid faces,

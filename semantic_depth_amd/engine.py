@@ -17,6 +17,9 @@ RW_DTYPE = np.dtype([("width", "<f8"), ("x_left", "<f4"), ("x_right", "<f4"), ("
                      ("found", "<i4"), ("n_road", "<i4"), ("n_zcut", "<i4"), ("n_mad_y", "<i4"), ("n_mad_x", "<i4"),
                      ("n_plane", "<i4"), ("n_sor", "<i4"), ("n_ror", "<i4"), ("plane", "<f8", 4)])
 assert RW_DTYPE.itemsize == C.sizeof(L.sd_rw_result)
+F2F_DTYPE = np.dtype([("dist", "<f8"), ("left_pt", "<f8", 3), ("right_pt", "<f8", 3), ("plane_left", "<f8", 4), ("plane_right", "<f8", 4),
+                      ("counts", "<i4", 7), ("ok", "<i4")])
+assert F2F_DTYPE.itemsize == C.sizeof(L.sd_f2f_result)
 
 
 @dataclass
@@ -39,6 +42,20 @@ class RoadWidthParams:
         d = asdict(self)
         d["use_o3d"] = int(d["use_o3d"])
         return L.sd_rw_params(**d)
+
+
+@dataclass
+class FenceParams:
+    """literals of the reference's fence chain, semantic_depth.py:273-334 (defaults = the reference's)."""
+    depth: float = 10.0
+    mad_y: float = 5.0
+    z_max: float = 35.0
+    mad_left: float = 5.0
+    mad_right: float = 1.0
+    plane_thr: float = 1.0
+
+    def to_c(self) -> L.sd_f2f_params:
+        return L.sd_f2f_params(**asdict(self))
 
 
 @dataclass
@@ -181,6 +198,21 @@ class Engine:
                                     self._stream())
         L.check(self.lib, self.h, st, "sd_road_width")
         return (res, fin, nfin) if want_final else res
+
+    def fence_to_fence(self, fence_xyz, n_fence, road_records: torch.Tensor, params: FenceParams = FenceParams()):
+        """fence chain + fence-to-fence distance (semantic_depth.py:273-334) for B frames; ``road_records`` is the device
+        buffer returned by road_width (its plane is the road plane).  Returns a device buffer of sd_f2f_result."""
+        B, cap = fence_xyz.shape[0], fence_xyz.shape[1]
+        res = torch.zeros((B, F2F_DTYPE.itemsize), dtype=torch.uint8, device=self.device)
+        prm = params.to_c()
+        st = self.lib.sd_fence_to_fence(self.h, _ptr(fence_xyz), _ptr(n_fence), B, cap, _ptr(road_records), C.byref(prm), _ptr(res),
+                                        self._stream())
+        L.check(self.lib, self.h, st, "sd_fence_to_fence")
+        return res
+
+    @staticmethod
+    def f2f_records(res: torch.Tensor) -> np.ndarray:
+        return res.cpu().numpy().view(F2F_DTYPE).reshape(-1)
 
     @staticmethod
     def records(res: torch.Tensor) -> np.ndarray:

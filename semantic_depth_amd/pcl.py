@@ -115,6 +115,21 @@ def threshold_complete(points3D, colors, axis, threshold=15.0):
     return _filter("sd_pcl_threshold_complete", points3D, colors, int(axis), float(threshold))
 
 
+def extract_pcls(points3D, colors, axis=0):
+    """pcl.py:253-268: (left, left_colors, right, right_colors), split at np.mean of the ``axis`` column."""
+    e, pts, d_pts, d_col = _up(points3D, colors)
+    n = len(pts)
+    outs = [torch.empty_like(d_pts), torch.empty_like(d_pts)]
+    cols = [torch.empty_like(d_col) if d_col is not None else None for _ in range(2)]
+    ns = [torch.zeros(1, dtype=torch.int32, device=e.device) for _ in range(2)]
+    st = e.lib.sd_pcl_extract_pcls(e.h, _ptr(d_pts), _ptr(d_col), n, int(axis), _ptr(outs[0]), _ptr(cols[0]), _ptr(ns[0]),
+                                   _ptr(outs[1]), _ptr(cols[1]), _ptr(ns[1]), None, e._stream())
+    L.check(e.lib, e.h, st, "sd_pcl_extract_pcls")
+    l, lc = _down(e, ns[0], outs[0], cols[0], points3D, colors)
+    r, rc = _down(e, ns[1], outs[1], cols[1], points3D, colors)
+    return l, lc, r, rc
+
+
 def get_end_points_of_road(points3D, depth):
     """pcl.py:271-313.  (None, None) when no point lies in the +-0.05 depth window."""
     e, pts, d_pts, _ = _up(points3D, None)

@@ -109,6 +109,20 @@ def main():
     z["line_in_left"], z["line_in_right"] = lp.copy(), rp.copy()
     line, lcol = ref.create_3Dline_from_3Dpoints(lp, rp, [250, 0, 0])
     z["line"], z["line_col"], z["line_left_after"], z["line_right_after"] = line, lcol, lp, rp
+    # fence chain of semantic_depth.py:273-309 with the reference's functions (plane intersection cannot run on numpy 2)
+    def fence_chain(fp, fc, tag, store):
+        p1, c1 = ref.remove_noise_by_mad(fp, fc, 1, 5.0)
+        p2, c2 = ref.threshold_complete(p1, c1, 2, 35.0)
+        l, lc, r, rc = ref.extract_pcls(p2, c2)
+        l1, lc1 = ref.remove_noise_by_mad(l, lc, 0, 5.0)
+        l2, lc2, _, _, cl = ref.remove_noise_by_fitting_plane(l1, lc1, axis=0, threshold=1.0, plane_color=[40, 70, 40])
+        r1, rc1 = ref.remove_noise_by_mad(r, rc, 0, 1.0)
+        r2, rc2, _, _, cr = ref.remove_noise_by_fitting_plane(r1, rc1, axis=0, threshold=1.0, plane_color=[40, 70, 40])
+        store(tag, dict(mad_y=p1, thr=p2, left=l, right=r, left_final=l2, right_final=r2,
+                        plane_left=np.array([cl[k] for k in ("Cx", "Cy", "Cz", "C")], np.float64),
+                        plane_right=np.array([cr[k] for k in ("Cx", "Cy", "Cz", "C")], np.float64),
+                        mean_x=np.float32(np.mean(p2[:, 0]))))
+    fence_chain(fp, fc, "fc", lambda tag, d: z.update({f"{tag}_{k}": v for k, v in d.items()}))
     np.savez_compressed(os.path.join(HERE, "pcl_mini.npz"), **z)
 
     # ---------------- full size: digests ----------------
@@ -127,6 +141,21 @@ def main():
     full["left_pt"] = [float(v) for v in ch["left"][0]]
     full["right_pt"] = [float(v) for v in ch["right"][0]]
     full["dist_rw"] = float(abs(ch["left"][0][0] - ch["right"][0][0]))
+    # fence scene at full size: digests of the reference's fence chain
+    dpf, roadf, fencef, framef, camf, fzf = scene_inputs(512, 1024, seed=77, f=1000.0, fences=True)
+    fdig = {}
+    def store_digest(tag, d):
+        for k, v in d.items():
+            if v.ndim == 2:
+                fdig[f"n_{k}"] = int(v.shape[0]); fdig[f"{k}_checksum"] = checksum(v)
+            elif v.ndim == 1:
+                fdig[k] = [float(x) for x in v]
+            else:
+                fdig[k] = float(v)
+    fence_chain(fzf["fence3d"], fzf["fence_rgb"], "ff", store_digest)
+    fdig["scene"] = dict(h=512, w=1024, seed=77, f=1000.0, fences=True)
+    fdig["n_fence"] = int(fzf["fence3d"].shape[0])
+    full["fence"] = fdig
     full["numpy"] = np.__version__
     with open(os.path.join(HERE, "pcl_full.json"), "w") as fh:
         json.dump(full, fh, indent=1, sort_keys=True)

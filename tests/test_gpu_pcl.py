@@ -183,3 +183,65 @@ def test_tail_batch_and_degenerate_frames(pcl):
     assert rec[1]["found"] == 0 and rec[1]["n_road"] == 0 and rec[1]["n_ror"] == 0 and np.isnan(rec[1]["width"])
     rec = e.records(e.road_width(fz["road_xyz"], fz["n_road"], RoadWidthParams(depth=500.0)))
     assert rec[0]["found"] == 0 and rec[0]["n_ror"] == ref["n_ror"]
+
+
+def test_extract_pcls_and_mean_bit_exact(pcl, mini):
+    """pcl.extract_pcls: the split mean reproduces np.mean of the float32 column bit for bit (chunked pairwise sum)."""
+    a, ac, b, bc = pcl.extract_pcls(mini["thr_pts"], mini["thr_col"])
+    _eq(a, mini["split_left"]); _eq(ac, mini["split_left_col"]); _eq(b, mini["split_right"]); _eq(bc, mini["split_right_col"])
+    from semantic_depth_amd.engine import _ptr
+    from semantic_depth_amd import _lib as L
+    e = pcl._eng()
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 8, 129, 8191, 8192, 8193, 20011, 70001, 300007):
+        pts = (rng.standard_normal((n, 3)) * 5).astype(np.float32)
+        d = dev(pts)
+        o1, o2 = torch.empty_like(d), torch.empty_like(d)
+        n1 = torch.zeros(1, dtype=torch.int32, device="cuda"); n2 = torch.zeros(1, dtype=torch.int32, device="cuda")
+        mean = torch.zeros(1, dtype=torch.float32, device="cuda")
+        for axis in (0, 2):
+            st = e.lib.sd_pcl_extract_pcls(e.h, _ptr(d), None, n, axis, _ptr(o1), None, _ptr(n1), _ptr(o2), None, _ptr(n2), _ptr(mean), e._stream())
+            L.check(e.lib, e.h, st, "extract")
+            ref = np.mean(pts[:, axis])
+            assert np.float32(mean.item()) == ref, (n, axis, mean.item(), ref)
+            assert int(n1) == int((pts[:, axis] < ref).sum()) and int(n2) == int((pts[:, axis] > ref).sum())
+
+
+def test_fence_chain_golden_and_oracle(pcl, mini, golden_dir):
+    """fence chain + fence-to-fence: mini scene vs the reference-captured arrays, 512x1024 fence scene vs digests."""
+    from oracle import pipeline as op
+    from semantic_depth_amd.engine import FenceParams
+    e = pcl._eng()
+    # --- mini: through the pcl mirror, stage by stage
+    p, c = pcl.remove_noise_by_mad(mini["fence3d"], mini["fence_rgb"], 1, 5.0)
+    _eq(p, mini["fc_mad_y"])
+    p, c = pcl.threshold_complete(p, c, 2, 35.0)
+    _eq(p, mini["fc_thr"])
+    l, lc, r, rc = pcl.extract_pcls(p, c)
+    _eq(l, mini["fc_left"]); _eq(r, mini["fc_right"])
+    l, lc = pcl.remove_noise_by_mad(l, lc, 0, 5.0)
+    l, lc, _, _, cl = pcl.remove_noise_by_fitting_plane(l, lc, axis=0, threshold=1.0)
+    r, rc = pcl.remove_noise_by_mad(r, rc, 0, 1.0)
+    r, rc, _, _, cr = pcl.remove_noise_by_fitting_plane(r, rc, axis=0, threshold=1.0)
+    _eq(l, mini["fc_left_final"]); _eq(r, mini["fc_right_final"])
+    assert np.allclose([cl[k] for k in ("Cx", "Cy", "Cz", "C")], mini["fc_plane_left"], rtol=1e-8, atol=1e-10)
+    # --- full size, batched device path
+    g = json.load(open(os.path.join(golden_dir, "pcl_full.json")))["fence"]
+    sc = g["scene"]
+    dp, road, fence, frame, cam = op.synthetic_scene(sc["h"], sc["w"], seed=sc["seed"], f=sc["f"], fences=True)
+    pp = e.post_process(dev(np.stack([dp, dp])))
+    masks_r = np.stack([road, road]).astype(np.uint8)
+    masks_f = np.stack([fence, np.zeros_like(fence)]).astype(np.uint8)      # frame 1 has no fence at all
+    fz = e.fuse_backproject(pp, dev(masks_r), dev(masks_f), dev(np.stack([frame, frame])), [Camera(**cam)] * 2)
+    rw = e.road_width(fz["road_xyz"], fz["n_road"], RoadWidthParams())
+    f2f = e.f2f_records(e.fence_to_fence(fz["fence_xyz"], fz["n_fence"], rw, FenceParams()))
+    c = f2f[0]["counts"]
+    assert tuple(c) == (g["n_fence"], g["n_mad_y"], g["n_thr"], g["n_left"], g["n_right"], g["n_left_final"], g["n_right_final"])
+    assert np.allclose(f2f[0]["plane_left"], g["plane_left"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(f2f[0]["plane_right"], g["plane_right"], rtol=1e-8, atol=1e-10)
+    # oracle for the distance (the reference's own plane-intersection cannot run on numpy 2: closed form)
+    ref_fz = op.frame_tail(dp, road, fence, frame, cam)
+    ft = op.fence_tail(ref_fz["fence3d"], ref_fz["fence_rgb"], ref_fz["rw"]["plane"])
+    assert f2f[0]["ok"] == 1 and abs(f2f[0]["dist"] - ft["dist"]) <= 1e-9 * ft["dist"]
+    assert np.allclose(f2f[0]["left_pt"], ft["left_pt"], rtol=1e-9, atol=1e-9)
+    assert f2f[1]["ok"] == 0 and f2f[1]["counts"][0] == 0

@@ -118,3 +118,56 @@ def test_full_scene_digests(golden_dir):
     assert float(abs(l[0][0] - r[0][0])) == g["dist_rw"]
     # the mask half-width is 3.5 m -> ~7 m, plane offset = -camera height
     assert abs(g["dist_rw"] - 7.0) < 0.05 and abs(g["plane_coeff"]["C"] + 1.5) < 1e-3
+
+
+def test_fence_chain_matches_reference(mini):
+    """semantic_depth.py:273-309 with the oracle's pcl restatement vs the reference's functions (mini scene, full arrays)."""
+    from oracle.pipeline import fence_tail
+    road_plane = dict(zip(("Cx", "Cy", "Cz", "C"), mini["plane_coeff"]))
+    ft = fence_tail(mini["fence3d"], mini["fence_rgb"], road_plane)
+    assert ft["n_mad_y"] == len(mini["fc_mad_y"]) and ft["n_thr"] == len(mini["fc_thr"])
+    assert (ft["n_left"], ft["n_right"]) == (len(mini["fc_left"]), len(mini["fc_right"]))
+    _eq(ft["left"], mini["fc_left_final"]); _eq(ft["right"], mini["fc_right_final"])
+    for side in ("left", "right"):
+        got = np.array([ft[f"plane_{side}"][k] for k in ("Cx", "Cy", "Cz", "C")], np.float64)
+        _eq(got, mini[f"fc_plane_{side}"])
+    # both intersection points satisfy the road plane and their fence plane at z = -10
+    for pt, plane in ((ft["left_pt"], ft["plane_left"]), (ft["right_pt"], ft["plane_right"])):
+        for c in (road_plane, plane):
+            assert abs(c["Cx"] * pt[0] + c["Cy"] * pt[1] + c["Cz"] * pt[2] + c["C"]) < 1e-9
+    assert 7.5 < ft["dist"] < 9.0          # fence strips at |X| in [4, 4.3)
+
+
+def test_numpy_mean_is_chunked_pairwise():
+    """the documented summation order of np.mean on a float32 column (what the HIP extract_pcls reproduces):
+    8192-element chunks, numpy's pairwise routine per chunk, chunk sums added in order, float32 division."""
+    def pw(a):
+        n = len(a)
+        if n < 8:
+            r = np.float32(0.)
+            for v in a:
+                r = np.float32(r + v)
+            return r
+        if n <= 128:
+            r = [np.float32(a[j]) for j in range(8)]
+            i = 8
+            while i < n - (n % 8):
+                for j in range(8):
+                    r[j] = np.float32(r[j] + a[i + j])
+                i += 8
+            res = np.float32(np.float32(np.float32(r[0] + r[1]) + np.float32(r[2] + r[3])) +
+                             np.float32(np.float32(r[4] + r[5]) + np.float32(r[6] + r[7])))
+            while i < n:
+                res = np.float32(res + a[i]); i += 1
+            return res
+        n2 = n // 2
+        n2 -= n2 % 8
+        return np.float32(pw(a[:n2]) + pw(a[n2:]))
+    rng = np.random.default_rng(3)
+    for n in (1, 7, 8, 129, 8191, 8192, 8193, 20011, 70001):
+        col = (rng.standard_normal((n, 3)) * 5).astype(np.float32)[:, 0]
+        tot = None
+        for i in range(0, n, 8192):
+            s = pw(col[i:i + 8192])
+            tot = s if tot is None else np.float32(tot + s)
+        assert np.float32(tot / np.float32(n)) == np.mean(col), n
