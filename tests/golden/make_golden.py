@@ -125,6 +125,21 @@ def main():
     fence_chain(fp, fc, "fc", lambda tag, d: z.update({f"{tag}_{k}": v for k, v in d.items()}))
     np.savez_compressed(os.path.join(HERE, "pcl_mini.npz"), **z)
 
+    # ---------------- PLY writer: bytes written by the reference's own class ----------------
+    from semantic_depth_lib.point_cloud_2_ply import PointCloud2Ply as RefPly
+    import tempfile, io, contextlib
+    pts_p, col_p = ch["plane"][0][:40].astype(np.float64), ch["plane"][1][:40]
+    lp2, rp2 = ch["left"][:1].copy(), ch["right"][:1].copy()
+    line2, lcol2 = ref.create_3Dline_from_3Dpoints(lp2, rp2, [250, 0, 0])
+    with tempfile.TemporaryDirectory() as td, contextlib.redirect_stdout(io.StringIO()):
+        pc = RefPly(pts_p, col_p, os.path.join(td, "cloud"))
+        pc.add_extra_point_cloud(line2[:25], lcol2[:25])
+        pc.prepare_and_save_point_cloud()
+        ply_text = open(os.path.join(td, "cloud.ply")).read()
+    with open(os.path.join(HERE, "ply_small.ply.txt"), "w") as fh:
+        fh.write(ply_text)
+    np.savez_compressed(os.path.join(HERE, "ply_small_inputs.npz"), pts=pts_p, col=col_p, line=line2[:25], line_col=lcol2[:25])
+
     # ---------------- full size: digests ----------------
     full = {"scene": dict(h=512, w=1024, seed=1234, f=1000.0, fences=False)}
     dp, road, fence, frame, cam, fz = scene_inputs(512, 1024, seed=1234, f=1000.0)
