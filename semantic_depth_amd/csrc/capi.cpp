@@ -100,16 +100,18 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
     const int N = nframes * (p.images / p.frames);
     auto T = [&](int t) -> float* { return reinterpret_cast<float*>(abase + p.tensors[t].offset); };
     auto Wp = [&](int w) -> const float* { return reinterpret_cast<const float*>(wbase + p.weights[w].offset); };
+    auto PL = [&](int t) -> size_t { const TensorDesc& d = p.tensors[t]; return (size_t)p.images * d.H * d.W * d.C; };   // lo-plane offset
+    auto FMT = [&](int t) -> int { return p.tensors[t].fmt; };
     for (const WeightSlot& wsl : p.weights)
         if (!wsl.loaded) return fail(h, SD_ERR_STATE, "weight not loaded: " + wsl.name);
     for (const OpDesc& op : p.ops) {
         hipError_t e = hipSuccess;
         switch (op.kind) {
             case OP_PRE_VGG:
-                e = launch_pre_vgg(frames, T(op.dst), (long)nframes * h->H * h->W, s);
+                e = launch_pre_vgg(frames, T(op.dst), (long)nframes * h->H * h->W, FMT(op.dst), PL(op.dst), s);
                 break;
             case OP_PRE_MONO:
-                e = launch_pre_mono(frames, T(op.dst), nframes, h->H, h->W, s);
+                e = launch_pre_mono(frames, T(op.dst), nframes, h->H, h->W, FMT(op.dst), PL(op.dst), s);
                 break;
             case OP_CONV: {
                 const TensorDesc& d = p.tensors[op.dst];
@@ -126,6 +128,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.residual = op.residual >= 0 ? T(op.residual) : nullptr;
                 c.out = T(op.dst);
                 c.act = op.act; c.m_fastest = op.m_fastest;
+                c.out_plane = PL(op.dst); c.Nmax = p.images;
                 const bool split = h->prec == SD_PREC_BF16X2;
                 hipEvent_t ea = nullptr, eb = nullptr;
                 if (h->prof) {
@@ -151,17 +154,18 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 SmallNParams c{};
                 c.x = T(op.src[0]); c.N = N; c.H = s0.H; c.W = s0.W; c.C = s0.C; c.k = op.k; c.nout = op.nout;
                 c.wt = Wp(op.w); c.bias = Wp(op.b); c.out = T(op.dst); c.act = op.act;
+                c.in_split = FMT(op.src[0]); c.out_split = FMT(op.dst); c.in_plane = PL(op.src[0]); c.out_plane = PL(op.dst);
                 e = launch_conv_smalln(c, s);
                 break;
             }
             case OP_POOL2: {
                 const TensorDesc& s0 = p.tensors[op.src[0]];
-                e = launch_maxpool2(T(op.src[0]), T(op.dst), N, s0.H, s0.W, s0.C, s);
+                e = launch_maxpool2(T(op.src[0]), T(op.dst), N, s0.H, s0.W, s0.C, FMT(op.src[0]), PL(op.src[0]), PL(op.dst), s);
                 break;
             }
             case OP_POOL3Z: {
                 const TensorDesc& s0 = p.tensors[op.src[0]];
-                e = launch_maxpool3z(T(op.src[0]), T(op.dst), N, s0.H, s0.W, s0.C, s);
+                e = launch_maxpool3z(T(op.src[0]), T(op.dst), N, s0.H, s0.W, s0.C, FMT(op.src[0]), PL(op.src[0]), PL(op.dst), s);
                 break;
             }
             case OP_DECONV4_ADD: {
@@ -527,7 +531,10 @@ sd_status sd_net_tensor(sd_handle* h, sd_net net, const char* name, float* out, 
     const size_t numel = (size_t)N * t.H * t.W * t.C;
     if (numel > cap_floats) return fail(h, SD_ERR_INVALID, "output buffer too small");
     const char* abase = h->ws + (net == SD_NET_FCN8S ? h->o_fcn : h->o_mono);
-    HIPCHK(h, hipMemcpyAsync(out, abase + t.offset, numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (t.fmt)      // split-bf16 planes -> f32
+        HIPCHK(h, launch_unsplit(reinterpret_cast<const float*>(abase + t.offset), out, (long)numel, (size_t)p.images * t.H * t.W * t.C, (hipStream_t)stream));
+    else
+        HIPCHK(h, hipMemcpyAsync(out, abase + t.offset, numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return SD_OK;
 }
 

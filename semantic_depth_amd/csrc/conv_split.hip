@@ -7,14 +7,16 @@
 // f32 MFMA, at ~1e-5 relative error per product (measured end-to-end in tests/test_gpu_nets.py against the 1e-3 budget
 // of BASELINE.json).  gfx950 has no xf32/TF32 MFMA; this is the explicit, error-bounded substitute.
 //
-// Same gather tables, tile mapping, epilogue and activation layout (NHWC f32 in HBM) as conv_igemm.hip; differences:
-//   * activations are split into hi/lo while they are staged into LDS; weights are split offline (relayout_weight)
-//     into two bf16 planes laid out exactly like their LDS image [k/8][n][8]
+// Same gather tables and tile mapping as conv_igemm.hip; differences:
+//   * activations live in HBM as split-bf16 planes (split_fmt.hpp): the producer's epilogue splits ONCE, consumers read
+//     16-byte runs of 8 channels from the hi and the lo plane and stage them unchanged; weights are split offline
+//     (relayout_weight) into two bf16 planes laid out exactly like their LDS image [k/8][n][8]
 //   * LDS images are [k/8][row][8] bf16 (16 B per lane per fragment): conflict-free ds_read_b128 for the 32x32x16
 //     fragments (lane = row & 31, k-octet = lane >> 5)
 //   * wave tile = (MT*32) x (NT*32) from 32x32x16 MFMAs; weights are the A operand so that a lane owns runs of 4
 //     consecutive output channels of one pixel (16-byte NHWC stores)
 #include "kernels.hpp"
+#include "split_fmt.hpp"
 
 namespace sd {
 
@@ -31,16 +33,52 @@ __device__ __forceinline__ float split_act(float v, int act) {
     return v;
 }
 
-// 8 floats -> 8 bf16 hi (one 16-B vector) + 8 bf16 lo
-__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, u32x4& hi, u32x4& lo) {
-    const f32x2 v[4] = {{a[0], a[1]}, {a[2], a[3]}, {b[0], b[1]}, {b[2], b[3]}};
+// Output path shared by the split kernels.  A wave owns a (MT*32) x (NT*32) tile; per 32-pixel slab it applies bias +
+// activation, splits ONCE into hi/lo, transposes through a wave-private LDS slab and writes 16-byte runs of 8 channels,
+// so every pixel's NT*64 bytes per plane leave as one contiguous segment (the MFMA layout alone gives 8-byte fragments).
+template <int MT, int NT>
+__device__ __forceinline__ void split_epilogue(f32x16 (&acc)[MT][NT], unsigned char* slab, const ConvParams& p, int m0, int n0, int M, int lane) {
+    constexpr int ROW = NT * 64 + 16;
+    unsigned char* sh = slab;
+    unsigned char* sl = slab + 32 * ROW;
+    constexpr int SEGS = NT * 4;                  // 16-B segments per pixel row
+    constexpr int PPP = 64 / SEGS;                // pixels per read pass
+    const int seg = lane % SEGS, prow = lane / SEGS;
+    uint16_t* const out_hi = reinterpret_cast<uint16_t*>(p.out);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const bf16x2 h = __builtin_convertvector(v[i], bf16x2);            // v_cvt_pk_bf16_f32 (RNE)
-        const f32x2 r = v[i] - __builtin_convertvector(h, f32x2);          // exact in f32
-        const bf16x2 l = __builtin_convertvector(r, bf16x2);
-        hi[i] = __builtin_bit_cast(unsigned, h);
-        lo[i] = __builtin_bit_cast(unsigned, l);
+    for (int a = 0; a < MT; ++a) {
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int nl = b * 32 + 8 * r4 + 4 * (lane >> 5);
+                const int n = n0 + nl;
+                f32x4 v = {acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
+                if (n < p.Cout) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = split_act(v[r], p.act);
+                uint2 h, l;
+                split4(v, h, l);
+                *reinterpret_cast<uint2*>(sh + (lane & 31) * ROW + nl * 2) = h;
+                *reinterpret_cast<uint2*>(sl + (lane & 31) * ROW + nl * 2) = l;
+            }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ps = 0; ps < 32 / PPP; ++ps) {
+            const int pix = ps * PPP + prow;
+            const int mo = m0 + a * 32 + pix;
+            const u32x4 h = *reinterpret_cast<const u32x4*>(sh + pix * ROW + seg * 16);
+            const u32x4 l = *reinterpret_cast<const u32x4*>(sl + pix * ROW + seg * 16);
+            const int n = n0 + seg * 8;
+            if (mo < M && n < p.Cout) {
+                uint16_t* o = out_hi + (size_t)mo * p.Cout + n;
+                *reinterpret_cast<u32x4*>(o) = h;
+                *reinterpret_cast<u32x4*>(o + p.out_plane) = l;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
 
@@ -51,7 +89,10 @@ struct STile {
     static constexpr int NTHR = WAVES_M * WAVES_N * 64;
     static constexpr int A_IT = BM * 4 / NTHR;                // (pixel, k-octet) items per thread per k-tile
     static constexpr int B_LD = (BN * 4 + NTHR - 1) / NTHR;   // 16-B loads per thread per k-tile and plane
-    static constexpr int LDS_BYTES = (BM + BN) * 32 * 2 * 2;  // hi + lo, bf16
+    static constexpr int STAGE_BYTES = (BM + BN) * 32 * 2 * 2;                  // hi + lo, bf16
+    static constexpr int EPI_ROW = NT * 64 + 16;                                // bytes per pixel row of a wave's output slab (+16 pad)
+    static constexpr int EPI_BYTES = WAVES_M * WAVES_N * 2 * 32 * EPI_ROW;      // per wave: hi + lo planes of 32 pixels
+    static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
 };
 
 template <int WAVES_M, int WAVES_N, int MT, int NT, bool VEC>
@@ -101,7 +142,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_split_kernel(cons
     const u32x4* __restrict__ const wt_hi = reinterpret_cast<const u32x4*>(p.wt);
     const u32x4* __restrict__ const wt_lo = wt_hi + (size_t)(p.Kpad / 8) * CoutPad;
 
-    f32x4 ra[T::A_IT][2];
+    u32x4 rxh[T::A_IT], rxl[T::A_IT];      // one k-octet of one pixel: 8 bf16 hi, 8 bf16 lo
+    const int Nmax = p.Nmax;
     u32x4 rwh[T::B_LD], rwl[T::B_LD];
     const int ktiles = p.Kpad / 32, vtiles = p.vtiles;
 
@@ -122,39 +164,51 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_split_kernel(cons
             int iy = oy * st + e.dy, ix = ox * st + e.dx;
             const bool ok = (e.flags & 0x10000) && m_ok && iy >= 0 && ix >= 0 && iy < (e.H << up) && ix < (e.W << up);
             iy >>= up; ix >>= up;
-            const float* base = e.base + ((size_t)(img * e.H + iy) * e.W + ix) * e.C;
+            const uint16_t* base = reinterpret_cast<const uint16_t*>(e.base) + ((size_t)(img * e.H + iy) * e.W + ix) * e.C;
+            const size_t plane = (size_t)Nmax * e.H * e.W * e.C;
 #pragma unroll
             for (int i = 0; i < T::A_IT; ++i) {
                 const int kg = kg0 + KG_STEP * i;
-                f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+                u32x4 h = {0u, 0u, 0u, 0u}, l = h;
                 if (ok) {
-                    v0 = *reinterpret_cast<const f32x4*>(base + kg * 8);
-                    v1 = *reinterpret_cast<const f32x4*>(base + kg * 8 + 4);
+                    h = *reinterpret_cast<const u32x4*>(base + kg * 8);
+                    l = *reinterpret_cast<const u32x4*>(base + plane + kg * 8);
                 }
-                ra[i][0] = v0; ra[i][1] = v1;
+                rxh[i] = h; rxl[i] = l;
             }
         } else {
             const KEntry* __restrict__ const qtab = ktab + ktiles + (kt - vtiles) * 8;   // this tile's 8 quad descriptors
 #pragma unroll
             for (int i = 0; i < T::A_IT; ++i) {
                 const int kg = __builtin_amdgcn_readfirstlane(kg0 + KG_STEP * i);
+                u32x4 h = {0u, 0u, 0u, 0u}, l = h;
 #pragma unroll
                 for (int hq = 0; hq < 2; ++hq) {
                     const KEntry q4 = qtab[kg * 2 + hq];
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
                     const int st = (q4.flags >> 4) & 3, up = q4.flags & 1;
                     int iy = oy * st + q4.dy, ix = ox * st + q4.dx;
                     const bool ok = (q4.flags & 0x10000) && m_ok && iy >= 0 && ix >= 0 && iy < (q4.H << up) && ix < (q4.W << up);
                     iy >>= up; ix >>= up;
                     const int nv = (q4.flags >> 8) & 7;
-                    const float* q = q4.base + ((size_t)(img * q4.H + iy) * q4.W + ix) * q4.C;
+                    const uint16_t* q = reinterpret_cast<const uint16_t*>(q4.base) + ((size_t)(img * q4.H + iy) * q4.W + ix) * q4.C;
+                    const size_t plane = (size_t)Nmax * q4.H * q4.W * q4.C;
+                    unsigned h0 = 0, h1 = 0, l0 = 0, l1 = 0;
                     if (ok) {
-                        if (nv == 4) v = *reinterpret_cast<const f32x4*>(q);
-                        else if (nv == 2) { const float2 t2 = *reinterpret_cast<const float2*>(q); v[0] = t2.x; v[1] = t2.y; }
-                        else { for (int j = 0; j < nv; ++j) v[j] = q[j]; }
+                        if (nv == 4) {
+                            const uint2 a = *reinterpret_cast<const uint2*>(q), b = *reinterpret_cast<const uint2*>(q + plane);
+                            h0 = a.x; h1 = a.y; l0 = b.x; l1 = b.y;
+                        } else if (nv == 2) {
+                            h0 = *reinterpret_cast<const unsigned*>(q); l0 = *reinterpret_cast<const unsigned*>(q + plane);
+                        } else {
+                            for (int j = 0; j < nv; ++j) {
+                                const unsigned a = q[j], b = q[plane + j];
+                                if (j == 0) { h0 |= a; l0 |= b; } else if (j == 1) { h0 |= a << 16; l0 |= b << 16; } else { h1 |= a; l1 |= b; }
+                            }
+                        }
                     }
-                    ra[i][hq] = v;
+                    h[2 * hq] = h0; h[2 * hq + 1] = h1; l[2 * hq] = l0; l[2 * hq + 1] = l1;
                 }
+                rxh[i] = h; rxl[i] = l;
             }
         }
     };
@@ -174,10 +228,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_split_kernel(cons
 #pragma unroll
         for (int i = 0; i < T::A_IT; ++i) {
             const int kg = kg0 + KG_STEP * i;
-            u32x4 h, l;
-            split8(ra[i][0], ra[i][1], h, l);
-            Xh[kg * BM + m_l] = h;
-            Xl[kg * BM + m_l] = l;
+            Xh[kg * BM + m_l] = rxh[i];
+            Xl[kg * BM + m_l] = rxl[i];
         }
 #pragma unroll
         for (int i = 0; i < T::B_LD; ++i) {
@@ -213,25 +265,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_split_kernel(cons
     }
 
     // ---- epilogue: D[row = channel (r&3) + 8*(r>>2) + 4*(lane>>5)][col = pixel lane&31] ----
-#pragma unroll
-    for (int b = 0; b < NT; ++b)
-#pragma unroll
-        for (int a = 0; a < MT; ++a) {
-            const int mo = bm0 + wm0 + a * 32 + (lane & 31);
-            if (mo >= M) continue;
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int n = bn0 + wn0 + b * 32 + 8 * r4 + 4 * (lane >> 5);
-                if (n >= p.Cout) continue;
-                f32x4 v = {acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
-                v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                const size_t o = (size_t)mo * p.Cout + n;
-                if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + o);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = split_act(v[r], p.act);
-                *reinterpret_cast<f32x4*>(p.out + o) = v;
-            }
-        }
+    __syncthreads();                      // every wave is done with the stage memory: reuse it as output staging
+    split_epilogue<MT, NT>(acc, lds + wave * (2 * 32 * T::EPI_ROW), p, bm0 + wm0, bn0 + wn0, M, lane);
 }
 
 template <int WAVES_M, int WAVES_N, int MT, int NT>

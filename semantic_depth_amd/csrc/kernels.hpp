@@ -38,6 +38,8 @@ struct ConvParams {
     const float* residual;  // nullable [M][Cout], added before the activation (resnet shortcut)
     float* out;             // [M][Cout]
     int act;
+    size_t out_plane;  // split engine: element offset of the output's lo plane
+    int Nmax;          // split engine: images of a full chunk (plane stride of a source = Nmax*H*W*C elements)
     int m_fastest;     // block order: 1 = consecutive blocks walk M (share a weight panel), 0 = walk N
 };
 hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t s);
@@ -49,7 +51,9 @@ int conv_split_tile_n(int Cout);
 
 // small-N convolution (N <= 4 output channels: score 1x1 convs, monodepth disparity heads)
 struct SmallNParams {
-    const float* x;     // [N,H,W,C]
+    const float* x;     // [N,H,W,C] (f32, or split planes when in_split)
+    int in_split, out_split;       // activation formats (split_fmt.hpp); out_split needs nout == 2
+    size_t in_plane, out_plane;    // element offset of the lo plane
     int N, H, W, C;
     int k;              // 1 or 3 (stride 1, zero pad (k-1)/2)
     int nout;           // computed output channels (<= 4)
@@ -63,10 +67,12 @@ hipError_t launch_conv_smalln(const SmallNParams& p, hipStream_t s);
 // ---------------------------------------------------------------------------------------------
 // misc network ops (ops_misc.hip)
 // ---------------------------------------------------------------------------------------------
-hipError_t launch_pre_vgg(const uint8_t* frames, float* out, long npix, hipStream_t s);                 // K1
-hipError_t launch_pre_mono(const uint8_t* frames, float* out, int B, int H, int W, hipStream_t s);      // /255 + fliplr pair
-hipError_t launch_maxpool2(const float* x, float* y, int N, int H, int W, int C, hipStream_t s);        // 2x2 s2 (even dims)
-hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C, hipStream_t s);       // zero-pad 1, 3x3 s2
+// `split`: activations are split-bf16 planes (split_fmt.hpp); `plane*` = element offset of the lo plane
+hipError_t launch_pre_vgg(const uint8_t* frames, float* out, long npix, int split, size_t plane, hipStream_t s);                 // K1
+hipError_t launch_pre_mono(const uint8_t* frames, float* out, int B, int H, int W, int split, size_t plane, hipStream_t s);      // /255 + fliplr pair
+hipError_t launch_maxpool2(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s);
+hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s);
+hipError_t launch_unsplit(const float* x, float* y, long numel, size_t plane, hipStream_t s);             // split planes -> f32
 // y[n,2i+ky-1,2j+kx-1,o] += x[n,i,j,c]*w[ky,kx,o,c]; y += bias + skip   (3->3 channels; fcn8s/fcn.py:186-204)
 hipError_t launch_deconv4s2_add(const float* x, const float* w, const float* bias, const float* skip, float* y,
                                 int N, int H, int W, hipStream_t s);

@@ -2,28 +2,57 @@
 // (score layers, disparity heads), the FCN-8s transposed-conv ladder and its softmax/threshold/argmax head.
 // SURVEY.md §2.2 rows K1, K3, K6-K9, K11, K15.
 #include "kernels.hpp"
+#include "split_fmt.hpp"
 
 namespace sd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Every op below exists for both activation formats: f32 NHWC, and the split-bf16 planes of split_fmt.hpp
+// (template parameter SPLIT; `plane` = element offset of the lo plane).
 // ---------------------------------------------------------------------------------------------
 // K1: VGG 'Processing' block [UPSTREAM Udacity vgg]: split (c0,c1,c2), subtract means, concat reversed.
+// 4 stored channels (the 4th is zero and meets zero weight rows): conv1_1 gathers whole channel quads.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pre_vgg_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, long npix) {
+template <bool SPLIT>
+__device__ __forceinline__ void store4(float* base, size_t plane, long quad_index, f32x4 v) {
+    if (SPLIT) {
+        uint2 h, l;
+        split4(v, h, l);
+        uint2* hp = reinterpret_cast<uint2*>(base);             // bf16 plane: one uint2 per channel quad
+        hp[quad_index] = h;
+        reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + plane)[quad_index] = l;
+    } else {
+        reinterpret_cast<f32x4*>(base)[quad_index] = v;
+    }
+}
+template <bool SPLIT>
+__device__ __forceinline__ f32x4 load4(const float* base, size_t plane, long quad_index) {
+    if (SPLIT) {
+        const uint2 h = reinterpret_cast<const uint2*>(base)[quad_index];
+        const uint2 l = reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + plane)[quad_index];
+        return recon4(h, l);
+    }
+    return reinterpret_cast<const f32x4*>(base)[quad_index];
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void pre_vgg_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, long npix, size_t plane) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= npix) return;
     const uint8_t* p = in + i * 3;
-    // 4 stored channels (the 4th is zero and meets zero weight rows): conv1_1 gathers whole float4 quads
-    reinterpret_cast<f32x4*>(out)[i] = (f32x4){(float)p[2] - 103.939f, (float)p[1] - 116.779f, (float)p[0] - 123.68f, 0.f};
+    store4<SPLIT>(out, plane, i, (f32x4){(float)p[2] - 103.939f, (float)p[1] - 116.779f, (float)p[0] - 123.68f, 0.f});
 }
-hipError_t launch_pre_vgg(const uint8_t* frames, float* out, long npix, hipStream_t s) {
-    hipLaunchKernelGGL(pre_vgg_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, frames, out, npix);
+hipError_t launch_pre_vgg(const uint8_t* frames, float* out, long npix, int split, size_t plane, hipStream_t s) {
+    const dim3 grid((unsigned)((npix + 255) / 256));
+    if (split) hipLaunchKernelGGL(pre_vgg_kernel<true>, grid, dim3(256), 0, s, frames, out, npix, plane);
+    else hipLaunchKernelGGL(pre_vgg_kernel<false>, grid, dim3(256), 0, s, frames, out, npix, plane);
     return hipGetLastError();
 }
 
 // monodepth input: frame.astype(f32)/255 and its fliplr, stacked per frame (semantic_depth.py:671-672)
-__global__ __launch_bounds__(256) void pre_mono_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int B, int H, int W) {
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void pre_mono_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int B, int H, int W, size_t plane) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     long npix = (long)B * H * W;
     if (i >= npix) return;
@@ -32,21 +61,24 @@ __global__ __launch_bounds__(256) void pre_mono_kernel(const uint8_t* __restrict
     int b = (int)(row / H);
     int y = (int)(row - (long)b * H);
     const uint8_t* p = in + i * 3;
-    float v0 = (float)p[0] / 255.0f, v1 = (float)p[1] / 255.0f, v2 = (float)p[2] / 255.0f;
-    const f32x4 v = {v0, v1, v2, 0.f};       // 4 stored channels, see pre_vgg_kernel
-    reinterpret_cast<f32x4*>(out)[((long)(2 * b) * H + y) * W + x] = v;
-    reinterpret_cast<f32x4*>(out)[((long)(2 * b + 1) * H + y) * W + (W - 1 - x)] = v;
+    const f32x4 v = {(float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f, 0.f};
+    store4<SPLIT>(out, plane, ((long)(2 * b) * H + y) * W + x, v);
+    store4<SPLIT>(out, plane, ((long)(2 * b + 1) * H + y) * W + (W - 1 - x), v);
 }
-hipError_t launch_pre_mono(const uint8_t* frames, float* out, int B, int H, int W, hipStream_t s) {
+hipError_t launch_pre_mono(const uint8_t* frames, float* out, int B, int H, int W, int split, size_t plane, hipStream_t s) {
     long npix = (long)B * H * W;
-    hipLaunchKernelGGL(pre_mono_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, frames, out, B, H, W);
+    const dim3 grid((unsigned)((npix + 255) / 256));
+    if (split) hipLaunchKernelGGL(pre_mono_kernel<true>, grid, dim3(256), 0, s, frames, out, B, H, W, plane);
+    else hipLaunchKernelGGL(pre_mono_kernel<false>, grid, dim3(256), 0, s, frames, out, B, H, W, plane);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
 // K3: max-pool 2x2 stride 2 (TF SAME on even dims = no padding); K11: zero-pad 1 then 3x3 stride 2 VALID
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void maxpool2_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, int N, int H, int W, int C4) {
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C4,
+                                                       size_t plane_in, size_t plane_out) {
     const int Ho = H / 2, Wo = W / 2;
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     long total = (long)N * Ho * Wo * C4;
@@ -56,20 +88,25 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const f32x4* __restrict__
     int ox = (int)(r % Wo); r /= Wo;
     int oy = (int)(r % Ho);
     int n = (int)(r / Ho);
-    const f32x4* p = x + (((long)n * H + 2 * oy) * W + 2 * ox) * C4 + c;
-    f32x4 a = p[0], b = p[C4], d = p[(long)W * C4], e = p[(long)W * C4 + C4];
+    const long q = (((long)n * H + 2 * oy) * W + 2 * ox) * C4 + c;
+    const f32x4 a = load4<SPLIT>(x, plane_in, q), b = load4<SPLIT>(x, plane_in, q + C4);
+    const f32x4 d = load4<SPLIT>(x, plane_in, q + (long)W * C4), e = load4<SPLIT>(x, plane_in, q + (long)W * C4 + C4);
     f32x4 m;
 #pragma unroll
     for (int j = 0; j < 4; ++j) m[j] = fmaxf(fmaxf(a[j], b[j]), fmaxf(d[j], e[j]));
-    y[i] = m;
+    store4<SPLIT>(y, plane_out, i, m);
 }
-hipError_t launch_maxpool2(const float* x, float* y, int N, int H, int W, int C, hipStream_t s) {
+hipError_t launch_maxpool2(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s) {
     long total = (long)N * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f32x4*)x, (f32x4*)y, N, H, W, C / 4);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (split) hipLaunchKernelGGL(maxpool2_kernel<true>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
+    else hipLaunchKernelGGL(maxpool2_kernel<false>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void maxpool3z_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, int N, int H, int W, int C4) {
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void maxpool3z_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C4,
+                                                        size_t plane_in, size_t plane_out) {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     long total = (long)N * Ho * Wo * C4;
@@ -86,16 +123,18 @@ __global__ __launch_bounds__(256) void maxpool3z_kernel(const f32x4* __restrict_
         for (int dx = 0; dx < 3; ++dx) {
             int iy = 2 * oy - 1 + dy, ix = 2 * ox - 1 + dx;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};   // the padding is ZERO and takes part in the max (upstream quirk)
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((long)n * H + iy) * W + ix) * C4 + c];
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = load4<SPLIT>(x, plane_in, (((long)n * H + iy) * W + ix) * C4 + c);
 #pragma unroll
             for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], v[j]);
         }
-    y[i] = m;
+    store4<SPLIT>(y, plane_out, i, m);
 }
-hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C, hipStream_t s) {
+hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     long total = (long)N * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL(maxpool3z_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f32x4*)x, (f32x4*)y, N, H, W, C / 4);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (split) hipLaunchKernelGGL(maxpool3z_kernel<true>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
+    else hipLaunchKernelGGL(maxpool3z_kernel<false>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
     return hipGetLastError();
 }
 
@@ -103,6 +142,7 @@ hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C
 // K6 / K15: convolution with <= 4 output channels, k in {1,3}, stride 1, zero pad (k-1)/2.
 //   THREAD variant: one thread per output pixel, weights [nout][K] staged in LDS
 //   WAVE   variant: one wave per output pixel, lanes stride over the channel quads, shuffle reduction
+// Input in either format; output f32, or split planes for the 2-channel disparity maps that feed the next iconv.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float smalln_act(float v, int act) {
     if (act == ACT_SIGMOID03) return 0.3f * (1.0f / (1.0f + expf(-v)));
@@ -112,7 +152,7 @@ __device__ __forceinline__ float smalln_act(float v, int act) {
 }
 
 // weights are laid out [nout][K] (K = k*k*C): one broadcast ds_read_b128 + 4 FMAs per output channel and input quad
-template <int NOUT>
+template <int NOUT, bool IN_SPLIT>
 __global__ __launch_bounds__(256) void conv_smalln_thread_kernel(const SmallNParams p) {
     extern __shared__ __attribute__((aligned(16))) float wl[];   // [NOUT][K]
     const int K = p.k * p.k * p.C;
@@ -136,11 +176,11 @@ __global__ __launch_bounds__(256) void conv_smalln_thread_kernel(const SmallNPar
         for (int kx = 0; kx < p.k; ++kx) {
             int ix = x + kx - pad;
             if (ix < 0 || ix >= p.W) continue;
-            const f32x4* xp = reinterpret_cast<const f32x4*>(p.x + (((long)n * p.H + iy) * p.W + ix) * p.C);
+            const long q0 = (((long)n * p.H + iy) * p.W + ix) * C4;
             const f32x4* wp = reinterpret_cast<const f32x4*>(wl) + (ky * p.k + kx) * C4;
 #pragma unroll 4
             for (int c = 0; c < C4; ++c) {
-                const f32x4 v = xp[c];
+                const f32x4 v = load4<IN_SPLIT>(p.x, p.in_plane, q0 + c);
 #pragma unroll
                 for (int j = 0; j < NOUT; ++j) {
                     const f32x4 w = wp[j * (K / 4) + c];
@@ -149,11 +189,19 @@ __global__ __launch_bounds__(256) void conv_smalln_thread_kernel(const SmallNPar
             }
         }
     }
-    float* o = p.out + pix * NOUT;
+    if (p.out_split) {            // NOUT == 2: one bf16 pair per plane
+        unsigned h, l;
+        split2(f32x2_t{smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)}, h, l);
+        reinterpret_cast<unsigned*>(p.out)[pix] = h;
+        reinterpret_cast<unsigned*>(reinterpret_cast<uint16_t*>(p.out) + p.out_plane)[pix] = l;
+    } else {
+        float* o = p.out + pix * NOUT;
 #pragma unroll
-    for (int j = 0; j < NOUT; ++j) o[j] = smalln_act(acc[j], p.act);
+        for (int j = 0; j < NOUT; ++j) o[j] = smalln_act(acc[j], p.act);
+    }
 }
 
+template <bool IN_SPLIT>
 __global__ __launch_bounds__(256) void conv_smalln_wave_kernel(const SmallNParams p) {
     const int lane = threadIdx.x & 63;
     long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -172,11 +220,11 @@ __global__ __launch_bounds__(256) void conv_smalln_wave_kernel(const SmallNParam
         for (int kx = 0; kx < p.k; ++kx) {
             int ix = x + kx - pad;
             if (ix < 0 || ix >= p.W) continue;
-            const f32x4* xp = reinterpret_cast<const f32x4*>(p.x + (((long)n * p.H + iy) * p.W + ix) * p.C);
+            const long q0 = (((long)n * p.H + iy) * p.W + ix) * C4;
             const f32x4* wp = reinterpret_cast<const f32x4*>(p.wt) + (long)(ky * p.k + kx) * C4;
             const int K4 = p.k * p.k * C4;
             for (int c = lane; c < C4; c += 64) {
-                const f32x4 v = xp[c];
+                const f32x4 v = load4<IN_SPLIT>(p.x, p.in_plane, q0 + c);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (j < p.nout) {
@@ -196,21 +244,43 @@ __global__ __launch_bounds__(256) void conv_smalln_wave_kernel(const SmallNParam
     }
 }
 
-hipError_t launch_conv_smalln(const SmallNParams& p, hipStream_t s) {
+template <bool IN_SPLIT>
+static void launch_smalln_t(const SmallNParams& p, hipStream_t s) {
     const long npix = (long)p.N * p.H * p.W;
     const int K = p.k * p.k * p.C;
     if (K <= 2048) {
         const dim3 grid((unsigned)((npix + 255) / 256));
         const size_t lds = (size_t)K * 4 * p.nout;
         switch (p.nout) {
-            case 1: hipLaunchKernelGGL(conv_smalln_thread_kernel<1>, grid, dim3(256), lds, s, p); break;
-            case 2: hipLaunchKernelGGL(conv_smalln_thread_kernel<2>, grid, dim3(256), lds, s, p); break;
-            case 3: hipLaunchKernelGGL(conv_smalln_thread_kernel<3>, grid, dim3(256), lds, s, p); break;
-            default: hipLaunchKernelGGL(conv_smalln_thread_kernel<4>, grid, dim3(256), lds, s, p); break;
+            case 1: hipLaunchKernelGGL((conv_smalln_thread_kernel<1, IN_SPLIT>), grid, dim3(256), lds, s, p); break;
+            case 2: hipLaunchKernelGGL((conv_smalln_thread_kernel<2, IN_SPLIT>), grid, dim3(256), lds, s, p); break;
+            case 3: hipLaunchKernelGGL((conv_smalln_thread_kernel<3, IN_SPLIT>), grid, dim3(256), lds, s, p); break;
+            default: hipLaunchKernelGGL((conv_smalln_thread_kernel<4, IN_SPLIT>), grid, dim3(256), lds, s, p); break;
         }
     } else {
-        hipLaunchKernelGGL(conv_smalln_wave_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(conv_smalln_wave_kernel<IN_SPLIT>, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, p);
     }
+}
+hipError_t launch_conv_smalln(const SmallNParams& p, hipStream_t s) {
+    if (p.out_split && (p.nout != 2 || p.k * p.k * p.C > 2048)) return hipErrorInvalidValue;
+    if (p.in_split) launch_smalln_t<true>(p, s); else launch_smalln_t<false>(p, s);
+    return hipGetLastError();
+}
+
+// split planes -> f32 (introspection: sd_net_tensor)
+__global__ __launch_bounds__(256) void unsplit_kernel(const float* __restrict__ x, float* __restrict__ y, long nquads, size_t plane) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < nquads) reinterpret_cast<f32x4*>(y)[i] = load4<true>(x, plane, i);
+}
+__global__ __launch_bounds__(256) void unsplit2_kernel(const float* __restrict__ x, float* __restrict__ y, long npairs, size_t plane) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npairs) return;
+    const f32x2_t v = recon2(reinterpret_cast<const unsigned*>(x)[i], reinterpret_cast<const unsigned*>(reinterpret_cast<const uint16_t*>(x) + plane)[i]);
+    y[2 * i] = v[0]; y[2 * i + 1] = v[1];
+}
+hipError_t launch_unsplit(const float* x, float* y, long numel, size_t plane, hipStream_t s) {
+    if (numel % 4 == 0) hipLaunchKernelGGL(unsplit_kernel, dim3((unsigned)((numel / 4 + 255) / 256)), dim3(256), 0, s, x, y, numel / 4, plane);
+    else hipLaunchKernelGGL(unsplit2_kernel, dim3((unsigned)((numel / 2 + 255) / 256)), dim3(256), 0, s, x, y, numel / 2, plane);
     return hipGetLastError();
 }
 

@@ -22,6 +22,7 @@ struct Builder {
     int tensor(const std::string& name, int N, int H, int W, int C) {
         TensorDesc t;
         t.name = name; t.N = N; t.H = H; t.W = W; t.C = C; t.Ctf = C;
+        t.fmt = p.prec ? 1 : 0;          // the split engine keeps its activations as split-bf16 planes
         t.bytes = (size_t)N * H * W * C * sizeof(float);
         p.tensors.push_back(t);
         p.tensor_by_name[name] = (int)p.tensors.size() - 1;
@@ -137,14 +138,16 @@ struct Builder {
         return op.dst;
     }
 
-    int smalln(const std::string& name, int src, int nout, int k, int act, const std::string& wname, const std::string& bname, int cout_tf) {
+    int smalln(const std::string& name, int src, int nout, int k, int act, const std::string& wname, const std::string& bname, int cout_tf,
+               bool feeds_conv = false) {
         OpDesc op;
         op.kind = OP_SMALLN; op.name = name; op.nsrc = 1; op.src[0] = src; op.k = k; op.pad = (k - 1) / 2; op.act = act; op.nout = nout;
         const TensorDesc& t = p.tensors[src];
         op.w = wslot(wname, {k, k, t.C, cout_tf}, WL_SMALLN, 0, 0, nout);
         op.b = wslot(bname, {cout_tf}, WL_BIAS4, 0, 0, nout);
         op.dst = tensor(name, t.N, t.H, t.W, nout);
-        op.flops = 2.0 * t.N * t.H * t.W * nout * k * k * t.C;
+        if (!feeds_conv) p.tensors[op.dst].fmt = 0;      // consumed by f32 kernels (deconv ladder, post-processing)
+        op.flops = 2.0 * p.tensors[src].N * p.tensors[src].H * p.tensors[src].W * nout * k * k * p.tensors[src].C;
         push(op);
         return op.dst;
     }
@@ -258,6 +261,7 @@ NetPlan build_fcn8s(int frames, int H, int W, int prec) {
         op.b = b.wslot("dec/" + wn + "/bias", {3}, WL_RAW);
         const TensorDesc& t = b.p.tensors[src];
         op.dst = b.tensor(name, t.N, t.H * 2, t.W * 2, 3);
+        b.p.tensors[op.dst].fmt = 0;          // the deconv ladder is f32
         b.push(op);
         return op.dst;
     };
@@ -342,7 +346,8 @@ NetPlan build_monodepth(int encoder, int frames, int H, int W, int prec) {
         if (lvl <= 4) {
             // scales 4..2 feed udisp (both channels); at scale 1 only channel 0 = disp_left_est[0] is fetched (semantic_depth.py:675)
             const int nout = lvl == 1 ? 1 : 2;
-            disp_prev = b.smalln("dec/disp" + L, x, nout, 3, ACT_SIGMOID03, "dec/disp" + L + "/weights", "dec/disp" + L + "/biases", 2);
+            disp_prev = b.smalln("dec/disp" + L, x, nout, 3, ACT_SIGMOID03, "dec/disp" + L + "/weights", "dec/disp" + L + "/biases", 2,
+                                 /*feeds_conv=*/lvl > 1);
         }
     }
     b.p.t_output = disp_prev;
@@ -414,7 +419,7 @@ void build_conv_tables(const NetPlan& p, const OpDesc& op, const char* act_base,
     auto describe = [&](int s, int cl, int tap) {
         const TensorDesc& t = p.tensors[op.src[s]];
         KEntry e{nullptr, 1, 1, 1, 0, 0, 0};
-        e.base = reinterpret_cast<const float*>(act_base + t.offset) + cl;
+        e.base = reinterpret_cast<const float*>(act_base + t.offset + (size_t)cl * (t.fmt ? 2 : 4));   // hi plane when split
         e.H = t.H; e.W = t.W; e.C = t.C;
         e.dy = tap / op.k - op.pad; e.dx = tap % op.k - op.pad;
         const int nv = std::max(0, std::min(4, t.C - cl));

@@ -15,6 +15,7 @@ struct TensorDesc {
     std::string name;
     int N = 0, H = 0, W = 0, C = 0;   // C = stored channels
     int Ctf = 0;                      // channels the TensorFlow graph sees (input_pre stores 4, TF sees 3)
+    int fmt = 0;                      // 0: f32 NHWC; 1: split-bf16 planes (split_fmt.hpp)
     size_t bytes = 0;
     size_t offset = 0;      // byte offset in the activation arena
     int first = -1, last = -1;   // op indices (liveness)
