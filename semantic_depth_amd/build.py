@@ -19,6 +19,7 @@ ARCH = "gfx950"
 SOURCES = [
     ("conv_igemm.hip", []),
     ("conv_split.hip", []),
+    ("conv_dma.hip", []),
     ("ops_misc.hip", []),
     ("fuse.hip", ["-ffp-contract=off"]),
     ("pcl.hip", ["-ffp-contract=off"]),

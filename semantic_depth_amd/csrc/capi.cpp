@@ -129,6 +129,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.out = T(op.dst);
                 c.act = op.act; c.m_fastest = op.m_fastest;
                 c.out_plane = PL(op.dst); c.Nmax = p.images;
+                c.zero16 = h->ws + h->o_misc + 256;        // the arena is zero-filled and nothing writes here
                 const bool split = h->prec == SD_PREC_BF16X2;
                 hipEvent_t ea = nullptr, eb = nullptr;
                 if (h->prof) {
@@ -141,10 +142,11 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                     ++h->prof_used;
                     hipEventRecord(ea, s);
                 }
-                e = split ? launch_conv_split(c, s) : launch_conv_igemm(c, s);
+                const bool dma = split && conv_dma_variant(c) != 0 && !std::getenv("SEMDEPTH_NO_DMA");
+                e = dma ? launch_conv_dma(c, s) : split ? launch_conv_split(c, s) : launch_conv_igemm(c, s);
                 if (h->prof) {
                     hipEventRecord(eb, s);
-                    h->prof_recs.push_back({split ? conv_split_kernel_name(c) : conv_igemm_kernel_name(c), op.flops * N / p.images, ea, eb,
+                    h->prof_recs.push_back({dma ? conv_dma_kernel_name(c) : split ? conv_split_kernel_name(c) : conv_igemm_kernel_name(c), op.flops * N / p.images, ea, eb,
                                             op.name.c_str(), N * d.H * d.W, d.C, op.K});
                 }
                 break;

@@ -1,0 +1,249 @@
+// Split-bf16 implicit-GEMM convolution, LDS-DMA pipeline (vec layers of SD_PREC_BF16X2 with Cout % 128 == 0).
+//
+// Same math as conv_split.hip (3 x v_mfma_f32_32x32x16_bf16 per product on hi/lo bf16 planes), but nothing passes through
+// VGPRs on the way in: activations are already split-bf16 planes in HBM (split_fmt.hpp) and weights are stored in their
+// LDS image, so both operands are staged with global_load_lds_dwordx4 (16 B per lane, 1 KiB per wave-instruction) into a
+// 3-stage LDS ring.  Per k-tile a wave issues 6 DMA instructions, 16 ds_read_b128 and 24 MFMAs, and the workgroup
+// meets at ONE barrier:
+//      wait(tile t landed) ; barrier ; issue DMA(tile t+2) ; 16 ds_read + 24 MFMA on stage t%3
+// (stage (t+2)%3 was last read in iteration t-1, which every wave finished before this barrier).
+// 8 waves, wave tile 64x64, block 128x256 (Cout % 256 == 0) or 256x128; 3 x 48 KiB of LDS, one workgroup per CU.
+// Out-of-image taps and pixels beyond M read a 16-byte zero page, so zero padding costs no branch in the pipeline.
+// Gather granularity: four consecutive lanes fetch the four 16-byte octets of ONE pixel (64 contiguous bytes per plane),
+// so a wave-instruction touches 16 cache lines instead of 64; the LDS image is therefore [pixel][octet] and the octet
+// slot is XOR-swizzled with (pixel >> 2) & 3 on the SOURCE side (LDS-DMA writes lane-linear), which makes the
+// ds_read_b128 fragment reads bank-conflict free.
+#include "kernels.hpp"
+#include "split_fmt.hpp"
+
+namespace sd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// One LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS [dst, dst + 1 KiB) (lane-linear).  Inline asm so
+// that hipcc neither counts it nor drains it: the pipeline below waits with its own counted s_waitcnt vmcnt(N)
+// (the builtin makes hipcc insert vmcnt(0) before every following DMA, i.e. a one-tile-deep pipeline).
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ float dma_act(float v, int act) {
+    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == ACT_ELU) return v > 0.f ? v : expm1f(v);
+    return v;
+}
+
+// the gather descriptor of a k-tile through the scalar cache.  (A compiler-visible vector load inside the pipeline would
+// bring a compiler-counted s_waitcnt vmcnt(0) with it, which also drains the LDS-DMAs it does not know about.)
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ KEntry load_kentry(const KEntry* ptr) {
+    i32x8 v;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ptr) : "memory");
+    KEntry e;
+    e.base = reinterpret_cast<const float*>(((unsigned long long)(unsigned)v[1] << 32) | (unsigned)v[0]);
+    e.H = v[2]; e.W = v[3]; e.C = v[4]; e.dy = v[5]; e.dx = v[6]; e.flags = v[7];
+    return e;
+}
+
+template <int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(512) void conv_dma_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
+    constexpr int MT = 2, NT = 2, NW = WAVES_M * WAVES_N;
+    static_assert(NW == 8, "8 waves");
+    constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
+    constexpr int STAGE_UNITS = 8 * (BM + BN);                // 16-B units: Xh [4][BM] | Xl [4][BM] | Wh [4][BN] | Wl [4][BN]
+    constexpr int NDMA = STAGE_UNITS / 64 / NW;               // DMA instructions per wave per tile (6)
+    constexpr int XI = 8 * BM / 64 / NW;                      // of which activation instructions (2 or 4), hi first then lo
+    constexpr int STAGES = 3;
+    constexpr int EPI_ROW = NT * 64 + 16;
+    static_assert(NW * 2 * 32 * EPI_ROW <= STAGES * STAGE_UNITS * 16, "epilogue slabs fit in the ring");
+    __shared__ __attribute__((aligned(16))) u32x4 ring[STAGES * STAGE_UNITS];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm0 = (wave % WAVES_M) * 64, wn0 = (wave / WAVES_M) * 64;
+
+    int tid_;
+    {
+        const int nwg = tilesM * tilesN, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        tid_ = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = tid_ % tilesM, tn = tid_ / tilesM;
+    const int bm0 = tm * BM, bn0 = tn * BN;
+
+    // activation DMA: instruction j of a plane covers pixels [16j, 16j+16) x 4 octets; lane -> (pixel 16j + lane/4, slot lane%4)
+    constexpr int XH = XI / 2;                                // hi instructions per wave (1 for BM=128, 2 for BM=256)
+    int pimg[XH], poy[XH], pox[XH], pkg[XH];
+    bool pok[XH];
+#pragma unroll
+    for (int i = 0; i < XH; ++i) {
+        const int m_l = (wave + NW * i) * 16 + (lane >> 2);
+        const int m = bm0 + m_l;
+        pok[i] = m < M;
+        const int hw = p.Hout * p.Wout;
+        const int mm = pok[i] ? m : 0;
+        pimg[i] = mm / hw;
+        const int r = mm - pimg[i] * hw;
+        poy[i] = r / p.Wout;
+        pox[i] = r - poy[i] * p.Wout;
+        pkg[i] = (lane & 3) ^ ((m_l >> 2) & 3);               // the octet this lane fetches into slot lane%4
+    }
+    const KEntry* __restrict__ const ktab = p.ktab;
+    const int CoutPad = p.CoutPad, Nmax = p.Nmax;
+    const u32x4* __restrict__ const wt_hi = reinterpret_cast<const u32x4*>(p.wt);
+    const size_t wplane = (size_t)(p.Kpad / 8) * CoutPad;     // units
+    const u32x4* const zero = reinterpret_cast<const u32x4*>(p.zero16);
+    const int ktiles = p.Kpad / 32;
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ring;   // wave-uniform LDS address
+
+    auto issue = [&](int kt, int stage) {
+        const unsigned sbyte = ring_lds + (unsigned)(stage * STAGE_UNITS * 16);      // LDS byte address of the stage
+        // ---- activations: hi plane instruction(s) then lo plane instruction(s) ----
+        const KEntry e = load_kentry(ktab + kt);
+        const int st = (e.flags >> 4) & 3, up = e.flags & 1;
+        const size_t plane = (size_t)Nmax * e.H * e.W * e.C;
+#pragma unroll
+        for (int i = 0; i < XH; ++i) {
+            int iy = poy[i] * st + e.dy, ix = pox[i] * st + e.dx;
+            const bool ok = pok[i] && iy >= 0 && ix >= 0 && iy < (e.H << up) && ix < (e.W << up);
+            iy >>= up; ix >>= up;
+            const uint16_t* px = reinterpret_cast<const uint16_t*>(e.base) + ((size_t)(pimg[i] * e.H + iy) * e.W + ix) * e.C + pkg[i] * 8;
+            const u32x4* gh = ok ? reinterpret_cast<const u32x4*>(px) : zero;
+            const u32x4* gl = ok ? reinterpret_cast<const u32x4*>(px + plane) : zero;
+            dma16(gh, sbyte + (unsigned)((wave + NW * i) * 1024));
+            dma16(gl, sbyte + (unsigned)((4 * BM + (wave + NW * i) * 64) * 16));
+        }
+        // ---- weights: the stage image is the global image ----
+#pragma unroll
+        for (int i = XI; i < NDMA; ++i) {
+            const int j = wave + NW * i;
+            const int wu = (j - XI * NW) * 64 + lane;         // unit inside the W region: [plane][kg][n]
+            const int pl = wu / (4 * BN), r = wu % (4 * BN), kg = r / BN, n_l = r % BN;
+            const u32x4* g = wt_hi + pl * wplane + (size_t)(kt * 4 + kg) * CoutPad + bn0 + n_l;
+            dma16(g, sbyte + (unsigned)(j * 1024));
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    issue(0, 0);
+    if (ktiles > 1) issue(1, 1);
+    const int frow = lane & 31, fk = lane >> 5;
+    for (int kt = 0; kt < ktiles; ++kt) {
+        if (kt + 1 < ktiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < ktiles) issue(kt + 2, (kt + 2) % STAGES);
+        const u32x4* Xh = ring + (kt % STAGES) * STAGE_UNITS;
+        const u32x4* Xl = Xh + 4 * BM;
+        const u32x4* Wh = Xl + 4 * BM;
+        const u32x4* Wl = Wh + 4 * BN;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int kg = 2 * s + fk;
+            bf16x8 wh[NT], wl[NT], xh[MT], xl[MT];
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                wh[b] = __builtin_bit_cast(bf16x8, Wh[kg * BN + wn0 + b * 32 + frow]);
+                wl[b] = __builtin_bit_cast(bf16x8, Wl[kg * BN + wn0 + b * 32 + frow]);
+            }
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const int mrow = wm0 + a * 32 + frow;
+                const int slot = mrow * 4 + (kg ^ ((mrow >> 2) & 3));        // [pixel][octet ^ swizzle]
+                xh[a] = __builtin_bit_cast(bf16x8, Xh[slot]);
+                xl[a] = __builtin_bit_cast(bf16x8, Xl[slot]);
+            }
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+#pragma unroll
+                    for (int a = 0; a < MT; ++a)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 0 ? wl[b] : wh[b], pr == 1 ? xl[a] : xh[a], acc[a][b], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue (as conv_split.hip): bias + activation, split once, LDS transpose, 16-byte runs per pixel ----
+    __syncthreads();
+    {
+        constexpr int ROW = EPI_ROW;
+        unsigned char* sh = reinterpret_cast<unsigned char*>(ring) + wave * (2 * 32 * ROW);
+        unsigned char* sl = sh + 32 * ROW;
+        constexpr int SEGS = NT * 4, PPP = 64 / SEGS;
+        const int seg = lane % SEGS, prow = lane / SEGS;
+        uint16_t* const out_hi = reinterpret_cast<uint16_t*>(p.out);
+        const int m0 = bm0 + wm0, n0 = bn0 + wn0;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int nl = b * 32 + 8 * r4 + 4 * (lane >> 5);
+                    f32x4 v = {acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
+                    v += *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = dma_act(v[r], p.act);
+                    uint2 h, l;
+                    split4(v, h, l);
+                    *reinterpret_cast<uint2*>(sh + (lane & 31) * ROW + nl * 2) = h;
+                    *reinterpret_cast<uint2*>(sl + (lane & 31) * ROW + nl * 2) = l;
+                }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ps = 0; ps < 32 / PPP; ++ps) {
+                const int pix = ps * PPP + prow;
+                const int mo = m0 + a * 32 + pix;
+                const u32x4 h = *reinterpret_cast<const u32x4*>(sh + pix * ROW + seg * 16);
+                const u32x4 l = *reinterpret_cast<const u32x4*>(sl + pix * ROW + seg * 16);
+                if (mo < M) {
+                    uint16_t* o = out_hi + (size_t)mo * p.Cout + n0 + seg * 8;
+                    *reinterpret_cast<u32x4*>(o) = h;
+                    *reinterpret_cast<u32x4*>(o + p.out_plane) = l;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+}
+
+// which layers take the DMA pipeline: vec layers, Cout a multiple of 128, and enough tiles to fill 256 CUs
+int conv_dma_variant(const ConvParams& p) {
+    if (!p.vec || !p.zero16 || p.Cout % 128 || p.Kpad < 64) return 0;
+    const long M = (long)p.N * p.Hout * p.Wout;
+    if (p.Cout % 256 == 0 && ((M + 127) / 128) * (p.Cout / 256) >= 224) return 1;     // 128 x 256
+    if (((M + 255) / 256) * (p.Cout / 128) >= 224) return 2;                           // 256 x 128
+    return 0;
+}
+
+hipError_t launch_conv_dma(const ConvParams& p, hipStream_t s) {
+    const long M = (long)p.N * p.Hout * p.Wout;
+    const int v = conv_dma_variant(p);
+    if (v == 1) {
+        const int tilesM = (int)((M + 127) / 128), tilesN = p.Cout / 256;
+        hipLaunchKernelGGL((conv_dma_kernel<2, 4>), dim3((unsigned)(tilesM * tilesN)), dim3(512), 0, s, p, (int)M, tilesM, tilesN);
+    } else if (v == 2) {
+        const int tilesM = (int)((M + 255) / 256), tilesN = p.Cout / 128;
+        hipLaunchKernelGGL((conv_dma_kernel<4, 2>), dim3((unsigned)(tilesM * tilesN)), dim3(512), 0, s, p, (int)M, tilesM, tilesN);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+const char* conv_dma_kernel_name(const ConvParams& p) { return conv_dma_variant(p) == 1 ? "conv_dma_kernel<2,4>" : "conv_dma_kernel<4,2>"; }
+
+}  // namespace sd

@@ -39,6 +39,7 @@ struct ConvParams {
     float* out;             // [M][Cout]
     int act;
     size_t out_plane;  // split engine: element offset of the output's lo plane
+    const void* zero16;  // split engine: 16 zero bytes in device memory (source of out-of-image taps for the LDS-DMA pipeline)
     int Nmax;          // split engine: images of a full chunk (plane stride of a source = Nmax*H*W*C elements)
     int m_fastest;     // block order: 1 = consecutive blocks walk M (share a weight panel), 0 = walk N
 };
@@ -48,6 +49,10 @@ const char* conv_igemm_kernel_name(const ConvParams& p);
 hipError_t launch_conv_split(const ConvParams& p, hipStream_t s);
 const char* conv_split_kernel_name(const ConvParams& p);
 int conv_split_tile_n(int Cout);
+// LDS-DMA pipeline for the wide vec layers of the split engine (conv_dma.hip); variant 0 = not applicable
+int conv_dma_variant(const ConvParams& p);
+hipError_t launch_conv_dma(const ConvParams& p, hipStream_t s);
+const char* conv_dma_kernel_name(const ConvParams& p);
 
 // small-N convolution (N <= 4 output channels: score 1x1 convs, monodepth disparity heads)
 struct SmallNParams {
