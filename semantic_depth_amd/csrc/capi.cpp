@@ -220,7 +220,8 @@ sd_status sd_create(sd_handle** out, int device, int H, int W, int max_batch, sd
     if (!out || H <= 0 || W <= 0 || max_batch <= 0 || (prec != SD_PREC_F32 && prec != SD_PREC_BF16X2)) return SD_ERR_INVALID;
     sd_handle* h = new sd_handle();
     h->device = device; h->H = H; h->W = W; h->max_batch = max_batch; h->enc = (int)enc; h->cap = H * W; h->prec = (int)prec;
-    int chunk = 8;
+    int chunk = 32;      // frames per network pass: the deep layers (M = 512 px per frame) need ~32 frames to fill 256 CUs;
+                         // activations of a 32-frame chunk are ~17 GB at 512x1024, nothing on a 288 GB part
     if (const char* e = std::getenv("SEMDEPTH_CHUNK")) chunk = std::max(1, atoi(e));
     h->chunk = std::min(max_batch, chunk);
     try {

@@ -143,7 +143,6 @@ __global__ __launch_bounds__(512) void conv_dma_kernel(const ConvParams p, int M
         if (kt + 1 < ktiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < ktiles) issue(kt + 2, (kt + 2) % STAGES);
         const u32x4* Xh = ring + (kt % STAGES) * STAGE_UNITS;
         const u32x4* Xl = Xh + 4 * BM;
         const u32x4* Wh = Xl + 4 * BM;
@@ -171,6 +170,9 @@ __global__ __launch_bounds__(512) void conv_dma_kernel(const ConvParams p, int M
 #pragma unroll
                     for (int a = 0; a < MT; ++a)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 0 ? wl[b] : wh[b], pr == 1 ? xl[a] : xh[a], acc[a][b], 0, 0, 0);
+            // the DMA issue of tile kt+2 (address arithmetic + 6 DMAs) sits between the two MFMA clusters, so it issues in
+            // the shadow of the first cluster's 12 MFMAs instead of in front of an idle matrix pipe
+            if (s == 0 && kt + 2 < ktiles) issue(kt + 2, (kt + 2) % STAGES);
         }
     }
 
@@ -224,8 +226,9 @@ __global__ __launch_bounds__(512) void conv_dma_kernel(const ConvParams p, int M
 int conv_dma_variant(const ConvParams& p) {
     if (!p.vec || !p.zero16 || p.Cout % 128 || p.Kpad < 64) return 0;
     const long M = (long)p.N * p.Hout * p.Wout;
-    if (p.Cout % 256 == 0 && ((M + 127) / 128) * (p.Cout / 256) >= 224) return 1;     // 128 x 256
-    if (((M + 255) / 256) * (p.Cout / 128) >= 224) return 2;                           // 256 x 128
+    const long thr = 96;     // tiles needed: the DMA pipeline at half occupancy still beats the register-staged kernel
+    if (p.Cout % 256 == 0 && ((M + 127) / 128) * (p.Cout / 256) >= thr) return 1;     // 128 x 256
+    if (((M + 255) / 256) * (p.Cout / 128) >= thr) return 2;                           // 256 x 128
     return 0;
 }
 

@@ -87,9 +87,14 @@ def test_monodepth_matches_oracle(encoder, H, W, precision):
 
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_batch_and_chunk_independence(precision):
-    """B=9 > chunk(8): two chunks; every frame's outputs equal the solo run bit for bit (kernels are deterministic)."""
+    """B=9 with SEMDEPTH_CHUNK=4: three network passes (4+4+1); every frame's outputs equal the solo run bit for bit
+    (kernels are deterministic and images never interact)."""
     H, W, B = 128, 256, 9
-    eng, _, _ = engine(H, W, B, "resnet50", fcn_kw=dict(decoder_std=0.05), load=("fcn", "mono"), precision=precision)
+    os.environ["SEMDEPTH_CHUNK"] = "4"
+    try:
+        eng, _, _ = engine(H, W, B, "resnet50", fcn_kw=dict(decoder_std=0.05), load=("fcn", "mono"), precision=precision)
+    finally:
+        os.environ.pop("SEMDEPTH_CHUNK", None)
     fr = dev(_frames(B, H, W, seed=8))
     seg = eng.fcn8s_forward(fr, want_logits=True)
     pp = eng.monodepth_forward(fr)
