@@ -111,11 +111,6 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     stage_ms = np.zeros(4)
-    # software pipeline over steps: the road chain of step i (one workgroup per frame for most of its kernels, it cannot
-    # fill the chip) runs on a side stream underneath the conv stacks of step i+1; everything is joined before the clock stops
-    main = torch.cuda.current_stream()
-    side = torch.cuda.Stream()
-    fused_done = torch.cuda.Event()
     for _ in range(args.steps):
         ev[0].record()
         seg = eng.fcn8s_forward(frames)
@@ -124,16 +119,10 @@ def main():
         ev[2].record()
         fz = eng.fuse_backproject(disp_pp, seg["road"], seg["fence"], frames, cams)
         ev[3].record()
-        fused_done.record(main)
-        with torch.cuda.stream(side):
-            side.wait_event(fused_done)
-            rec = eng.road_width(fz["road_xyz"], fz["n_road"], prm)
-            allrec = gather_records(rec, world * B)
-            for t_ in (fz["road_xyz"], fz["n_road"], rec):
-                t_.record_stream(side)
-        ev[4].record(side)
+        rec = eng.road_width(fz["road_xyz"], fz["n_road"], prm)
+        allrec = gather_records(rec, world * B)
+        ev[4].record()
         out = dict(seg=seg, disp_pp=disp_pp, fuse=fz, records=rec)
-    main.wait_stream(side)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -477,7 +477,7 @@ constexpr int SOR_RMAX = 16;       // shells searched before the brute-force fal
 constexpr int SCAN_SEG = 2048;     // cells per scan segment
 constexpr int SCAN_NSEG = GRID_CELLS / SCAN_SEG;
 
-struct GridMeta { double ox, oy, oz, inv; double cell; int gx, gy, gz, pad; };
+struct GridMeta { double ox, oy, oz, inv; double cell; int gx, gy, gz, occupied; double ext[3], mn[3], mxz; };
 
 struct O3dScratch {       // carved from one arena, per-frame strides
     GridMeta* meta;       // [B]
@@ -518,6 +518,35 @@ __device__ __forceinline__ int cell_coord(double p, double o, double inv, int g)
 }
 __device__ __forceinline__ int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+// cell size -> grid dims (powers of two with gx*gy*gz == GRID_CELLS) and origin, from the stored bounding box
+__device__ void grid_layout(GridMeta& g, double cell) {
+    g.cell = cell; g.inv = 1.0 / cell;
+    // x and y sized to the box (clamped), z takes the rest
+    const int gy = min(pow2ceil((int)fmin(g.ext[1] / cell + 2.0, 4096.0)), 64);
+    const int gx = min(pow2ceil((int)fmin(g.ext[0] / cell + 2.0, 4096.0)), 256);
+    g.gx = gx; g.gy = gy; g.gz = GRID_CELLS / (gx * gy);
+    g.ox = g.mn[0]; g.oy = g.mn[1]; g.oz = g.mn[2];
+    // scene z is negative and dense near the camera (large z): if the z range does not fit, anchor the grid at the
+    // near end so the dense part is resolved and the far tail clamps into the first layer
+    const double span = cell * (double)g.gz;
+    if (g.ext[2] > span) g.oz = g.mxz - span + 0.5 * cell;
+}
+
+// second look at the cell size of the statistical filter: the first grid's occupancy tells how the cloud really fills
+// space (a road cloud is a sheet, not a volume); aim at ~8 points per OCCUPIED cell, assuming occupancy ~ cell^2
+__global__ void grid_refine_kernel(CloudView in, int cap, GridMeta* meta, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    GridMeta g = meta[b];
+    const int n = min(in.n[b], cap);
+    if (g.occupied > 0 && n > 0) {
+        const double avg = (double)n / (double)g.occupied;
+        if (avg > 12.0) grid_layout(g, fmax(g.cell * sqrt(8.0 / avg), g.cell * 0.125));
+    }
+    g.occupied = 0;
+    meta[b] = g;
+}
+
 // bounding box (finite coordinates only) -> cell size, grid dims, origin.  fixed_cell > 0: use it; else adapt to ~6 points/cell
 __global__ __launch_bounds__(TB) void grid_meta_kernel(CloudView in, int cap, double fixed_cell, GridMeta* meta) {
     const int b = blockIdx.x;
@@ -554,16 +583,10 @@ __global__ __launch_bounds__(TB) void grid_meta_kernel(CloudView in, int cap, do
             cell = fmin(fmax(cell, 0.01), 4.0);
         }
         GridMeta g;
-        g.cell = cell; g.inv = 1.0 / cell; g.pad = 0;
-        // dims: powers of two with gx*gy*gz == GRID_CELLS; x and y sized to the box (clamped), z takes the rest
-        const int gy = min(pow2ceil((int)fmin(ext[1] / cell + 2.0, 4096.0)), 64);
-        const int gx = min(pow2ceil((int)fmin(ext[0] / cell + 2.0, 4096.0)), 256);
-        g.gx = gx; g.gy = gy; g.gz = GRID_CELLS / (gx * gy);
-        g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
-        // scene z is negative and dense near the camera (large z): if the z range does not fit, anchor the grid at the
-        // near end so the dense part is resolved and the far tail clamps into the first layer
-        const double span = cell * (double)g.gz;
-        if (ext[2] > span) g.oz = (double)mx[2] - span + 0.5 * cell;
+        for (int j = 0; j < 3; ++j) { g.ext[j] = ext[j]; g.mn[j] = mn[j]; }
+        g.mxz = mx[2];
+        g.occupied = 0;
+        grid_layout(g, cell);
         meta[b] = g;
     }
 }
@@ -583,11 +606,15 @@ __global__ __launch_bounds__(256) void grid_count_kernel(CloudView in, int cap, 
 }
 
 // exclusive scan of the per-frame cell counts in three parallel passes (segment sums, scan of sums, write-back)
-__global__ __launch_bounds__(256) void grid_scan_a_kernel(const int* cell_cnt, int* seg_sum) {
+__global__ __launch_bounds__(256) void grid_scan_a_kernel(const int* cell_cnt, int* seg_sum, GridMeta* meta) {
     const int b = blockIdx.y, seg = blockIdx.x, t = threadIdx.x;
     const int4* c = reinterpret_cast<const int4*>(cell_cnt + (size_t)b * GRID_CELLS + (size_t)seg * SCAN_SEG) + t * 2;
     const int4 a = c[0], d = c[1];
     int s = a.x + a.y + a.z + a.w + d.x + d.y + d.z + d.w;
+    int occ = (a.x > 0) + (a.y > 0) + (a.z > 0) + (a.w > 0) + (d.x > 0) + (d.y > 0) + (d.z > 0) + (d.w > 0);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) occ += __shfl_xor(occ, o);
+    if ((t & 63) == 0 && occ) atomicAdd(&meta[b].occupied, occ);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     __shared__ int ws[4];
@@ -818,12 +845,12 @@ __global__ __launch_bounds__(TB) void keep_select_kernel(CloudView in, CloudOut 
     block_compact(xyz, rgb, n, oxyz, orgb, on, cap, [=](int i, float, float, float) { return kp[i] != 0; }, L);
 }
 
-static void build_grid(CloudView in, int B, int cap, double fixed_cell, const O3dScratch& sc, hipStream_t s) {
+static void build_grid(CloudView in, int B, int cap, double fixed_cell, const O3dScratch& sc, hipStream_t s, bool keep_meta = false) {
     hipMemsetAsync(sc.cell_cnt, 0, (size_t)B * GRID_CELLS * 4, s);
-    hipLaunchKernelGGL(grid_meta_kernel, dim3(B), dim3(TB), 0, s, in, cap, fixed_cell, sc.meta);
+    if (!keep_meta) hipLaunchKernelGGL(grid_meta_kernel, dim3(B), dim3(TB), 0, s, in, cap, fixed_cell, sc.meta);
     dim3 grid((cap + 255) / 256, B);
     hipLaunchKernelGGL(grid_count_kernel, grid, dim3(256), 0, s, in, cap, sc.meta, sc.cell_cnt, sc.cell_of);
-    hipLaunchKernelGGL(grid_scan_a_kernel, dim3(SCAN_NSEG, B), dim3(256), 0, s, sc.cell_cnt, sc.seg_sum);
+    hipLaunchKernelGGL(grid_scan_a_kernel, dim3(SCAN_NSEG, B), dim3(256), 0, s, sc.cell_cnt, sc.seg_sum, sc.meta);
     hipLaunchKernelGGL(grid_scan_b_kernel, dim3(B), dim3(SCAN_NSEG), 0, s, sc.seg_sum, sc.cell_start);
     hipLaunchKernelGGL(grid_scan_c_kernel, dim3(SCAN_NSEG, B), dim3(256), 0, s, sc.cell_cnt, sc.seg_sum, sc.cell_start);
     hipLaunchKernelGGL(grid_scatter_kernel, grid, dim3(256), 0, s, in, cap, sc.cell_cnt, sc.cell_start, sc.cell_of, sc.sidx, sc.sxyz);
@@ -833,6 +860,8 @@ hipError_t launch_sor(CloudView in, CloudOut out, int B, int cap, int k, double 
     if (k > KMAX) return hipErrorInvalidValue;
     O3dScratch sc = carve(scratch, B, cap);
     build_grid(in, B, cap, 0.0, sc, s);
+    hipLaunchKernelGGL(grid_refine_kernel, dim3((B + 63) / 64), dim3(64), 0, s, in, cap, sc.meta, B);   // re-size the cells from the
+    build_grid(in, B, cap, 0.0, sc, s, /*keep_meta=*/true);                                              // measured occupancy, rebuild
     double* md = mean_out ? mean_out : sc.mean_d;
     hipLaunchKernelGGL(sor_knn_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx, sc.sxyz, k, md);
     hipLaunchKernelGGL(sor_select_kernel, dim3(B), dim3(TB), 0, s, in, out, cap, ratio, md);
