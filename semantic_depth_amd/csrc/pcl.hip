@@ -680,31 +680,33 @@ __device__ __forceinline__ double dist2(double ax, double ay, double az, const f
     return (dx * dx + dy * dy) + dz * dz;
 }
 
+template <int CAPK>
 struct TopK {
-    double v[KMAX];
+    double v[CAPK];
     double kth;      // v[k-1]
     int k;
     __device__ __forceinline__ void init(int k_) {
         k = k_;
 #pragma unroll
-        for (int t = 0; t < KMAX; ++t) v[t] = INFINITY;
+        for (int t = 0; t < CAPK; ++t) v[t] = INFINITY;
         kth = INFINITY;
     }
     __device__ __forceinline__ void push(double d) {
         if (!(d < kth)) return;
 #pragma unroll
-        for (int t = 0; t < KMAX; ++t) {      // bubble the new value into the ascending array
+        for (int t = 0; t < CAPK; ++t) {      // bubble the new value into the ascending array
             const double lo = d < v[t] ? d : v[t];
             const double hi = d < v[t] ? v[t] : d;
             v[t] = lo; d = hi;
         }
         double kv = v[0];
 #pragma unroll
-        for (int t = 1; t < KMAX; ++t) kv = (t == k - 1) ? v[t] : kv;
+        for (int t = 1; t < CAPK; ++t) kv = (t == k - 1) ? v[t] : kv;
         kth = kv;
     }
 };
 
+template <int CAPK>
 __global__ __launch_bounds__(256) void sor_knn_kernel(CloudView in, int cap, const GridMeta* meta, const int* cell_start,
                                                       const int* sidx, const float* sxyz, int k, double* mean_d) {
     const int b = blockIdx.y;
@@ -718,7 +720,7 @@ __global__ __launch_bounds__(256) void sor_knn_kernel(CloudView in, int cap, con
     const double qx = q[0], qy = q[1], qz = q[2];
     const int cx = cell_coord(qx, g.ox, g.inv, g.gx), cy = cell_coord(qy, g.oy, g.inv, g.gy), cz = cell_coord(qz, g.oz, g.inv, g.gz);
     const int kk = k < n ? k : n;
-    TopK top;
+    TopK<CAPK> top;
     top.init(kk);
     const int rall = max(g.gx, max(g.gy, g.gz));
     bool done = false;
@@ -756,7 +758,7 @@ __global__ __launch_bounds__(256) void sor_knn_kernel(CloudView in, int cap, con
     }
     double acc = 0.0;
 #pragma unroll
-    for (int t = 0; t < KMAX; ++t) if (t < kk) acc = acc + sqrt(top.v[t]);   // ascending, sequential adds
+    for (int t = 0; t < CAPK; ++t) if (t < kk) acc = acc + sqrt(top.v[t]);   // ascending, sequential adds
     mean_d[(size_t)b * cap + sidx[(size_t)b * cap + j]] = acc / (double)kk;
 }
 
@@ -863,7 +865,9 @@ hipError_t launch_sor(CloudView in, CloudOut out, int B, int cap, int k, double 
     hipLaunchKernelGGL(grid_refine_kernel, dim3((B + 63) / 64), dim3(64), 0, s, in, cap, sc.meta, B);   // re-size the cells from the
     build_grid(in, B, cap, 0.0, sc, s, /*keep_meta=*/true);                                              // measured occupancy, rebuild
     double* md = mean_out ? mean_out : sc.mean_d;
-    hipLaunchKernelGGL(sor_knn_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx, sc.sxyz, k, md);
+    // the top-k array is walked by every lane of a wave whenever ANY lane inserts: keep it as short as k allows
+    if (k <= 10) hipLaunchKernelGGL(sor_knn_kernel<10>, dim3((cap + 255) / 256, B), dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx, sc.sxyz, k, md);
+    else hipLaunchKernelGGL(sor_knn_kernel<KMAX>, dim3((cap + 255) / 256, B), dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx, sc.sxyz, k, md);
     hipLaunchKernelGGL(sor_select_kernel, dim3(B), dim3(TB), 0, s, in, out, cap, ratio, md);
     return hipGetLastError();
 }
