@@ -7,7 +7,8 @@
 // meets at ONE barrier:
 //      wait(tile t landed) ; barrier ; issue DMA(tile t+2) ; 16 ds_read + 24 MFMA on stage t%3
 // (stage (t+2)%3 was last read in iteration t-1, which every wave finished before this barrier).
-// 8 waves, wave tile 64x64, block 128x256 (Cout % 256 == 0) or 256x128; 3 x 48 KiB of LDS, one workgroup per CU.
+// 8 waves; block 128x256 (Cout % 256 == 0), 256x128 (Cout % 128 == 0) or 256x64 (Cout = 64); 3 x 40-48 KiB of LDS, one
+// workgroup per CU.
 // Out-of-image taps and pixels beyond M read a 16-byte zero page, so zero padding costs no branch in the pipeline.
 // Gather granularity: four consecutive lanes fetch the four 16-byte octets of ONE pixel (64 contiguous bytes per plane),
 // so a wave-instruction touches 16 cache lines instead of 64; the LDS image is therefore [pixel][octet] and the octet
@@ -50,22 +51,23 @@ __device__ __forceinline__ KEntry load_kentry(const KEntry* ptr) {
     return e;
 }
 
-template <int WAVES_M, int WAVES_N>
+template <int WAVES_M, int WAVES_N, int MT, int NT>
 __global__ __launch_bounds__(512) void conv_dma_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
-    constexpr int MT = 2, NT = 2, NW = WAVES_M * WAVES_N;
+    constexpr int NW = WAVES_M * WAVES_N;
     static_assert(NW == 8, "8 waves");
-    constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
+    constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
     constexpr int STAGE_UNITS = 8 * (BM + BN);                // 16-B units: Xh [4][BM] | Xl [4][BM] | Wh [4][BN] | Wl [4][BN]
     constexpr int NDMA = STAGE_UNITS / 64 / NW;               // DMA instructions per wave per tile (6)
     constexpr int XI = 8 * BM / 64 / NW;                      // of which activation instructions (2 or 4), hi first then lo
     constexpr int STAGES = 3;
     constexpr int EPI_ROW = NT * 64 + 16;
     static_assert(NW * 2 * 32 * EPI_ROW <= STAGES * STAGE_UNITS * 16, "epilogue slabs fit in the ring");
+    static_assert((8 * BM / 64) % (2 * NW) == 0 && (8 * BN / 64) % NW == 0, "whole DMA instructions per wave and plane");
     __shared__ __attribute__((aligned(16))) u32x4 ring[STAGES * STAGE_UNITS];
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm0 = (wave % WAVES_M) * 64, wn0 = (wave / WAVES_M) * 64;
+    const int wm0 = (wave % WAVES_M) * (MT * 32), wn0 = (wave / WAVES_M) * (NT * 32);
 
     int tid_;
     {
@@ -222,13 +224,14 @@ __global__ __launch_bounds__(512) void conv_dma_kernel(const ConvParams p, int M
     }
 }
 
-// which layers take the DMA pipeline: vec layers, Cout a multiple of 128, and enough tiles to fill 256 CUs
+// which layers take the DMA pipeline: vec layers with Cout a multiple of 64 and enough tiles to occupy the chip
 int conv_dma_variant(const ConvParams& p) {
-    if (!p.vec || !p.zero16 || p.Cout % 128 || p.Kpad < 64) return 0;
+    if (!p.vec || !p.zero16 || p.Cout % 64 || p.Kpad < 64) return 0;
     const long M = (long)p.N * p.Hout * p.Wout;
     const long thr = 96;     // tiles needed: the DMA pipeline at half occupancy still beats the register-staged kernel
     if (p.Cout % 256 == 0 && ((M + 127) / 128) * (p.Cout / 256) >= thr) return 1;     // 128 x 256
-    if (((M + 255) / 256) * (p.Cout / 128) >= thr) return 2;                           // 256 x 128
+    if (p.Cout % 128 == 0 && ((M + 255) / 256) * (p.Cout / 128) >= thr) return 2;     // 256 x 128
+    if (p.Cout % 128 != 0 && ((M + 255) / 256) * (p.Cout / 64) >= thr) return 3;      // 256 x 64
     return 0;
 }
 
@@ -237,16 +240,25 @@ hipError_t launch_conv_dma(const ConvParams& p, hipStream_t s) {
     const int v = conv_dma_variant(p);
     if (v == 1) {
         const int tilesM = (int)((M + 127) / 128), tilesN = p.Cout / 256;
-        hipLaunchKernelGGL((conv_dma_kernel<2, 4>), dim3((unsigned)(tilesM * tilesN)), dim3(512), 0, s, p, (int)M, tilesM, tilesN);
+        hipLaunchKernelGGL((conv_dma_kernel<2, 4, 2, 2>), dim3((unsigned)(tilesM * tilesN)), dim3(512), 0, s, p, (int)M, tilesM, tilesN);
     } else if (v == 2) {
         const int tilesM = (int)((M + 255) / 256), tilesN = p.Cout / 128;
-        hipLaunchKernelGGL((conv_dma_kernel<4, 2>), dim3((unsigned)(tilesM * tilesN)), dim3(512), 0, s, p, (int)M, tilesM, tilesN);
+        hipLaunchKernelGGL((conv_dma_kernel<4, 2, 2, 2>), dim3((unsigned)(tilesM * tilesN)), dim3(512), 0, s, p, (int)M, tilesM, tilesN);
+    } else if (v == 3) {
+        const int tilesM = (int)((M + 255) / 256), tilesN = p.Cout / 64;
+        hipLaunchKernelGGL((conv_dma_kernel<4, 2, 2, 1>), dim3((unsigned)(tilesM * tilesN)), dim3(512), 0, s, p, (int)M, tilesM, tilesN);
     } else {
         return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
-const char* conv_dma_kernel_name(const ConvParams& p) { return conv_dma_variant(p) == 1 ? "conv_dma_kernel<2,4>" : "conv_dma_kernel<4,2>"; }
+const char* conv_dma_kernel_name(const ConvParams& p) {
+    switch (conv_dma_variant(p)) {
+        case 1: return "conv_dma_kernel<2,4,2,2>";
+        case 2: return "conv_dma_kernel<4,2,2,2>";
+        default: return "conv_dma_kernel<4,2,2,1>";
+    }
+}
 
 }  // namespace sd
