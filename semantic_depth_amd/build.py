@@ -20,6 +20,7 @@ SOURCES = [
     ("conv_igemm.hip", []),
     ("conv_split.hip", []),
     ("conv_dma.hip", []),
+    ("conv_direct.hip", []),
     ("ops_misc.hip", []),
     ("fuse.hip", ["-ffp-contract=off"]),
     ("pcl.hip", ["-ffp-contract=off"]),

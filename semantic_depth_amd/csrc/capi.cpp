@@ -82,6 +82,12 @@ sd_status upload_tables(sd_handle* h, sd_net net) {
     char* wbase = warena(h, net);
     const char* abase = h->ws + (net == SD_NET_FCN8S ? h->o_fcn : h->o_mono);
     for (const OpDesc& op : p.ops) {
+        if (op.kind == OP_CONV_DIRECT) {
+            std::vector<DirectChunk> chunks;
+            build_direct_chunks(p, op, abase, chunks);
+            HIPCHK(h, hipMemcpy(wbase + op.tab_offset, chunks.data(), chunks.size() * sizeof(DirectChunk), hipMemcpyHostToDevice));
+            continue;
+        }
         if (op.kind != OP_CONV) continue;
         std::vector<KEntry> ktab;
         build_conv_tables(p, op, abase, wbase + op.tab_offset, ktab);
@@ -151,12 +157,40 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 }
                 break;
             }
+            case OP_CONV_DIRECT: {
+                const TensorDesc& d = p.tensors[op.dst];
+                ConvDirectParams c{};
+                c.chunks = reinterpret_cast<const DirectChunk*>(wbase + op.tab_offset);
+                c.nchunks = op.nchunks;
+                c.N = N; c.H = d.H; c.W = d.W; c.Cout = d.C;
+                c.wt = reinterpret_cast<const u32x4_t*>(Wp(op.w)); c.bias = Wp(op.b);
+                c.out = T(op.dst); c.out_plane = PL(op.dst); c.act = op.act; c.Nmax = p.images;
+                c.zero16 = h->ws + h->o_misc + 256;
+                hipEvent_t ea = nullptr, eb = nullptr;
+                if (h->prof) {
+                    if (h->prof_used == h->prof_pool.size()) {
+                        hipEvent_t a, b;
+                        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return fail(h, SD_ERR_HIP, "hipEventCreate");
+                        h->prof_pool.push_back({a, b});
+                    }
+                    ea = h->prof_pool[h->prof_used].first; eb = h->prof_pool[h->prof_used].second;
+                    ++h->prof_used;
+                    hipEventRecord(ea, s);
+                }
+                e = launch_conv_direct(c, s);
+                if (h->prof) {
+                    hipEventRecord(eb, s);
+                    h->prof_recs.push_back({"conv_direct_kernel", op.flops * N / p.images, ea, eb, op.name.c_str(), N * d.H * d.W, d.C, op.K});
+                }
+                break;
+            }
             case OP_SMALLN: {
                 const TensorDesc& s0 = p.tensors[op.src[0]];
                 SmallNParams c{};
                 c.x = T(op.src[0]); c.N = N; c.H = s0.H; c.W = s0.W; c.C = s0.C; c.k = op.k; c.nout = op.nout;
                 c.wt = Wp(op.w); c.bias = Wp(op.b); c.out = T(op.dst); c.act = op.act;
                 c.in_split = FMT(op.src[0]); c.out_split = FMT(op.dst); c.in_plane = PL(op.src[0]); c.out_plane = PL(op.dst);
+                c.out_c = p.tensors[op.dst].C;
                 e = launch_conv_smalln(c, s);
                 break;
             }
@@ -528,14 +562,14 @@ sd_status sd_net_tensor(sd_handle* h, sd_net net, const char* name, float* out, 
     if (it == p.tensor_by_name.end()) return fail(h, SD_ERR_NOTFOUND, std::string("unknown tensor ") + name);
     const TensorDesc& t = p.tensors[it->second];
     const int N = net == SD_NET_FCN8S ? h->last_fcn_images : h->last_mono_images;
-    if (shape_out) { shape_out[0] = N; shape_out[1] = t.H; shape_out[2] = t.W; shape_out[3] = t.C; }
+    if (shape_out) { shape_out[0] = N; shape_out[1] = t.H; shape_out[2] = t.W; shape_out[3] = t.fmt ? t.Ctf : t.C; }
     if (!out) return SD_OK;
     if (!h->bound) return fail(h, SD_ERR_STATE, "sd_bind_memory first");
-    const size_t numel = (size_t)N * t.H * t.W * t.C;
+    const size_t numel = (size_t)N * t.H * t.W * (t.fmt ? t.Ctf : t.C);
     if (numel > cap_floats) return fail(h, SD_ERR_INVALID, "output buffer too small");
     const char* abase = h->ws + (net == SD_NET_FCN8S ? h->o_fcn : h->o_mono);
     if (t.fmt)      // split-bf16 planes -> f32
-        HIPCHK(h, launch_unsplit(reinterpret_cast<const float*>(abase + t.offset), out, (long)numel, (size_t)p.images * t.H * t.W * t.C, (hipStream_t)stream));
+        HIPCHK(h, launch_unsplit(reinterpret_cast<const float*>(abase + t.offset), out, (long)N * t.H * t.W, t.C, t.Ctf, (size_t)p.images * t.H * t.W * t.C, (hipStream_t)stream));
     else
         HIPCHK(h, hipMemcpyAsync(out, abase + t.offset, numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return SD_OK;

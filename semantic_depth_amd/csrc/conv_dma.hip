@@ -33,11 +33,6 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-__device__ __forceinline__ float dma_act(float v, int act) {
-    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == ACT_ELU) return v > 0.f ? v : expm1f(v);
-    return v;
-}
 
 // the gather descriptor of a k-tile through the scalar cache.  (A compiler-visible vector load inside the pipeline would
 // bring a compiler-counted s_waitcnt vmcnt(0) with it, which also drains the LDS-DMAs it does not know about.)
@@ -180,7 +175,8 @@ __global__ __launch_bounds__(512) void conv_dma_kernel(const ConvParams p, int M
 
     // ---- epilogue (as conv_split.hip): bias + activation, split once, LDS transpose, 16-byte runs per pixel ----
     __syncthreads();
-    {
+    auto epilogue = [&](auto tag) {
+        constexpr int ACT = decltype(tag)::value;
         constexpr int ROW = EPI_ROW;
         unsigned char* sh = reinterpret_cast<unsigned char*>(ring) + wave * (2 * 32 * ROW);
         unsigned char* sl = sh + 32 * ROW;
@@ -198,7 +194,7 @@ __global__ __launch_bounds__(512) void conv_dma_kernel(const ConvParams p, int M
                     f32x4 v = {acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
                     v += *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = dma_act(v[r], p.act);
+                    for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
                     uint2 h, l;
                     split4(v, h, l);
                     *reinterpret_cast<uint2*>(sh + (lane & 31) * ROW + nl * 2) = h;
@@ -221,7 +217,10 @@ __global__ __launch_bounds__(512) void conv_dma_kernel(const ConvParams p, int M
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-    }
+    };
+    if (p.act == ACT_RELU) epilogue(ActTag<ACT_RELU>{});
+    else if (p.act == ACT_ELU) epilogue(ActTag<ACT_ELU>{});
+    else epilogue(ActTag<ACT_NONE>{});
 }
 
 // which layers take the DMA pipeline: vec layers with Cout a multiple of 64 and enough tiles to occupy the chip

@@ -23,11 +23,6 @@ namespace sd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == ACT_ELU) return v > 0.f ? v : expm1f(v);
-    return v;
-}
 
 template <int WAVES_M, int WAVES_N, int MT, int NT>
 struct Tile {
@@ -180,23 +175,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p, int
     }
 
     // ---- epilogue: D[row = channel (lane>>4)*4 + r][col = pixel lane&15] ----
+    auto epilogue = [&](auto tag) {
+        constexpr int ACT = decltype(tag)::value;
 #pragma unroll
-    for (int b = 0; b < NT; ++b) {
-        const int n = bn0 + wn0 + b * 16 + (lane >> 4) * 4;
-        if (n >= p.Cout) continue;
-        const f32x4 bi = *reinterpret_cast<const f32x4*>(p.bias + n);
+        for (int b = 0; b < NT; ++b) {
+            const int n = bn0 + wn0 + b * 16 + (lane >> 4) * 4;
+            if (n >= p.Cout) continue;
+            const f32x4 bi = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
-        for (int a = 0; a < MT; ++a) {
-            const int mo = bm0 + wm0 + a * 16 + (lane & 15);
-            if (mo >= M) continue;
-            f32x4 v = acc[a][b] + bi;
-            const size_t o = (size_t)mo * p.Cout + n;
-            if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + o);
+            for (int a = 0; a < MT; ++a) {
+                const int mo = bm0 + wm0 + a * 16 + (lane & 15);
+                if (mo >= M) continue;
+                f32x4 v = acc[a][b] + bi;
+                const size_t o = (size_t)mo * p.Cout + n;
+                if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + o);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
-            *reinterpret_cast<f32x4*>(p.out + o) = v;
+                for (int r = 0; r < 4; ++r) v[r] = act_f32<ACT>(v[r]);
+                *reinterpret_cast<f32x4*>(p.out + o) = v;
+            }
         }
-    }
+    };
+    if (p.act == ACT_RELU) epilogue(ActTag<ACT_RELU>{});
+    else if (p.act == ACT_ELU) epilogue(ActTag<ACT_ELU>{});
+    else epilogue(ActTag<ACT_NONE>{});
 }
 
 template <int WAVES_M, int WAVES_N, int MT, int NT>

@@ -27,17 +27,12 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float split_act(float v, int act) {
-    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == ACT_ELU) return v > 0.f ? v : expm1f(v);
-    return v;
-}
 
 // Output path shared by the split kernels.  A wave owns a (MT*32) x (NT*32) tile; per 32-pixel slab it applies bias +
 // activation, splits ONCE into hi/lo, transposes through a wave-private LDS slab and writes 16-byte runs of 8 channels,
 // so every pixel's NT*64 bytes per plane leave as one contiguous segment (the MFMA layout alone gives 8-byte fragments).
-template <int MT, int NT>
-__device__ __forceinline__ void split_epilogue(f32x16 (&acc)[MT][NT], unsigned char* slab, const ConvParams& p, int m0, int n0, int M, int lane) {
+template <int ACT, int MT, int NT>
+__device__ __forceinline__ void split_epilogue_act(f32x16 (&acc)[MT][NT], unsigned char* slab, const ConvParams& p, int m0, int n0, int M, int lane) {
     constexpr int ROW = NT * 64 + 16;
     unsigned char* sh = slab;
     unsigned char* sl = slab + 32 * ROW;
@@ -56,7 +51,7 @@ __device__ __forceinline__ void split_epilogue(f32x16 (&acc)[MT][NT], unsigned c
                 f32x4 v = {acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
                 if (n < p.Cout) v += *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = split_act(v[r], p.act);
+                for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
                 uint2 h, l;
                 split4(v, h, l);
                 *reinterpret_cast<uint2*>(sh + (lane & 31) * ROW + nl * 2) = h;
@@ -80,6 +75,12 @@ __device__ __forceinline__ void split_epilogue(f32x16 (&acc)[MT][NT], unsigned c
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+}
+template <int MT, int NT>
+__device__ __forceinline__ void split_epilogue(f32x16 (&acc)[MT][NT], unsigned char* slab, const ConvParams& p, int m0, int n0, int M, int lane) {
+    if (p.act == ACT_RELU) split_epilogue_act<ACT_RELU, MT, NT>(acc, slab, p, m0, n0, M, lane);
+    else if (p.act == ACT_ELU) split_epilogue_act<ACT_ELU, MT, NT>(acc, slab, p, m0, n0, M, lane);
+    else split_epilogue_act<ACT_NONE, MT, NT>(acc, slab, p, m0, n0, M, lane);
 }
 
 template <int WAVES_M, int WAVES_N, int MT, int NT>

@@ -5,6 +5,8 @@
 
 namespace sd {
 
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_SIGMOID03 = 3 /* 0.3*sigmoid, monodepth get_disp */ };
 
 // ---------------------------------------------------------------------------------------------
@@ -54,10 +56,64 @@ int conv_dma_variant(const ConvParams& p);
 hipError_t launch_conv_dma(const ConvParams& p, hipStream_t s);
 const char* conv_dma_kernel_name(const ConvParams& p);
 
+#ifdef __HIPCC__
+// ELU for the conv epilogues.  expm1f() is a ~60-instruction library routine and the monodepth layers apply it to every
+// output element; this is exp2 (one transcendental) away from zero and the Taylor series near it, |abs error| < 2.5e-7
+// (the reference graph itself evaluates exp(x) - 1 in f32: monodepth_model.py conv -> tf.nn.elu).
+__device__ __forceinline__ float fast_elu(float v) {
+    const float e = __builtin_amdgcn_exp2f(v * 1.4426950408889634f) - 1.0f;
+    const float q = v * (1.0f + v * (0.5f + v * (0.16666667f + v * (0.041666668f + v * 0.008333334f))));
+    const float r = v > -0.125f ? q : e;
+    return v > 0.f ? v : r;
+}
+// branch-free form for the split-bf16 engine (abs error < 2e-7, below the 2^-17 relative step of the split format for
+// every |value| > 0.02): elu(v) = max(v, 0) + (exp(min(v, 0)) - 1)
+__device__ __forceinline__ float fast_elu_split(float v) {
+    return fmaxf(v, 0.f) + (__builtin_amdgcn_exp2f(fminf(v, 0.f) * 1.4426950408889634f) - 1.0f);
+}
+template <int ACT> struct ActTag { static constexpr int value = ACT; };
+// activation selected at compile time inside the epilogues (a run-time switch per value costs more than the arithmetic)
+template <int ACT> __device__ __forceinline__ float act_split(float v) {
+    if (ACT == 1) return fmaxf(v, 0.f);
+    if (ACT == 2) return fast_elu_split(v);
+    return v;
+}
+template <int ACT> __device__ __forceinline__ float act_f32(float v) {
+    if (ACT == 1) return fmaxf(v, 0.f);
+    if (ACT == 2) return fast_elu(v);
+    return v;
+}
+#endif
+
+// direct 3x3 convolution for full-resolution, few-channel layers of the split engine (conv_direct.hip)
+struct DirectChunk {       // one 16-channel chunk of one source (32 bytes)
+    const void* base;      // hi plane of the source + first channel of the chunk
+    int H, W, C;           // physical dims of the source tensor
+    int up;                // 1: read through a x2 nearest-neighbour upsample
+    int nvalid;            // channel octets of the chunk that exist (1..2)
+    int pad;
+};
+static_assert(sizeof(DirectChunk) == 32, "DirectChunk must be 32 bytes");
+struct ConvDirectParams {
+    const DirectChunk* chunks;   // DEVICE [nchunks]
+    int nchunks;
+    int N, H, W;                 // output (= logical input) dims
+    int Cout;                    // <= 32, multiple of 8
+    const u32x4_t* wt;           // [plane][chunk][tap 9][octet 2][32][8 bf16]
+    const float* bias;
+    float* out;                  // split planes [N,H,W,Cout]
+    size_t out_plane;
+    int act, Nmax;
+    const void* zero16;
+    int dbg;
+};
+hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s);
+
 // small-N convolution (N <= 4 output channels: score 1x1 convs, monodepth disparity heads)
 struct SmallNParams {
     const float* x;     // [N,H,W,C] (f32, or split planes when in_split)
     int in_split, out_split;       // activation formats (split_fmt.hpp); out_split needs nout == 2
+    int out_c;                     // stored channels of a split output (2, or 8 = zero-padded octet for the direct conv)
     size_t in_plane, out_plane;    // element offset of the lo plane
     int N, H, W, C;
     int k;              // 1 or 3 (stride 1, zero pad (k-1)/2)
@@ -77,7 +133,7 @@ hipError_t launch_pre_vgg(const uint8_t* frames, float* out, long npix, int spli
 hipError_t launch_pre_mono(const uint8_t* frames, float* out, int B, int H, int W, int split, size_t plane, hipStream_t s);      // /255 + fliplr pair
 hipError_t launch_maxpool2(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s);
 hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s);
-hipError_t launch_unsplit(const float* x, float* y, long numel, size_t plane, hipStream_t s);             // split planes -> f32
+hipError_t launch_unsplit(const float* x, float* y, long npix, int C, int Ctf, size_t plane, hipStream_t s);  // split planes -> f32 [npix][Ctf]
 // y[n,2i+ky-1,2j+kx-1,o] += x[n,i,j,c]*w[ky,kx,o,c]; y += bias + skip   (3->3 channels; fcn8s/fcn.py:186-204)
 hipError_t launch_deconv4s2_add(const float* x, const float* w, const float* bias, const float* skip, float* y,
                                 int N, int H, int W, hipStream_t s);

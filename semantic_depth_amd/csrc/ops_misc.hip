@@ -147,7 +147,7 @@ hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C
 __device__ __forceinline__ float smalln_act(float v, int act) {
     if (act == ACT_SIGMOID03) return 0.3f * (1.0f / (1.0f + expf(-v)));
     if (act == ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == ACT_ELU) return v > 0.f ? v : expm1f(v);
+    if (act == ACT_ELU) return fast_elu(v);
     return v;
 }
 
@@ -192,8 +192,13 @@ __global__ __launch_bounds__(256) void conv_smalln_thread_kernel(const SmallNPar
     if (p.out_split) {            // NOUT == 2: one bf16 pair per plane
         unsigned h, l;
         split2(f32x2_t{smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)}, h, l);
-        reinterpret_cast<unsigned*>(p.out)[pix] = h;
-        reinterpret_cast<unsigned*>(reinterpret_cast<uint16_t*>(p.out) + p.out_plane)[pix] = l;
+        if (p.out_c == 8) {       // one zero-padded channel octet per pixel (source of the direct 3x3 kernel)
+            reinterpret_cast<u32x4_t*>(p.out)[pix] = (u32x4_t){h, 0u, 0u, 0u};
+            reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(p.out) + p.out_plane)[pix] = (u32x4_t){l, 0u, 0u, 0u};
+        } else {
+            reinterpret_cast<unsigned*>(p.out)[pix] = h;
+            reinterpret_cast<unsigned*>(reinterpret_cast<uint16_t*>(p.out) + p.out_plane)[pix] = l;
+        }
     } else {
         float* o = p.out + pix * NOUT;
 #pragma unroll
@@ -267,20 +272,18 @@ hipError_t launch_conv_smalln(const SmallNParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
-// split planes -> f32 (introspection: sd_net_tensor)
-__global__ __launch_bounds__(256) void unsplit_kernel(const float* __restrict__ x, float* __restrict__ y, long nquads, size_t plane) {
+// split planes [npix][C] -> f32 [npix][Ctf] (introspection: sd_net_tensor); Ctf < C for zero-padded tensors
+__global__ __launch_bounds__(256) void unsplit_kernel(const float* __restrict__ x, float* __restrict__ y, long total, int C, int Ctf, size_t plane) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < nquads) reinterpret_cast<f32x4*>(y)[i] = load4<true>(x, plane, i);
+    if (i >= total) return;
+    const long pix = i / Ctf;
+    const int c = (int)(i - pix * Ctf);
+    const uint16_t* h = reinterpret_cast<const uint16_t*>(x) + pix * C + c;
+    y[i] = __uint_as_float((unsigned)h[0] << 16) + __uint_as_float((unsigned)h[plane] << 16);
 }
-__global__ __launch_bounds__(256) void unsplit2_kernel(const float* __restrict__ x, float* __restrict__ y, long npairs, size_t plane) {
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= npairs) return;
-    const f32x2_t v = recon2(reinterpret_cast<const unsigned*>(x)[i], reinterpret_cast<const unsigned*>(reinterpret_cast<const uint16_t*>(x) + plane)[i]);
-    y[2 * i] = v[0]; y[2 * i + 1] = v[1];
-}
-hipError_t launch_unsplit(const float* x, float* y, long numel, size_t plane, hipStream_t s) {
-    if (numel % 4 == 0) hipLaunchKernelGGL(unsplit_kernel, dim3((unsigned)((numel / 4 + 255) / 256)), dim3(256), 0, s, x, y, numel / 4, plane);
-    else hipLaunchKernelGGL(unsplit2_kernel, dim3((unsigned)((numel / 2 + 255) / 256)), dim3(256), 0, s, x, y, numel / 2, plane);
+hipError_t launch_unsplit(const float* x, float* y, long npix, int C, int Ctf, size_t plane, hipStream_t s) {
+    const long total = npix * Ctf;
+    hipLaunchKernelGGL(unsplit_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, total, C, Ctf, plane);
     return hipGetLastError();
 }
 

@@ -38,6 +38,7 @@ struct Builder {
         size_t n = 0;
         switch (layout) {
             case WL_IGEMM: case WL_IGEMM_SPLIT: n = (size_t)Kpad * CoutPad; break;
+            case WL_DIRECT_SPLIT: n = (size_t)Kpad * CoutPad; break;     // Kpad = nchunks * 9 * 16, CoutPad = 32
             case WL_SMALLN: n = (size_t)s.shape[0] * s.shape[1] * s.shape[2] * 4; break;
             case WL_BIAS4: n = 4; break;
             default: n = 1; for (int j = 0; j < s.rank; ++j) n *= (size_t)s.shape[j];
@@ -81,6 +82,27 @@ struct Builder {
         op.Ctot = Ctot; op.K = k * k * Ctot; op.vec = vec ? 1 : 0;
         op.Kvec = k * k * Cvec; op.CqPad = CqPad;
         op.Kpad = op.Kvec + (k * k * CqPad + 31) / 32 * 32;
+        // full-resolution few-channel 3x3 layers of the split engine go to the direct (halo-tile) kernel
+        bool direct = p.prec && k == 3 && stride == 1 && Cout <= 32 && Cout % 8 == 0 && Win % 32 == 0 && residual < 0 &&
+                      !std::getenv("SEMDEPTH_NO_DIRECT");
+        for (int i = 0; i < op.nsrc; ++i)
+            if (p.tensors[op.src[i]].C % 8 || op.sstride[i] != 1) direct = false;
+        if (direct) {
+            op.kind = OP_CONV_DIRECT;
+            int nch = 0;
+            for (int i = 0; i < op.nsrc; ++i) nch += (p.tensors[op.src[i]].C + 15) / 16;
+            op.nchunks = nch;
+            op.w = wslot(wname, {k, k, Ctf, Cout}, WL_DIRECT_SPLIT, nch * 9 * 16, 32);
+            WeightSlot& ws = p.weights[op.w];
+            ws.nsrc = op.nsrc;
+            for (int i = 0; i < 3; ++i) { ws.srcCtf[i] = srcCtf[i]; ws.srcCpad[i] = i < op.nsrc ? p.tensors[op.src[i]].C : 0; }
+            op.b = wslot(bname, {Cout}, WL_RAW);
+            op.dst = tensor(name, N, Hout, Wout, Cout);
+            op.tab_bytes = (size_t)nch * sizeof(DirectChunk);
+            op.flops = 2.0 * (double)N * Hout * Wout * Cout * (double)(k * k * Ctf);
+            push(op);
+            return op.dst;
+        }
         const int bn = p.prec ? conv_split_tile_n(Cout) : conv_tile_n(Cout);
         const int CoutPad = (Cout + bn - 1) / bn * bn;
         op.w = wslot(wname, {k, k, Ctf, Cout}, p.prec ? WL_IGEMM_SPLIT : WL_IGEMM, op.Kpad, CoutPad);
@@ -145,7 +167,11 @@ struct Builder {
         const TensorDesc& t = p.tensors[src];
         op.w = wslot(wname, {k, k, t.C, cout_tf}, WL_SMALLN, 0, 0, nout);
         op.b = wslot(bname, {cout_tf}, WL_BIAS4, 0, 0, nout);
-        op.dst = tensor(name, t.N, t.H, t.W, nout);
+        // a disparity map that feeds the next iconv is stored as ONE zero-padded channel octet per pixel in the split
+        // engine (8 stored channels, 2 real), so the direct 3x3 kernel can DMA it like any other source
+        const bool octet = feeds_conv && p.prec;
+        op.dst = tensor(name, t.N, t.H, t.W, octet ? 8 : nout);
+        p.tensors[op.dst].Ctf = nout;
         if (!feeds_conv) p.tensors[op.dst].fmt = 0;      // consumed by f32 kernels (deconv ladder, post-processing)
         op.flops = 2.0 * p.tensors[src].N * p.tensors[src].H * p.tensors[src].W * nout * k * k * p.tensors[src].C;
         push(op);
@@ -185,7 +211,7 @@ struct Builder {
         }
         for (auto& s : p.weights) if (s.owner >= 0) s.offset = p.weights[s.owner].offset;
         for (auto& op : p.ops)
-            if (op.kind == OP_CONV) {
+            if (op.kind == OP_CONV || op.kind == OP_CONV_DIRECT) {
                 op.tab_offset = off; off += align_up(op.tab_bytes);
             }
         p.weight_bytes = off;
@@ -401,6 +427,29 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
                 if (s.srcVec[i]) cv += s.srcCpad[i]; else cq += s.srcCpad[i];
             }
         }
+    } else if (s.layout == WL_DIRECT_SPLIT) {
+        // [plane][chunk][tap 9][octet 2][32 n][8]: chunk = 16 stored channels of one source
+        const int64_t Ctf = s.shape[2], Cout = s.shape[3];
+        uint16_t* hi = reinterpret_cast<uint16_t*>(out.data());
+        uint16_t* lo = hi + (size_t)s.Kpad * s.CoutPad;
+        auto bf16 = [](float v) -> uint16_t { uint32_t u; std::memcpy(&u, &v, 4); u += 0x7FFFu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
+        auto bf16_to_f = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; };
+        int chunk = 0, cb_tf = 0;
+        for (int i = 0; i < s.nsrc; ++i) {
+            for (int c0 = 0; c0 < s.srcCpad[i]; c0 += 16, ++chunk)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int c = c0; c < std::min(c0 + 16, s.srcCtf[i]); ++c) {
+                        const int oct = (c - c0) / 8, e = (c - c0) % 8;
+                        const float* src = w + ((int64_t)tap * Ctf + cb_tf + c) * Cout;
+                        const size_t base = (((size_t)chunk * 9 + tap) * 2 + oct) * 32 * 8 + e;
+                        for (int64_t n = 0; n < Cout; ++n) {
+                            const uint16_t h = bf16(src[n]);
+                            hi[base + n * 8] = h;
+                            lo[base + n * 8] = bf16(src[n] - bf16_to_f(h));
+                        }
+                    }
+            cb_tf += s.srcCtf[i];
+        }
     } else if (s.layout == WL_SMALLN) {
         const int64_t K = s.shape[0] * s.shape[1] * s.shape[2], Cout = s.shape[3];
         for (int64_t k = 0; k < K; ++k)
@@ -455,6 +504,21 @@ void build_conv_tables(const NetPlan& p, const OpDesc& op, const char* act_base,
             const int tap = kq / op.CqPad, c = kq % op.CqPad;
             int s, cl;
             if (locate(c, false, s, cl)) ktab[(size_t)ktiles + (size_t)qt * 8 + j] = describe(s, cl, tap);
+        }
+    }
+}
+
+void build_direct_chunks(const NetPlan& p, const OpDesc& op, const char* act_base, std::vector<DirectChunk>& chunks) {
+    chunks.clear();
+    for (int i = 0; i < op.nsrc; ++i) {
+        const TensorDesc& t = p.tensors[op.src[i]];
+        for (int c0 = 0; c0 < t.C; c0 += 16) {
+            DirectChunk ch;
+            ch.base = act_base + t.offset + (size_t)c0 * 2;      // hi plane, bf16 elements
+            ch.H = t.H; ch.W = t.W; ch.C = t.C; ch.up = op.up[i];
+            ch.nvalid = std::min(2, (t.C - c0) / 8);
+            ch.pad = 0;
+            chunks.push_back(ch);
         }
     }
 }

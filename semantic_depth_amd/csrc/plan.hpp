@@ -21,8 +21,8 @@ struct TensorDesc {
     int first = -1, last = -1;   // op indices (liveness)
 };
 
-enum OpKind { OP_PRE_VGG, OP_PRE_MONO, OP_CONV, OP_SMALLN, OP_POOL2, OP_POOL3Z, OP_DECONV4_ADD, OP_HEAD16 };
-enum WLayout { WL_RAW = 0, WL_IGEMM = 1, WL_SMALLN = 2, WL_BIAS4 = 3, WL_IGEMM_SPLIT = 4 };
+enum OpKind { OP_PRE_VGG, OP_PRE_MONO, OP_CONV, OP_CONV_DIRECT, OP_SMALLN, OP_POOL2, OP_POOL3Z, OP_DECONV4_ADD, OP_HEAD16 };
+enum WLayout { WL_RAW = 0, WL_IGEMM = 1, WL_SMALLN = 2, WL_BIAS4 = 3, WL_IGEMM_SPLIT = 4, WL_DIRECT_SPLIT = 5 };
 
 struct WeightSlot {
     std::string name;
@@ -55,6 +55,7 @@ struct OpDesc {
     // conv engine
     int Ctot = 0;          // padded channels per tap (every source rounded up to a multiple of 4)
     int K = 0, Kpad = 0, vec = 0, m_fastest = 0;
+    int nchunks = 0;             // OP_CONV_DIRECT: 32-channel chunks over the concatenated sources
     int Kvec = 0, CqPad = 0;     // mixed layers: K = [vec region: (32-channel block, tap, channel)] + [quad tail: (tap, channel quads)]
     size_t tab_offset = 0, tab_bytes = 0;    // KEntry table, in the weight arena
     double flops = 0;                        // 2*M*N*K for the whole chunk
@@ -83,6 +84,7 @@ NetPlan build_monodepth(int encoder /*0 vgg, 1 resnet50*/, int frames, int H, in
 void relayout_weight(const WeightSlot& s, const float* tf_data, std::vector<float>& out);
 // gather-descriptor table of one conv op, given the bound activation arena
 void build_conv_tables(const NetPlan& p, const OpDesc& op, const char* act_base, const char* tab_dev, std::vector<KEntry>& ktab);
+void build_direct_chunks(const NetPlan& p, const OpDesc& op, const char* act_base, std::vector<DirectChunk>& chunks);
 
 int conv_tile_n(int Cout);   // conv_igemm.hip
 
