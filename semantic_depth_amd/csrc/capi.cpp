@@ -166,6 +166,10 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.wt = reinterpret_cast<const u32x4_t*>(Wp(op.w)); c.bias = Wp(op.b);
                 c.out = T(op.dst); c.out_plane = PL(op.dst); c.act = op.act; c.Nmax = p.images;
                 c.zero16 = h->ws + h->o_misc + 256;
+                c.rows_per_wave = 2;
+                for (int i = 0; i < op.nsrc; ++i)
+                    if (!op.up[i] && p.tensors[op.src[i]].C > 16) c.rows_per_wave = 2;   // (8-row tiles measured no better)
+                if (const char* e = std::getenv("SEMDEPTH_DIRECT_ROWS")) c.rows_per_wave = atoi(e) == 1 ? 1 : 2;
                 hipEvent_t ea = nullptr, eb = nullptr;
                 if (h->prof) {
                     if (h->prof_used == h->prof_pool.size()) {

@@ -26,15 +26,21 @@ __device__ __forceinline__ void ddma16(const void* gsrc, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-constexpr int D_TH = 16, D_TW = 32;                      // output tile
-constexpr int D_HW = D_TW + 2, D_HH = D_TH + 2;          // halo tile 18 x 34
-constexpr int D_XI = 20;                                 // DMA instructions per halo plane: 612 pixels x 2 slots = 1224 units
-constexpr int D_XUNITS = D_XI * 64;
-constexpr int D_WI = 9;                                  // DMA instructions per weight plane
-constexpr int D_WUNITS = 9 * 2 * 32;                     // taps x octets x 32 output channels
-constexpr int D_STAGE = 2 * D_XUNITS + 2 * D_WUNITS;     // 3712 units = 58 KiB
-constexpr int D_NDMA = 2 * D_XI + 2 * D_WI;              // 58 DMA instructions per stage, 8 waves
+constexpr int D_TW = 32, D_HW = D_TW + 2;                // output tile / halo tile width
 constexpr int D_WAVES = 8;
+// NB = 32-channel blocks of output channels (Cout <= 32 NB); MT = output rows per wave (tile height 8 MT).
+// MT = 2 halves the halo and weight traffic per pixel; MT = 1 keeps the source footprint of the workgroups of one XCD
+// inside its 4 MiB L2 when a source pixel is wider than one 16-channel chunk (each chunk pass touches only 32 B of a
+// pixel's 128-B line, so a line evicted between passes is fetched from the fabric again).
+template <int NB, int MT> struct DirectCfg {
+    static constexpr int TH = 8 * MT, HH = TH + 2;
+    static constexpr int XI = (HH * D_HW * 2 + 63) / 64;      // DMA instructions per halo plane (2 slots per pixel)
+    static constexpr int XUNITS = XI * 64;
+    static constexpr int XS = (2 * XI + D_WAVES - 1) / D_WAVES;    // X-DMA slots per wave
+    static constexpr int WI = 9 * NB;                    // DMA instructions per weight plane
+    static constexpr int WUNITS = 9 * 2 * 32 * NB;       // taps x octets x output channels
+    static constexpr int STAGE = 2 * XUNITS + 2 * WUNITS;
+};
 
 
 // the chunk descriptor through the scalar cache (a compiler-visible vector load would bring a vmcnt(0) that drains the DMAs)
@@ -50,7 +56,11 @@ __device__ __forceinline__ DirectChunk load_chunk(const DirectChunk* ptr) {
 
 // persistent: workgroup b walks tiles b, b + grid, ...; the (tile, chunk) sequence is one software pipeline, so the first
 // chunk of the next tile lands while the current tile's epilogue runs.
+template <int NB, int MT>
 __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectParams p) {
+    using Cfg = DirectCfg<NB, MT>;
+    constexpr int D_WI = Cfg::WI, D_WUNITS = Cfg::WUNITS, D_STAGE = Cfg::STAGE;
+    constexpr int D_TH = Cfg::TH, D_HH = Cfg::HH, D_XI = Cfg::XI, D_XUNITS = Cfg::XUNITS, XS = Cfg::XS;
     __shared__ __attribute__((aligned(16))) u32x4 lds[2 * D_STAGE];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -71,11 +81,11 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
 
     // halo geometry of this lane's five X-DMA slots (instruction j = wave + 8 i, i < 5; i = 5..7 are weight DMAs): constant
     // over tiles and chunks.  packed: ry | rx << 8 | octet << 16 | inside-halo << 17
-    int geo[5];
+    int geo[XS];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < XS; ++i) {
         const int j = wave + D_WAVES * i;
-        const int u = (j - (j >= D_XI ? D_XI : 0)) * 64 + lane;
+        const int u = (j - (j >= D_XI ? D_XI : 0)) * 64 + lane;      // (slots with j >= 2 XI are never issued)
         const int pix = u >> 1;
         const int oct = (u & 1) ^ ((pix >> 3) & 1);
         const int ry = pix / D_HW, rx = pix - ry * D_HW;
@@ -89,9 +99,9 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
         const unsigned sbyte = lds0 + (unsigned)(stage * D_STAGE * 16);
         const uint16_t* const img_hi = reinterpret_cast<const uint16_t*>(ch.base) + (size_t)tl.img * ch.H * ch.W * ch.C;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < XS; ++i) {
             const int j = wave + D_WAVES * i;
-            if (p.dbg & 1) continue;
+            if (j >= 2 * D_XI || (p.dbg & 1)) continue;
             const int ry = geo[i] & 0xff, rx = (geo[i] >> 8) & 0xff, oct = (geo[i] >> 16) & 1;
             const int gy = tl.ty0 - 1 + ry, gx = tl.tx0 - 1 + rx;
             const bool ok = (geo[i] >> 17) && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && oct < ch.nvalid;
@@ -100,10 +110,9 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
             ddma16(ok ? reinterpret_cast<const u32x4*>(src) : zero, sbyte + (unsigned)(j * 1024));
         }
 #pragma unroll
-        for (int i = 5; i < (D_NDMA + D_WAVES - 1) / D_WAVES; ++i) {
-            const int j = wave + D_WAVES * i;
-            if (j < D_NDMA && !(p.dbg & 2)) {
-                const int jw = j - 2 * D_XI;
+        for (int i = 0; i < (2 * D_WI + D_WAVES - 1) / D_WAVES; ++i) {
+            const int jw = wave + D_WAVES * i;
+            if (jw < 2 * D_WI && !(p.dbg & 2)) {
                 const int pl = jw >= D_WI ? 1 : 0;
                 const u32x4* gw = p.wt + ((size_t)pl * p.nchunks + c) * D_WUNITS + (jw - pl * D_WI) * 64 + lane;
                 ddma16(gw, sbyte + (unsigned)((2 * D_XUNITS + jw * 64) * 16));
@@ -112,9 +121,9 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
     };
 
     // bias of this lane's accumulator rows, once
-    f32x4 bias[4];
+    f32x4 bias[4 * NB];
 #pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
+    for (int r4 = 0; r4 < 4 * NB; ++r4) {
         const int nl = 8 * r4 + 4 * fk;
         bias[r4] = nl < p.Cout ? *reinterpret_cast<const f32x4*>(p.bias + nl) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
@@ -126,11 +135,13 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
     issue(cur, 0, 0);
     int g = 0;                                     // stages consumed so far
     for (; tid < total; tid += gridDim.x) {
-        f32x16 acc[2];
+        f32x16 acc[MT][NB];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < MT; ++a)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][nb][r] = 0.f;
         Tile nxt = cur;
         for (int c = 0; c < p.nchunks; ++c, ++g) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -144,25 +155,27 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
             if (!(p.dbg & 4))
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                bf16x8 xh[4], xl[4];
+                bf16x8 xh[MT + 2], xl[MT + 2];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int lp = (2 * wave + r) * D_HW + frow + dx;
+                for (int r = 0; r < MT + 2; ++r) {
+                    const int lp = (MT * wave + r) * D_HW + frow + dx;
                     const int idx = lp * 2 + (fk ^ ((lp >> 3) & 1));
                     xh[r] = __builtin_bit_cast(bf16x8, Xh[idx]);
                     xl[r] = __builtin_bit_cast(bf16x8, Xl[idx]);
                 }
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const int wi = ((dy * 3 + dx) * 2 + fk) * 32 + frow;
-                    const bf16x8 wh = __builtin_bit_cast(bf16x8, Wh[wi]);
-                    const bf16x8 wl = __builtin_bit_cast(bf16x8, Wl[wi]);
+                for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                    for (int pr = 0; pr < 3; ++pr)
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int wi = ((dy * 3 + dx) * 2 + fk) * (32 * NB) + nb * 32 + frow;
+                        const bf16x8 wh = __builtin_bit_cast(bf16x8, Wh[wi]);
+                        const bf16x8 wl = __builtin_bit_cast(bf16x8, Wl[wi]);
 #pragma unroll
-                        for (int a = 0; a < 2; ++a)
-                            acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 0 ? wl : wh, pr == 1 ? xl[a + dy] : xh[a + dy], acc[a], 0, 0, 0);
-                }
+                        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                            for (int a = 0; a < MT; ++a)
+                                acc[a][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 0 ? wl : wh, pr == 1 ? xl[a + dy] : xh[a + dy], acc[a][nb], 0, 0, 0);
+                    }
             }
         }
 
@@ -171,42 +184,64 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
         __builtin_amdgcn_s_barrier();
         auto epilogue = [&](auto tag) {
             constexpr int ACT = decltype(tag)::value;
-            constexpr int ROW = 64 + 16;
-            unsigned char* sh = reinterpret_cast<unsigned char*>(lds + ((g - 1) & 1) * D_STAGE) + wave * (2 * 32 * ROW);
-            unsigned char* sl = sh + 32 * ROW;
-            const int seg = lane & 3, prow = lane >> 2;          // 4 segments of 8 channels, 16 pixels per pass
+            constexpr int ROW = 64 * NB + 16;
+            constexpr int SEGS = 4 * NB, PPP = 64 / SEGS;        // 16-byte segments per pixel, pixels per store pass
+            // per wave: hi slab and lo slab of 32 pixels (a lo slab that does not fit the stage reuses the hi slab)
+            constexpr bool TWO = D_WAVES * 2 * 32 * ROW <= D_STAGE * 16;
+            static_assert(D_WAVES * 32 * ROW <= D_STAGE * 16, "epilogue slab must fit one stage");
+            unsigned char* sh = reinterpret_cast<unsigned char*>(lds + ((g - 1) & 1) * D_STAGE) + wave * ((TWO ? 2 : 1) * 32 * ROW);
+            unsigned char* sl = TWO ? sh + 32 * ROW : sh;
+            const int seg = lane % SEGS, prow = lane / SEGS;
             uint16_t* const out_hi = reinterpret_cast<uint16_t*>(p.out);
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const int y = cur.ty0 + 2 * wave + a;
+            for (int a = 0; a < MT; ++a) {
+                const int y = cur.ty0 + MT * wave + a;
+                uint2 hh[4 * NB], ll[4 * NB];
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
+                for (int r4 = 0; r4 < 4 * NB; ++r4) {
                     if (8 * r4 >= p.Cout) continue;         // rows past Cout are padding, never stored
-                    const int nl = 8 * r4 + 4 * fk;
-                    f32x4 v = {acc[a][4 * r4], acc[a][4 * r4 + 1], acc[a][4 * r4 + 2], acc[a][4 * r4 + 3]};
+                    const int nb = r4 >> 2, q = r4 & 3;
+                    f32x4 v = {acc[a][nb][4 * q], acc[a][nb][4 * q + 1], acc[a][nb][4 * q + 2], acc[a][nb][4 * q + 3]};
                     v += bias[r4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
-                    uint2 h, l;
-                    split4(v, h, l);
-                    *reinterpret_cast<uint2*>(sh + frow * ROW + nl * 2) = h;
-                    *reinterpret_cast<uint2*>(sl + frow * ROW + nl * 2) = l;
+                    split4(v, hh[r4], ll[r4]);
                 }
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int ps = 0; ps < 2; ++ps) {
-                    const int pix = ps * 16 + prow;
-                    const u32x4 h = *reinterpret_cast<const u32x4*>(sh + pix * ROW + seg * 16);
-                    const u32x4 l = *reinterpret_cast<const u32x4*>(sl + pix * ROW + seg * 16);
-                    if (y < p.H && seg * 8 < p.Cout && !(p.dbg & 8)) {
-                        uint16_t* o = out_hi + ((size_t)(cur.img * p.H + y) * p.W + cur.tx0 + pix) * p.Cout + seg * 8;
-                        *reinterpret_cast<u32x4*>(o) = h;
-                        *reinterpret_cast<u32x4*>(o + p.out_plane) = l;
+                for (int pl = 0; pl < 2; ++pl) {
+                    if (TWO && pl == 1) break;
+#pragma unroll
+                    for (int r4 = 0; r4 < 4 * NB; ++r4) {
+                        if (8 * r4 >= p.Cout) continue;
+                        const int nl = 8 * r4 + 4 * fk;
+                        if (TWO) {
+                            *reinterpret_cast<uint2*>(sh + frow * ROW + nl * 2) = hh[r4];
+                            *reinterpret_cast<uint2*>(sl + frow * ROW + nl * 2) = ll[r4];
+                        } else {
+                            *reinterpret_cast<uint2*>(sh + frow * ROW + nl * 2) = pl ? ll[r4] : hh[r4];
+                        }
                     }
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int ps = 0; ps < 32 / PPP; ++ps) {
+                        const int pix = ps * PPP + prow;
+                        const u32x4 h = *reinterpret_cast<const u32x4*>(sh + pix * ROW + seg * 16);
+                        u32x4 l = h;
+                        if (TWO) l = *reinterpret_cast<const u32x4*>(sl + pix * ROW + seg * 16);
+                        if (y < p.H && seg * 8 < p.Cout && !(p.dbg & 8)) {
+                            uint16_t* o = out_hi + ((size_t)(cur.img * p.H + y) * p.W + cur.tx0 + pix) * p.Cout + seg * 8;
+                            if (TWO) {
+                                *reinterpret_cast<u32x4*>(o) = h;
+                                *reinterpret_cast<u32x4*>(o + p.out_plane) = l;
+                            } else {
+                                *reinterpret_cast<u32x4*>(pl ? o + p.out_plane : o) = h;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         };
         if (p.act == ACT_RELU) epilogue(ActTag<ACT_RELU>{});
@@ -217,8 +252,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
 }
 
 hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
-    if (p.W % D_TW || p.Cout > 32 || p.Cout % 8) return hipErrorInvalidValue;
-    const int tiles = (p.W / D_TW) * ((p.H + D_TH - 1) / D_TH) * p.N;
+    if (p.W % D_TW || p.Cout > 64 || p.Cout % 8) return hipErrorInvalidValue;
     static int cus = 0;
     if (!cus) {
         int dev = 0;
@@ -229,7 +263,14 @@ hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
     ConvDirectParams q = p;
     static const char* dbg = std::getenv("SEMDEPTH_DIRECT_DBG");
     q.dbg = dbg ? atoi(dbg) : 0;
-    hipLaunchKernelGGL(conv_direct_kernel, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(512), 0, s, q);
+    const int th = 8 * p.rows_per_wave;
+    const int tiles = (p.W / D_TW) * ((p.H + th - 1) / th) * p.N;
+    const dim3 grid((unsigned)(tiles < cus ? tiles : cus));
+    const int nb = p.Cout <= 32 ? 1 : 2;
+    if (nb == 1 && p.rows_per_wave == 2) hipLaunchKernelGGL((conv_direct_kernel<1, 2>), grid, dim3(512), 0, s, q);
+    else if (nb == 1) hipLaunchKernelGGL((conv_direct_kernel<1, 1>), grid, dim3(512), 0, s, q);
+    else if (p.rows_per_wave == 2) hipLaunchKernelGGL((conv_direct_kernel<2, 2>), grid, dim3(512), 0, s, q);
+    else hipLaunchKernelGGL((conv_direct_kernel<2, 1>), grid, dim3(512), 0, s, q);
     return hipGetLastError();
 }
 

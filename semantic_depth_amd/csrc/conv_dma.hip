@@ -14,6 +14,7 @@
 // so a wave-instruction touches 16 cache lines instead of 64; the LDS image is therefore [pixel][octet] and the octet
 // slot is XOR-swizzled with (pixel >> 2) & 3 on the SOURCE side (LDS-DMA writes lane-linear), which makes the
 // ds_read_b128 fragment reads bank-conflict free.
+#include <cstdlib>
 #include "kernels.hpp"
 #include "split_fmt.hpp"
 
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(512) void conv_dma_kernel(const ConvParams p, int M
         const size_t plane = (size_t)Nmax * e.H * e.W * e.C;
 #pragma unroll
         for (int i = 0; i < XH; ++i) {
+            if (p.dbg & 1) continue;
             int iy = poy[i] * st + e.dy, ix = pox[i] * st + e.dx;
             const bool ok = pok[i] && iy >= 0 && ix >= 0 && iy < (e.H << up) && ix < (e.W << up);
             iy >>= up; ix >>= up;
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(512) void conv_dma_kernel(const ConvParams p, int M
         // ---- weights: the stage image is the global image ----
 #pragma unroll
         for (int i = XI; i < NDMA; ++i) {
+            if (p.dbg & 2) continue;
             const int j = wave + NW * i;
             const int wu = (j - XI * NW) * 64 + lane;         // unit inside the W region: [plane][kg][n]
             const int pl = wu / (4 * BN), r = wu % (4 * BN), kg = r / BN, n_l = r % BN;
@@ -146,6 +149,7 @@ __global__ __launch_bounds__(512) void conv_dma_kernel(const ConvParams p, int M
         const u32x4* Wl = Wh + 4 * BN;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
+            if (p.dbg & 4) { if (s == 0 && kt + 2 < ktiles) issue(kt + 2, (kt + 2) % STAGES); continue; }
             const int kg = 2 * s + fk;
             bf16x8 wh[NT], wl[NT], xh[MT], xl[MT];
 #pragma unroll
@@ -234,7 +238,10 @@ int conv_dma_variant(const ConvParams& p) {
     return 0;
 }
 
-hipError_t launch_conv_dma(const ConvParams& p, hipStream_t s) {
+hipError_t launch_conv_dma(const ConvParams& p0, hipStream_t s) {
+    ConvParams p = p0;
+    static const char* dbg = std::getenv("SEMDEPTH_DMA_DBG");
+    p.dbg = dbg ? atoi(dbg) : 0;
     const long M = (long)p.N * p.Hout * p.Wout;
     const int v = conv_dma_variant(p);
     if (v == 1) {

@@ -43,6 +43,7 @@ struct ConvParams {
     size_t out_plane;  // split engine: element offset of the output's lo plane
     const void* zero16;  // split engine: 16 zero bytes in device memory (source of out-of-image taps for the LDS-DMA pipeline)
     int Nmax;          // split engine: images of a full chunk (plane stride of a source = Nmax*H*W*C elements)
+    int dbg;           // SEMDEPTH_DMA_DBG: development ablation switches of conv_dma.hip (0 in production)
     int m_fastest;     // block order: 1 = consecutive blocks walk M (share a weight panel), 0 = walk N
 };
 hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t s);
@@ -98,14 +99,15 @@ struct ConvDirectParams {
     const DirectChunk* chunks;   // DEVICE [nchunks]
     int nchunks;
     int N, H, W;                 // output (= logical input) dims
-    int Cout;                    // <= 32, multiple of 8
-    const u32x4_t* wt;           // [plane][chunk][tap 9][octet 2][32][8 bf16]
+    int Cout;                    // <= 32 or 64, multiple of 8
+    const u32x4_t* wt;           // [plane][chunk][tap 9][octet 2][32 or 64][8 bf16]
     const float* bias;
     float* out;                  // split planes [N,H,W,Cout]
     size_t out_plane;
     int act, Nmax;
     const void* zero16;
     int dbg;
+    int rows_per_wave;           // 1: 8 x 32 tiles, 2: 16 x 32 tiles (see conv_direct.hip)
 };
 hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s);
 

@@ -8,6 +8,9 @@
 // frame with wave ballots / shuffles inside; the Open3D filters run one thread per point over a uniform grid.
 // All filters keep the input row order (ordered compaction), which the reference's "first min / first max"
 // end-point pick depends on (pcl.py:307-311, semantic_depth.py:259).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include "kernels.hpp"
 
 namespace sd {
@@ -474,6 +477,7 @@ hipError_t launch_gather_planes(const RwResultDev* res, int B, double* planes, h
 constexpr int GRID_CELLS = 1 << 19;
 constexpr int KMAX = 16;
 constexpr int SOR_RMAX = 16;       // shells searched before the brute-force fallback
+constexpr int SOR_RSOFT = 2;       // shells searched one-thread-per-query; deeper queries go to the wave-cooperative kernel
 constexpr int SCAN_SEG = 2048;     // cells per scan segment
 constexpr int SCAN_NSEG = GRID_CELLS / SCAN_SEG;
 
@@ -489,10 +493,11 @@ struct O3dScratch {       // carved from one arena, per-frame strides
     float* sxyz;          // [B][cap][3]
     double* mean_d;       // [B][cap]  (by original index)
     uint8_t* keep;        // [B][cap]
+    int* hard_n;          // [B]  statistical filter: queries deferred to the wave-cooperative search (list in cell_of)
 };
 size_t o3d_scratch_bytes(int B, int cap) {
     size_t per = sizeof(GridMeta) + (size_t)GRID_CELLS * 4 + (size_t)(GRID_CELLS + 1) * 4 + SCAN_NSEG * 4 + (size_t)cap * (4 + 4 + 12 + 8 + 1);
-    return (size_t)B * per + 8192;
+    return (size_t)B * (per + 4) + 8192 + 256;
 }
 static O3dScratch carve(void* base, int B, int cap) {
     O3dScratch s;
@@ -507,6 +512,7 @@ static O3dScratch carve(void* base, int B, int cap) {
     s.sidx = (int*)take((size_t)B * cap * 4);
     s.sxyz = (float*)take((size_t)B * cap * 12);
     s.keep = (uint8_t*)take((size_t)B * cap);
+    s.hard_n = (int*)take((size_t)B * 4);
     return s;
 }
 
@@ -706,9 +712,34 @@ struct TopK {
     }
 };
 
+// points of shell row (dz, dy) at Chebyshev radius r around cell (cx, cy, cz): face rows are one contiguous range of the
+// cell-sorted points, interior rows contribute their two end cells
+template <class F>
+__device__ __forceinline__ void shell_row(const GridMeta& g, const int* st, int cx, int cy, int cz, int r, int dz, int dy, F&& visit) {
+    const int z = cz + dz, y = cy + dy;
+    if (z < 0 || z >= g.gz || y < 0 || y >= g.gy) return;
+    const int rowbase = (z * g.gy + y) * g.gx;
+    const bool face = (dz == -r || dz == r || dy == -r || dy == r);
+    if (face) {
+        const int x0 = max(cx - r, 0), x1 = min(cx + r, g.gx - 1);
+        const int e = st[rowbase + x1 + 1];
+        for (int t = st[rowbase + x0]; t < e; ++t) visit(t);
+    } else {
+        const int step = r == 0 ? 1 : 2 * r;
+        for (int dx = -r; dx <= r; dx += step) {
+            const int x = cx + dx;
+            if (x < 0 || x >= g.gx) continue;
+            const int e = st[rowbase + x + 1];
+            for (int t = st[rowbase + x]; t < e; ++t) visit(t);
+        }
+    }
+}
+
+// one thread per query for the first SOR_RSOFT shells (99 % of a dense cloud); a query whose k-th neighbour is still
+// farther than the searched shells is appended to the frame's hard list (one slow lane would stall its whole wave)
 template <int CAPK>
 __global__ __launch_bounds__(256) void sor_knn_kernel(CloudView in, int cap, const GridMeta* meta, const int* cell_start,
-                                                      const int* sidx, const float* sxyz, int k, double* mean_d) {
+                                                      const int* sidx, const float* sxyz, int k, double* mean_d, int* hard_n, int* hard_idx) {
     const int b = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int n = min(in.n[b], cap);
@@ -724,42 +755,114 @@ __global__ __launch_bounds__(256) void sor_knn_kernel(CloudView in, int cap, con
     top.init(kk);
     const int rall = max(g.gx, max(g.gy, g.gz));
     bool done = false;
-    for (int r = 0; r <= SOR_RMAX && !done; ++r) {
-        for (int dz = -r; dz <= r; ++dz) {
-            const int z = cz + dz;
-            if (z < 0 || z >= g.gz) continue;
-            for (int dy = -r; dy <= r; ++dy) {
-                const int y = cy + dy;
-                if (y < 0 || y >= g.gy) continue;
-                const bool face = (dz == -r || dz == r || dy == -r || dy == r);
-                const int step = face ? 1 : (r == 0 ? 1 : 2 * r);    // interior rows: only dx = -r and dx = +r
-                const int rowbase = (z * g.gy + y) * g.gx;
-                if (face) {                                           // a full row of cells is one contiguous point range
-                    const int x0 = max(cx - r, 0), x1 = min(cx + r, g.gx - 1);
-                    const int e = st[rowbase + x1 + 1];
-                    for (int t = st[rowbase + x0]; t < e; ++t) top.push(dist2(qx, qy, qz, pts + (size_t)t * 3));
-                } else {
-                    for (int dx = -r; dx <= r; dx += step) {
-                        const int x = cx + dx;
-                        if (x < 0 || x >= g.gx) continue;
-                        const int e = st[rowbase + x + 1];
-                        for (int t = st[rowbase + x]; t < e; ++t) top.push(dist2(qx, qy, qz, pts + (size_t)t * 3));
-                    }
-                }
-            }
-        }
+    for (int r = 0; r <= SOR_RSOFT && !done; ++r) {
+        for (int dz = -r; dz <= r; ++dz)
+            for (int dy = -r; dy <= r; ++dy)
+                shell_row(g, st, cx, cy, cz, r, dz, dy, [&](int t) { top.push(dist2(qx, qy, qz, pts + (size_t)t * 3)); });
         const double bound = (double)r * g.cell * (1.0 - 1e-9);
         if (top.kth <= bound * bound) done = true;    // nothing unvisited can be closer than r cells
         if (r >= rall) done = true;                    // whole grid visited
     }
-    if (!done) {                                       // isolated point: exact brute force over the frame
-        top.init(kk);
-        for (int t = 0; t < n; ++t) top.push(dist2(qx, qy, qz, pts + (size_t)t * 3));
+    if (!done) {
+        hard_idx[(size_t)b * cap + atomicAdd(&hard_n[b], 1)] = j;
+        return;
     }
     double acc = 0.0;
 #pragma unroll
     for (int t = 0; t < CAPK; ++t) if (t < kk) acc = acc + sqrt(top.v[t]);   // ascending, sequential adds
     mean_d[(size_t)b * cap + sidx[(size_t)b * cap + j]] = acc / (double)kk;
+}
+
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v, o); v = t < v ? t : v; }
+    return v;
+}
+
+// the hard queries, one WAVE each: the rows of a shell are dealt to the lanes, every lane keeps the k best of its rows
+// (pruned by the wave's current k-th distance), and after each shell the 64 sorted lists are merged into the wave's k
+// best.  Same candidates, same canonical d2, same ascending summation as the per-thread search: identical result.
+template <int CAPK>
+__global__ __launch_bounds__(256) void sor_knn_hard_kernel(CloudView in, int cap, const GridMeta* meta, const int* cell_start,
+                                                           const int* sidx, const float* sxyz, int k, double* mean_d, const int* hard_n,
+                                                           const int* hard_idx) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int n = min(in.n[b], cap);
+    const int nh = hard_n[b];
+    const GridMeta g = meta[b];
+    const int* st = cell_start + (size_t)b * (GRID_CELLS + 1);
+    const float* pts = sxyz + (size_t)b * cap * 3;
+    const int kk = k < n ? k : n;
+    const int rall = max(g.gx, max(g.gy, g.gz));
+    for (int h = blockIdx.x * 4 + (threadIdx.x >> 6); h < nh; h += gridDim.x * 4) {
+        const int j = hard_idx[(size_t)b * cap + h];
+        const float* q = pts + (size_t)j * 3;
+        const double qx = q[0], qy = q[1], qz = q[2];
+        const int cx = cell_coord(qx, g.ox, g.inv, g.gx), cy = cell_coord(qy, g.oy, g.inv, g.gy), cz = cell_coord(qz, g.oz, g.inv, g.gz);
+        TopK<CAPK> top;          // this lane's candidates of the current shell
+        double best[CAPK];       // the wave's k best so far (same in every lane), ascending
+#pragma unroll
+        for (int t = 0; t < CAPK; ++t) best[t] = INFINITY;
+        double gk = INFINITY;    // best[kk-1]
+        auto merge = [&]() {     // best <- k smallest of best U all lanes' lists
+            double nb[CAPK];
+#pragma unroll
+            for (int t = 0; t < CAPK; ++t) nb[t] = INFINITY;
+            if (lane == 0) {     // lane 0 also offers the previous best list: merge it into its own list first
+#pragma unroll
+                for (int t = 0; t < CAPK; ++t) { top.kth = INFINITY; if (best[t] < INFINITY) top.push(best[t]); }
+            }
+#pragma unroll
+            for (int t = 0; t < CAPK; ++t) {
+                if (t < kk) {
+                    const double m = wave_min_f64(top.v[0]);
+                    nb[t] = m;
+                    const unsigned long long owners = __ballot(top.v[0] == m);
+                    if (m < INFINITY && lane == (int)__builtin_ctzll(owners)) {      // pop the head of ONE owning lane
+#pragma unroll
+                        for (int u = 0; u + 1 < CAPK; ++u) top.v[u] = top.v[u + 1];
+                        top.v[CAPK - 1] = INFINITY;
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < CAPK; ++t) best[t] = nb[t];
+            double kv = best[0];
+#pragma unroll
+            for (int t = 1; t < CAPK; ++t) kv = (t == kk - 1) ? best[t] : kv;
+            gk = kv;
+        };
+        bool done = false;
+        for (int r = 0; r <= SOR_RMAX && !done; ++r) {
+            top.init(kk);
+            top.kth = gk;                       // prune by the wave's k-th distance; lists hold only this shell's candidates
+            const int side = 2 * r + 1;
+            for (int t = lane; t < side * side; t += 64)
+                shell_row(g, st, cx, cy, cz, r, t / side - r, t % side - r, [&](int i) {
+                    const double d = dist2(qx, qy, qz, pts + (size_t)i * 3);
+                    if (d < gk) top.push(d);
+                });
+            merge();
+            const double bound = (double)r * g.cell * (1.0 - 1e-9);
+            if (gk <= bound * bound) done = true;
+            if (r >= rall) done = true;
+        }
+        if (!done) {                             // isolated point: exact brute force over the frame
+#pragma unroll
+            for (int t = 0; t < CAPK; ++t) best[t] = INFINITY;
+            gk = INFINITY;
+            top.init(kk);
+            for (int t = lane; t < n; t += 64) top.push(dist2(qx, qy, qz, pts + (size_t)t * 3));
+            merge();
+        }
+        if (lane == 0) {
+            double acc = 0.0;
+#pragma unroll
+            for (int t = 0; t < CAPK; ++t) if (t < kk) acc = acc + sqrt(best[t]);
+            mean_d[(size_t)b * cap + sidx[(size_t)b * cap + j]] = acc / (double)kk;
+        }
+    }
 }
 
 __global__ __launch_bounds__(TB) void sor_select_kernel(CloudView in, CloudOut out, int cap, double ratio, const double* mean_d) {
@@ -866,8 +969,15 @@ hipError_t launch_sor(CloudView in, CloudOut out, int B, int cap, int k, double 
     build_grid(in, B, cap, 0.0, sc, s, /*keep_meta=*/true);                                              // measured occupancy, rebuild
     double* md = mean_out ? mean_out : sc.mean_d;
     // the top-k array is walked by every lane of a wave whenever ANY lane inserts: keep it as short as k allows
-    if (k <= 10) hipLaunchKernelGGL(sor_knn_kernel<10>, dim3((cap + 255) / 256, B), dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx, sc.sxyz, k, md);
-    else hipLaunchKernelGGL(sor_knn_kernel<KMAX>, dim3((cap + 255) / 256, B), dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx, sc.sxyz, k, md);
+    hipMemsetAsync(sc.hard_n, 0, (size_t)B * 4, s);
+    const dim3 qgrid((cap + 255) / 256, B), hgrid(64, B);
+    if (k <= 10) {
+        hipLaunchKernelGGL(sor_knn_kernel<10>, qgrid, dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx, sc.sxyz, k, md, sc.hard_n, sc.cell_of);
+        hipLaunchKernelGGL(sor_knn_hard_kernel<10>, hgrid, dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx, sc.sxyz, k, md, sc.hard_n, sc.cell_of);
+    } else {
+        hipLaunchKernelGGL(sor_knn_kernel<KMAX>, qgrid, dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx, sc.sxyz, k, md, sc.hard_n, sc.cell_of);
+        hipLaunchKernelGGL(sor_knn_hard_kernel<KMAX>, hgrid, dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx, sc.sxyz, k, md, sc.hard_n, sc.cell_of);
+    }
     hipLaunchKernelGGL(sor_select_kernel, dim3(B), dim3(TB), 0, s, in, out, cap, ratio, md);
     return hipGetLastError();
 }

@@ -38,7 +38,7 @@ struct Builder {
         size_t n = 0;
         switch (layout) {
             case WL_IGEMM: case WL_IGEMM_SPLIT: n = (size_t)Kpad * CoutPad; break;
-            case WL_DIRECT_SPLIT: n = (size_t)Kpad * CoutPad; break;     // Kpad = nchunks * 9 * 16, CoutPad = 32
+            case WL_DIRECT_SPLIT: n = (size_t)Kpad * CoutPad; break;     // Kpad = nchunks * 9 * 16, CoutPad = 32 or 64
             case WL_SMALLN: n = (size_t)s.shape[0] * s.shape[1] * s.shape[2] * 4; break;
             case WL_BIAS4: n = 4; break;
             default: n = 1; for (int j = 0; j < s.rank; ++j) n *= (size_t)s.shape[j];
@@ -83,7 +83,7 @@ struct Builder {
         op.Kvec = k * k * Cvec; op.CqPad = CqPad;
         op.Kpad = op.Kvec + (k * k * CqPad + 31) / 32 * 32;
         // full-resolution few-channel 3x3 layers of the split engine go to the direct (halo-tile) kernel
-        bool direct = p.prec && k == 3 && stride == 1 && Cout <= 32 && Cout % 8 == 0 && Win % 32 == 0 && residual < 0 &&
+        bool direct = p.prec && k == 3 && stride == 1 && (Cout <= 32 || Cout == 64) && Cout % 8 == 0 && Win % 32 == 0 && residual < 0 &&
                       !std::getenv("SEMDEPTH_NO_DIRECT");
         for (int i = 0; i < op.nsrc; ++i)
             if (p.tensors[op.src[i]].C % 8 || op.sstride[i] != 1) direct = false;
@@ -92,7 +92,7 @@ struct Builder {
             int nch = 0;
             for (int i = 0; i < op.nsrc; ++i) nch += (p.tensors[op.src[i]].C + 15) / 16;
             op.nchunks = nch;
-            op.w = wslot(wname, {k, k, Ctf, Cout}, WL_DIRECT_SPLIT, nch * 9 * 16, 32);
+            op.w = wslot(wname, {k, k, Ctf, Cout}, WL_DIRECT_SPLIT, nch * 9 * 16, Cout <= 32 ? 32 : 64);
             WeightSlot& ws = p.weights[op.w];
             ws.nsrc = op.nsrc;
             for (int i = 0; i < 3; ++i) { ws.srcCtf[i] = srcCtf[i]; ws.srcCpad[i] = i < op.nsrc ? p.tensors[op.src[i]].C : 0; }
@@ -428,7 +428,7 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
             }
         }
     } else if (s.layout == WL_DIRECT_SPLIT) {
-        // [plane][chunk][tap 9][octet 2][32 n][8]: chunk = 16 stored channels of one source
+        // [plane][chunk][tap 9][octet 2][CoutPad n][8]: chunk = 16 stored channels of one source
         const int64_t Ctf = s.shape[2], Cout = s.shape[3];
         uint16_t* hi = reinterpret_cast<uint16_t*>(out.data());
         uint16_t* lo = hi + (size_t)s.Kpad * s.CoutPad;
@@ -441,7 +441,7 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
                     for (int c = c0; c < std::min(c0 + 16, s.srcCtf[i]); ++c) {
                         const int oct = (c - c0) / 8, e = (c - c0) % 8;
                         const float* src = w + ((int64_t)tap * Ctf + cb_tf + c) * Cout;
-                        const size_t base = (((size_t)chunk * 9 + tap) * 2 + oct) * 32 * 8 + e;
+                        const size_t base = (((size_t)chunk * 9 + tap) * 2 + oct) * s.CoutPad * 8 + e;
                         for (int64_t n = 0; n < Cout; ++n) {
                             const uint16_t h = bf16(src[n]);
                             hi[base + n * 8] = h;
