@@ -131,6 +131,8 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.wt = Wp(op.w); c.bias = Wp(op.b);
                 c.ktab = reinterpret_cast<const KEntry*>(wbase + op.tab_offset);
                 c.vec = op.vec; c.vtiles = op.Kvec / 32;
+                c.simple = op.nsrc == 1 && op.vec && op.Kvec == op.Kpad && op.sstride[0] == 1 && !op.up[0] && op.k * op.k <= 64 &&
+                           op.Kpad == op.k * op.k * s0.C;
                 c.residual = op.residual >= 0 ? T(op.residual) : nullptr;
                 c.out = T(op.dst);
                 c.act = op.act; c.m_fastest = op.m_fastest;
@@ -195,6 +197,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.wt = Wp(op.w); c.bias = Wp(op.b); c.out = T(op.dst); c.act = op.act;
                 c.in_split = FMT(op.src[0]); c.out_split = FMT(op.dst); c.in_plane = PL(op.src[0]); c.out_plane = PL(op.dst);
                 c.out_c = p.tensors[op.dst].C;
+                c.zero16 = h->ws + h->o_misc + 256;
                 e = launch_conv_smalln(c, s);
                 break;
             }

@@ -43,6 +43,7 @@ struct ConvParams {
     size_t out_plane;  // split engine: element offset of the output's lo plane
     const void* zero16;  // split engine: 16 zero bytes in device memory (source of out-of-image taps for the LDS-DMA pipeline)
     int Nmax;          // split engine: images of a full chunk (plane stride of a source = Nmax*H*W*C elements)
+    int simple;        // one source, stride 1, no upsample, all k-tiles vec: the DMA kernel computes its gather addresses
     int dbg;           // SEMDEPTH_DMA_DBG: development ablation switches of conv_dma.hip (0 in production)
     int m_fastest;     // block order: 1 = consecutive blocks walk M (share a weight panel), 0 = walk N
 };
@@ -124,6 +125,7 @@ struct SmallNParams {
     const float* bias;  // [4]
     float* out;         // [N,H,W,nout]
     int act;
+    const void* zero16; // 16 zero bytes (padding source of the LDS-DMA halo loads of the tiled kernel)
 };
 hipError_t launch_conv_smalln(const SmallNParams& p, hipStream_t s);
 

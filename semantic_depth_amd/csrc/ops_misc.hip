@@ -1,6 +1,7 @@
 // HBM-bound network ops around the conv engine (gfx950): input pre-processing, pools, small-N convs
 // (score layers, disparity heads), the FCN-8s transposed-conv ladder and its softmax/threshold/argmax head.
 // SURVEY.md §2.2 rows K1, K3, K6-K9, K11, K15.
+#include <cstdlib>
 #include "kernels.hpp"
 #include "split_fmt.hpp"
 
@@ -249,10 +250,103 @@ __global__ __launch_bounds__(256) void conv_smalln_wave_kernel(const SmallNParam
     }
 }
 
+// TILED variant for the 3x3 heads on split-plane inputs (monodepth get_disp at every scale): a workgroup owns an 8 x 32
+// pixel tile, DMAs the 10 x 34 halo of 16 channels at a time into LDS (the layout of conv_direct.hip: 32 B per pixel and
+// plane, octet slot XOR-swizzled by (pixel >> 3) & 1) and every thread accumulates its pixel's nine taps from LDS; the
+// thread kernel above re-reads every input nine times through L1/L2 with 8-byte accesses at pixel stride.
+__device__ __forceinline__ void sn_dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+constexpr int SN_TH = 8, SN_TW = 32, SN_HW = SN_TW + 2, SN_HH = SN_TH + 2;
+constexpr int SN_XI = (SN_HH * SN_HW * 2 + 63) / 64;        // 11 DMA instructions per plane
+constexpr int SN_XUNITS = SN_XI * 64;
+template <int NOUT>
+__global__ __launch_bounds__(256) void conv_smalln_tile_kernel(const SmallNParams p) {
+    __shared__ __attribute__((aligned(16))) u32x4_t X[2 * SN_XUNITS];
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [NOUT][9 C]
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int K = 9 * p.C;
+    for (int i = t; i < NOUT * K / 4; i += 256) reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(p.wt)[i];
+    const int tiles_x = p.W / SN_TW, tiles_y = (p.H + SN_TH - 1) / SN_TH;
+    int bid = blockIdx.x;
+    const int tx0 = (bid % tiles_x) * SN_TW; bid /= tiles_x;
+    const int ty0 = (bid % tiles_y) * SN_TH;
+    const int img = bid / tiles_y;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)X;
+    const uint16_t* const img_hi = reinterpret_cast<const uint16_t*>(p.x) + (size_t)img * p.H * p.W * p.C;
+    const int row = t >> 5, col = t & 31;
+    float acc[NOUT];
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) acc[j] = p.bias[j];
+    for (int c0 = 0; c0 < p.C; c0 += 16) {
+        const int nvalid = (p.C - c0) >= 16 ? 2 : 1;
+        __syncthreads();                                   // the previous chunk is consumed (and the weights are staged)
+        for (int j = wave; j < 2 * SN_XI; j += 4) {        // wave-uniform: instruction j of [hi plane | lo plane]
+            const int pl = j >= SN_XI ? 1 : 0;
+            const int u = (j - pl * SN_XI) * 64 + lane;
+            const int pix = u >> 1;
+            const int oct = (u & 1) ^ ((pix >> 3) & 1);
+            const int ry = pix / SN_HW, rx = pix - ry * SN_HW;
+            const int gy = ty0 - 1 + ry, gx = tx0 - 1 + rx;
+            const bool ok = pix < SN_HH * SN_HW && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && oct < nvalid;
+            const uint16_t* src = img_hi + (pl ? p.in_plane : (size_t)0) + ((size_t)gy * p.W + gx) * p.C + c0 + oct * 8;
+            sn_dma16(ok ? (const void*)src : p.zero16, lds0 + (unsigned)(j * 1024));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int lp = (row + tap / 3) * SN_HW + col + tap % 3;
+            for (int oct = 0; oct < nvalid; ++oct) {
+                const int idx = lp * 2 + (oct ^ ((lp >> 3) & 1));
+                const u32x4_t h = X[idx], l = X[SN_XUNITS + idx];
+                const f32x4 v0 = recon4(uint2{h[0], h[1]}, uint2{l[0], l[1]});
+                const f32x4 v1 = recon4(uint2{h[2], h[3]}, uint2{l[2], l[3]});
+#pragma unroll
+                for (int j = 0; j < NOUT; ++j) {
+                    const f32x4* wp = reinterpret_cast<const f32x4*>(wl + j * K + tap * p.C + c0 + oct * 8);
+                    const f32x4 w0 = wp[0], w1 = wp[1];
+                    acc[j] += v0[0] * w0[0] + v0[1] * w0[1] + v0[2] * w0[2] + v0[3] * w0[3];
+                    acc[j] += v1[0] * w1[0] + v1[1] * w1[1] + v1[2] * w1[2] + v1[3] * w1[3];
+                }
+            }
+        }
+    }
+    const int y = ty0 + row;
+    if (y >= p.H) return;
+    const long pix = ((long)img * p.H + y) * p.W + tx0 + col;
+    if (p.out_split) {            // NOUT == 2: one bf16 pair per plane
+        unsigned h, l;
+        split2(f32x2_t{smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)}, h, l);
+        if (p.out_c == 8) {
+            reinterpret_cast<u32x4_t*>(p.out)[pix] = (u32x4_t){h, 0u, 0u, 0u};
+            reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(p.out) + p.out_plane)[pix] = (u32x4_t){l, 0u, 0u, 0u};
+        } else {
+            reinterpret_cast<unsigned*>(p.out)[pix] = h;
+            reinterpret_cast<unsigned*>(reinterpret_cast<uint16_t*>(p.out) + p.out_plane)[pix] = l;
+        }
+    } else {
+        float* o = p.out + pix * NOUT;
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) o[j] = smalln_act(acc[j], p.act);
+    }
+}
+
 template <bool IN_SPLIT>
 static void launch_smalln_t(const SmallNParams& p, hipStream_t s) {
     const long npix = (long)p.N * p.H * p.W;
     const int K = p.k * p.k * p.C;
+    if (IN_SPLIT && p.k == 3 && p.W % SN_TW == 0 && p.C % 8 == 0 && p.nout <= 2 && p.zero16 && (size_t)K * 4 * p.nout <= 24576 &&
+        !std::getenv("SEMDEPTH_NO_SMALLN_TILE")) {
+        const dim3 grid((unsigned)((p.W / SN_TW) * ((p.H + SN_TH - 1) / SN_TH) * p.N));
+        const size_t lds = (size_t)K * 4 * p.nout;
+        if (p.nout == 1) hipLaunchKernelGGL(conv_smalln_tile_kernel<1>, grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL(conv_smalln_tile_kernel<2>, grid, dim3(256), lds, s, p);
+        return;
+    }
     if (K <= 2048) {
         const dim3 grid((unsigned)((npix + 255) / 256));
         const size_t lds = (size_t)K * 4 * p.nout;
