@@ -164,7 +164,8 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 ConvDirectParams c{};
                 c.chunks = reinterpret_cast<const DirectChunk*>(wbase + op.tab_offset);
                 c.nchunks = op.nchunks;
-                c.N = N; c.H = d.H; c.W = d.W; c.Cout = d.C;
+                c.pool = op.fuse_pool;
+                c.N = N; c.H = d.H << c.pool; c.W = d.W << c.pool; c.Cout = d.C;
                 c.wt = reinterpret_cast<const u32x4_t*>(Wp(op.w)); c.bias = Wp(op.b);
                 c.out = T(op.dst); c.out_plane = PL(op.dst); c.act = op.act; c.Nmax = p.images;
                 c.zero16 = h->ws + h->o_misc + 256;
@@ -186,7 +187,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 e = launch_conv_direct(c, s);
                 if (h->prof) {
                     hipEventRecord(eb, s);
-                    h->prof_recs.push_back({"conv_direct_kernel", op.flops * N / p.images, ea, eb, op.name.c_str(), N * d.H * d.W, d.C, op.K});
+                    h->prof_recs.push_back({"conv_direct_kernel", op.flops * N / p.images, ea, eb, op.name.c_str(), N * c.H * c.W, d.C, op.K});
                 }
                 break;
             }

@@ -193,6 +193,65 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
             unsigned char* sl = TWO ? sh + 32 * ROW : sh;
             const int seg = lane % SEGS, prow = lane / SEGS;
             uint16_t* const out_hi = reinterpret_cast<uint16_t*>(p.out);
+            if (MT == 2 && p.pool) {
+                // fused 2x2 max pool: vertical max across the wave's two rows (same lane), horizontal across lane pairs
+                // (pixel = lane & 31), THEN bias + activation (monotonic) on a quarter of the values
+                uint2 hh[4 * NB], ll[4 * NB];
+#pragma unroll
+                for (int r4 = 0; r4 < 4 * NB; ++r4) {
+                    if (8 * r4 >= p.Cout) continue;
+                    const int nb = r4 >> 2, q = r4 & 3;
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float m = fmaxf(acc[0][nb][4 * q + r], acc[MT - 1][nb][4 * q + r]);
+                        v[r] = fmaxf(m, __shfl_xor(m, 1));
+                    }
+                    v += bias[r4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
+                    split4(v, hh[r4], ll[r4]);
+                }
+                const int pp = frow >> 1;                    // pooled pixel of this lane pair
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    if (TWO && pl == 1) break;
+                    if (!(lane & 1)) {
+#pragma unroll
+                        for (int r4 = 0; r4 < 4 * NB; ++r4) {
+                            if (8 * r4 >= p.Cout) continue;
+                            const int nl = 8 * r4 + 4 * fk;
+                            if (TWO) {
+                                *reinterpret_cast<uint2*>(sh + pp * ROW + nl * 2) = hh[r4];
+                                *reinterpret_cast<uint2*>(sl + pp * ROW + nl * 2) = ll[r4];
+                            } else {
+                                *reinterpret_cast<uint2*>(sh + pp * ROW + nl * 2) = pl ? ll[r4] : hh[r4];
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const int yp = (cur.ty0 >> 1) + wave, Hp = p.H >> 1, Wp = p.W >> 1;
+#pragma unroll
+                    for (int ps = 0; ps < (16 + PPP - 1) / PPP; ++ps) {
+                        const int pix = ps * PPP + prow;
+                        if (pix < 16 && yp < Hp && seg * 8 < p.Cout) {
+                            const u32x4 h = *reinterpret_cast<const u32x4*>(sh + pix * ROW + seg * 16);
+                            uint16_t* o = out_hi + ((size_t)(cur.img * Hp + yp) * Wp + (cur.tx0 >> 1) + pix) * p.Cout + seg * 8;
+                            if (TWO) {
+                                const u32x4 l = *reinterpret_cast<const u32x4*>(sl + pix * ROW + seg * 16);
+                                *reinterpret_cast<u32x4*>(o) = h;
+                                *reinterpret_cast<u32x4*>(o + p.out_plane) = l;
+                            } else {
+                                *reinterpret_cast<u32x4*>(pl ? o + p.out_plane : o) = h;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                return;
+            }
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
                 const int y = cur.ty0 + MT * wave + a;
@@ -263,6 +322,7 @@ hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
     ConvDirectParams q = p;
     static const char* dbg = std::getenv("SEMDEPTH_DIRECT_DBG");
     q.dbg = dbg ? atoi(dbg) : 0;
+    if (p.pool && (p.rows_per_wave != 2 || (p.H & 1) || (p.W & 1))) return hipErrorInvalidValue;
     const int th = 8 * p.rows_per_wave;
     const int tiles = (p.W / D_TW) * ((p.H + th - 1) / th) * p.N;
     const dim3 grid((unsigned)(tiles < cus ? tiles : cus));

@@ -109,6 +109,7 @@ struct ConvDirectParams {
     const void* zero16;
     int dbg;
     int rows_per_wave;           // 1: 8 x 32 tiles, 2: 16 x 32 tiles (see conv_direct.hip)
+    int pool;                    // 1: fused 2x2 stride-2 max pool, out is [N,H/2,W/2,Cout] (needs rows_per_wave == 2)
 };
 hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s);
 

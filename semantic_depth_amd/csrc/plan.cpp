@@ -181,8 +181,19 @@ struct Builder {
     int pool(const std::string& name, int src, bool zero3) {
         OpDesc op;
         op.kind = zero3 ? OP_POOL3Z : OP_POOL2; op.name = name; op.nsrc = 1; op.src[0] = src;
-        const TensorDesc& t = p.tensors[src];
+        const TensorDesc t = p.tensors[src];
         const int Ho = zero3 ? (t.H - 1) / 2 + 1 : t.H / 2, Wo = zero3 ? (t.W - 1) / 2 + 1 : t.W / 2;
+        // a direct conv whose only consumer is this pool applies it in its epilogue (max commutes with bias + ReLU/ELU);
+        // the full-resolution tensor is then never written
+        if (!zero3 && !p.ops.empty() && p.ops.back().kind == OP_CONV_DIRECT && p.ops.back().dst == src && t.H % 2 == 0 && t.W % 2 == 0 &&
+            (p.ops.back().act == ACT_RELU || p.ops.back().act == ACT_ELU || p.ops.back().act == ACT_NONE) && !std::getenv("SEMDEPTH_NO_POOL_FUSE")) {
+            OpDesc& prod = p.ops.back();
+            prod.fuse_pool = 1;
+            for (auto it = p.tensor_by_name.begin(); it != p.tensor_by_name.end();)
+                it = it->second == src ? p.tensor_by_name.erase(it) : std::next(it);
+            prod.dst = tensor(name, t.N, Ho, Wo, t.C);
+            return prod.dst;
+        }
         op.dst = tensor(name, t.N, Ho, Wo, t.C);
         push(op);
         return op.dst;
