@@ -50,8 +50,12 @@ __device__ __forceinline__ KEntry load_kentry(const KEntry* ptr) {
 // SIMPLE: one source, stride 1, no upsample (every VGG conv, fc6, the stride-1 ResNet convs): the per-tile gather descriptor
 // is replaced by arithmetic -- a per-lane base pointer and in-bounds mask over the taps, computed once per workgroup, plus
 // a wave-uniform (tap, channel block) offset per k-tile.
-// STAGES = 3 with 8 waves and one workgroup per CU (two k-tiles in flight).  (A STAGES = 2, 4-wave, two-workgroups-per-CU
-// 128 x 128 instantiation was measured 4-20 % slower on every layer of both networks, short K included.)
+// STAGES = 3 with 8 waves and one workgroup per CU (two k-tiles in flight).  Measured and rejected on MI355X: a STAGES = 2,
+// 4-wave, two-workgroups-per-CU 128 x 128 instantiation (4-20 % slower on every layer, short K included), and a six-stage
+// ring of 16-channel k-steps whose fragments are read one barrier ahead (13-15 % slower: twice the barriers and 32-byte
+// gather pieces cost more than the hidden LDS round trip gains).  With random operands the chip sustains 1.81 PFLOP/s of
+// v_mfma_f32_32x32x16_bf16 (scripts/probe_mfma_peak.hip; 2.47 with constant operands): the power limit, not the issue
+// rate, is the practical ceiling this kernel runs against.
 template <int WAVES_M, int WAVES_N, int MT, int NT, bool SIMPLE, int STAGES>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 2 ? 2 : 1) void conv_dma_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
     constexpr int NW = WAVES_M * WAVES_N;
@@ -132,8 +136,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 2 ? 2 : 1) void c
             const long soff = (long)(s_ty * sW + s_tx) * sC + s_cb * 32;          // elements, wave-uniform
 #pragma unroll
             for (int i = 0; i < XH; ++i) {
-                if (p.dbg & 1) continue;
-                const bool ok = (smask[i] >> tap) & 1;
+                    const bool ok = (smask[i] >> tap) & 1;
                 const uint16_t* px = sbase[i] + soff;
                 const u32x4* gh = ok ? reinterpret_cast<const u32x4*>(px) : zero;
                 const u32x4* gl = ok ? reinterpret_cast<const u32x4*>(px + splane) : zero;
@@ -147,8 +150,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 2 ? 2 : 1) void c
             const size_t plane = (size_t)Nmax * e.H * e.W * e.C;
 #pragma unroll
             for (int i = 0; i < XH; ++i) {
-                if (p.dbg & 1) continue;
-                int iy = poy[i] * st + e.dy, ix = pox[i] * st + e.dx;
+                    int iy = poy[i] * st + e.dy, ix = pox[i] * st + e.dx;
                 const bool ok = pok[i] && iy >= 0 && ix >= 0 && iy < (e.H << up) && ix < (e.W << up);
                 iy >>= up; ix >>= up;
                 const uint16_t* px = reinterpret_cast<const uint16_t*>(e.base) + ((size_t)(pimg[i] * e.H + iy) * e.W + ix) * e.C + pkg[i] * 8;
@@ -161,7 +163,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 2 ? 2 : 1) void c
         // ---- weights: the stage image is the global image ----
 #pragma unroll
         for (int i = XI; i < NDMA; ++i) {
-            if (p.dbg & 2) continue;
             const int j = wave + NW * i;
             const int wu = (j - XI * NW) * 64 + lane;         // unit inside the W region: [plane][kg][n]
             const int pl = wu / (4 * BN), r = wu % (4 * BN), kg = r / BN, n_l = r % BN;
@@ -190,33 +191,41 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 2 ? 2 : 1) void c
         const u32x4* Xl = Xh + 4 * BM;
         const u32x4* Wh = Xl + 4 * BM;
         const u32x4* Wl = Wh + 4 * BN;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            if (p.dbg & 4) { if (s == 0 && kt + AHEAD < ktiles) issue(kt + AHEAD, (kt + AHEAD) % STAGES); continue; }
+        // schedule of one k-tile, pinned with sched_barriers (left alone, hipcc hoists the DMA issue to the top and sinks
+        // every LDS read to just before its first use, which exposes the LDS latency four times per tile):
+        //   fragments of k-step 0 -> DMA issue of tile kt+2 (its address arithmetic runs under the LDS latency) ->
+        //   fragments of k-step 1 -> 12 MFMAs of k-step 0 -> 12 MFMAs of k-step 1
+        bf16x8 wh[2][NT], wl[2][NT], xh[2][MT], xl[2][MT];
+        auto fragments = [&](int s) {
             const int kg = 2 * s + fk;
-            bf16x8 wh[NT], wl[NT], xh[MT], xl[MT];
 #pragma unroll
             for (int b = 0; b < NT; ++b) {
-                wh[b] = __builtin_bit_cast(bf16x8, Wh[kg * BN + wn0 + b * 32 + frow]);
-                wl[b] = __builtin_bit_cast(bf16x8, Wl[kg * BN + wn0 + b * 32 + frow]);
+                wh[s][b] = __builtin_bit_cast(bf16x8, Wh[kg * BN + wn0 + b * 32 + frow]);
+                wl[s][b] = __builtin_bit_cast(bf16x8, Wl[kg * BN + wn0 + b * 32 + frow]);
             }
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
                 const int mrow = wm0 + a * 32 + frow;
                 const int slot = mrow * 4 + (kg ^ ((mrow >> 2) & 3));        // [pixel][octet ^ swizzle]
-                xh[a] = __builtin_bit_cast(bf16x8, Xh[slot]);
-                xl[a] = __builtin_bit_cast(bf16x8, Xl[slot]);
+                xh[s][a] = __builtin_bit_cast(bf16x8, Xh[slot]);
+                xl[s][a] = __builtin_bit_cast(bf16x8, Xl[slot]);
             }
+        };
+        fragments(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + AHEAD < ktiles) issue(kt + AHEAD, (kt + AHEAD) % STAGES);
+        __builtin_amdgcn_sched_barrier(0);
+        fragments(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
 #pragma unroll
                     for (int a = 0; a < MT; ++a)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 0 ? wl[b] : wh[b], pr == 1 ? xl[a] : xh[a], acc[a][b], 0, 0, 0);
-            // the DMA issue of tile kt+2 (address arithmetic + 6 DMAs) sits between the two MFMA clusters, so it issues in
-            // the shadow of the first cluster's 12 MFMAs instead of in front of an idle matrix pipe
-            if (s == 0 && kt + AHEAD < ktiles) issue(kt + AHEAD, (kt + AHEAD) % STAGES);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 0 ? wl[s][b] : wh[s][b], pr == 1 ? xl[s][a] : xh[s][a], acc[a][b], 0, 0, 0);
         }
     }
 

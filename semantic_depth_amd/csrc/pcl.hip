@@ -700,15 +700,19 @@ struct TopK {
     __device__ __forceinline__ void push(double d) {
         if (!(d < kth)) return;
 #pragma unroll
-        for (int t = 0; t < CAPK; ++t) {      // bubble the new value into the ascending array
-            const double lo = d < v[t] ? d : v[t];
-            const double hi = d < v[t] ? v[t] : d;
+        for (int t = 0; t < CAPK; ++t) {      // bubble the new value into the ascending array (v_min_f64 / v_max_f64;
+            const double lo = fmin(d, v[t]);  // squared distances are never NaN)
+            const double hi = fmax(d, v[t]);
             v[t] = lo; d = hi;
         }
-        double kv = v[0];
+        if (k == CAPK) {
+            kth = v[CAPK - 1];
+        } else {
+            double kv = v[0];
 #pragma unroll
-        for (int t = 1; t < CAPK; ++t) kv = (t == k - 1) ? v[t] : kv;
-        kth = kv;
+            for (int t = 1; t < CAPK; ++t) kv = (t == k - 1) ? v[t] : kv;
+            kth = kv;
+        }
     }
 };
 
