@@ -31,7 +31,7 @@ __device__ __forceinline__ float key2f(unsigned k) {
 struct Lds {
     unsigned hist[256];
     unsigned sh[8];
-    int wsum[NW];
+    int wsum[4][NW];
     int base;
     double dred[NW];
     float fred[NW];
@@ -48,26 +48,32 @@ __device__ float block_select(F val, int n, unsigned rank, Lds& L) {
         for (int i = tid; i < 256; i += TB) L.hist[i] = 0;
         __syncthreads();
         const int shift = pass * 8;
-        for (int i0 = 0; i0 < n; i0 += TB) {
-            const int i = i0 + tid;
-            bool valid = false;
-            unsigned bin = 0;
-            if (i < n) {
-                const unsigned k = f2key(val(i));
-                valid = (k & mask) == prefix;
-                bin = (k >> shift) & 255u;
+        constexpr int U = 4;       // independent loads in flight per thread (the passes are latency bound otherwise)
+        for (int i0 = 0; i0 < n; i0 += TB * U) {
+            unsigned keys[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * TB + tid;
+                keys[u] = i < n ? f2key(val(i)) : 0u;
             }
-            // a few rounds of wave aggregation (the top bytes of a coordinate column take only a handful of values)
-            unsigned long long act = __ballot(valid);
-            for (int it = 0; it < 4 && act; ++it) {
-                const int leader = __ffsll((long long)act) - 1;
-                const unsigned b0 = __shfl(bin, leader);
-                const unsigned long long m = __ballot(valid && bin == b0);
-                if (lane == leader) atomicAdd(&L.hist[b0], (unsigned)__popcll(m));
-                if (bin == b0) valid = false;
-                act = __ballot(valid);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * TB + tid;
+                const unsigned k = keys[u];
+                bool valid = i < n && (k & mask) == prefix;
+                const unsigned bin = (k >> shift) & 255u;
+                // a few rounds of wave aggregation (the top bytes of a coordinate column take only a handful of values)
+                unsigned long long act = __ballot(valid);
+                for (int it = 0; it < 4 && act; ++it) {
+                    const int leader = __ffsll((long long)act) - 1;
+                    const unsigned b0 = __shfl(bin, leader);
+                    const unsigned long long m = __ballot(valid && bin == b0);
+                    if (lane == leader) atomicAdd(&L.hist[b0], (unsigned)__popcll(m));
+                    if (bin == b0) valid = false;
+                    act = __ballot(valid);
+                }
+                if (valid) atomicAdd(&L.hist[bin], 1u);
             }
-            if (valid) atomicAdd(&L.hist[bin], 1u);
         }
         __syncthreads();
         if (tid == 0) {
@@ -129,7 +135,13 @@ template <class F>
 __device__ float block_median(F val, int n, Lds& L) {
     if (n <= 0) return __uint_as_float(0x7fc00000u);
     int nan_local = 0;
-    for (int i = threadIdx.x; i < n; i += TB) { float v = val(i); nan_local |= (v != v); }
+    for (int i0 = threadIdx.x; i0 < n; i0 += TB * 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = i0 + u * TB < n ? val(i0 + u * TB) : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) nan_local |= (v[u] != v[u]);
+    }
     if (block_sum_int(nan_local, L) > 0) return __uint_as_float(0x7fc00000u);
     if (n & 1) return block_select(val, n, (unsigned)(n / 2), L);
     const float a = block_select(val, n, (unsigned)(n / 2 - 1), L);
@@ -137,9 +149,13 @@ __device__ float block_median(F val, int n, Lds& L) {
     int le = 0;
     unsigned nxt = 0xFFFFFFFFu;
     const unsigned ka = f2key(a);
-    for (int i = threadIdx.x; i < n; i += TB) {
-        const unsigned k = f2key(val(i));
-        if (k <= ka) ++le; else nxt = k < nxt ? k : nxt;
+    for (int i0 = threadIdx.x; i0 < n; i0 += TB * 4) {
+        unsigned k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k[u] = i0 + u * TB < n ? f2key(val(i0 + u * TB)) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * TB < n) { if (k[u] <= ka) ++le; else nxt = k[u] < nxt ? k[u] : nxt; }
     }
     const int cnt_le = block_sum_int(le, L);
     const unsigned kmin = block_min_u32(nxt, L);
@@ -154,29 +170,44 @@ __device__ void block_compact(const float* __restrict__ xyz, const uint8_t* __re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) L.base = 0;
     __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += TB) {
-        const int i = i0 + tid;
-        float x = 0.f, y = 0.f, z = 0.f;
-        uint8_t c0 = 0, c1 = 0, c2 = 0;
-        bool keep = false;
-        if (i < n) {
-            x = xyz[(size_t)i * 3]; y = xyz[(size_t)i * 3 + 1]; z = xyz[(size_t)i * 3 + 2];
-            if (rgb) { c0 = rgb[(size_t)i * 3]; c1 = rgb[(size_t)i * 3 + 1]; c2 = rgb[(size_t)i * 3 + 2]; }
-            keep = pred(i, x, y, z);
-        }
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) L.wsum[wave] = __popcll(m);
-        __syncthreads();           // all rows of this chunk are in registers; wave totals visible
-        int pos = L.base + __popcll(m & ((1ull << lane) - 1ull));
-        int tot = 0;
+    constexpr int U = 4;           // row chunks per iteration: 4 independent loads per thread, one barrier pair per 4 chunks
+    for (int i0 = 0; i0 < n; i0 += TB * U) {
+        float x[U], y[U], z[U];
+        uint8_t c0[U], c1[U], c2[U];
+        bool keep[U];
+        unsigned long long m[U];
 #pragma unroll
-        for (int w = 0; w < NW; ++w) { const int c = L.wsum[w]; if (w < wave) pos += c; tot += c; }
-        if (keep && pos < cap) {
-            oxyz[(size_t)pos * 3] = x; oxyz[(size_t)pos * 3 + 1] = y; oxyz[(size_t)pos * 3 + 2] = z;
-            if (orgb) { orgb[(size_t)pos * 3] = c0; orgb[(size_t)pos * 3 + 1] = c1; orgb[(size_t)pos * 3 + 2] = c2; }
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * TB + tid;
+            x[u] = y[u] = z[u] = 0.f; c0[u] = c1[u] = c2[u] = 0;
+            if (i < n) {
+                x[u] = xyz[(size_t)i * 3]; y[u] = xyz[(size_t)i * 3 + 1]; z[u] = xyz[(size_t)i * 3 + 2];
+                if (rgb) { c0[u] = rgb[(size_t)i * 3]; c1[u] = rgb[(size_t)i * 3 + 1]; c2[u] = rgb[(size_t)i * 3 + 2]; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * TB + tid;
+            keep[u] = i < n && pred(i, x[u], y[u], z[u]);
+            m[u] = __ballot(keep[u]);
+            if (lane == 0) L.wsum[u][wave] = __popcll(m[u]);
+        }
+        __syncthreads();           // all rows of these chunks are in registers; wave totals visible
+        int run = L.base, tot_all = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int pos = run + __popcll(m[u] & ((1ull << lane) - 1ull));
+            int tot = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { const int c = L.wsum[u][w]; if (w < wave) pos += c; tot += c; }
+            if (keep[u] && pos < cap) {
+                oxyz[(size_t)pos * 3] = x[u]; oxyz[(size_t)pos * 3 + 1] = y[u]; oxyz[(size_t)pos * 3 + 2] = z[u];
+                if (orgb) { orgb[(size_t)pos * 3] = c0[u]; orgb[(size_t)pos * 3 + 1] = c1[u]; orgb[(size_t)pos * 3 + 2] = c2[u]; }
+            }
+            run += tot; tot_all += tot;
         }
         __syncthreads();
-        if (tid == 0) L.base += tot;
+        if (tid == 0) L.base += tot_all;
         __syncthreads();
     }
     if (tid == 0) *n_out = L.base;
@@ -716,6 +747,19 @@ struct TopK {
     }
 };
 
+// per-axis squared distance bounds from coordinate q to grid layer idx (box slightly inflated: a point may sit an ulp
+// outside its nominal cell).  Clamped face layers are unbounded outward.
+__device__ __forceinline__ void axis_bounds(double q, double o, double cell, int idx, int g, double& dmin, double& dmax) {
+    const double eps = 1e-9 * cell;
+    const double lo = o + (double)idx * cell - eps, hi = o + (double)(idx + 1) * cell + eps;
+    const bool open_lo = idx == 0, open_hi = idx == g - 1;
+    double a = 0.0;
+    if (!open_lo && q < lo) a = lo - q;
+    if (!open_hi && q > hi) a = q - hi;
+    dmin = a;
+    dmax = (open_lo || open_hi) ? INFINITY : fmax(q - lo, hi - q);
+}
+
 // points of shell row (dz, dy) at Chebyshev radius r around cell (cx, cy, cz): face rows are one contiguous range of the
 // cell-sorted points, interior rows contribute their two end cells
 template <class F>
@@ -760,9 +804,18 @@ __global__ __launch_bounds__(256) void sor_knn_kernel(CloudView in, int cap, con
     const int rall = max(g.gx, max(g.gy, g.gz));
     bool done = false;
     for (int r = 0; r <= SOR_RSOFT && !done; ++r) {
-        for (int dz = -r; dz <= r; ++dz)
-            for (int dy = -r; dy <= r; ++dy)
+        for (int dz = -r; dz <= r; ++dz) {
+            double zmin = 0.0, zmax;
+            if (r >= 2 && cz + dz >= 0 && cz + dz < g.gz) axis_bounds(qz, g.oz, g.cell, cz + dz, g.gz, zmin, zmax);
+            for (int dy = -r; dy <= r; ++dy) {
+                if (r >= 2) {       // a row whose cells all lie farther than the current k-th distance cannot contribute
+                    double ymin = 0.0, ymax;
+                    if (cy + dy >= 0 && cy + dy < g.gy) axis_bounds(qy, g.oy, g.cell, cy + dy, g.gy, ymin, ymax);
+                    if (ymin * ymin + zmin * zmin >= top.kth) continue;
+                }
                 shell_row(g, st, cx, cy, cz, r, dz, dy, [&](int t) { top.push(dist2(qx, qy, qz, pts + (size_t)t * 3)); });
+            }
+        }
         const double bound = (double)r * g.cell * (1.0 - 1e-9);
         if (top.kth <= bound * bound) done = true;    // nothing unvisited can be closer than r cells
         if (r >= rall) done = true;                    // whole grid visited
@@ -884,19 +937,6 @@ __global__ __launch_bounds__(TB) void sor_select_kernel(CloudView in, CloudOut o
         const double v = md[i];
         return v > 0.0 && v < thr;
     }, L);
-}
-
-// per-axis squared distance bounds from coordinate q to grid layer idx (box slightly inflated: a point may sit an ulp
-// outside its nominal cell).  Clamped face layers are unbounded outward.
-__device__ __forceinline__ void axis_bounds(double q, double o, double cell, int idx, int g, double& dmin, double& dmax) {
-    const double eps = 1e-9 * cell;
-    const double lo = o + (double)idx * cell - eps, hi = o + (double)(idx + 1) * cell + eps;
-    const bool open_lo = idx == 0, open_hi = idx == g - 1;
-    double a = 0.0;
-    if (!open_lo && q < lo) a = lo - q;
-    if (!open_hi && q > hi) a = q - hi;
-    dmin = a;
-    dmax = (open_lo || open_hi) ? INFINITY : fmax(q - lo, hi - q);
 }
 
 constexpr int ROR_RINGS = 4;       // cell = radius / 4
