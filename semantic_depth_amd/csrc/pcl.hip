@@ -163,6 +163,64 @@ __device__ float block_median(F val, int n, Lds& L) {
     return (a + b) / 2.0f;
 }
 
+// np.median again, in ~1.3 passes over the column instead of ~6: a systematic sample of 4096 values brackets the
+// median ranks (select on the sample in LDS), ONE pass over the column counts what lies below the bracket and collects
+// the keys inside it into LDS, and the exact order statistics are selected from that buffer.  Exact by construction;
+// if the bracket misses (adversarial order) or overflows, the full radix select above runs instead.
+constexpr int MED_S = 4096;         // sample size
+constexpr int MED_D = 160;          // bracket half-width in sample ranks (5 sigma of the sample-rank error at the median)
+constexpr int MED_CAP = 16384;      // keys collected inside the bracket (expected ~8 % of n <= 14 k at n = 175 k)
+struct MedLds {
+    unsigned samp[MED_S];
+    unsigned buf[MED_CAP];
+    unsigned cnt, below, nan;
+};
+template <class F>
+__device__ float block_median_fast(F val, int n, Lds& L, MedLds& M) {
+    if (n <= 0) return __uint_as_float(0x7fc00000u);
+    if (n < 4 * MED_S) return block_median(val, n, L);
+    const int tid = threadIdx.x;
+    for (int j = tid; j < MED_S; j += TB) M.samp[j] = f2key(val((int)(((long)j * n) / MED_S)));
+    if (tid == 0) { M.cnt = 0; M.below = 0; M.nan = 0; }
+    __syncthreads();
+    const unsigned r1 = (unsigned)((n - 1) / 2), r2 = (unsigned)(n / 2);       // the two middle ranks (equal when n is odd)
+    const int ts = (int)(((long)r1 * MED_S) / n);
+    const int slo = max(ts - MED_D, 0), shi = min(ts + MED_D, MED_S - 1);
+    auto sval = [&](int j) { return key2f(M.samp[j]); };
+    const unsigned klo = f2key(block_select(sval, MED_S, (unsigned)slo, L));
+    const unsigned khi = f2key(block_select(sval, MED_S, (unsigned)shi, L));
+    // one pass: count keys below the bracket, collect the keys inside it
+    unsigned below = 0, nanf = 0;
+    for (int i0 = tid; i0 < n; i0 += TB * 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = i0 + u * TB < n ? val(i0 + u * TB) : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * TB >= n) continue;
+            nanf |= (v[u] != v[u]);
+            const unsigned k = f2key(v[u]);
+            if (k < klo) ++below;
+            else if (k <= khi) {
+                const unsigned pos = atomicAdd(&M.cnt, 1u);
+                if (pos < MED_CAP) M.buf[pos] = k;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { below += __shfl_xor(below, o); nanf |= __shfl_xor(nanf, o); }
+    if ((tid & 63) == 0) { atomicAdd(&M.below, below); if (nanf) atomicOr(&M.nan, 1u); }
+    __syncthreads();
+    const unsigned cnt = M.cnt, bel = M.below;
+    if (M.nan) return __uint_as_float(0x7fc00000u);
+    if (cnt > MED_CAP || r1 < bel || r2 >= bel + cnt) return block_median(val, n, L);       // bracket missed: exact fallback
+    auto bval = [&](int j) { return key2f(M.buf[j]); };
+    const float a = block_select(bval, (int)cnt, r1 - bel, L);
+    if (r1 == r2) return a;
+    const float b = block_select(bval, (int)cnt, r2 - bel, L);
+    return (a + b) / 2.0f;
+}
+
 // ordered compaction of one frame: keeps rows with pred(i, x, y, z); in and out may alias
 template <class P>
 __device__ void block_compact(const float* __restrict__ xyz, const uint8_t* __restrict__ rgb, int n, float* oxyz,
@@ -243,10 +301,11 @@ hipError_t launch_filter_coord(CloudView in, CloudOut out, int B, int cap, int k
 //   med = median(v); dev = |v - med|; MAD = median(dev); keep 0.6745f*dev/MAD < thr
 __global__ __launch_bounds__(TB) void mad_filter_kernel(CloudView in, CloudOut out, int cap, int axis, float thr, float* stats) {
     FRAME_VIEW();
+    __shared__ MedLds M;
     auto col = [=](int i) { return xyz[(size_t)i * 3 + axis]; };
-    const float med = block_median(col, n, L);
+    const float med = block_median_fast(col, n, L, M);
     auto dev = [=](int i) { return fabsf(xyz[(size_t)i * 3 + axis] - med); };
-    const float madv = block_median(dev, n, L);
+    const float madv = block_median_fast(dev, n, L, M);
     if (stats && threadIdx.x == 0) { stats[b * 2] = med; stats[b * 2 + 1] = madv; }
     block_compact(xyz, rgb, n, oxyz, orgb, on, cap, [=](int, float x, float y, float z) {
         const float v = axis == 0 ? x : (axis == 1 ? y : z);
@@ -267,12 +326,14 @@ __global__ __launch_bounds__(TB) void plane_filter_kernel(CloudView in, CloudOut
     FRAME_VIEW();
     const int iu = axis == 0 ? 1 : 0, iv = axis == 2 ? 1 : 2, id = axis;
     double su = 0, sv = 0, sd_ = 0;
+#pragma unroll 4
     for (int i = threadIdx.x; i < n; i += TB) {
         su += (double)xyz[(size_t)i * 3 + iu]; sv += (double)xyz[(size_t)i * 3 + iv]; sd_ += (double)xyz[(size_t)i * 3 + id];
     }
     const double inv_n = 1.0 / (double)n;
     const double mu = block_sum_f64(su, L) * inv_n, mv = block_sum_f64(sv, L) * inv_n, md = block_sum_f64(sd_, L) * inv_n;
     double suu = 0, suv = 0, svv = 0, sud = 0, svd = 0;
+#pragma unroll 4
     for (int i = threadIdx.x; i < n; i += TB) {
         const double u = (double)xyz[(size_t)i * 3 + iu] - mu, v = (double)xyz[(size_t)i * 3 + iv] - mv;
         const double d = (double)xyz[(size_t)i * 3 + id] - md;
@@ -314,6 +375,7 @@ __global__ __launch_bounds__(TB) void end_points_kernel(CloudView in, int cap, d
     // key = (monotone x key << 32) | index : min picks smallest x then smallest index;
     // for the max: (~xkey << 32) | index, min of that picks largest x then smallest index
     unsigned long long kmin = ~0ull, kmax = ~0ull;
+#pragma unroll 4
     for (int i = threadIdx.x; i < n; i += TB) {
         const double z = (double)xyz[(size_t)i * 3 + 2];
         if (z < hi && z > lo) {
@@ -591,6 +653,7 @@ __global__ __launch_bounds__(TB) void grid_meta_kernel(CloudView in, int cap, do
     const int n = min(in.n[b], cap);
     __shared__ float smin[3][NW], smax[3][NW];
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll 4
     for (int i = threadIdx.x; i < n; i += TB)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -926,9 +989,11 @@ __global__ __launch_bounds__(TB) void sor_select_kernel(CloudView in, CloudOut o
     FRAME_VIEW();
     const double* md = mean_d + (size_t)b * cap;
     double s = 0.0;
+#pragma unroll 4
     for (int i = threadIdx.x; i < n; i += TB) { const double v = md[i]; if (v > 0.0) s += v; }
     const double cloud_mean = block_sum_f64(s, L) / (double)n;
     double q = 0.0;
+#pragma unroll 4
     for (int i = threadIdx.x; i < n; i += TB) { const double v = md[i]; if (v > 0.0) q += (v - cloud_mean) * (v - cloud_mean); }
     const double sq = block_sum_f64(q, L);
     const double stdv = sqrt(sq / (double)(n - 1));
@@ -994,12 +1059,14 @@ __global__ __launch_bounds__(TB) void keep_select_kernel(CloudView in, CloudOut 
     block_compact(xyz, rgb, n, oxyz, orgb, on, cap, [=](int i, float, float, float) { return kp[i] != 0; }, L);
 }
 
-static void build_grid(CloudView in, int B, int cap, double fixed_cell, const O3dScratch& sc, hipStream_t s, bool keep_meta = false) {
+static void build_grid(CloudView in, int B, int cap, double fixed_cell, const O3dScratch& sc, hipStream_t s, bool keep_meta = false,
+                       bool occupancy_only = false) {
     hipMemsetAsync(sc.cell_cnt, 0, (size_t)B * GRID_CELLS * 4, s);
     if (!keep_meta) hipLaunchKernelGGL(grid_meta_kernel, dim3(B), dim3(TB), 0, s, in, cap, fixed_cell, sc.meta);
     dim3 grid((cap + 255) / 256, B);
     hipLaunchKernelGGL(grid_count_kernel, grid, dim3(256), 0, s, in, cap, sc.meta, sc.cell_cnt, sc.cell_of);
     hipLaunchKernelGGL(grid_scan_a_kernel, dim3(SCAN_NSEG, B), dim3(256), 0, s, sc.cell_cnt, sc.seg_sum, sc.meta);
+    if (occupancy_only) return;       // the caller only wants GridMeta::occupied (cell-size refinement)
     hipLaunchKernelGGL(grid_scan_b_kernel, dim3(B), dim3(SCAN_NSEG), 0, s, sc.seg_sum, sc.cell_start);
     hipLaunchKernelGGL(grid_scan_c_kernel, dim3(SCAN_NSEG, B), dim3(256), 0, s, sc.cell_cnt, sc.seg_sum, sc.cell_start);
     hipLaunchKernelGGL(grid_scatter_kernel, grid, dim3(256), 0, s, in, cap, sc.cell_cnt, sc.cell_start, sc.cell_of, sc.sidx, sc.sxyz);
@@ -1008,7 +1075,7 @@ static void build_grid(CloudView in, int B, int cap, double fixed_cell, const O3
 hipError_t launch_sor(CloudView in, CloudOut out, int B, int cap, int k, double ratio, void* scratch, double* mean_out, hipStream_t s) {
     if (k > KMAX) return hipErrorInvalidValue;
     O3dScratch sc = carve(scratch, B, cap);
-    build_grid(in, B, cap, 0.0, sc, s);
+    build_grid(in, B, cap, 0.0, sc, s, /*keep_meta=*/false, /*occupancy_only=*/true);
     hipLaunchKernelGGL(grid_refine_kernel, dim3((B + 63) / 64), dim3(64), 0, s, in, cap, sc.meta, B);   // re-size the cells from the
     build_grid(in, B, cap, 0.0, sc, s, /*keep_meta=*/true);                                              // measured occupancy, rebuild
     double* md = mean_out ? mean_out : sc.mean_d;

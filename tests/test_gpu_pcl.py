@@ -95,6 +95,34 @@ def test_median_matches_numpy(pcl, n):
     assert np.float32(m) == np.float32(ref_m) or (np.isnan(m) and np.isnan(ref_m))
 
 
+@pytest.mark.parametrize("kind", ["random", "sorted", "ties", "periodic", "two_level", "even_gap"])
+def test_median_large_sample_bracket_and_fallback(pcl, kind):
+    """n >= 16384 takes the sample-bracketed median (one collecting pass); "periodic" and "two_level" are built so that
+    the systematic sample misrepresents the column and the exact radix select has to take over.  Bit-exact either way."""
+    rng = np.random.default_rng(7)
+    n = 70_000 if kind != "even_gap" else 65_536
+    v = rng.standard_normal(n).astype(np.float32)
+    if kind == "sorted":
+        v = np.sort(v)[::-1].copy()
+    elif kind == "ties":
+        v = np.round(v * 2).astype(np.float32)
+    elif kind == "periodic":          # every sampled row (stride n/4096) is an outlier
+        idx = (np.arange(4096, dtype=np.int64) * n) // 4096
+        v[idx] = 1e6
+    elif kind == "two_level":         # half the column is one value: the bracket overflows its buffer
+        v[: n // 2 + 5] = 0.25
+    elif kind == "even_gap":          # even n, the two middle elements far apart
+        v = np.concatenate([np.full(n // 2, -3.0, np.float32), np.full(n // 2, 5.0, np.float32)])
+        rng.shuffle(v)
+    dev_, m = pcl.mad(v)
+    ref_dev, ref_m = oracle_pcl.mad(v)
+    assert np.array_equal(dev_, ref_dev)
+    assert np.float32(m) == np.float32(ref_m)
+    v[123] = np.nan
+    _, m = pcl.mad(v)
+    assert np.isnan(m)
+
+
 def test_median_with_nan_is_nan(pcl):
     v = np.arange(100, dtype=np.float32)
     v[17] = np.nan
@@ -123,6 +151,22 @@ def test_o3d_filters_mini(pcl, mini):
     _o3d_compare(pcl, pts, col, nb=5)
     # fewer points than k
     _o3d_compare(pcl, mini["zcut_pts"][:7], mini["zcut_col"][:7], nb=2)
+
+
+def test_o3d_sparse_cloud_deep_shells(pcl):
+    """a dense sheet plus a sparse halo and far strays: most halo points need shells beyond the per-thread search (the
+    wave-cooperative kernel), the strays walk every shell and end in the brute-force scan.  Mean kNN distance and both
+    filters stay bit-exact vs the oracle."""
+    rng = np.random.default_rng(11)
+    sheet = np.stack([rng.uniform(-4, 4, 6000), rng.normal(-1.6, 0.01, 6000), rng.uniform(-20, -8, 6000)], 1)
+    halo = np.stack([rng.uniform(-30, 30, 400), rng.uniform(-10, 10, 400), rng.uniform(-60, -2, 400)], 1)
+    strays = np.float64([[400, 0, -10], [-350, 90, -700], [0, 0, 5000]])
+    pts = np.concatenate([sheet, halo, strays]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    col = rng.integers(0, 256, (len(pts), 3), dtype=np.uint8)
+    n1, n2 = _o3d_compare(pcl, pts, col, nb=20)
+    assert 0 < n2 <= n1 < len(pts)
+    _o3d_compare(pcl, pts, col, k=16, ratio=1.5, nb=3, radius=2.0)
 
 
 def test_o3d_knn_mean_distance_exact(pcl, mini):
