@@ -55,7 +55,8 @@ __device__ __forceinline__ KEntry load_kentry(const KEntry* ptr) {
 // ring of 16-channel k-steps whose fragments are read one barrier ahead (13-15 % slower: twice the barriers and 32-byte
 // gather pieces cost more than the hidden LDS round trip gains).  With random operands the chip sustains 1.81 PFLOP/s of
 // v_mfma_f32_32x32x16_bf16 (scripts/probe_mfma_peak.hip; 2.47 with constant operands): the power limit, not the issue
-// rate, is the practical ceiling this kernel runs against.
+// rate, is the practical ceiling this kernel runs against.  A persistent variant (workgroups walking output tiles, the next
+// tile's first k-tiles in flight under the epilogue) measured the same fps within noise (348.4 vs 347.4) and was dropped.
 template <int WAVES_M, int WAVES_N, int MT, int NT, bool SIMPLE, int STAGES>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 2 ? 2 : 1) void conv_dma_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
     constexpr int NW = WAVES_M * WAVES_N;
