@@ -187,8 +187,11 @@ def main():
         "bound": "mfma", "achieved": round(achieved, 2), "peak": round(PEAK_TFLOPS[args.precision], 1), "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_TFLOPS[args.precision], 4), "traffic": traffic,
         "peak_note": ("f32 MFMA dense peak" if args.precision == "f32" else
-                      "dense bf16 MFMA peak 2500 TF/s / 3 MFMA products per algorithmic product; achieved counts algorithmic flops"),
-        "kernel": ("conv_igemm_kernel" if args.precision == "f32" else "conv_split_kernel") + " (all instantiations)", "launches": tot_n,
+                      "dense bf16 MFMA peak 2500 TF/s / 3 MFMA products per algorithmic product; achieved counts algorithmic flops. "
+                      "Measured on this pool: with random operands the chip sustains 1812 TF/s of v_mfma_f32_32x32x16_bf16 "
+                      "(power limit; profiles/r01_mfma_sustained_probe.txt), i.e. 604 TF/s of algorithmic work"),
+        "kernel": ("conv_igemm_kernel (all instantiations)" if args.precision == "f32" else
+                   "split-bf16 conv engine: conv_dma_kernel + conv_direct_kernel + conv_split_kernel (all instantiations)"), "launches": tot_n,
         "avg_launch_us": round(tot_ms * 1e3 / max(tot_n, 1), 2),
         "algorithmic_gflop_per_launch": round(tot_fl / max(tot_n, 1) / 1e9, 3),
         "conv_time_share_of_step": round(tot_ms * 1e-3 / dt, 4),
