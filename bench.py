@@ -29,8 +29,10 @@ H, W = 512, 1024
 # MI355X_MICROARCH.md peaks.  f32: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz.
 # bf16x2: every algorithmic product costs three dense-bf16 MFMA products (hi*hi + hi*lo + lo*hi), so the ceiling for
 # ALGORITHMIC flops is the dense bf16 peak / 3 (frac is then also executed-MFMA-flops / dense bf16 peak).
-PEAK_TFLOPS = {"f32": 157.3, "bf16x2": 2500.0 / 3.0}
-DTYPE = {"f32": "f32", "bf16x2": "bf16x2 split operands (hi+lo, 16 mantissa bits), 3 bf16 MFMA products per product, f32 accumulate"}
+PEAK_TFLOPS = {"f32": 157.3, "bf16x2": 2500.0 / 3.0, "mixed": 2500.0 / 3.0}      # mixed: per-kernel peaks, see below
+DTYPE = {"f32": "f32", "bf16x2": "bf16x2 split operands (hi+lo, 16 mantissa bits), 3 bf16 MFMA products per product, f32 accumulate",
+         "mixed": "FCN-8s: bf16x2 split operands, 3 bf16 MFMA products; monodepth: fp16x2 split activations (22 bits) x fp16 weights, "
+                  "2 fp16 MFMA products; f32 accumulate"}
 
 
 def log(*a):
@@ -47,7 +49,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step (configs[3]: 32)")
     ap.add_argument("--encoder", default="resnet50")
-    ap.add_argument("--precision", default="bf16x2", choices=["f32", "bf16x2"],
+    ap.add_argument("--precision", default="bf16x2", choices=["f32", "bf16x2", "mixed"],
                     help="conv arithmetic: exact f32 MFMA, or split-bf16 (3 bf16 MFMA products per product, f32 accumulate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -174,18 +176,22 @@ def main():
     tot_n = sum(b["launches"] for b in buckets)
     dom = max(buckets, key=lambda b: b["ms"])
     achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    peak_of = lambda b: (2500.0 / 2.0 if "f16w" in b["kernel"] else PEAK_TFLOPS[args.precision])
+    # effective peak of the launch mix: total flops / time at peak (harmonic mean over the kernels' own peaks)
+    t_at_peak = sum(b["flops"] / (peak_of(b) * 1e12) for b in buckets)
+    eff_peak = tot_fl / t_at_peak / 1e12 if t_at_peak > 0 else PEAK_TFLOPS[args.precision]
     # HBM bytes per conv launch from the committed PMC profile of this same command (rocprofv3 FETCH_SIZE / WRITE_SIZE passes)
     traffic = None
     try:
         import glob
         pf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_conv_traffic.json")))
-        if pf and args.precision == "bf16x2":
+        if pf and args.precision in ("bf16x2", "mixed"):
             traffic = round(json.load(open(pf[-1]))["all_conv"]["hbm_bytes_per_launch"])
     except Exception:
         traffic = None
     roofline = {
-        "bound": "mfma", "achieved": round(achieved, 2), "peak": round(PEAK_TFLOPS[args.precision], 1), "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_TFLOPS[args.precision], 4), "traffic": traffic,
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": round(eff_peak, 1), "unit": "TFLOP/s",
+        "frac": round(achieved / eff_peak, 4), "traffic": traffic,
         "peak_note": ("f32 MFMA dense peak" if args.precision == "f32" else
                       "dense bf16 MFMA peak 2500 TF/s / 3 MFMA products per algorithmic product; achieved counts algorithmic flops. "
                       "Measured on this pool: with random operands the chip sustains 1812 TF/s of v_mfma_f32_32x32x16_bf16 "

@@ -37,8 +37,11 @@ enum {
 typedef enum { SD_ENC_VGG = 0, SD_ENC_RESNET50 = 1 } sd_encoder;      /* semantic_depth.py:721-722 --encoder */
 typedef enum { SD_NET_FCN8S = 0, SD_NET_MONODEPTH = 1 } sd_net;
 /* arithmetic of the conv stacks: SD_PREC_F32 = exact f32 MFMA; SD_PREC_BF16X2 = every f32 operand split into two bf16
- * (hi + lo), three bf16 MFMA products per product, f32 accumulate (~1e-5 relative; gfx950 has no TF32) */
-typedef enum { SD_PREC_F32 = 0, SD_PREC_BF16X2 = 1 } sd_precision;
+ * (hi + lo), three bf16 MFMA products per product, f32 accumulate (~1e-5 relative; gfx950 has no TF32);
+ * SD_PREC_MIXED = FCN-8s as SD_PREC_BF16X2, monodepth with activations split into two fp16 (22 bits) and weights rounded
+ * once to fp16, two fp16 MFMA products per product (~2e-4 relative on the disparity: the 2^-12 weight rounding; the
+ * same scheme on FCN-8s gives 6e-4..1.6e-3 on the logits, over the 1e-3 budget, hence "mixed") */
+typedef enum { SD_PREC_F32 = 0, SD_PREC_BF16X2 = 1, SD_PREC_MIXED = 2 } sd_precision;
 
 typedef struct sd_handle sd_handle;
 

@@ -107,7 +107,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
     auto T = [&](int t) -> float* { return reinterpret_cast<float*>(abase + p.tensors[t].offset); };
     auto Wp = [&](int w) -> const float* { return reinterpret_cast<const float*>(wbase + p.weights[w].offset); };
     auto PL = [&](int t) -> size_t { const TensorDesc& d = p.tensors[t]; return (size_t)p.images * d.H * d.W * d.C; };   // lo-plane offset
-    auto FMT = [&](int t) -> int { return p.tensors[t].fmt; };
+    auto FMT = [&](int t) -> int { return p.tensors[t].fmt ? (p.f16 ? 2 : 1) : 0; };     // 0 f32, 1 split bf16, 2 split fp16
     for (const WeightSlot& wsl : p.weights)
         if (!wsl.loaded) return fail(h, SD_ERR_STATE, "weight not loaded: " + wsl.name);
     for (const OpDesc& op : p.ops) {
@@ -138,7 +138,8 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.act = op.act; c.m_fastest = op.m_fastest;
                 c.out_plane = PL(op.dst); c.Nmax = p.images;
                 c.zero16 = h->ws + h->o_misc + 256;        // the arena is zero-filled and nothing writes here
-                const bool split = h->prec == SD_PREC_BF16X2;
+                const bool split = p.prec != 0;
+                c.f16 = p.f16;
                 hipEvent_t ea = nullptr, eb = nullptr;
                 if (h->prof) {
                     if (h->prof_used == h->prof_pool.size()) {
@@ -170,9 +171,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.out = T(op.dst); c.out_plane = PL(op.dst); c.act = op.act; c.Nmax = p.images;
                 c.zero16 = h->ws + h->o_misc + 256;
                 c.rows_per_wave = 2;
-                for (int i = 0; i < op.nsrc; ++i)
-                    if (!op.up[i] && p.tensors[op.src[i]].C > 16) c.rows_per_wave = 2;   // (8-row tiles measured no better)
-                if (const char* e = std::getenv("SEMDEPTH_DIRECT_ROWS")) c.rows_per_wave = atoi(e) == 1 ? 1 : 2;
+                c.f16 = p.f16;
                 hipEvent_t ea = nullptr, eb = nullptr;
                 if (h->prof) {
                     if (h->prof_used == h->prof_pool.size()) {
@@ -187,7 +186,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 e = launch_conv_direct(c, s);
                 if (h->prof) {
                     hipEventRecord(eb, s);
-                    h->prof_recs.push_back({"conv_direct_kernel", op.flops * N / p.images, ea, eb, op.name.c_str(), N * c.H * c.W, d.C, op.K});
+                    h->prof_recs.push_back({p.f16 ? "conv_direct_f16w_kernel" : "conv_direct_kernel", op.flops * N / p.images, ea, eb, op.name.c_str(), N * c.H * c.W, d.C, op.K});
                 }
                 break;
             }
@@ -196,7 +195,8 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 SmallNParams c{};
                 c.x = T(op.src[0]); c.N = N; c.H = s0.H; c.W = s0.W; c.C = s0.C; c.k = op.k; c.nout = op.nout;
                 c.wt = Wp(op.w); c.bias = Wp(op.b); c.out = T(op.dst); c.act = op.act;
-                c.in_split = FMT(op.src[0]); c.out_split = FMT(op.dst); c.in_plane = PL(op.src[0]); c.out_plane = PL(op.dst);
+                c.in_split = FMT(op.src[0]) != 0; c.out_split = FMT(op.dst) != 0; c.in_plane = PL(op.src[0]); c.out_plane = PL(op.dst);
+                c.f16 = p.f16;
                 c.out_c = p.tensors[op.dst].C;
                 c.zero16 = h->ws + h->o_misc + 256;
                 e = launch_conv_smalln(c, s);
@@ -259,7 +259,7 @@ const char* sd_status_string(sd_status s) {
 }
 
 sd_status sd_create(sd_handle** out, int device, int H, int W, int max_batch, sd_encoder enc, sd_precision prec) {
-    if (!out || H <= 0 || W <= 0 || max_batch <= 0 || (prec != SD_PREC_F32 && prec != SD_PREC_BF16X2)) return SD_ERR_INVALID;
+    if (!out || H <= 0 || W <= 0 || max_batch <= 0 || (prec != SD_PREC_F32 && prec != SD_PREC_BF16X2 && prec != SD_PREC_MIXED)) return SD_ERR_INVALID;
     sd_handle* h = new sd_handle();
     h->device = device; h->H = H; h->W = W; h->max_batch = max_batch; h->enc = (int)enc; h->cap = H * W; h->prec = (int)prec;
     int chunk = 32;      // frames per network pass: the deep layers (M = 512 px per frame) need ~32 frames to fill 256 CUs;
@@ -267,8 +267,8 @@ sd_status sd_create(sd_handle** out, int device, int H, int W, int max_batch, sd
     if (const char* e = std::getenv("SEMDEPTH_CHUNK")) chunk = std::max(1, atoi(e));
     h->chunk = std::min(max_batch, chunk);
     try {
-        h->fcn = build_fcn8s(h->chunk, H, W, h->prec);
-        h->mono = build_monodepth(enc == SD_ENC_VGG ? 0 : 1, h->chunk, H, W, h->prec);
+        h->fcn = build_fcn8s(h->chunk, H, W, h->prec != SD_PREC_F32 ? 1 : 0, 0);
+        h->mono = build_monodepth(enc == SD_ENC_VGG ? 0 : 1, h->chunk, H, W, h->prec != SD_PREC_F32 ? 1 : 0, h->prec == SD_PREC_MIXED ? 1 : 0);
     } catch (const std::exception& ex) {
         std::fprintf(stderr, "sd_create: %s\n", ex.what());
         delete h;
@@ -577,7 +577,7 @@ sd_status sd_net_tensor(sd_handle* h, sd_net net, const char* name, float* out, 
     if (numel > cap_floats) return fail(h, SD_ERR_INVALID, "output buffer too small");
     const char* abase = h->ws + (net == SD_NET_FCN8S ? h->o_fcn : h->o_mono);
     if (t.fmt)      // split-bf16 planes -> f32
-        HIPCHK(h, launch_unsplit(reinterpret_cast<const float*>(abase + t.offset), out, (long)N * t.H * t.W, t.C, t.Ctf, (size_t)p.images * t.H * t.W * t.C, (hipStream_t)stream));
+        HIPCHK(h, launch_unsplit(reinterpret_cast<const float*>(abase + t.offset), out, (long)N * t.H * t.W, t.C, t.Ctf, (size_t)p.images * t.H * t.W * t.C, p.f16, (hipStream_t)stream));
     else
         HIPCHK(h, hipMemcpyAsync(out, abase + t.offset, numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return SD_OK;

@@ -56,7 +56,8 @@ __device__ __forceinline__ DirectChunk load_chunk(const DirectChunk* ptr) {
 
 // persistent: workgroup b walks tiles b, b + grid, ...; the (tile, chunk) sequence is one software pipeline, so the first
 // chunk of the next tile lands while the current tile's epilogue runs.
-template <int NB, int MT>
+// F16: fp16 planes, ONE fp16 weight plane, two MFMA products per product (split_fmt.hpp)
+template <int NB, int MT, bool F16>
 __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectParams p) {
     using Cfg = DirectCfg<NB, MT>;
     constexpr int D_WI = Cfg::WI, D_WUNITS = Cfg::WUNITS, D_STAGE = Cfg::STAGE;
@@ -110,9 +111,9 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
             ddma16(ok ? reinterpret_cast<const u32x4*>(src) : zero, sbyte + (unsigned)(j * 1024));
         }
 #pragma unroll
-        for (int i = 0; i < (2 * D_WI + D_WAVES - 1) / D_WAVES; ++i) {
+        for (int i = 0; i < ((F16 ? 1 : 2) * D_WI + D_WAVES - 1) / D_WAVES; ++i) {
             const int jw = wave + D_WAVES * i;
-            if (jw < 2 * D_WI && !(p.dbg & 2)) {
+            if (jw < (F16 ? 1 : 2) * D_WI && !(p.dbg & 2)) {
                 const int pl = jw >= D_WI ? 1 : 0;
                 const u32x4* gw = p.wt + ((size_t)pl * p.nchunks + c) * D_WUNITS + (jw - pl * D_WI) * 64 + lane;
                 ddma16(gw, sbyte + (unsigned)((2 * D_XUNITS + jw * 64) * 16));
@@ -155,26 +156,26 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
             if (!(p.dbg & 4))
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                bf16x8 xh[MT + 2], xl[MT + 2];
+                u32x4 xh[MT + 2], xl[MT + 2];
 #pragma unroll
                 for (int r = 0; r < MT + 2; ++r) {
                     const int lp = (MT * wave + r) * D_HW + frow + dx;
                     const int idx = lp * 2 + (fk ^ ((lp >> 3) & 1));
-                    xh[r] = __builtin_bit_cast(bf16x8, Xh[idx]);
-                    xl[r] = __builtin_bit_cast(bf16x8, Xl[idx]);
+                    xh[r] = Xh[idx];
+                    xl[r] = Xl[idx];
                 }
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
                         const int wi = ((dy * 3 + dx) * 2 + fk) * (32 * NB) + nb * 32 + frow;
-                        const bf16x8 wh = __builtin_bit_cast(bf16x8, Wh[wi]);
-                        const bf16x8 wl = __builtin_bit_cast(bf16x8, Wl[wi]);
+                        const u32x4 wh = Wh[wi];
+                        const u32x4 wl = F16 ? wh : Wl[wi];
 #pragma unroll
-                        for (int pr = 0; pr < 3; ++pr)
+                        for (int pr = (F16 ? 1 : 0); pr < 3; ++pr)
 #pragma unroll
                             for (int a = 0; a < MT; ++a)
-                                acc[a][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 0 ? wl : wh, pr == 1 ? xl[a + dy] : xh[a + dy], acc[a][nb], 0, 0, 0);
+                                acc[a][nb] = mfma_frag<F16>(pr == 0 ? wl : wh, pr == 1 ? xl[a + dy] : xh[a + dy], acc[a][nb]);
                     }
             }
         }
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
                     v += bias[r4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
-                    split4(v, hh[r4], ll[r4]);
+                    split4_t<F16>(v, hh[r4], ll[r4]);
                 }
                 const int pp = frow >> 1;                    // pooled pixel of this lane pair
 #pragma unroll
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
                     v += bias[r4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
-                    split4(v, hh[r4], ll[r4]);
+                    split4_t<F16>(v, hh[r4], ll[r4]);
                 }
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
@@ -327,10 +328,14 @@ hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
     const int tiles = (p.W / D_TW) * ((p.H + th - 1) / th) * p.N;
     const dim3 grid((unsigned)(tiles < cus ? tiles : cus));
     const int nb = p.Cout <= 32 ? 1 : 2;
-    if (nb == 1 && p.rows_per_wave == 2) hipLaunchKernelGGL((conv_direct_kernel<1, 2>), grid, dim3(512), 0, s, q);
-    else if (nb == 1) hipLaunchKernelGGL((conv_direct_kernel<1, 1>), grid, dim3(512), 0, s, q);
-    else if (p.rows_per_wave == 2) hipLaunchKernelGGL((conv_direct_kernel<2, 2>), grid, dim3(512), 0, s, q);
-    else hipLaunchKernelGGL((conv_direct_kernel<2, 1>), grid, dim3(512), 0, s, q);
+    if (p.rows_per_wave != 2) return hipErrorInvalidValue;       // (8-row tiles were measured no better and are not built)
+    if (p.f16) {
+        if (nb == 1) hipLaunchKernelGGL((conv_direct_kernel<1, 2, true>), grid, dim3(512), 0, s, q);
+        else hipLaunchKernelGGL((conv_direct_kernel<2, 2, true>), grid, dim3(512), 0, s, q);
+    } else {
+        if (nb == 1) hipLaunchKernelGGL((conv_direct_kernel<1, 2, false>), grid, dim3(512), 0, s, q);
+        else hipLaunchKernelGGL((conv_direct_kernel<2, 2, false>), grid, dim3(512), 0, s, q);
+    }
     return hipGetLastError();
 }
 

@@ -57,13 +57,18 @@ __device__ __forceinline__ KEntry load_kentry(const KEntry* ptr) {
 // v_mfma_f32_32x32x16_bf16 (scripts/probe_mfma_peak.hip; 2.47 with constant operands): the power limit, not the issue
 // rate, is the practical ceiling this kernel runs against.  A persistent variant (workgroups walking output tiles, the next
 // tile's first k-tiles in flight under the epilogue) measured the same fps within noise (348.4 vs 347.4) and was dropped.
-template <int WAVES_M, int WAVES_N, int MT, int NT, bool SIMPLE, int STAGES>
+// F16: fp16 planes, ONE fp16 weight plane, two MFMA products per product (split_fmt.hpp): a k-tile then carries 4 weight
+// DMAs less per workgroup and 16 instead of 24 MFMAs per wave.
+template <int WAVES_M, int WAVES_N, int MT, int NT, bool SIMPLE, int STAGES, bool F16 = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 2 ? 2 : 1) void conv_dma_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
     constexpr int STAGE_UNITS = 8 * (BM + BN);                // 16-B units: Xh [4][BM] | Xl [4][BM] | Wh [4][BN] | Wl [4][BN]
-    constexpr int NDMA = STAGE_UNITS / 64 / NW;               // DMA instructions per wave per tile (6)
-    constexpr int XI = 8 * BM / 64 / NW;                      // of which activation instructions (2 or 4), hi first then lo
+    constexpr int XI = 8 * BM / 64 / NW;                      // activation DMA instructions per wave and tile (2 or 4), hi first then lo
+    constexpr int WI_ALL = 8 * BN / 64;                       // weight instructions of a tile, both planes (32, 16 or 8)
+    constexpr int WI = (F16 ? WI_ALL / 2 : WI_ALL);           // F16: the hi plane only
+    constexpr int WPW = (WI + NW - 1) / NW;                   // per wave (a short last round re-fetches earlier units: equal counts)
+    constexpr int NDMA = XI + WPW;                            // DMA instructions per wave per tile (6; F16: 4 or 5)
     constexpr int EPI_ROW = NT * 64 + 16;
     static_assert(NW * 2 * 32 * EPI_ROW <= STAGES * STAGE_UNITS * 16, "epilogue slabs fit in the ring");
     static_assert((8 * BM / 64) % (2 * NW) == 0 && (8 * BN / 64) % NW == 0, "whole DMA instructions per wave and plane");
@@ -163,12 +168,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 2 ? 2 : 1) void c
         }
         // ---- weights: the stage image is the global image ----
 #pragma unroll
-        for (int i = XI; i < NDMA; ++i) {
-            const int j = wave + NW * i;
-            const int wu = (j - XI * NW) * 64 + lane;         // unit inside the W region: [plane][kg][n]
+        for (int i = 0; i < WPW; ++i) {
+            const int jw = (wave + NW * i) % WI;              // weight instruction (wraps when WI < 8: duplicate fetch)
+            const int wu = jw * 64 + lane;                    // unit inside the W region: [plane][kg][n]
             const int pl = wu / (4 * BN), r = wu % (4 * BN), kg = r / BN, n_l = r % BN;
             const u32x4* g = wt_hi + pl * wplane + (size_t)(kt * 4 + kg) * CoutPad + bn0 + n_l;
-            dma16(g, sbyte + (unsigned)(j * 1024));
+            dma16(g, sbyte + (unsigned)((XI * NW + jw) * 1024));
         }
     };
 
@@ -196,20 +201,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 2 ? 2 : 1) void c
         // every LDS read to just before its first use, which exposes the LDS latency four times per tile):
         //   fragments of k-step 0 -> DMA issue of tile kt+2 (its address arithmetic runs under the LDS latency) ->
         //   fragments of k-step 1 -> 12 MFMAs of k-step 0 -> 12 MFMAs of k-step 1
-        bf16x8 wh[2][NT], wl[2][NT], xh[2][MT], xl[2][MT];
+        u32x4 wh[2][NT], wl[2][NT], xh[2][MT], xl[2][MT];
         auto fragments = [&](int s) {
             const int kg = 2 * s + fk;
 #pragma unroll
             for (int b = 0; b < NT; ++b) {
-                wh[s][b] = __builtin_bit_cast(bf16x8, Wh[kg * BN + wn0 + b * 32 + frow]);
-                wl[s][b] = __builtin_bit_cast(bf16x8, Wl[kg * BN + wn0 + b * 32 + frow]);
+                wh[s][b] = Wh[kg * BN + wn0 + b * 32 + frow];
+                wl[s][b] = F16 ? wh[s][b] : Wl[kg * BN + wn0 + b * 32 + frow];
             }
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
                 const int mrow = wm0 + a * 32 + frow;
                 const int slot = mrow * 4 + (kg ^ ((mrow >> 2) & 3));        // [pixel][octet ^ swizzle]
-                xh[s][a] = __builtin_bit_cast(bf16x8, Xh[slot]);
-                xl[s][a] = __builtin_bit_cast(bf16x8, Xl[slot]);
+                xh[s][a] = Xh[slot];
+                xl[s][a] = Xl[slot];
             }
         };
         fragments(0);
@@ -221,12 +226,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 2 ? 2 : 1) void c
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
-            for (int pr = 0; pr < 3; ++pr)
+            for (int pr = (F16 ? 1 : 0); pr < 3; ++pr)
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
 #pragma unroll
                     for (int a = 0; a < MT; ++a)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 0 ? wl[s][b] : wh[s][b], pr == 1 ? xl[s][a] : xh[s][a], acc[a][b], 0, 0, 0);
+                        acc[a][b] = mfma_frag<F16>(pr == 0 ? wl[s][b] : wh[s][b], pr == 1 ? xl[s][a] : xh[s][a], acc[a][b]);
         }
     }
 
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 2 ? 2 : 1) void c
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
                     uint2 h, l;
-                    split4(v, h, l);
+                    split4_t<F16>(v, h, l);
                     *reinterpret_cast<uint2*>(sh + (lane & 31) * ROW + nl * 2) = h;
                     *reinterpret_cast<uint2*>(sl + (lane & 31) * ROW + nl * 2) = l;
                 }
@@ -295,7 +300,10 @@ template <int WM, int WN, int MT, int NT, int STAGES>
 static void launch_dma_variant(const ConvParams& p, long M, hipStream_t s) {
     const int tilesM = (int)((M + WM * MT * 32 - 1) / (WM * MT * 32)), tilesN = p.Cout / (WN * NT * 32);
     const dim3 grid((unsigned)(tilesM * tilesN)), block(64 * WM * WN);
-    if (p.simple && !(p.dbg & 16)) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, true, STAGES>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+    if (p.f16) {
+        if (p.simple) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, true, STAGES, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+        else hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, false, STAGES, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+    } else if (p.simple && !(p.dbg & 16)) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, true, STAGES>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
     else hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, false, STAGES>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
 }
 
@@ -313,6 +321,13 @@ hipError_t launch_conv_dma(const ConvParams& p0, hipStream_t s) {
 }
 
 const char* conv_dma_kernel_name(const ConvParams& p) {
+    if (p.f16) {
+        switch (conv_dma_variant(p)) {
+            case 1: return "conv_dma_f16w_kernel<2,4,2,2>";
+            case 2: return "conv_dma_f16w_kernel<4,2,2,2>";
+            default: return "conv_dma_f16w_kernel<4,2,2,1>";
+        }
+    }
     switch (conv_dma_variant(p)) {
         case 1: return "conv_dma_kernel<2,4,2,2>";
         case 2: return "conv_dma_kernel<4,2,2,2>";

@@ -31,7 +31,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // Output path shared by the split kernels.  A wave owns a (MT*32) x (NT*32) tile; per 32-pixel slab it applies bias +
 // activation, splits ONCE into hi/lo, transposes through a wave-private LDS slab and writes 16-byte runs of 8 channels,
 // so every pixel's NT*64 bytes per plane leave as one contiguous segment (the MFMA layout alone gives 8-byte fragments).
-template <int ACT, int MT, int NT>
+template <int ACT, int MT, int NT, bool F16>
 __device__ __forceinline__ void split_epilogue_act(f32x16 (&acc)[MT][NT], unsigned char* slab, const ConvParams& p, int m0, int n0, int M, int lane) {
     constexpr int ROW = NT * 64 + 16;
     unsigned char* sh = slab;
@@ -53,7 +53,7 @@ __device__ __forceinline__ void split_epilogue_act(f32x16 (&acc)[MT][NT], unsign
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
                 uint2 h, l;
-                split4(v, h, l);
+                split4_t<F16>(v, h, l);
                 *reinterpret_cast<uint2*>(sh + (lane & 31) * ROW + nl * 2) = h;
                 *reinterpret_cast<uint2*>(sl + (lane & 31) * ROW + nl * 2) = l;
             }
@@ -76,11 +76,11 @@ __device__ __forceinline__ void split_epilogue_act(f32x16 (&acc)[MT][NT], unsign
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
-template <int MT, int NT>
+template <int MT, int NT, bool F16>
 __device__ __forceinline__ void split_epilogue(f32x16 (&acc)[MT][NT], unsigned char* slab, const ConvParams& p, int m0, int n0, int M, int lane) {
-    if (p.act == ACT_RELU) split_epilogue_act<ACT_RELU, MT, NT>(acc, slab, p, m0, n0, M, lane);
-    else if (p.act == ACT_ELU) split_epilogue_act<ACT_ELU, MT, NT>(acc, slab, p, m0, n0, M, lane);
-    else split_epilogue_act<ACT_NONE, MT, NT>(acc, slab, p, m0, n0, M, lane);
+    if (p.act == ACT_RELU) split_epilogue_act<ACT_RELU, MT, NT, F16>(acc, slab, p, m0, n0, M, lane);
+    else if (p.act == ACT_ELU) split_epilogue_act<ACT_ELU, MT, NT, F16>(acc, slab, p, m0, n0, M, lane);
+    else split_epilogue_act<ACT_NONE, MT, NT, F16>(acc, slab, p, m0, n0, M, lane);
 }
 
 template <int WAVES_M, int WAVES_N, int MT, int NT>
@@ -96,7 +96,8 @@ struct STile {
     static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
 };
 
-template <int WAVES_M, int WAVES_N, int MT, int NT, bool VEC>
+// F16: fp16 planes, one fp16 weight plane, two MFMA products per product (split_fmt.hpp)
+template <int WAVES_M, int WAVES_N, int MT, int NT, bool VEC, bool F16 = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_split_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
     using T = STile<WAVES_M, WAVES_N, MT, NT>;
     constexpr int BM = T::BM, BN = T::BN, NTHR = T::NTHR;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_split_kernel(cons
             if (BN * 4 >= NTHR || idx < BN * 4) {
                 const size_t o = (size_t)(kt * 4 + kg) * CoutPad + bn0 + n_l;
                 rwh[i] = wt_hi[o];
-                rwl[i] = wt_lo[o];
+                if (!F16) rwl[i] = wt_lo[o];
             }
         }
         if (VEC || kt < vtiles) {
@@ -235,39 +236,39 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_split_kernel(cons
 #pragma unroll
         for (int i = 0; i < T::B_LD; ++i) {
             const int idx = t + NTHR * i;
-            if (BN * 4 >= NTHR || idx < BN * 4) { Wh[idx] = rwh[i]; Wl[idx] = rwl[i]; }
+            if (BN * 4 >= NTHR || idx < BN * 4) { Wh[idx] = rwh[i]; if (!F16) Wl[idx] = rwl[i]; }
         }
         __syncthreads();
         if (kt + 1 < ktiles) load_tile(kt + 1);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int kg = 2 * s + fk;
-            bf16x8 wh[NT], wl[NT], xh[MT], xl[MT];
+            u32x4 wh[NT], wl[NT], xh[MT], xl[MT];
 #pragma unroll
             for (int b = 0; b < NT; ++b) {
-                wh[b] = __builtin_bit_cast(bf16x8, Wh[kg * BN + wn0 + b * 32 + frow]);
-                wl[b] = __builtin_bit_cast(bf16x8, Wl[kg * BN + wn0 + b * 32 + frow]);
+                wh[b] = Wh[kg * BN + wn0 + b * 32 + frow];
+                wl[b] = F16 ? wh[b] : Wl[kg * BN + wn0 + b * 32 + frow];
             }
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
-                xh[a] = __builtin_bit_cast(bf16x8, Xh[kg * BM + wm0 + a * 32 + frow]);
-                xl[a] = __builtin_bit_cast(bf16x8, Xl[kg * BM + wm0 + a * 32 + frow]);
+                xh[a] = Xh[kg * BM + wm0 + a * 32 + frow];
+                xl[a] = Xl[kg * BM + wm0 + a * 32 + frow];
             }
             // the three products of one accumulator are issued MT*NT MFMAs apart (no back-to-back dependent MFMAs).
             // (s_setprio(1) around this cluster was measured: -25 %, the co-resident blocks' staging starves)
 #pragma unroll
-            for (int pr = 0; pr < 3; ++pr)
+            for (int pr = (F16 ? 1 : 0); pr < 3; ++pr)
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
 #pragma unroll
                     for (int a = 0; a < MT; ++a)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 0 ? wl[b] : wh[b], pr == 1 ? xl[a] : xh[a], acc[a][b], 0, 0, 0);
+                        acc[a][b] = mfma_frag<F16>(pr == 0 ? wl[b] : wh[b], pr == 1 ? xl[a] : xh[a], acc[a][b]);
         }
     }
 
     // ---- epilogue: D[row = channel (r&3) + 8*(r>>2) + 4*(lane>>5)][col = pixel lane&31] ----
     __syncthreads();                      // every wave is done with the stage memory: reuse it as output staging
-    split_epilogue<MT, NT>(acc, lds + wave * (2 * 32 * T::EPI_ROW), p, bm0 + wm0, bn0 + wn0, M, lane);
+    split_epilogue<MT, NT, F16>(acc, lds + wave * (2 * 32 * T::EPI_ROW), p, bm0 + wm0, bn0 + wn0, M, lane);
 }
 
 template <int WAVES_M, int WAVES_N, int MT, int NT>
@@ -277,7 +278,12 @@ static hipError_t launch_scfg(const ConvParams& p, hipStream_t s) {
     const int tilesM = (int)((M + T::BM - 1) / T::BM);
     const int tilesN = (p.Cout + T::BN - 1) / T::BN;
     dim3 grid((unsigned)(tilesM * tilesN));
-    if (p.vec)
+    if (p.f16) {
+        if (p.vec)
+            hipLaunchKernelGGL((conv_split_kernel<WAVES_M, WAVES_N, MT, NT, true, true>), grid, dim3(T::NTHR), 0, s, p, (int)M, tilesM, tilesN);
+        else
+            hipLaunchKernelGGL((conv_split_kernel<WAVES_M, WAVES_N, MT, NT, false, true>), grid, dim3(T::NTHR), 0, s, p, (int)M, tilesM, tilesN);
+    } else if (p.vec)
         hipLaunchKernelGGL((conv_split_kernel<WAVES_M, WAVES_N, MT, NT, true>), grid, dim3(T::NTHR), 0, s, p, (int)M, tilesM, tilesN);
     else
         hipLaunchKernelGGL((conv_split_kernel<WAVES_M, WAVES_N, MT, NT, false>), grid, dim3(T::NTHR), 0, s, p, (int)M, tilesM, tilesN);
@@ -313,6 +319,15 @@ hipError_t launch_conv_split(const ConvParams& p, hipStream_t s) {
 }
 
 const char* conv_split_kernel_name(const ConvParams& p) {
+    if (p.f16) {
+        switch (split_variant(p)) {
+            case 0:  return "conv_split_f16w_kernel<2,4,2,2>";
+            case 1:  return "conv_split_f16w_kernel<4,2,2,2>";
+            case 2:  return "conv_split_f16w_kernel<2,2,2,2>";
+            case 3:  return "conv_split_f16w_kernel<4,1,2,2>";
+            default: return "conv_split_f16w_kernel<4,1,2,1>";
+        }
+    }
     switch (split_variant(p)) {
         case 0:  return p.vec ? "conv_split_kernel<2,4,2,2,true>" : "conv_split_kernel<2,4,2,2,false>";
         case 1:  return p.vec ? "conv_split_kernel<4,2,2,2,true>" : "conv_split_kernel<4,2,2,2,false>";

@@ -43,6 +43,7 @@ struct ConvParams {
     size_t out_plane;  // split engine: element offset of the output's lo plane
     const void* zero16;  // split engine: 16 zero bytes in device memory (source of out-of-image taps for the LDS-DMA pipeline)
     int Nmax;          // split engine: images of a full chunk (plane stride of a source = Nmax*H*W*C elements)
+    int f16;           // split planes are fp16 and the weights one fp16 plane (2 MFMA products): split_fmt.hpp
     int simple;        // one source, stride 1, no upsample, all k-tiles vec: the DMA kernel computes its gather addresses
     int dbg;           // SEMDEPTH_DMA_DBG: development ablation switches of conv_dma.hip (0 in production)
     int m_fastest;     // block order: 1 = consecutive blocks walk M (share a weight panel), 0 = walk N
@@ -109,6 +110,7 @@ struct ConvDirectParams {
     const void* zero16;
     int dbg;
     int rows_per_wave;           // 1: 8 x 32 tiles, 2: 16 x 32 tiles (see conv_direct.hip)
+    int f16;                     // fp16 planes + single fp16 weight plane (2 MFMA products)
     int pool;                    // 1: fused 2x2 stride-2 max pool, out is [N,H/2,W/2,Cout] (needs rows_per_wave == 2)
 };
 hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s);
@@ -127,6 +129,7 @@ struct SmallNParams {
     float* out;         // [N,H,W,nout]
     int act;
     const void* zero16; // 16 zero bytes (padding source of the LDS-DMA halo loads of the tiled kernel)
+    int f16;            // split planes (in and out) are fp16 instead of bf16
 };
 hipError_t launch_conv_smalln(const SmallNParams& p, hipStream_t s);
 
@@ -138,7 +141,7 @@ hipError_t launch_pre_vgg(const uint8_t* frames, float* out, long npix, int spli
 hipError_t launch_pre_mono(const uint8_t* frames, float* out, int B, int H, int W, int split, size_t plane, hipStream_t s);      // /255 + fliplr pair
 hipError_t launch_maxpool2(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s);
 hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s);
-hipError_t launch_unsplit(const float* x, float* y, long npix, int C, int Ctf, size_t plane, hipStream_t s);  // split planes -> f32 [npix][Ctf]
+hipError_t launch_unsplit(const float* x, float* y, long npix, int C, int Ctf, size_t plane, int f16, hipStream_t s);  // split planes -> f32 [npix][Ctf]
 // y[n,2i+ky-1,2j+kx-1,o] += x[n,i,j,c]*w[ky,kx,o,c]; y += bias + skip   (3->3 channels; fcn8s/fcn.py:186-204)
 hipError_t launch_deconv4s2_add(const float* x, const float* w, const float* bias, const float* skip, float* y,
                                 int N, int H, int W, hipStream_t s);

@@ -9,17 +9,17 @@ namespace sd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Every op below exists for both activation formats: f32 NHWC, and the split-bf16 planes of split_fmt.hpp
-// (template parameter SPLIT; `plane` = element offset of the lo plane).
+// Every op below exists for the three activation formats: f32 NHWC (0), split-bf16 planes (1) and split-fp16 planes (2)
+// of split_fmt.hpp (template parameter SPLIT; `plane` = element offset of the lo plane).
 // ---------------------------------------------------------------------------------------------
 // K1: VGG 'Processing' block [UPSTREAM Udacity vgg]: split (c0,c1,c2), subtract means, concat reversed.
 // 4 stored channels (the 4th is zero and meets zero weight rows): conv1_1 gathers whole channel quads.
 // ---------------------------------------------------------------------------------------------
-template <bool SPLIT>
+template <int SPLIT>
 __device__ __forceinline__ void store4(float* base, size_t plane, long quad_index, f32x4 v) {
     if (SPLIT) {
         uint2 h, l;
-        split4(v, h, l);
+        split4_t<SPLIT == 2>(v, h, l);
         uint2* hp = reinterpret_cast<uint2*>(base);             // bf16 plane: one uint2 per channel quad
         hp[quad_index] = h;
         reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + plane)[quad_index] = l;
@@ -27,17 +27,17 @@ __device__ __forceinline__ void store4(float* base, size_t plane, long quad_inde
         reinterpret_cast<f32x4*>(base)[quad_index] = v;
     }
 }
-template <bool SPLIT>
+template <int SPLIT>
 __device__ __forceinline__ f32x4 load4(const float* base, size_t plane, long quad_index) {
     if (SPLIT) {
         const uint2 h = reinterpret_cast<const uint2*>(base)[quad_index];
         const uint2 l = reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + plane)[quad_index];
-        return recon4(h, l);
+        return recon4_t<SPLIT == 2>(h, l);
     }
     return reinterpret_cast<const f32x4*>(base)[quad_index];
 }
 
-template <bool SPLIT>
+template <int SPLIT>
 __global__ __launch_bounds__(256) void pre_vgg_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, long npix, size_t plane) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= npix) return;
@@ -46,13 +46,14 @@ __global__ __launch_bounds__(256) void pre_vgg_kernel(const uint8_t* __restrict_
 }
 hipError_t launch_pre_vgg(const uint8_t* frames, float* out, long npix, int split, size_t plane, hipStream_t s) {
     const dim3 grid((unsigned)((npix + 255) / 256));
-    if (split) hipLaunchKernelGGL(pre_vgg_kernel<true>, grid, dim3(256), 0, s, frames, out, npix, plane);
-    else hipLaunchKernelGGL(pre_vgg_kernel<false>, grid, dim3(256), 0, s, frames, out, npix, plane);
+    if (split == 2) hipLaunchKernelGGL(pre_vgg_kernel<2>, grid, dim3(256), 0, s, frames, out, npix, plane);
+    else if (split) hipLaunchKernelGGL(pre_vgg_kernel<1>, grid, dim3(256), 0, s, frames, out, npix, plane);
+    else hipLaunchKernelGGL(pre_vgg_kernel<0>, grid, dim3(256), 0, s, frames, out, npix, plane);
     return hipGetLastError();
 }
 
 // monodepth input: frame.astype(f32)/255 and its fliplr, stacked per frame (semantic_depth.py:671-672)
-template <bool SPLIT>
+template <int SPLIT>
 __global__ __launch_bounds__(256) void pre_mono_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int B, int H, int W, size_t plane) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     long npix = (long)B * H * W;
@@ -69,15 +70,16 @@ __global__ __launch_bounds__(256) void pre_mono_kernel(const uint8_t* __restrict
 hipError_t launch_pre_mono(const uint8_t* frames, float* out, int B, int H, int W, int split, size_t plane, hipStream_t s) {
     long npix = (long)B * H * W;
     const dim3 grid((unsigned)((npix + 255) / 256));
-    if (split) hipLaunchKernelGGL(pre_mono_kernel<true>, grid, dim3(256), 0, s, frames, out, B, H, W, plane);
-    else hipLaunchKernelGGL(pre_mono_kernel<false>, grid, dim3(256), 0, s, frames, out, B, H, W, plane);
+    if (split == 2) hipLaunchKernelGGL(pre_mono_kernel<2>, grid, dim3(256), 0, s, frames, out, B, H, W, plane);
+    else if (split) hipLaunchKernelGGL(pre_mono_kernel<1>, grid, dim3(256), 0, s, frames, out, B, H, W, plane);
+    else hipLaunchKernelGGL(pre_mono_kernel<0>, grid, dim3(256), 0, s, frames, out, B, H, W, plane);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
 // K3: max-pool 2x2 stride 2 (TF SAME on even dims = no padding); K11: zero-pad 1 then 3x3 stride 2 VALID
 // ---------------------------------------------------------------------------------------------
-template <bool SPLIT>
+template <int SPLIT>
 __global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C4,
                                                        size_t plane_in, size_t plane_out) {
     const int Ho = H / 2, Wo = W / 2;
@@ -100,12 +102,13 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__
 hipError_t launch_maxpool2(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s) {
     long total = (long)N * (H / 2) * (W / 2) * (C / 4);
     const dim3 grid((unsigned)((total + 255) / 256));
-    if (split) hipLaunchKernelGGL(maxpool2_kernel<true>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
-    else hipLaunchKernelGGL(maxpool2_kernel<false>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
+    if (split == 2) hipLaunchKernelGGL(maxpool2_kernel<2>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
+    else if (split) hipLaunchKernelGGL(maxpool2_kernel<1>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
+    else hipLaunchKernelGGL(maxpool2_kernel<0>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
     return hipGetLastError();
 }
 
-template <bool SPLIT>
+template <int SPLIT>
 __global__ __launch_bounds__(256) void maxpool3z_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C4,
                                                         size_t plane_in, size_t plane_out) {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
@@ -134,8 +137,9 @@ hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     long total = (long)N * Ho * Wo * (C / 4);
     const dim3 grid((unsigned)((total + 255) / 256));
-    if (split) hipLaunchKernelGGL(maxpool3z_kernel<true>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
-    else hipLaunchKernelGGL(maxpool3z_kernel<false>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
+    if (split == 2) hipLaunchKernelGGL(maxpool3z_kernel<2>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
+    else if (split) hipLaunchKernelGGL(maxpool3z_kernel<1>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
+    else hipLaunchKernelGGL(maxpool3z_kernel<0>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
     return hipGetLastError();
 }
 
@@ -153,7 +157,7 @@ __device__ __forceinline__ float smalln_act(float v, int act) {
 }
 
 // weights are laid out [nout][K] (K = k*k*C): one broadcast ds_read_b128 + 4 FMAs per output channel and input quad
-template <int NOUT, bool IN_SPLIT>
+template <int NOUT, int IN_SPLIT>
 __global__ __launch_bounds__(256) void conv_smalln_thread_kernel(const SmallNParams p) {
     extern __shared__ __attribute__((aligned(16))) float wl[];   // [NOUT][K]
     const int K = p.k * p.k * p.C;
@@ -192,7 +196,8 @@ __global__ __launch_bounds__(256) void conv_smalln_thread_kernel(const SmallNPar
     }
     if (p.out_split) {            // NOUT == 2: one bf16 pair per plane
         unsigned h, l;
-        split2(f32x2_t{smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)}, h, l);
+        if (p.f16) split2_t<true>(f32x2_t{smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)}, h, l);
+        else split2_t<false>(f32x2_t{smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)}, h, l);
         if (p.out_c == 8) {       // one zero-padded channel octet per pixel (source of the direct 3x3 kernel)
             reinterpret_cast<u32x4_t*>(p.out)[pix] = (u32x4_t){h, 0u, 0u, 0u};
             reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(p.out) + p.out_plane)[pix] = (u32x4_t){l, 0u, 0u, 0u};
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(256) void conv_smalln_thread_kernel(const SmallNPar
     }
 }
 
-template <bool IN_SPLIT>
+template <int IN_SPLIT>
 __global__ __launch_bounds__(256) void conv_smalln_wave_kernel(const SmallNParams p) {
     const int lane = threadIdx.x & 63;
     long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -262,7 +267,7 @@ __device__ __forceinline__ void sn_dma16(const void* gsrc, unsigned lds_dst) {
 constexpr int SN_TH = 8, SN_TW = 32, SN_HW = SN_TW + 2, SN_HH = SN_TH + 2;
 constexpr int SN_XI = (SN_HH * SN_HW * 2 + 63) / 64;        // 11 DMA instructions per plane
 constexpr int SN_XUNITS = SN_XI * 64;
-template <int NOUT>
+template <int NOUT, bool F16>
 __global__ __launch_bounds__(256) void conv_smalln_tile_kernel(const SmallNParams p) {
     __shared__ __attribute__((aligned(16))) u32x4_t X[2 * SN_XUNITS];
     extern __shared__ __attribute__((aligned(16))) float wl[];   // [NOUT][9 C]
@@ -303,8 +308,8 @@ __global__ __launch_bounds__(256) void conv_smalln_tile_kernel(const SmallNParam
             for (int oct = 0; oct < nvalid; ++oct) {
                 const int idx = lp * 2 + (oct ^ ((lp >> 3) & 1));
                 const u32x4_t h = X[idx], l = X[SN_XUNITS + idx];
-                const f32x4 v0 = recon4(uint2{h[0], h[1]}, uint2{l[0], l[1]});
-                const f32x4 v1 = recon4(uint2{h[2], h[3]}, uint2{l[2], l[3]});
+                const f32x4 v0 = recon4_t<F16>(uint2{h[0], h[1]}, uint2{l[0], l[1]});
+                const f32x4 v1 = recon4_t<F16>(uint2{h[2], h[3]}, uint2{l[2], l[3]});
 #pragma unroll
                 for (int j = 0; j < NOUT; ++j) {
                     const f32x4* wp = reinterpret_cast<const f32x4*>(wl + j * K + tap * p.C + c0 + oct * 8);
@@ -320,7 +325,8 @@ __global__ __launch_bounds__(256) void conv_smalln_tile_kernel(const SmallNParam
     const long pix = ((long)img * p.H + y) * p.W + tx0 + col;
     if (p.out_split) {            // NOUT == 2: one bf16 pair per plane
         unsigned h, l;
-        split2(f32x2_t{smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)}, h, l);
+        if (p.f16) split2_t<true>(f32x2_t{smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)}, h, l);
+        else split2_t<false>(f32x2_t{smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)}, h, l);
         if (p.out_c == 8) {
             reinterpret_cast<u32x4_t*>(p.out)[pix] = (u32x4_t){h, 0u, 0u, 0u};
             reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(p.out) + p.out_plane)[pix] = (u32x4_t){l, 0u, 0u, 0u};
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(256) void conv_smalln_tile_kernel(const SmallNParam
     }
 }
 
-template <bool IN_SPLIT>
+template <int IN_SPLIT>
 static void launch_smalln_t(const SmallNParams& p, hipStream_t s) {
     const long npix = (long)p.N * p.H * p.W;
     const int K = p.k * p.k * p.C;
@@ -343,8 +349,13 @@ static void launch_smalln_t(const SmallNParams& p, hipStream_t s) {
         !std::getenv("SEMDEPTH_NO_SMALLN_TILE")) {
         const dim3 grid((unsigned)((p.W / SN_TW) * ((p.H + SN_TH - 1) / SN_TH) * p.N));
         const size_t lds = (size_t)K * 4 * p.nout;
-        if (p.nout == 1) hipLaunchKernelGGL(conv_smalln_tile_kernel<1>, grid, dim3(256), lds, s, p);
-        else hipLaunchKernelGGL(conv_smalln_tile_kernel<2>, grid, dim3(256), lds, s, p);
+        if (IN_SPLIT == 2) {
+            if (p.nout == 1) hipLaunchKernelGGL((conv_smalln_tile_kernel<1, true>), grid, dim3(256), lds, s, p);
+            else hipLaunchKernelGGL((conv_smalln_tile_kernel<2, true>), grid, dim3(256), lds, s, p);
+        } else {
+            if (p.nout == 1) hipLaunchKernelGGL((conv_smalln_tile_kernel<1, false>), grid, dim3(256), lds, s, p);
+            else hipLaunchKernelGGL((conv_smalln_tile_kernel<2, false>), grid, dim3(256), lds, s, p);
+        }
         return;
     }
     if (K <= 2048) {
@@ -362,22 +373,25 @@ static void launch_smalln_t(const SmallNParams& p, hipStream_t s) {
 }
 hipError_t launch_conv_smalln(const SmallNParams& p, hipStream_t s) {
     if (p.out_split && (p.nout != 2 || p.k * p.k * p.C > 2048)) return hipErrorInvalidValue;
-    if (p.in_split) launch_smalln_t<true>(p, s); else launch_smalln_t<false>(p, s);
+    if (p.in_split && p.f16) launch_smalln_t<2>(p, s);
+    else if (p.in_split) launch_smalln_t<1>(p, s);
+    else launch_smalln_t<0>(p, s);
     return hipGetLastError();
 }
 
 // split planes [npix][C] -> f32 [npix][Ctf] (introspection: sd_net_tensor); Ctf < C for zero-padded tensors
-__global__ __launch_bounds__(256) void unsplit_kernel(const float* __restrict__ x, float* __restrict__ y, long total, int C, int Ctf, size_t plane) {
+__global__ __launch_bounds__(256) void unsplit_kernel(const float* __restrict__ x, float* __restrict__ y, long total, int C, int Ctf, size_t plane, int f16) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const long pix = i / Ctf;
     const int c = (int)(i - pix * Ctf);
     const uint16_t* h = reinterpret_cast<const uint16_t*>(x) + pix * C + c;
-    y[i] = __uint_as_float((unsigned)h[0] << 16) + __uint_as_float((unsigned)h[plane] << 16);
+    if (f16) y[i] = (float)__builtin_bit_cast(_Float16, h[0]) + (float)__builtin_bit_cast(_Float16, h[plane]);
+    else y[i] = __uint_as_float((unsigned)h[0] << 16) + __uint_as_float((unsigned)h[plane] << 16);
 }
-hipError_t launch_unsplit(const float* x, float* y, long npix, int C, int Ctf, size_t plane, hipStream_t s) {
+hipError_t launch_unsplit(const float* x, float* y, long npix, int C, int Ctf, size_t plane, int f16, hipStream_t s) {
     const long total = npix * Ctf;
-    hipLaunchKernelGGL(unsplit_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, total, C, Ctf, plane);
+    hipLaunchKernelGGL(unsplit_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, total, C, Ctf, plane, f16);
     return hipGetLastError();
 }
 

@@ -33,6 +33,7 @@ struct Builder {
     int wslot(const std::string& name, std::initializer_list<int64_t> shape, int layout, int Kpad = 0, int CoutPad = 0, int nout = 0) {
         WeightSlot s;
         s.name = name; s.rank = (int)shape.size(); s.layout = layout; s.Kpad = Kpad; s.CoutPad = CoutPad; s.nout = nout;
+        s.f16 = p.f16;
         int i = 0;
         for (auto v : shape) s.shape[i++] = v;
         size_t n = 0;
@@ -262,10 +263,10 @@ struct Builder {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
-NetPlan build_fcn8s(int frames, int H, int W, int prec) {
+NetPlan build_fcn8s(int frames, int H, int W, int prec, int f16) {
     if (H % 32 || W % 32) throw std::runtime_error("FCN-8s needs H, W multiples of 32");
     Builder b;
-    b.p.prec = prec;
+    b.p.prec = prec; b.p.f16 = prec ? f16 : 0;
     b.p.net = "fcn8s"; b.p.frames = frames; b.p.images = frames; b.p.H = H; b.p.W = W;
     int x = b.tensor("input_pre", frames, H, W, 4);      // 4th channel is zero: float4 gathers in conv1_1
     b.p.tensors[x].Ctf = 3;
@@ -317,11 +318,11 @@ NetPlan build_fcn8s(int frames, int H, int W, int prec) {
 }
 
 // ---------------------------------------------------------------------------------------------
-NetPlan build_monodepth(int encoder, int frames, int H, int W, int prec) {
+NetPlan build_monodepth(int encoder, int frames, int H, int W, int prec, int f16) {
     const int mult = encoder == 0 ? 128 : 64;
     if (H % mult || W % mult) throw std::runtime_error("monodepth needs H, W multiples of 128 (vgg) / 64 (resnet50)");
     Builder b;
-    b.p.prec = prec;
+    b.p.prec = prec; b.p.f16 = prec ? f16 : 0;
     b.p.net = encoder == 0 ? "monodepth-vgg" : "monodepth-resnet50";
     b.p.frames = frames; b.p.images = 2 * frames; b.p.H = H; b.p.W = W;
     const int N = 2 * frames;
@@ -392,6 +393,29 @@ NetPlan build_monodepth(int encoder, int frames, int H, int W, int prec) {
     return b.p;
 }
 
+// f32 -> IEEE fp16 bits, round to nearest even, subnormals kept, overflow -> inf (the weights of the 2-product scheme)
+static uint16_t f32_to_f16_rne(float v) {
+    uint32_t u; std::memcpy(&u, &v, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    u &= 0x7fffffffu;
+    if (u >= 0x7f800000u) return (uint16_t)(sign | (u > 0x7f800000u ? 0x7e00u : 0x7c00u));    // NaN / inf
+    if (u >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                                   // rounds to >= 65520 -> inf
+    if (u < 0x38800000u) {                                                                     // below 2^-14: subnormal
+        if (u < 0x33000000u) return (uint16_t)sign;                                            // < 2^-25 -> 0
+        const int e = (int)(u >> 23);                                                          // 102..112
+        uint32_t m = (u & 0x7fffffu) | 0x800000u;                                              // 24-bit significand
+        const int shift = 126 - e;                                                             // 14..24: value = m * 2^(e-150), unit 2^-24
+        const uint32_t q = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        uint32_t r = q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u);
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = u - 0x38000000u;                                                              // rebias 127 -> 15
+    const uint32_t rem = r & 0x1fffu;
+    r >>= 13;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;
+    return (uint16_t)(sign | r);
+}
+
 // ---------------------------------------------------------------------------------------------
 void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& out) {
     out.assign(s.bytes / sizeof(float), 0.f);
@@ -404,6 +428,7 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
             u += 0x7FFFu + ((u >> 16) & 1u);
             return (uint16_t)(u >> 16);
         };
+        const bool f16 = s.f16 != 0;                   // hi plane = fp16(w) (RNE, subnormals kept), lo plane stays zero
         auto bf16_to_f = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; };
         const int64_t taps = s.shape[0] * s.shape[1], Ctf = s.shape[2], Cout = s.shape[3];
         int CtotPad = 0;
@@ -428,6 +453,7 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
                     } else {                          // two bf16 planes [k/8][n][8]
                         const size_t base = (size_t)(k / 8) * s.CoutPad * 8 + (k % 8);
                         for (int64_t n = 0; n < Cout; ++n) {
+                            if (f16) { hi[base + n * 8] = f32_to_f16_rne(src[n]); continue; }
                             const uint16_t h = bf16(src[n]);
                             hi[base + n * 8] = h;
                             lo[base + n * 8] = bf16(src[n] - bf16_to_f(h));
@@ -454,6 +480,7 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
                         const float* src = w + ((int64_t)tap * Ctf + cb_tf + c) * Cout;
                         const size_t base = (((size_t)chunk * 9 + tap) * 2 + oct) * s.CoutPad * 8 + e;
                         for (int64_t n = 0; n < Cout; ++n) {
+                            if (s.f16) { hi[base + n * 8] = f32_to_f16_rne(src[n]); continue; }
                             const uint16_t h = bf16(src[n]);
                             hi[base + n * 8] = h;
                             lo[base + n * 8] = bf16(src[n] - bf16_to_f(h));

@@ -32,6 +32,7 @@ struct WeightSlot {
     int Kpad = 0, CoutPad = 0, nout = 0;
     int nsrc = 1, srcCtf[3] = {0, 0, 0}, srcCpad[3] = {0, 0, 0};   // WL_IGEMM: channel structure of the K axis
     int vec = 0;           // 1: K axis is ordered (32-channel block, tap, channel) instead of (tap, channel)
+    int f16 = 0;           // split layouts: hi plane = fp16(w), lo plane unused (the 2-product scheme of split_fmt.hpp)
     // a slot may be a VIEW of rows [k_off, k_off+Kpad) of a larger device matrix of Ktotal rows owned by slot `owner`
     // (ResNet block: conv3 and the projection shortcut are one GEMM over the concatenated K axis); a bias view is ADDED
     // to its owner's bias
@@ -67,7 +68,8 @@ struct NetPlan {
     int frames = 0;        // frames per chunk
     int images = 0;        // images per chunk (monodepth: 2 per frame)
     int H = 0, W = 0;
-    int prec = 0;          // 0: exact f32 MFMA, 1: split-bf16 (3 bf16 MFMA products per f32 product)
+    int prec = 0;          // 0: exact f32 MFMA, 1: split engine (planes of split_fmt.hpp)
+    int f16 = 0;           // split engine only: fp16 planes + fp16 weights, 2 MFMA products (else bf16, 3 products)
     std::vector<TensorDesc> tensors;
     std::vector<OpDesc> ops;
     std::vector<WeightSlot> weights;
@@ -78,8 +80,8 @@ struct NetPlan {
     int t_input = -1, t_output = -1;
 };
 
-NetPlan build_fcn8s(int frames, int H, int W, int prec);
-NetPlan build_monodepth(int encoder /*0 vgg, 1 resnet50*/, int frames, int H, int W, int prec);
+NetPlan build_fcn8s(int frames, int H, int W, int prec, int f16 = 0);
+NetPlan build_monodepth(int encoder /*0 vgg, 1 resnet50*/, int frames, int H, int W, int prec, int f16 = 0);
 
 // host-side re-layout of one TensorFlow-layout weight into its slot's kernel layout
 void relayout_weight(const WeightSlot& s, const float* tf_data, std::vector<float>& out);

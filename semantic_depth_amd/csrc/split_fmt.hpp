@@ -1,7 +1,11 @@
-// "Split planes" activation format of the split-bf16 precision (SD_PREC_BF16X2): a tensor [N,H,W,C] is stored as two
-// bf16 planes, hi = RNE_bf16(v) and lo = RNE_bf16(v - hi), the lo plane following the hi plane at a fixed element
-// offset (plane stride = Nmax*H*W*C, Nmax = images of a full chunk).  Same bytes as f32; the MFMA operands of the conv
-// engine are read straight from the planes (16-byte runs of 8 channels), nothing is split at load time.
+// "Split planes" activation format of the split precisions: a tensor [N,H,W,C] is stored as two 16-bit planes,
+// hi = RNE(v) and lo = RNE(v - hi), the lo plane following the hi plane at a fixed element offset (plane stride =
+// Nmax*H*W*C, Nmax = images of a full chunk).  Same bytes as f32; the MFMA operands of the conv engine are read straight
+// from the planes (16-byte runs of 8 channels), nothing is split at load time.
+//   bf16 planes (16 mantissa bits, f32 range): SD_PREC_BF16X2, weights split the same way, 3 MFMA products per product;
+//   fp16 planes (22 mantissa bits, |v| < 65504; the MFMA honours fp16 subnormals): the monodepth network of
+//   SD_PREC_MIXED, weights rounded ONCE to fp16, 2 MFMA products per product (x_hi*w + x_lo*w): the only error is the
+//   2^-12 relative rounding of the weights.  The F16 template argument of the helpers selects the element type.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -39,6 +43,44 @@ __device__ __forceinline__ void split2(f32x2_t v, unsigned& h, unsigned& l) {
 __device__ __forceinline__ void split4(f32x4_t v, uint2& h, uint2& l) {
     split2(f32x2_t{v[0], v[1]}, h.x, l.x);
     split2(f32x2_t{v[2], v[3]}, h.y, l.y);
+}
+
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4s_t __attribute__((ext_vector_type(4)));
+
+template <bool F16> __device__ __forceinline__ f32x2_t recon2_t(unsigned h, unsigned l) {
+    if constexpr (F16) {
+        return __builtin_convertvector(__builtin_bit_cast(f16x2_t, h), f32x2_t) + __builtin_convertvector(__builtin_bit_cast(f16x2_t, l), f32x2_t);
+    } else {
+        return recon2(h, l);
+    }
+}
+template <bool F16> __device__ __forceinline__ f32x4_t recon4_t(uint2 h, uint2 l) {
+    const f32x2_t a = recon2_t<F16>(h.x, l.x), b = recon2_t<F16>(h.y, l.y);
+    return f32x4_t{a[0], a[1], b[0], b[1]};
+}
+template <bool F16> __device__ __forceinline__ void split2_t(f32x2_t v, unsigned& h, unsigned& l) {
+    if constexpr (F16) {
+        const f16x2_t hb = __builtin_convertvector(v, f16x2_t);                   // round to nearest even
+        const f32x2_t r = v - __builtin_convertvector(hb, f32x2_t);               // exact
+        const f16x2_t lb = __builtin_convertvector(r, f16x2_t);
+        h = __builtin_bit_cast(unsigned, hb);
+        l = __builtin_bit_cast(unsigned, lb);
+    } else {
+        split2(v, h, l);
+    }
+}
+template <bool F16> __device__ __forceinline__ void split4_t(f32x4_t v, uint2& h, uint2& l) {
+    split2_t<F16>(f32x2_t{v[0], v[1]}, h.x, l.x);
+    split2_t<F16>(f32x2_t{v[2], v[3]}, h.y, l.y);
+}
+// one 32x32x16 MFMA on raw 16-byte fragments of the selected element type
+template <bool F16> __device__ __forceinline__ f32x16_t mfma_frag(u32x4s_t a, u32x4s_t b, f32x16_t c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
 }  // namespace sd

@@ -83,7 +83,7 @@ class Engine:
         h = C.c_void_p()
         enc = {"vgg": L.SD_ENC_VGG, "resnet50": L.SD_ENC_RESNET50}[encoder]
         self.precision = precision
-        prec = {"f32": L.SD_PREC_F32, "bf16x2": L.SD_PREC_BF16X2}[precision]
+        prec = {"f32": L.SD_PREC_F32, "bf16x2": L.SD_PREC_BF16X2, "mixed": L.SD_PREC_MIXED}[precision]
         st = self.lib.sd_create(C.byref(h), device, H, W, max_batch, enc, prec)
         L.check(self.lib, None, st, f"sd_create(H={H}, W={W}, max_batch={max_batch}, {encoder})")
         self.h = h
