@@ -27,7 +27,7 @@ SOURCES = [
     ("plan.cpp", []),
     ("capi.cpp", []),
 ]
-HEADERS = ["kernels.hpp", "plan.hpp", os.path.join("..", "..", "include", "semdepth.h")]
+HEADERS = ["kernels.hpp", "plan.hpp", "split_fmt.hpp", os.path.join("..", "..", "include", "semdepth.h")]
 
 
 def _hipcc() -> str:
@@ -48,6 +48,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    # a library newer than every source needs nothing, even when the object directory did not travel with the tree
+    # (gpurun ships the .so but not csrc/build/): no one-minute rebuild at the start of every GPU-box command
+    if not force and not _stale(LIB, [os.path.join(CSRC, src) for src, _ in SOURCES] + hdrs):
+        return LIB
     jobs = []
     objs = []
     for src, extra in SOURCES:
