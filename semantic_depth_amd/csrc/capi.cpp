@@ -125,7 +125,8 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 ConvParams c{};
                 c.nsrc = op.nsrc; c.Ctot = op.Ctot;
                 c.N = N; c.Hin = s0.H * (op.up[0] ? 2 : 1); c.Win = s0.W * (op.up[0] ? 2 : 1);
-                c.Hout = d.H; c.Wout = d.W; c.Cout = d.C; c.CoutPad = p.weights[op.w].CoutPad;
+                c.pool = op.fuse_pool;
+                c.Hout = d.H << c.pool; c.Wout = d.W << c.pool; c.Cout = d.C; c.CoutPad = p.weights[op.w].CoutPad;
                 c.kh = c.kw = op.k; c.stride = op.sstride[0]; c.pad = op.pad;
                 c.K = op.K; c.Kpad = op.Kpad;
                 c.wt = Wp(op.w); c.bias = Wp(op.b);
@@ -152,11 +153,12 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                     hipEventRecord(ea, s);
                 }
                 const bool dma = split && conv_dma_variant(c) != 0 && !std::getenv("SEMDEPTH_NO_DMA");
+                if (c.pool && !dma) return fail(h, SD_ERR_STATE, "fused pool needs the LDS-DMA conv kernel");
                 e = dma ? launch_conv_dma(c, s) : split ? launch_conv_split(c, s) : launch_conv_igemm(c, s);
                 if (h->prof) {
                     hipEventRecord(eb, s);
                     h->prof_recs.push_back({dma ? conv_dma_kernel_name(c) : split ? conv_split_kernel_name(c) : conv_igemm_kernel_name(c), op.flops * N / p.images, ea, eb,
-                                            op.name.c_str(), N * d.H * d.W, d.C, op.K});
+                                            op.name.c_str(), N * c.Hout * c.Wout, d.C, op.K});
                 }
                 break;
             }

@@ -99,8 +99,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 2 ? 2 : 1) void c
         const int mm = pok[i] ? m : 0;
         pimg[i] = mm / hw;
         const int r = mm - pimg[i] * hw;
-        poy[i] = r / p.Wout;
-        pox[i] = r - poy[i] * p.Wout;
+        if (p.pool) {            // window-major order: m = (pooled pixel) * 4 + (row in window) * 2 + (column in window)
+            const int q = r >> 2, wp = p.Wout >> 1;
+            const int yp = q / wp, xp = q - yp * wp;
+            poy[i] = 2 * yp + ((r >> 1) & 1);
+            pox[i] = 2 * xp + (r & 1);
+        } else {
+            poy[i] = r / p.Wout;
+            pox[i] = r - poy[i] * p.Wout;
+        }
         pkg[i] = (lane & 3) ^ ((m_l >> 2) & 3);               // the octet this lane fetches into slot lane%4
     }
     const KEntry* __restrict__ const ktab = p.ktab;
@@ -246,6 +253,53 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 2 ? 2 : 1) void c
         const int seg = lane % SEGS, prow = lane / SEGS;
         uint16_t* const out_hi = reinterpret_cast<uint16_t*>(p.out);
         const int m0 = bm0 + wm0, n0 = bn0 + wn0;
+        if (p.pool) {
+            // fused 2x2 max pool: the four pixels of a window are four consecutive accumulator columns = lanes 4j..4j+3;
+            // max over the lane quad, THEN bias + activation (monotonic), one pooled pixel per quad
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int nl = b * 32 + 8 * r4 + 4 * (lane >> 5);
+                        f32x4 v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float mx = acc[a][b][4 * r4 + r];
+                            mx = fmaxf(mx, __shfl_xor(mx, 1));
+                            mx = fmaxf(mx, __shfl_xor(mx, 2));
+                            v[r] = mx;
+                        }
+                        v += *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
+                        uint2 h, l;
+                        split4_t<F16>(v, h, l);
+                        if ((lane & 3) == 0) {
+                            *reinterpret_cast<uint2*>(sh + ((lane & 31) >> 2) * ROW + nl * 2) = h;
+                            *reinterpret_cast<uint2*>(sl + ((lane & 31) >> 2) * ROW + nl * 2) = l;
+                        }
+                    }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int ps = 0; ps < (8 + PPP - 1) / PPP; ++ps) {
+                    const int pix = ps * PPP + prow;                 // pooled pixel of this 32-row block (0..7)
+                    const int mo = m0 + a * 32 + pix * 4;
+                    if (pix < 8 && mo < M) {
+                        const u32x4 h = *reinterpret_cast<const u32x4*>(sh + pix * ROW + seg * 16);
+                        const u32x4 l = *reinterpret_cast<const u32x4*>(sl + pix * ROW + seg * 16);
+                        uint16_t* o = out_hi + (size_t)(mo >> 2) * p.Cout + n0 + seg * 8;
+                        *reinterpret_cast<u32x4*>(o) = h;
+                        *reinterpret_cast<u32x4*>(o + p.out_plane) = l;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            return;
+        }
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
 #pragma unroll
@@ -289,7 +343,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 2 ? 2 : 1) void c
 int conv_dma_variant(const ConvParams& p) {
     if (!p.vec || !p.zero16 || p.Cout % 64 || p.Kpad < 64) return 0;
     const long M = (long)p.N * p.Hout * p.Wout;
-    const long thr = 96;     // tiles needed: the DMA pipeline at half occupancy still beats the register-staged kernel
+    const long thr = p.pool ? 0 : 96;     // tiles needed: the DMA pipeline at half occupancy still beats the register-staged
+                                          // kernel (a fused pool exists only here: such layers always take this kernel)
     if (p.Cout % 256 == 0 && ((M + 127) / 128) * (p.Cout / 256) >= thr) return 1;     // 128 x 256
     if (p.Cout % 128 == 0 && ((M + 255) / 256) * (p.Cout / 128) >= thr) return 2;     // 256 x 128
     if (p.Cout % 128 != 0 && ((M + 255) / 256) * (p.Cout / 64) >= thr) return 3;      // 256 x 64

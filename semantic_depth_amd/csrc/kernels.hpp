@@ -44,6 +44,8 @@ struct ConvParams {
     const void* zero16;  // split engine: 16 zero bytes in device memory (source of out-of-image taps for the LDS-DMA pipeline)
     int Nmax;          // split engine: images of a full chunk (plane stride of a source = Nmax*H*W*C elements)
     int f16;           // split planes are fp16 and the weights one fp16 plane (2 MFMA products): split_fmt.hpp
+    int pool;          // conv_dma.hip: output pixels are walked in 2x2-window-major order and the epilogue max-pools each
+                       // window: out is [N,Hout/2,Wout/2,Cout]
     int simple;        // one source, stride 1, no upsample, all k-tiles vec: the DMA kernel computes its gather addresses
     int dbg;           // SEMDEPTH_DMA_DBG: development ablation switches of conv_dma.hip (0 in production)
     int m_fastest;     // block order: 1 = consecutive blocks walk M (share a weight panel), 0 = walk N

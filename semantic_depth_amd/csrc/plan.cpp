@@ -195,6 +195,19 @@ struct Builder {
             prod.dst = tensor(name, t.N, Ho, Wo, t.C);
             return prod.dst;
         }
+        // the LDS-DMA conv kernel does the same by walking its output pixels in 2x2-window-major order
+        if (!zero3 && p.prec && !p.ops.empty() && p.ops.back().kind == OP_CONV && p.ops.back().dst == src && p.ops.back().vec &&
+            p.ops.back().nsrc == 1 && p.ops.back().Kvec == p.ops.back().Kpad && p.ops.back().Kpad >= 64 && t.C % 64 == 0 &&
+            p.ops.back().residual < 0 && t.H % 2 == 0 && t.W % 2 == 0 &&
+            (p.ops.back().act == ACT_RELU || p.ops.back().act == ACT_ELU || p.ops.back().act == ACT_NONE) && !std::getenv("SEMDEPTH_NO_POOL_FUSE") &&
+            !std::getenv("SEMDEPTH_NO_DMA")) {
+            OpDesc& prod = p.ops.back();
+            prod.fuse_pool = 1;
+            for (auto it = p.tensor_by_name.begin(); it != p.tensor_by_name.end();)
+                it = it->second == src ? p.tensor_by_name.erase(it) : std::next(it);
+            prod.dst = tensor(name, t.N, Ho, Wo, t.C);
+            return prod.dst;
+        }
         op.dst = tensor(name, t.N, Ho, Wo, t.C);
         push(op);
         return op.dst;

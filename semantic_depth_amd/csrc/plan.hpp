@@ -56,7 +56,7 @@ struct OpDesc {
     // conv engine
     int Ctot = 0;          // padded channels per tap (every source rounded up to a multiple of 4)
     int K = 0, Kpad = 0, vec = 0, m_fastest = 0;
-    int fuse_pool = 0;           // OP_CONV_DIRECT: the 2x2 max pool that follows is applied in the epilogue
+    int fuse_pool = 0;           // OP_CONV_DIRECT / OP_CONV (LDS-DMA kernel): the 2x2 max pool that follows is applied in the epilogue
     int nchunks = 0;             // OP_CONV_DIRECT: 32-channel chunks over the concatenated sources
     int Kvec = 0, CqPad = 0;     // mixed layers: K = [vec region: (32-channel block, tap, channel)] + [quad tail: (tap, channel quads)]
     size_t tab_offset = 0, tab_bytes = 0;    // KEntry table, in the weight arena
