@@ -570,7 +570,9 @@ hipError_t launch_gather_planes(const RwResultDev* res, int B, double* planes, h
 constexpr int GRID_CELLS = 1 << 19;
 constexpr int KMAX = 16;
 constexpr int SOR_RMAX = 16;       // shells searched before the brute-force fallback
-constexpr int SOR_RSOFT = 2;       // shells searched one-thread-per-query; deeper queries go to the wave-cooperative kernel
+constexpr int SOR_RSOFT = 2;       // shells searched one-thread-per-query (99 % of a dense cloud end here); a query that needs more
+                                   // hands its k best so far to the wave-cooperative kernel, which continues at the next shell
+                                   // (RSOFT = 1 measured: per-thread kernel 2.95 -> 2.64 ms, cooperative kernel 0.55 -> 1.37 ms)
 constexpr int SCAN_SEG = 2048;     // cells per scan segment
 constexpr int SCAN_NSEG = GRID_CELLS / SCAN_SEG;
 
@@ -587,9 +589,11 @@ struct O3dScratch {       // carved from one arena, per-frame strides
     double* mean_d;       // [B][cap]  (by original index)
     uint8_t* keep;        // [B][cap]
     int* hard_n;          // [B]  statistical filter: queries deferred to the wave-cooperative search (list in cell_of)
+    double* hard_best;    // [B][cap][KMAX]  their k best distances after the per-thread shells (ascending, inf padded)
 };
 size_t o3d_scratch_bytes(int B, int cap) {
-    size_t per = sizeof(GridMeta) + (size_t)GRID_CELLS * 4 + (size_t)(GRID_CELLS + 1) * 4 + SCAN_NSEG * 4 + (size_t)cap * (4 + 4 + 12 + 8 + 1);
+    size_t per = sizeof(GridMeta) + (size_t)GRID_CELLS * 4 + (size_t)(GRID_CELLS + 1) * 4 + SCAN_NSEG * 4 + (size_t)cap * (4 + 4 + 12 + 8 + 1) +
+                 (size_t)cap * KMAX * 8;
     return (size_t)B * (per + 4) + 8192 + 256;
 }
 static O3dScratch carve(void* base, int B, int cap) {
@@ -606,6 +610,7 @@ static O3dScratch carve(void* base, int B, int cap) {
     s.sxyz = (float*)take((size_t)B * cap * 12);
     s.keep = (uint8_t*)take((size_t)B * cap);
     s.hard_n = (int*)take((size_t)B * 4);
+    s.hard_best = (double*)take((size_t)B * cap * KMAX * 8);
     return s;
 }
 
@@ -850,7 +855,8 @@ __device__ __forceinline__ void shell_row(const GridMeta& g, const int* st, int 
 // farther than the searched shells is appended to the frame's hard list (one slow lane would stall its whole wave)
 template <int CAPK>
 __global__ __launch_bounds__(256) void sor_knn_kernel(CloudView in, int cap, const GridMeta* meta, const int* cell_start,
-                                                      const int* sidx, const float* sxyz, int k, double* mean_d, int* hard_n, int* hard_idx) {
+                                                      const int* sidx, const float* sxyz, int k, double* mean_d, int* hard_n, int* hard_idx,
+                                                      double* hard_best) {
     const int b = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int n = min(in.n[b], cap);
@@ -884,7 +890,11 @@ __global__ __launch_bounds__(256) void sor_knn_kernel(CloudView in, int cap, con
         if (r >= rall) done = true;                    // whole grid visited
     }
     if (!done) {
-        hard_idx[(size_t)b * cap + atomicAdd(&hard_n[b], 1)] = j;
+        const int slot = atomicAdd(&hard_n[b], 1);
+        hard_idx[(size_t)b * cap + slot] = j;
+        double* hb = hard_best + ((size_t)b * cap + slot) * CAPK;
+#pragma unroll
+        for (int t = 0; t < CAPK; ++t) hb[t] = top.v[t];
         return;
     }
     double acc = 0.0;
@@ -905,7 +915,7 @@ __device__ __forceinline__ double wave_min_f64(double v) {
 template <int CAPK>
 __global__ __launch_bounds__(256) void sor_knn_hard_kernel(CloudView in, int cap, const GridMeta* meta, const int* cell_start,
                                                            const int* sidx, const float* sxyz, int k, double* mean_d, const int* hard_n,
-                                                           const int* hard_idx) {
+                                                           const int* hard_idx, const double* hard_best) {
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int n = min(in.n[b], cap);
@@ -921,10 +931,13 @@ __global__ __launch_bounds__(256) void sor_knn_hard_kernel(CloudView in, int cap
         const double qx = q[0], qy = q[1], qz = q[2];
         const int cx = cell_coord(qx, g.ox, g.inv, g.gx), cy = cell_coord(qy, g.oy, g.inv, g.gy), cz = cell_coord(qz, g.oz, g.inv, g.gz);
         TopK<CAPK> top;          // this lane's candidates of the current shell
-        double best[CAPK];       // the wave's k best so far (same in every lane), ascending
+        double best[CAPK];       // the wave's k best so far (same in every lane), ascending: shells 0..SOR_RSOFT from the
+        const double* hb = hard_best + ((size_t)b * cap + h) * CAPK;      // per-thread search
 #pragma unroll
-        for (int t = 0; t < CAPK; ++t) best[t] = INFINITY;
-        double gk = INFINITY;    // best[kk-1]
+        for (int t = 0; t < CAPK; ++t) best[t] = hb[t];
+        double gk = best[0];     // best[kk-1]
+#pragma unroll
+        for (int t = 1; t < CAPK; ++t) gk = (t == kk - 1) ? best[t] : gk;
         auto merge = [&]() {     // best <- k smallest of best U all lanes' lists
             double nb[CAPK];
 #pragma unroll
@@ -954,15 +967,21 @@ __global__ __launch_bounds__(256) void sor_knn_hard_kernel(CloudView in, int cap
             gk = kv;
         };
         bool done = false;
-        for (int r = 0; r <= SOR_RMAX && !done; ++r) {
+        for (int r = SOR_RSOFT + 1; r <= SOR_RMAX && !done; ++r) {
             top.init(kk);
             top.kth = gk;                       // prune by the wave's k-th distance; lists hold only this shell's candidates
             const int side = 2 * r + 1;
-            for (int t = lane; t < side * side; t += 64)
-                shell_row(g, st, cx, cy, cz, r, t / side - r, t % side - r, [&](int i) {
+            for (int t = lane; t < side * side; t += 64) {
+                const int dz = t / side - r, dy = t % side - r;
+                double zmin = 0.0, ymin = 0.0, dmax;     // a row farther than the k-th distance cannot contribute
+                if (cz + dz >= 0 && cz + dz < g.gz) axis_bounds(qz, g.oz, g.cell, cz + dz, g.gz, zmin, dmax);
+                if (cy + dy >= 0 && cy + dy < g.gy) axis_bounds(qy, g.oy, g.cell, cy + dy, g.gy, ymin, dmax);
+                if (ymin * ymin + zmin * zmin >= gk) continue;
+                shell_row(g, st, cx, cy, cz, r, dz, dy, [&](int i) {
                     const double d = dist2(qx, qy, qz, pts + (size_t)i * 3);
                     if (d < gk) top.push(d);
                 });
+            }
             merge();
             const double bound = (double)r * g.cell * (1.0 - 1e-9);
             if (gk <= bound * bound) done = true;
@@ -1083,11 +1102,11 @@ hipError_t launch_sor(CloudView in, CloudOut out, int B, int cap, int k, double 
     hipMemsetAsync(sc.hard_n, 0, (size_t)B * 4, s);
     const dim3 qgrid((cap + 255) / 256, B), hgrid(64, B);
     if (k <= 10) {
-        hipLaunchKernelGGL(sor_knn_kernel<10>, qgrid, dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx, sc.sxyz, k, md, sc.hard_n, sc.cell_of);
-        hipLaunchKernelGGL(sor_knn_hard_kernel<10>, hgrid, dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx, sc.sxyz, k, md, sc.hard_n, sc.cell_of);
+        hipLaunchKernelGGL(sor_knn_kernel<10>, qgrid, dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx, sc.sxyz, k, md, sc.hard_n, sc.cell_of, sc.hard_best);
+        hipLaunchKernelGGL(sor_knn_hard_kernel<10>, hgrid, dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx, sc.sxyz, k, md, sc.hard_n, sc.cell_of, sc.hard_best);
     } else {
-        hipLaunchKernelGGL(sor_knn_kernel<KMAX>, qgrid, dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx, sc.sxyz, k, md, sc.hard_n, sc.cell_of);
-        hipLaunchKernelGGL(sor_knn_hard_kernel<KMAX>, hgrid, dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx, sc.sxyz, k, md, sc.hard_n, sc.cell_of);
+        hipLaunchKernelGGL(sor_knn_kernel<KMAX>, qgrid, dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx, sc.sxyz, k, md, sc.hard_n, sc.cell_of, sc.hard_best);
+        hipLaunchKernelGGL(sor_knn_hard_kernel<KMAX>, hgrid, dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx, sc.sxyz, k, md, sc.hard_n, sc.cell_of, sc.hard_best);
     }
     hipLaunchKernelGGL(sor_select_kernel, dim3(B), dim3(TB), 0, s, in, out, cap, ratio, md);
     return hipGetLastError();
