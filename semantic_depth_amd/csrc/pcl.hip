@@ -839,15 +839,32 @@ __device__ __forceinline__ void shell_row(const GridMeta& g, const int* st, int 
     if (face) {
         const int x0 = max(cx - r, 0), x1 = min(cx + r, g.gx - 1);
         const int e = st[rowbase + x1 + 1];
-        for (int t = st[rowbase + x0]; t < e; ++t) visit(t);
+        visit(st[rowbase + x0], e);
     } else {
         const int step = r == 0 ? 1 : 2 * r;
         for (int dx = -r; dx <= r; dx += step) {
             const int x = cx + dx;
             if (x < 0 || x >= g.gx) continue;
             const int e = st[rowbase + x + 1];
-            for (int t = st[rowbase + x]; t < e; ++t) visit(t);
+            visit(st[rowbase + x], e);
         }
+    }
+}
+// the candidates [t0, t1) of a range, four at a time: the twelve coordinate loads are issued together, so the search pays
+// one memory latency per four candidates instead of one each
+template <class F>
+__device__ __forceinline__ void visit_points(const float* __restrict__ pts, double qx, double qy, double qz, int t0, int t1, F&& push) {
+    for (int t = t0; t < t1; t += 4) {
+        float c[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int tt = min(t + u, t1 - 1);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) c[u][j] = pts[(size_t)tt * 3 + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (t + u < t1) push(dist2(qx, qy, qz, c[u]));
     }
 }
 
@@ -882,7 +899,9 @@ __global__ __launch_bounds__(256) void sor_knn_kernel(CloudView in, int cap, con
                     if (cy + dy >= 0 && cy + dy < g.gy) axis_bounds(qy, g.oy, g.cell, cy + dy, g.gy, ymin, ymax);
                     if (ymin * ymin + zmin * zmin >= top.kth) continue;
                 }
-                shell_row(g, st, cx, cy, cz, r, dz, dy, [&](int t) { top.push(dist2(qx, qy, qz, pts + (size_t)t * 3)); });
+                shell_row(g, st, cx, cy, cz, r, dz, dy, [&](int t0, int t1) {
+                    visit_points(pts, qx, qy, qz, t0, t1, [&](double d) { top.push(d); });
+                });
             }
         }
         const double bound = (double)r * g.cell * (1.0 - 1e-9);
@@ -977,9 +996,8 @@ __global__ __launch_bounds__(256) void sor_knn_hard_kernel(CloudView in, int cap
                 if (cz + dz >= 0 && cz + dz < g.gz) axis_bounds(qz, g.oz, g.cell, cz + dz, g.gz, zmin, dmax);
                 if (cy + dy >= 0 && cy + dy < g.gy) axis_bounds(qy, g.oy, g.cell, cy + dy, g.gy, ymin, dmax);
                 if (ymin * ymin + zmin * zmin >= gk) continue;
-                shell_row(g, st, cx, cy, cz, r, dz, dy, [&](int i) {
-                    const double d = dist2(qx, qy, qz, pts + (size_t)i * 3);
-                    if (d < gk) top.push(d);
+                shell_row(g, st, cx, cy, cz, r, dz, dy, [&](int t0, int t1) {
+                    visit_points(pts, qx, qy, qz, t0, t1, [&](double d) { if (d < gk) top.push(d); });
                 });
             }
             merge();
@@ -1064,7 +1082,17 @@ __global__ __launch_bounds__(256) void ror_count_kernel(CloudView in, int cap, c
                     axis_bounds(qx, g.ox, g.cell, x, g.gx, xmin, xmax);
                     if (xmin * xmin + yzmin > r2) continue;            // the whole cell is outside the ball
                     if (xmax * xmax + yzmax < r2) { cnt += e - s0; continue; }   // the whole cell is inside
-                    for (int t = s0; t < e && cnt <= nb; ++t) cnt += dist2(qx, qy, qz, pts + (size_t)t * 3) < r2;
+                    for (int t = s0; t < e && cnt <= nb; t += 4) {       // four candidates per memory latency
+                        float c4[4][3];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int tt = min(t + u, e - 1);
+#pragma unroll
+                            for (int jj = 0; jj < 3; ++jj) c4[u][jj] = pts[(size_t)tt * 3 + jj];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) cnt += (t + u < e) && dist2(qx, qy, qz, c4[u]) < r2;
+                    }
                 }
             }
         }
