@@ -21,6 +21,7 @@ SOURCES = [
     ("conv_split.hip", []),
     ("conv_dma.hip", []),
     ("conv_direct.hip", []),
+    ("conv_stem.hip", []),
     ("ops_misc.hip", []),
     ("fuse.hip", ["-ffp-contract=off"]),
     ("pcl.hip", ["-ffp-contract=off"]),

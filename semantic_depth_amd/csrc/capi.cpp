@@ -141,6 +141,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.zero16 = h->ws + h->o_misc + 256;        // the arena is zero-filled and nothing writes here
                 const bool split = p.prec != 0;
                 c.f16 = p.f16;
+                c.src0 = T(op.src[0]); c.src0_plane = PL(op.src[0]);
                 hipEvent_t ea = nullptr, eb = nullptr;
                 if (h->prof) {
                     if (h->prof_used == h->prof_pool.size()) {
@@ -153,11 +154,12 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                     hipEventRecord(ea, s);
                 }
                 const bool dma = split && conv_dma_variant(c) != 0 && !std::getenv("SEMDEPTH_NO_DMA");
+                const bool stem = split && !dma && conv_stem_eligible(c);
                 if (c.pool && !dma) return fail(h, SD_ERR_STATE, "fused pool needs the LDS-DMA conv kernel");
-                e = dma ? launch_conv_dma(c, s) : split ? launch_conv_split(c, s) : launch_conv_igemm(c, s);
+                e = dma ? launch_conv_dma(c, s) : stem ? launch_conv_stem(c, s) : split ? launch_conv_split(c, s) : launch_conv_igemm(c, s);
                 if (h->prof) {
                     hipEventRecord(eb, s);
-                    h->prof_recs.push_back({dma ? conv_dma_kernel_name(c) : split ? conv_split_kernel_name(c) : conv_igemm_kernel_name(c), op.flops * N / p.images, ea, eb,
+                    h->prof_recs.push_back({dma ? conv_dma_kernel_name(c) : stem ? (c.f16 ? "conv_stem_f16w_kernel" : "conv_stem_kernel") : split ? conv_split_kernel_name(c) : conv_igemm_kernel_name(c), op.flops * N / p.images, ea, eb,
                                             op.name.c_str(), N * c.Hout * c.Wout, d.C, op.K});
                 }
                 break;

@@ -43,6 +43,8 @@ struct ConvParams {
     size_t out_plane;  // split engine: element offset of the output's lo plane
     const void* zero16;  // split engine: 16 zero bytes in device memory (source of out-of-image taps for the LDS-DMA pipeline)
     int Nmax;          // split engine: images of a full chunk (plane stride of a source = Nmax*H*W*C elements)
+    const void* src0;  // first source tensor (hi plane) and the element offset of its lo plane: conv_stem.hip reads it directly
+    size_t src0_plane;
     int f16;           // split planes are fp16 and the weights one fp16 plane (2 MFMA products): split_fmt.hpp
     int pool;          // conv_dma.hip: output pixels are walked in 2x2-window-major order and the epilogue max-pools each
                        // window: out is [N,Hout/2,Wout/2,Cout]
@@ -59,6 +61,8 @@ int conv_split_tile_n(int Cout);
 // LDS-DMA pipeline for the wide vec layers of the split engine (conv_dma.hip); variant 0 = not applicable
 int conv_dma_variant(const ConvParams& p);
 hipError_t launch_conv_dma(const ConvParams& p, hipStream_t s);
+bool conv_stem_eligible(const ConvParams& p);                        // conv_stem.hip: layers on the 4-channel network input
+hipError_t launch_conv_stem(const ConvParams& p, hipStream_t s);
 const char* conv_dma_kernel_name(const ConvParams& p);
 
 #ifdef __HIPCC__

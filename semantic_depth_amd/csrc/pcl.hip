@@ -1106,9 +1106,14 @@ __global__ __launch_bounds__(TB) void keep_select_kernel(CloudView in, CloudOut 
     block_compact(xyz, rgb, n, oxyz, orgb, on, cap, [=](int i, float, float, float) { return kp[i] != 0; }, L);
 }
 
+// zero the cell counters (hipMemsetAsync of 64 MiB ran at ~270 GB/s here; 16-byte stores reach the HBM rate)
+__global__ __launch_bounds__(256) void zero16_kernel(uint4* p, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = uint4{0u, 0u, 0u, 0u};
+}
+
 static void build_grid(CloudView in, int B, int cap, double fixed_cell, const O3dScratch& sc, hipStream_t s, bool keep_meta = false,
                        bool occupancy_only = false) {
-    hipMemsetAsync(sc.cell_cnt, 0, (size_t)B * GRID_CELLS * 4, s);
+    hipLaunchKernelGGL(zero16_kernel, dim3(2048), dim3(256), 0, s, reinterpret_cast<uint4*>(sc.cell_cnt), (size_t)B * GRID_CELLS / 4);
     if (!keep_meta) hipLaunchKernelGGL(grid_meta_kernel, dim3(B), dim3(TB), 0, s, in, cap, fixed_cell, sc.meta);
     dim3 grid((cap + 255) / 256, B);
     hipLaunchKernelGGL(grid_count_kernel, grid, dim3(256), 0, s, in, cap, sc.meta, sc.cell_cnt, sc.cell_of);
