@@ -111,6 +111,12 @@ sd_status sd_fcn8s_forward(sd_handle* h, const uint8_t* frames, int B, float* lo
  * image width.  disp_raw (nullable): f32 [B,2,H,W] = the net's channel-0 output for frame and flipped frame. */
 sd_status sd_monodepth_forward(sd_handle* h, const uint8_t* frames, int B, float* disp_pp, float* disp_raw, void* stream);
 
+/* Input stage, semantic_depth.py:111 / seq:128: cv2.resize(frame, (dst_w, dst_h), interpolation=cv2.INTER_CUBIC) for B
+ * uint8 HWC frames already in device memory (OpenCV's scalar fixed-point path: A = -0.75, weights cvRound(w*2048), borders
+ * replicated, (sum + 2^21) >> 22).  dst_h x dst_w at most the handle's H x W; equal sizes copy. */
+sd_status sd_resize_cubic_u8(sd_handle* h, const uint8_t* src, int B, int src_h, int src_w, int channels, uint8_t* dst, int dst_h,
+                             int dst_w, void* stream);
+
 /* DepthFrame.post_processing alone, semantic_depth.py:656-664: disp_raw f32 [B,2,H,W] -> disp_pp f32 [B,H,W] */
 sd_status sd_post_process(sd_handle* h, const float* disp_raw, int B, float* disp_pp, void* stream);
 

@@ -108,8 +108,12 @@ class FrameProcessor:
     def process_frame(self, frame: np.ndarray, original_width: int | None = None):
         e = self.frame_depther.engine
         d = self.frame_depther
+        # semantic_depth.py:105-112: the frame as read from disk is cubic-resized to the network shape and its ORIGINAL width
+        # scales the disparities; a frame that is not H x W takes the same route here (on the GPU)
         mult = self.disp_multiplier if self.disp_multiplier is not None else (original_width or frame.shape[1])
         fr = torch.from_numpy(np.ascontiguousarray(frame, dtype=np.uint8))[None].to(e.device)
+        if tuple(fr.shape[1:3]) != (e.H, e.W):
+            fr = e.resize_cubic(fr)
         out = e.process_batch(fr, [Camera(d.cx, d.cy, d.f, d.b, float(mult))], self.params)
         rec = Engine.records(out["records"])[0]
         n = int(out["fuse"]["n_road"][0].item())

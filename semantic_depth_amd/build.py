@@ -23,6 +23,7 @@ SOURCES = [
     ("conv_direct.hip", []),
     ("conv_stem.hip", []),
     ("ops_misc.hip", []),
+    ("resize.hip", []),
     ("fuse.hip", ["-ffp-contract=off"]),
     ("pcl.hip", ["-ffp-contract=off"]),
     ("plan.cpp", []),

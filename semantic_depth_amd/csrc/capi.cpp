@@ -28,7 +28,9 @@ struct sd_handle {
     char* wm = nullptr;   // monodepth weight arena
     char* ws = nullptr;   // workspace arena
     // workspace carve (byte offsets)
-    size_t o_fcn = 0, o_mono = 0, o_fuse = 0, o_cams = 0, o_bufA = 0, o_bufB = 0, o_cnt = 0, o_plane = 0, o_o3d = 0, o_misc = 0;
+    size_t o_fcn = 0, o_mono = 0, o_fuse = 0, o_cams = 0, o_bufA = 0, o_bufB = 0, o_cnt = 0, o_plane = 0, o_o3d = 0, o_misc = 0, o_rsz = 0;
+    std::vector<int> rsz_host;      // tap tables of the last sd_resize_cubic_u8 geometry (kept alive for the async upload)
+    int rsz_key[4] = {0, 0, 0, 0};
     size_t ws_bytes = 0;
     int last_fcn_images = 0, last_mono_images = 0;
     std::vector<CamDev> cams_stage;
@@ -74,6 +76,7 @@ void carve_workspace(sd_handle* h) {
     h->o_plane = take(B * sizeof(double) * 4);
     h->o_o3d = take(o3d_scratch_bytes(h->max_batch, h->cap));
     h->o_misc = take(4096 + al(B * 7 * sizeof(int32_t)) + al(B * 12 * sizeof(double)));   // scalars | f2f counts | f2f planes
+    h->o_rsz = take((size_t)(h->H + h->W) * 8 * sizeof(int));     // resize tap tables: [W][4] idx | [W][4] weight | [H][4] idx | [H][4] weight
     h->ws_bytes = off;
 }
 
@@ -373,6 +376,58 @@ sd_status sd_fcn8s_forward(sd_handle* h, const uint8_t* frames, int B, float* lo
         sd_status st = run_plan(h, SD_NET_FCN8S, frames + (size_t)b0 * npix * 3, nb, &ho, (hipStream_t)stream);
         if (st != SD_OK) return st;
     }
+    return SD_OK;
+}
+
+// OpenCV's scalar INTER_CUBIC tables for one axis (imgproc/resize.cpp: resize() + interpolateCubic, A = -0.75, weights as
+// cvRound(w * 2048) int16, tap indices replicated at the borders); mirrored by oracle/resize.py
+static void resize_tables(int dst, int src, int* idx, int* wgt) {
+    const double inv = (double)dst / (double)src, scale = 1.0 / inv;
+    for (int d = 0; d < dst; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        const int s = (int)std::floor(f);
+        const float x = f - (float)s;
+        const float A = -0.75f;
+        float c[4];
+        c[0] = ((A * (x + 1.f) - 5.f * A) * (x + 1.f) + 8.f * A) * (x + 1.f) - 4.f * A;
+        c[1] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+        const float xm = 1.f - x;
+        c[2] = ((A + 2.f) * xm - (A + 3.f)) * xm * xm + 1.f;
+        c[3] = 1.f - c[0] - c[1] - c[2];
+        for (int k = 0; k < 4; ++k) {
+            long v = std::lrint((double)(c[k] * 2048.f));          // cvRound: round half to even
+            v = v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
+            wgt[d * 4 + k] = (int)v;
+            int i = s - 1 + k;
+            idx[d * 4 + k] = i < 0 ? 0 : (i > src - 1 ? src - 1 : i);
+        }
+    }
+}
+
+sd_status sd_resize_cubic_u8(sd_handle* h, const uint8_t* src, int B, int src_h, int src_w, int channels, uint8_t* dst, int dst_h,
+                             int dst_w, void* stream) {
+    if (!h || !src || !dst || B <= 0 || src_h <= 0 || src_w <= 0 || channels <= 0 || channels > 4 || dst_h <= 0 || dst_w <= 0 ||
+        dst_h > h->H || dst_w > h->W)
+        return fail(h, SD_ERR_INVALID, "sd_resize_cubic_u8: bad arguments (destination at most the handle's H x W)");
+    if (!h->bound) return fail(h, SD_ERR_STATE, "sd_bind_memory first");
+    hipStream_t s = (hipStream_t)stream;
+    if (src_h == dst_h && src_w == dst_w) {                        // cv2.resize returns a copy
+        HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)B * src_h * src_w * channels, hipMemcpyDeviceToDevice, s));
+        return SD_OK;
+    }
+    int* dev = reinterpret_cast<int*>(h->ws + h->o_rsz);
+    int *xi = dev, *xa = dev + 4 * (size_t)h->W, *yi = dev + 8 * (size_t)h->W, *ya = yi + 4 * (size_t)h->H;
+    const int key[4] = {src_h, src_w, dst_h, dst_w};
+    if (std::memcmp(key, h->rsz_key, sizeof(key)) != 0) {
+        HIPCHK(h, hipStreamSynchronize(s));                        // the previous tables may still be in use
+        h->rsz_host.assign((size_t)(h->H + h->W) * 8, 0);
+        int* hx = h->rsz_host.data();
+        resize_tables(dst_w, src_w, hx, hx + 4 * (size_t)h->W);
+        resize_tables(dst_h, src_h, hx + 8 * (size_t)h->W, hx + 8 * (size_t)h->W + 4 * (size_t)h->H);
+        HIPCHK(h, hipMemcpy(dev, hx, h->rsz_host.size() * sizeof(int), hipMemcpyHostToDevice));
+        std::memcpy(h->rsz_key, key, sizeof(key));
+    }
+    HIPCHK(h, launch_resize_cubic_u8(src, dst, B, src_h, src_w, dst_h, dst_w, channels, xi, xa, yi, ya, s));
     return SD_OK;
 }
 

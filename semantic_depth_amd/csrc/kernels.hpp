@@ -160,6 +160,9 @@ hipError_t launch_deconv16s8_head(const float* x, const float* w, const float* b
 // ---------------------------------------------------------------------------------------------
 struct CamDev { double q[16]; float mult; };   // Q rounded to f32 then widened; multiplier as f32
 hipError_t launch_post_process(const float* disp_raw, float* disp_pp, int B, int H, int W, hipStream_t s);
+// resize.hip: cv2.INTER_CUBIC for u8 frames; xi/xa (yi/ya): [dw][4] ([dh][4]) tap indices and fixed-point weights (device)
+hipError_t launch_resize_cubic_u8(const uint8_t* src, uint8_t* dst, int B, int sh, int sw, int dh, int dw, int C, const int* xi, const int* xa,
+                                  const int* yi, const int* ya, hipStream_t s);
 struct FuseParams {
     const float* disp_pp;      // [B,H,W]
     const uint8_t* road; const uint8_t* fence; const uint8_t* frames;

@@ -155,6 +155,16 @@ class Engine:
         L.check(self.lib, self.h, st, "sd_monodepth_forward")
         return (pp, raw) if want_raw else pp
 
+    def resize_cubic(self, frames: torch.Tensor, out_h: int | None = None, out_w: int | None = None) -> torch.Tensor:
+        """cv2.resize(frame, (out_w, out_h), interpolation=cv2.INTER_CUBIC) for u8 [B,h,w,C] device frames (semantic_depth.py:111)"""
+        out_h, out_w = out_h or self.H, out_w or self.W
+        assert frames.dtype == torch.uint8 and frames.is_cuda and frames.is_contiguous() and frames.dim() == 4
+        B, sh, sw, ch = frames.shape
+        out = torch.empty((B, out_h, out_w, ch), dtype=torch.uint8, device=self.device)
+        st = self.lib.sd_resize_cubic_u8(self.h, _ptr(frames), B, sh, sw, ch, _ptr(out), out_h, out_w, self._stream())
+        L.check(self.lib, self.h, st, "sd_resize_cubic_u8")
+        return out
+
     def post_process(self, disp_raw: torch.Tensor):
         B = disp_raw.shape[0]
         assert disp_raw.dtype == torch.float32 and tuple(disp_raw.shape[1:]) == (2, self.H, self.W) and disp_raw.is_contiguous()
