@@ -102,7 +102,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
 #pragma unroll
         for (int i = 0; i < XS; ++i) {
             const int j = wave + D_WAVES * i;
-            if (j >= 2 * D_XI || (p.dbg & 1)) continue;
+            if (j >= 2 * D_XI) continue;
             const int ry = geo[i] & 0xff, rx = (geo[i] >> 8) & 0xff, oct = (geo[i] >> 16) & 1;
             const int gy = tl.ty0 - 1 + ry, gx = tl.tx0 - 1 + rx;
             const bool ok = (geo[i] >> 17) && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && oct < ch.nvalid;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
 #pragma unroll
         for (int i = 0; i < ((F16 ? 1 : 2) * D_WI + D_WAVES - 1) / D_WAVES; ++i) {
             const int jw = wave + D_WAVES * i;
-            if (jw < (F16 ? 1 : 2) * D_WI && !(p.dbg & 2)) {
+            if (jw < (F16 ? 1 : 2) * D_WI) {
                 const int pl = jw >= D_WI ? 1 : 0;
                 const u32x4* gw = p.wt + ((size_t)pl * p.nchunks + c) * D_WUNITS + (jw - pl * D_WI) * 64 + lane;
                 ddma16(gw, sbyte + (unsigned)((2 * D_XUNITS + jw * 64) * 16));
@@ -153,7 +153,6 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
             const u32x4* Xl = Xh + D_XUNITS;
             const u32x4* Wh = Xl + D_XUNITS;
             const u32x4* Wl = Wh + D_WUNITS;
-            if (!(p.dbg & 4))
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 u32x4 xh[MT + 2], xl[MT + 2];
@@ -289,7 +288,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
                         const u32x4 h = *reinterpret_cast<const u32x4*>(sh + pix * ROW + seg * 16);
                         u32x4 l = h;
                         if (TWO) l = *reinterpret_cast<const u32x4*>(sl + pix * ROW + seg * 16);
-                        if (y < p.H && seg * 8 < p.Cout && !(p.dbg & 8)) {
+                        if (y < p.H && seg * 8 < p.Cout) {
                             uint16_t* o = out_hi + ((size_t)(cur.img * p.H + y) * p.W + cur.tx0 + pix) * p.Cout + seg * 8;
                             if (TWO) {
                                 *reinterpret_cast<u32x4*>(o) = h;
@@ -321,8 +320,6 @@ hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
         cus = prop.multiProcessorCount;
     }
     ConvDirectParams q = p;
-    static const char* dbg = std::getenv("SEMDEPTH_DIRECT_DBG");
-    q.dbg = dbg ? atoi(dbg) : 0;
     if (p.pool && (p.rows_per_wave != 2 || (p.H & 1) || (p.W & 1))) return hipErrorInvalidValue;
     const int th = 8 * p.rows_per_wave;
     const int tiles = (p.W / D_TW) * ((p.H + th - 1) / th) * p.N;

@@ -49,7 +49,7 @@ struct ConvParams {
     int pool;          // conv_dma.hip: output pixels are walked in 2x2-window-major order and the epilogue max-pools each
                        // window: out is [N,Hout/2,Wout/2,Cout]
     int simple;        // one source, stride 1, no upsample, all k-tiles vec: the DMA kernel computes its gather addresses
-    int dbg;           // SEMDEPTH_DMA_DBG: development ablation switches of conv_dma.hip (0 in production)
+    int dbg;           // SEMDEPTH_DMA_DBG=16: general gather path on SIMPLE layers too (A/B switch; 0 in production)
     int m_fastest;     // block order: 1 = consecutive blocks walk M (share a weight panel), 0 = walk N
 };
 hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t s);
@@ -114,7 +114,6 @@ struct ConvDirectParams {
     size_t out_plane;
     int act, Nmax;
     const void* zero16;
-    int dbg;
     int rows_per_wave;           // 1: 8 x 32 tiles, 2: 16 x 32 tiles (see conv_direct.hip)
     int f16;                     // fp16 planes + single fp16 weight plane (2 MFMA products)
     int pool;                    // 1: fused 2x2 stride-2 max pool, out is [N,H/2,W/2,Cout] (needs rows_per_wave == 2)
