@@ -58,7 +58,7 @@ __device__ __forceinline__ KEntry load_kentry(const KEntry* ptr) {
 // rate, is the practical ceiling this kernel runs against.  A persistent variant (workgroups walking output tiles, the next
 // tile's first k-tiles in flight under the epilogue) measured the same fps within noise (348.4 vs 347.4) and was dropped;
 // issuing the DMAs of the two waves of a SIMD at different points of the k-tile (one before, one between the MFMA clusters)
-// measured -2 % (337.7 vs 344.9 fps).
+// measured -2 % (337.7 vs 344.9 fps); four waves (one per SIMD) with 64 x 128 wave tiles on the same 128 x 256 block -8 %.
 // F16: fp16 planes, ONE fp16 weight plane, two MFMA products per product (split_fmt.hpp): a k-tile then carries 4 weight
 // DMAs less per workgroup and 16 instead of 24 MFMAs per wave.
 template <int WAVES_M, int WAVES_N, int MT, int NT, bool SIMPLE, int STAGES, bool F16 = false>
