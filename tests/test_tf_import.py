@@ -1,0 +1,83 @@
+"""TensorFlow-free readers for checkpoint V2 bundles and frozen GraphDefs.  No TensorFlow and no real
+checkpoint exist in the build container, so the fixtures come from the writers of the same module (UNPINNED against TF)."""
+import numpy as np
+import pytest
+
+from semantic_depth_amd import tf_import as T
+from semantic_depth_amd import weights as W
+
+
+def test_tensor_bundle_round_trip(tmp_path):
+    rng = np.random.default_rng(0)
+    tensors = {f"model/encoder/Conv_{i}/weights": rng.standard_normal((3, 3, 4, 5)).astype(np.float32) for i in range(23)}
+    tensors["model/encoder/Conv/biases"] = rng.standard_normal(7).astype(np.float32)
+    tensors["global_step"] = np.array(123456, np.int64)
+    tensors["scalar"] = np.float32(2.5)
+    prefix = str(tmp_path / "model")
+    T.write_tensor_bundle(prefix, tensors)
+    got = T.read_tensor_bundle(prefix)
+    assert set(got) == set(tensors)
+    for k, v in tensors.items():
+        assert got[k].dtype == np.asarray(v).dtype and np.array_equal(got[k], v), k
+    with pytest.raises(ValueError):
+        open(prefix + ".index", "ab").write(b"x")        # a damaged footer is reported, not mis-parsed
+        T.read_tensor_bundle(prefix)
+
+
+def test_snappy_block_and_varints():
+    raw = b"abcabcabcabc" + bytes(range(70)) + b"abcabc"
+    # literal(3) "abc", copy(len 9, off 3), literal 70 (length >= 60 form), copy2(len 6, off 79)
+    comp = T._put_varint(len(raw)) + bytes([2 << 2]) + b"abc" + bytes([(5 << 2) | 1 | (0 << 5), 3]) + bytes([60 << 2, 69]) + bytes(range(70)) + \
+        bytes([((6 - 1) << 2) | 2]) + (79).to_bytes(2, "little")
+    assert T._snappy(comp) == raw
+    for v in (0, 1, 127, 128, 300, 2 ** 35 + 17):
+        assert T._varint(T._put_varint(v), 0) == (v, len(T._put_varint(v)))
+
+
+def test_frozen_graph_round_trip(tmp_path):
+    rng = np.random.default_rng(1)
+    consts = {"conv1_1/filter": rng.standard_normal((3, 3, 3, 8)).astype(np.float32), "conv1_1/biases": rng.standard_normal(8).astype(np.float32)}
+    p = str(tmp_path / "frozen.pb")
+    T.write_frozen_graph(p, consts)
+    got = T.read_frozen_graph(p)
+    assert all(np.array_equal(got[k], v) for k, v in consts.items())
+
+
+@pytest.mark.parametrize("encoder", ["vgg", "resnet50"])
+def test_monodepth_checkpoint_to_slots(tmp_path, encoder):
+    shapes = W.monodepth_weight_shapes(encoder)
+    nm = T.monodepth_name_map(encoder)
+    assert list(nm) == list(shapes)                                   # every slot mapped, same order
+    assert nm["enc/conv1a/weights" if encoder == "vgg" else "enc/conv1/weights"] == "model/encoder/Conv/weights"
+    assert len(set(nm.values())) == len(nm)
+    if encoder == "resnet50":       # conv1 + 16 blocks x (3 convs + projection) = 65 encoder convs; the last one is Conv_64
+        assert nm["enc/res5_3/proj/biases"] == "model/encoder/Conv_64/biases"
+        assert nm["enc/res2_1/conv2/weights"] == "model/encoder/Conv_2/weights"
+    assert nm["dec/upconv7/weights" if encoder == "vgg" else "dec/upconv6/weights"] == "model/decoder/Conv/weights"
+    rng = np.random.default_rng(2)
+    w = {slot: rng.standard_normal(shape).astype(np.float32) for slot, shape in shapes.items()}
+    prefix = str(tmp_path / "model_cityscapes")
+    T.write_tensor_bundle(prefix, {nm[s]: a for s, a in w.items()} | {"global_step": np.array(1, np.int64)})
+    out = str(tmp_path / "mono.npz")
+    T.main(["--monodepth", prefix, "--encoder", encoder, "--out", out])
+    z = np.load(out)
+    assert set(z.files) == set(shapes) and all(np.array_equal(z[s], w[s]) for s in shapes)
+
+
+def test_fcn8s_frozen_to_slots(tmp_path):
+    shapes = W.fcn8s_weight_shapes()
+    nm = T.fcn8s_name_map()
+    assert nm["vgg/fc6/filter"] == "fc6/weights" and nm["vgg/conv3_2/biases"] == "conv3_2/biases"
+    assert nm["dec/score4/kernel"] == "conv2d_1/kernel" and nm["dec/deconv3/bias"] == "conv2d_transpose_2/bias"
+    rng = np.random.default_rng(3)
+    shapes = {s: shp for s, shp in shapes.items() if np.prod(shp) < 3e6}        # (fc6 alone is 411 MB: keep the fixture small)
+    nm = {s: nm[s] for s in shapes}
+    small = {s: rng.standard_normal(shape).astype(np.float32) for s, shape in shapes.items()}
+    p = str(tmp_path / "frozen.pb")
+    T.write_frozen_graph(p, {nm[s] + "": a for s, a in small.items()})
+    got = T.convert(T.read_frozen_graph(p), nm, shapes)
+    assert all(np.array_equal(got[s], small[s]) for s in shapes)
+    with pytest.raises(ValueError):
+        bad = dict(small); bad["vgg/conv1_1/filter"] = np.zeros((3, 3, 3, 63), np.float32)
+        T.write_frozen_graph(p, {nm[s]: a for s, a in bad.items()})
+        T.convert(T.read_frozen_graph(p), nm, shapes)
