@@ -28,7 +28,7 @@ struct sd_handle {
     char* wm = nullptr;   // monodepth weight arena
     char* ws = nullptr;   // workspace arena
     // workspace carve (byte offsets)
-    size_t o_fcn = 0, o_mono = 0, o_fuse = 0, o_cams = 0, o_bufA = 0, o_bufB = 0, o_cnt = 0, o_plane = 0, o_o3d = 0, o_misc = 0, o_rsz = 0;
+    size_t o_fcn = 0, o_mono = 0, o_fuse = 0, o_cams = 0, o_bufA = 0, o_bufB = 0, o_cnt = 0, o_plane = 0, o_o3d = 0, o_misc = 0, o_rsz = 0, o_cmp = 0;
     std::vector<int> rsz_host;      // tap tables of the last sd_resize_cubic_u8 geometry (kept alive for the async upload)
     int rsz_key[4] = {0, 0, 0, 0};
     size_t ws_bytes = 0;
@@ -76,6 +76,7 @@ void carve_workspace(sd_handle* h) {
     h->o_plane = take(B * sizeof(double) * 4);
     h->o_o3d = take(o3d_scratch_bytes(h->max_batch, h->cap));
     h->o_misc = take(4096 + al(B * 7 * sizeof(int32_t)) + al(B * 12 * sizeof(double)));   // scalars | f2f counts | f2f planes
+    h->o_cmp = take(cmp_scratch_bytes(h->max_batch));
     h->o_rsz = take((size_t)(h->H + h->W) * 8 * sizeof(int));     // resize tap tables: [W][4] idx | [W][4] weight | [H][4] idx | [H][4] weight
     h->ws_bytes = off;
 }
@@ -494,22 +495,26 @@ sd_status sd_road_width(sd_handle* h, const float* road_xyz, const int32_t* n_ro
     double* plane = reinterpret_cast<double*>(h->ws + h->o_plane);
     void* o3d = h->ws + h->o_o3d;
     RwResultDev* res = reinterpret_cast<RwResultDev*>(results);
-    // every stage compacts in place in arena A (ordered compaction only moves rows toward the front)
-    HIPCHK(h, launch_filter_coord({road_xyz, nullptr, n_road}, {A, nullptr, n1}, B, cap, F_LT_NEG, 2, prm->z_cut, s));
-    HIPCHK(h, launch_mad_filter({A, nullptr, n1}, {A, nullptr, n2}, B, cap, 1, prm->mad_y, nullptr, s));
-    HIPCHK(h, launch_mad_filter({A, nullptr, n2}, {A, nullptr, n3}, B, cap, 0, prm->mad_x, nullptr, s));
-    HIPCHK(h, launch_plane_filter({A, nullptr, n3}, {A, nullptr, n4}, B, cap, 1, prm->plane_thr, plane, s));
+    // the stages ping-pong between arenas A and B2: with distinct input and output the ordered compaction of a frame runs on
+    // 64 workgroups instead of one (pcl.hip: multi-block compaction)
+    float* B2 = reinterpret_cast<float*>(h->ws + h->o_bufB);
+    void* cmp = h->ws + h->o_cmp;
+    HIPCHK(h, launch_filter_coord({road_xyz, nullptr, n_road}, {A, nullptr, n1}, B, cap, F_LT_NEG, 2, prm->z_cut, cmp, s));
+    HIPCHK(h, launch_mad_filter({A, nullptr, n1}, {B2, nullptr, n2}, B, cap, 1, prm->mad_y, nullptr, cmp, s));
+    HIPCHK(h, launch_mad_filter({B2, nullptr, n2}, {A, nullptr, n3}, B, cap, 0, prm->mad_x, nullptr, cmp, s));
+    HIPCHK(h, launch_plane_filter({A, nullptr, n3}, {B2, nullptr, n4}, B, cap, 1, prm->plane_thr, plane, cmp, s));
     const int32_t* nlast = n4;
+    const float* fin = B2;
     if (prm->use_o3d) {
-        HIPCHK(h, launch_sor({A, nullptr, n4}, {A, nullptr, n5}, B, cap, prm->sor_k, prm->sor_ratio, o3d, nullptr, s));
-        HIPCHK(h, launch_ror({A, nullptr, n5}, {A, nullptr, n6}, B, cap, prm->ror_n, prm->ror_r, o3d, s));
+        HIPCHK(h, launch_sor({B2, nullptr, n4}, {A, nullptr, n5}, B, cap, prm->sor_k, prm->sor_ratio, o3d, nullptr, cmp, s));
+        HIPCHK(h, launch_ror({A, nullptr, n5}, {B2, nullptr, n6}, B, cap, prm->ror_n, prm->ror_r, o3d, cmp, s));
         nlast = n6;
     } else {
         n5 = n4; n6 = n4;
     }
-    HIPCHK(h, launch_end_points({A, nullptr, nlast}, B, cap, prm->depth - prm->depth_offset, prm->window, res, s));
+    HIPCHK(h, launch_end_points({fin, nullptr, nlast}, B, cap, prm->depth - prm->depth_offset, prm->window, res, s));
     HIPCHK(h, launch_record_counts(res, B, n_road, n1, n2, n3, n4, n5, n6, plane, s));
-    if (final_xyz) HIPCHK(h, hipMemcpyAsync(final_xyz, A, (size_t)B * cap * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (final_xyz) HIPCHK(h, hipMemcpyAsync(final_xyz, fin, (size_t)B * cap * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (n_final) HIPCHK(h, hipMemcpyAsync(n_final, nlast, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     return SD_OK;
 }
@@ -530,13 +535,13 @@ sd_status sd_fence_to_fence(sd_handle* h, const float* fence_xyz, const int32_t*
     double *p_road = planes, *p_left = planes + (size_t)B * 4, *p_right = planes + (size_t)B * 8;
     HIPCHK(h, hipMemcpyAsync(C(0), n_fence, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     HIPCHK(h, launch_gather_planes(reinterpret_cast<const RwResultDev*>(road), B, p_road, s));
-    HIPCHK(h, launch_mad_filter({fence_xyz, nullptr, n_fence}, {A, nullptr, C(1)}, B, cap, 1, prm->mad_y, nullptr, s));
-    HIPCHK(h, launch_filter_coord({A, nullptr, C(1)}, {A, nullptr, C(2)}, B, cap, F_ABS_LT, 2, prm->z_max, s));
+    HIPCHK(h, launch_mad_filter({fence_xyz, nullptr, n_fence}, {A, nullptr, C(1)}, B, cap, 1, prm->mad_y, nullptr, nullptr, s));
+    HIPCHK(h, launch_filter_coord({A, nullptr, C(1)}, {A, nullptr, C(2)}, B, cap, F_ABS_LT, 2, prm->z_max, nullptr, s));
     HIPCHK(h, launch_extract_pcls({A, nullptr, C(2)}, {Lb, nullptr, C(3)}, {Rb, nullptr, C(4)}, B, cap, 0, nullptr, s));
-    HIPCHK(h, launch_mad_filter({Lb, nullptr, C(3)}, {Lb, nullptr, C(5)}, B, cap, 0, prm->mad_left, nullptr, s));
-    HIPCHK(h, launch_plane_filter({Lb, nullptr, C(5)}, {Lb, nullptr, C(5)}, B, cap, 0, prm->plane_thr, p_left, s));
-    HIPCHK(h, launch_mad_filter({Rb, nullptr, C(4)}, {Rb, nullptr, C(6)}, B, cap, 0, prm->mad_right, nullptr, s));
-    HIPCHK(h, launch_plane_filter({Rb, nullptr, C(6)}, {Rb, nullptr, C(6)}, B, cap, 0, prm->plane_thr, p_right, s));
+    HIPCHK(h, launch_mad_filter({Lb, nullptr, C(3)}, {Lb, nullptr, C(5)}, B, cap, 0, prm->mad_left, nullptr, nullptr, s));
+    HIPCHK(h, launch_plane_filter({Lb, nullptr, C(5)}, {Lb, nullptr, C(5)}, B, cap, 0, prm->plane_thr, p_left, nullptr, s));
+    HIPCHK(h, launch_mad_filter({Rb, nullptr, C(4)}, {Rb, nullptr, C(6)}, B, cap, 0, prm->mad_right, nullptr, nullptr, s));
+    HIPCHK(h, launch_plane_filter({Rb, nullptr, C(6)}, {Rb, nullptr, C(6)}, B, cap, 0, prm->plane_thr, p_right, nullptr, s));
     // counts array for the kernel is [7][B] contiguous: compact the strided slots
     for (int j = 0; j < 7; ++j)
         HIPCHK(h, hipMemcpyAsync(packed + (size_t)j * B, C(j), (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
@@ -562,26 +567,26 @@ static sd_status set_n(sd_handle* h, int n, int32_t** dn, hipStream_t s) {
 sd_status sd_pcl_remove_from_to(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int axis, double to_meter,
                                 float* xyz_out, uint8_t* rgb_out, int32_t* n_out, void* stream) {
     PCL_PROLOGUE();
-    HIPCHK(h, launch_filter_coord({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, F_LT_NEG, axis, to_meter, s));
+    HIPCHK(h, launch_filter_coord({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, F_LT_NEG, axis, to_meter, nullptr, s));
     return SD_OK;
 }
 sd_status sd_pcl_threshold_complete(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int axis, double threshold,
                                     float* xyz_out, uint8_t* rgb_out, int32_t* n_out, void* stream) {
     PCL_PROLOGUE();
-    HIPCHK(h, launch_filter_coord({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, F_ABS_LT, axis, threshold, s));
+    HIPCHK(h, launch_filter_coord({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, F_ABS_LT, axis, threshold, nullptr, s));
     return SD_OK;
 }
 sd_status sd_pcl_remove_noise_by_mad(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int axis, double threshold,
                                      float* xyz_out, uint8_t* rgb_out, int32_t* n_out, float* stats_out, void* stream) {
     PCL_PROLOGUE();
-    HIPCHK(h, launch_mad_filter({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, axis, threshold, stats_out, s));
+    HIPCHK(h, launch_mad_filter({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, axis, threshold, stats_out, nullptr, s));
     return SD_OK;
 }
 sd_status sd_pcl_remove_noise_by_fitting_plane(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int axis, double threshold,
                                                float* xyz_out, uint8_t* rgb_out, int32_t* n_out, double* coeff_out, void* stream) {
     PCL_PROLOGUE();
     if (axis < 0 || axis > 2) return fail(h, SD_ERR_INVALID, "axis");
-    HIPCHK(h, launch_plane_filter({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, axis, threshold, coeff_out, s));
+    HIPCHK(h, launch_plane_filter({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, axis, threshold, coeff_out, nullptr, s));
     return SD_OK;
 }
 sd_status sd_pcl_extract_pcls(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int axis, float* left_xyz, uint8_t* left_rgb,
@@ -610,14 +615,14 @@ sd_status sd_o3d_statistical_outlier_removal(sd_handle* h, const float* xyz, con
     PCL_PROLOGUE();
     if (nb_neighbors < 1 || nb_neighbors > 16) return fail(h, SD_ERR_INVALID, "nb_neighbors must be in 1..16");
     if (o3d_scratch_bytes(1, cap1) > o3d_scratch_bytes(h->max_batch, h->cap)) return fail(h, SD_ERR_INVALID, "cloud too large");
-    HIPCHK(h, launch_sor({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, nb_neighbors, std_ratio, h->ws + h->o_o3d, mean_dist_out, s));
+    HIPCHK(h, launch_sor({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, nb_neighbors, std_ratio, h->ws + h->o_o3d, mean_dist_out, nullptr, s));
     return SD_OK;
 }
 sd_status sd_o3d_radius_outlier_removal(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int nb_points, double radius,
                                         float* xyz_out, uint8_t* rgb_out, int32_t* n_out, void* stream) {
     PCL_PROLOGUE();
     if (o3d_scratch_bytes(1, cap1) > o3d_scratch_bytes(h->max_batch, h->cap)) return fail(h, SD_ERR_INVALID, "cloud too large");
-    HIPCHK(h, launch_ror({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, nb_points, radius, h->ws + h->o_o3d, s));
+    HIPCHK(h, launch_ror({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, nb_points, radius, h->ws + h->o_o3d, nullptr, s));
     return SD_OK;
 }
 

@@ -191,9 +191,11 @@ struct CloudView { const float* xyz; const uint8_t* rgb; const int32_t* n; };   
 struct CloudOut { float* xyz; uint8_t* rgb; int32_t* n; };
 
 enum FilterKind { F_LT_NEG = 0 /* coord < -t */, F_ABS_LT = 1 /* |coord| < t */ };
-hipError_t launch_filter_coord(CloudView in, CloudOut out, int B, int cap, int kind, int axis, double t, hipStream_t s);
-hipError_t launch_mad_filter(CloudView in, CloudOut out, int B, int cap, int axis, double thr, float* stats, hipStream_t s);
-hipError_t launch_plane_filter(CloudView in, CloudOut out, int B, int cap, int axis, double thr, double* coeff, hipStream_t s);
+// cscratch (nullable, cmp_scratch_bytes(B)): with it and in != out the ordered compaction runs on 64 workgroups per frame
+size_t cmp_scratch_bytes(int B);
+hipError_t launch_filter_coord(CloudView in, CloudOut out, int B, int cap, int kind, int axis, double t, void* cscratch, hipStream_t s);
+hipError_t launch_mad_filter(CloudView in, CloudOut out, int B, int cap, int axis, double thr, float* stats, void* cscratch, hipStream_t s);
+hipError_t launch_plane_filter(CloudView in, CloudOut out, int B, int cap, int axis, double thr, double* coeff, void* cscratch, hipStream_t s);
 // fence chain
 struct F2fResultDev {   // layout == sd_f2f_result
     double dist; double left_pt[3], right_pt[3]; double plane_left[4], plane_right[4];
@@ -206,9 +208,9 @@ hipError_t launch_f2f(const double* road_plane, const double* left_plane, const 
 hipError_t launch_gather_planes(const RwResultDev* res, int B, double* planes, hipStream_t s);
 hipError_t launch_end_points(CloudView in, int B, int cap, double depth, double window, RwResultDev* res, hipStream_t s);
 size_t o3d_scratch_bytes(int B, int cap);
-hipError_t launch_sor(CloudView in, CloudOut out, int B, int cap, int k, double ratio, void* scratch, double* mean_out,
+hipError_t launch_sor(CloudView in, CloudOut out, int B, int cap, int k, double ratio, void* scratch, double* mean_out, void* cscratch,
                       hipStream_t s);
-hipError_t launch_ror(CloudView in, CloudOut out, int B, int cap, int nb, double radius, void* scratch, hipStream_t s);
+hipError_t launch_ror(CloudView in, CloudOut out, int B, int cap, int nb, double radius, void* scratch, void* cscratch, hipStream_t s);
 // writes the count fields of the per-frame records from device-side counters
 hipError_t launch_record_counts(RwResultDev* res, int B, const int32_t* n_road, const int32_t* n_zcut, const int32_t* n_mad_y,
                                 const int32_t* n_mad_x, const int32_t* n_plane, const int32_t* n_sor, const int32_t* n_ror,

@@ -281,6 +281,129 @@ __device__ void block_compact(const float* __restrict__ xyz, const uint8_t* __re
     int32_t* on = out.n + b;                                                                  \
     __shared__ Lds L;
 
+// ------------------------------------------------------------------------------------------ multi-block compaction
+// A frame's ordered compaction by ONE workgroup (block_compact above) moves 2 MB at ~12 GB/s.  When input and output do not
+// alias, the same result comes from CMP_G workgroups per frame in two launches: every block counts the rows it keeps in
+// its contiguous slice, then writes them at (kept rows of the slices before it) + (its own ballot prefix).  The filters
+// below compute their per-frame statistics with one workgroup as before (COMPACT = false: statistics only, written to the
+// frame's parameter record) and leave the data movement to these two kernels.
+constexpr int CMP_G = 64;            // slices (workgroups) per frame
+constexpr int CMP_PARAMS = 8;        // doubles per frame: MAD {median, mad}; plane {C0, C1, C2}; statistical filter {threshold}
+struct CmpScratch { int* blk_cnt; double* params; };
+size_t cmp_scratch_bytes(int B) { return (size_t)B * (CMP_G * sizeof(int) + CMP_PARAMS * sizeof(double)) + 512; }
+static CmpScratch cmp_carve(void* base, int B) {
+    CmpScratch c;
+    c.params = reinterpret_cast<double*>(base);
+    c.blk_cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(base) + ((size_t)B * CMP_PARAMS * sizeof(double) + 255) / 256 * 256);
+    return c;
+}
+__device__ __forceinline__ void cmp_slice(int n, int g, int& lo, int& hi) {
+    const int S = ((n + CMP_G - 1) / CMP_G + 255) / 256 * 256;
+    lo = min(n, g * S); hi = min(n, lo + S);
+}
+template <class P>
+__global__ __launch_bounds__(256) void cmp_count_kernel(CloudView in, int cap, P pred, int* blk_cnt) {
+    const int b = blockIdx.y, g = blockIdx.x;
+    const int n = min(in.n[b], cap);
+    const float* xyz = in.xyz + (size_t)b * cap * 3;
+    int lo, hi;
+    cmp_slice(n, g, lo, hi);
+    int c = 0;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) c += pred(b, i, xyz[(size_t)i * 3], xyz[(size_t)i * 3 + 1], xyz[(size_t)i * 3 + 2]) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    __shared__ int ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blk_cnt[b * CMP_G + g] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+template <class P>
+__global__ __launch_bounds__(256) void cmp_scatter_kernel(CloudView in, CloudOut out, int cap, P pred, const int* blk_cnt) {
+    const int b = blockIdx.y, g = blockIdx.x;
+    const int n = min(in.n[b], cap);
+    const float* xyz = in.xyz + (size_t)b * cap * 3;
+    const uint8_t* rgb = in.rgb ? in.rgb + (size_t)b * cap * 3 : nullptr;
+    float* oxyz = out.xyz + (size_t)b * cap * 3;
+    uint8_t* orgb = (out.rgb && in.rgb) ? out.rgb + (size_t)b * cap * 3 : nullptr;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // kept rows before this slice (and of the whole frame): 64 counts, one per lane
+    const int mine = blk_cnt[b * CMP_G + lane];
+    int before = lane < g ? mine : 0, total = mine;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o); total += __shfl_xor(total, o); }
+    if (g == 0 && threadIdx.x == 0) out.n[b] = total;
+    int lo, hi;
+    cmp_slice(n, g, lo, hi);
+    __shared__ int wsum[4];
+    int base = before;
+    for (int i0 = lo; i0 < hi; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        float x = 0.f, y = 0.f, z = 0.f;
+        uint8_t c0 = 0, c1 = 0, c2 = 0;
+        bool keep = false;
+        if (i < hi) {
+            x = xyz[(size_t)i * 3]; y = xyz[(size_t)i * 3 + 1]; z = xyz[(size_t)i * 3 + 2];
+            if (rgb) { c0 = rgb[(size_t)i * 3]; c1 = rgb[(size_t)i * 3 + 1]; c2 = rgb[(size_t)i * 3 + 2]; }
+            keep = pred(b, i, x, y, z);
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int c = wsum[w]; if (w < wave) pos += c; tot += c; }
+        if (keep && pos < cap) {
+            oxyz[(size_t)pos * 3] = x; oxyz[(size_t)pos * 3 + 1] = y; oxyz[(size_t)pos * 3 + 2] = z;
+            if (orgb) { orgb[(size_t)pos * 3] = c0; orgb[(size_t)pos * 3 + 1] = c1; orgb[(size_t)pos * 3 + 2] = c2; }
+        }
+        base += tot;
+        __syncthreads();
+    }
+}
+template <class P>
+static void cmp_run(CloudView in, CloudOut out, int B, int cap, P pred, const CmpScratch& c, hipStream_t s) {
+    hipLaunchKernelGGL(cmp_count_kernel<P>, dim3(CMP_G, B), dim3(256), 0, s, in, cap, pred, c.blk_cnt);
+    hipLaunchKernelGGL(cmp_scatter_kernel<P>, dim3(CMP_G, B), dim3(256), 0, s, in, out, cap, pred, c.blk_cnt);
+}
+// the predicates of the filters below, with the same expressions as their single-workgroup forms
+struct CoordPred {
+    int kind, axis; float t;
+    __device__ bool operator()(int, int, float x, float y, float z) const {
+        const float v = axis == 0 ? x : (axis == 1 ? y : z);
+        return kind == F_LT_NEG ? (v < -t) : (fabsf(v) < t);
+    }
+};
+struct MadPred {
+    int axis; float thr; const double* params;
+    __device__ bool operator()(int b, int, float x, float y, float z) const {
+        const float med = (float)params[b * CMP_PARAMS], madv = (float)params[b * CMP_PARAMS + 1];
+        const float v = axis == 0 ? x : (axis == 1 ? y : z);
+        const float pen = 0.6745f * fabsf(v - med) / madv;
+        return pen < thr;
+    }
+};
+struct PlanePred {
+    int iu, iv, id; double thr; const double* params;
+    __device__ bool operator()(int b, int, float x, float y, float z) const {
+        const double C0 = params[b * CMP_PARAMS], C1 = params[b * CMP_PARAMS + 1], C2 = params[b * CMP_PARAMS + 2];
+        const double p[3] = {(double)x, (double)y, (double)z};
+        const double a = ((C0 * p[iu] + C1 * p[iv]) - p[id]) + C2;
+        return fabs(a) < thr;
+    }
+};
+struct SorPred {
+    const double* mean_d; int cap; const double* params;
+    __device__ bool operator()(int b, int i, float, float, float) const {
+        const double v = mean_d[(size_t)b * cap + i];
+        return v > 0.0 && v < params[b * CMP_PARAMS];
+    }
+};
+struct KeepPred {
+    const uint8_t* keep; int cap;
+    __device__ bool operator()(int b, int i, float, float, float) const { return keep[(size_t)b * cap + i] != 0; }
+};
+
 // ------------------------------------------------------------------------------------------ K20 / threshold
 // pcl.remove_from_to (pcl.py:30-43): keep coord < -t.   pcl.threshold_complete (pcl.py:240-250): keep |coord| < t.
 // The comparison is float32 vs the float32-rounded literal, as numpy does for a float32 column.
@@ -291,7 +414,11 @@ __global__ __launch_bounds__(TB) void filter_coord_kernel(CloudView in, CloudOut
         return kind == F_LT_NEG ? (v < -t) : (fabsf(v) < t);
     }, L);
 }
-hipError_t launch_filter_coord(CloudView in, CloudOut out, int B, int cap, int kind, int axis, double t, hipStream_t s) {
+hipError_t launch_filter_coord(CloudView in, CloudOut out, int B, int cap, int kind, int axis, double t, void* cscratch, hipStream_t s) {
+    if (cscratch && in.xyz != out.xyz) {
+        cmp_run(in, out, B, cap, CoordPred{kind, axis, (float)t}, cmp_carve(cscratch, B), s);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(filter_coord_kernel, dim3(B), dim3(TB), 0, s, in, out, cap, kind, axis, (float)t);
     return hipGetLastError();
 }
@@ -299,7 +426,8 @@ hipError_t launch_filter_coord(CloudView in, CloudOut out, int B, int cap, int k
 // ------------------------------------------------------------------------------------------ K21 MAD
 // pcl.remove_noise_by_mad + mad (pcl.py:46-81), all float32 like numpy on a float32 column:
 //   med = median(v); dev = |v - med|; MAD = median(dev); keep 0.6745f*dev/MAD < thr
-__global__ __launch_bounds__(TB) void mad_filter_kernel(CloudView in, CloudOut out, int cap, int axis, float thr, float* stats) {
+template <bool COMPACT>
+__global__ __launch_bounds__(TB) void mad_filter_kernel(CloudView in, CloudOut out, int cap, int axis, float thr, float* stats, double* params) {
     FRAME_VIEW();
     __shared__ MedLds M;
     auto col = [=](int i) { return xyz[(size_t)i * 3 + axis]; };
@@ -307,14 +435,24 @@ __global__ __launch_bounds__(TB) void mad_filter_kernel(CloudView in, CloudOut o
     auto dev = [=](int i) { return fabsf(xyz[(size_t)i * 3 + axis] - med); };
     const float madv = block_median_fast(dev, n, L, M);
     if (stats && threadIdx.x == 0) { stats[b * 2] = med; stats[b * 2 + 1] = madv; }
+    if (!COMPACT) {
+        if (threadIdx.x == 0) { params[b * CMP_PARAMS] = (double)med; params[b * CMP_PARAMS + 1] = (double)madv; }
+        return;
+    }
     block_compact(xyz, rgb, n, oxyz, orgb, on, cap, [=](int, float x, float y, float z) {
         const float v = axis == 0 ? x : (axis == 1 ? y : z);
         const float pen = 0.6745f * fabsf(v - med) / madv;
         return pen < thr;
     }, L);
 }
-hipError_t launch_mad_filter(CloudView in, CloudOut out, int B, int cap, int axis, double thr, float* stats, hipStream_t s) {
-    hipLaunchKernelGGL(mad_filter_kernel, dim3(B), dim3(TB), 0, s, in, out, cap, axis, (float)thr, stats);
+hipError_t launch_mad_filter(CloudView in, CloudOut out, int B, int cap, int axis, double thr, float* stats, void* cscratch, hipStream_t s) {
+    if (cscratch && in.xyz != out.xyz) {
+        const CmpScratch c = cmp_carve(cscratch, B);
+        hipLaunchKernelGGL(mad_filter_kernel<false>, dim3(B), dim3(TB), 0, s, in, out, cap, axis, (float)thr, stats, c.params);
+        cmp_run(in, out, B, cap, MadPred{axis, (float)thr, c.params}, c, s);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(mad_filter_kernel<true>, dim3(B), dim3(TB), 0, s, in, out, cap, axis, (float)thr, stats, (double*)nullptr);
     return hipGetLastError();
 }
 
@@ -322,7 +460,8 @@ hipError_t launch_mad_filter(CloudView in, CloudOut out, int B, int cap, int axi
 // pcl.remove_noise_by_fitting_plane (pcl.py:84-209): least squares dep = C0*u + C1*v + C2 in float64
 // (the reference calls scipy.linalg.lstsq on float64 columns; here: centred normal equations, float64,
 // deterministic reduction order), then keep |C0*u + C1*v - dep + C2| < thr (float64).
-__global__ __launch_bounds__(TB) void plane_filter_kernel(CloudView in, CloudOut out, int cap, int axis, double thr, double* coeff) {
+template <bool COMPACT>
+__global__ __launch_bounds__(TB) void plane_filter_kernel(CloudView in, CloudOut out, int cap, int axis, double thr, double* coeff, double* params) {
     FRAME_VIEW();
     const int iu = axis == 0 ? 1 : 0, iv = axis == 2 ? 1 : 2, id = axis;
     double su = 0, sv = 0, sd_ = 0;
@@ -352,14 +491,24 @@ __global__ __launch_bounds__(TB) void plane_filter_kernel(CloudView in, CloudOut
         else                { c[0] = C0; c[1] = C1; c[2] = -1.0; }
         c[3] = C2;
     }
+    if (!COMPACT) {
+        if (threadIdx.x == 0) { params[b * CMP_PARAMS] = C0; params[b * CMP_PARAMS + 1] = C1; params[b * CMP_PARAMS + 2] = C2; }
+        return;
+    }
     block_compact(xyz, rgb, n, oxyz, orgb, on, cap, [=](int, float x, float y, float z) {
         const double p[3] = {(double)x, (double)y, (double)z};
         const double a = ((C0 * p[iu] + C1 * p[iv]) - p[id]) + C2;
         return fabs(a) < thr;
     }, L);
 }
-hipError_t launch_plane_filter(CloudView in, CloudOut out, int B, int cap, int axis, double thr, double* coeff, hipStream_t s) {
-    hipLaunchKernelGGL(plane_filter_kernel, dim3(B), dim3(TB), 0, s, in, out, cap, axis, thr, coeff);
+hipError_t launch_plane_filter(CloudView in, CloudOut out, int B, int cap, int axis, double thr, double* coeff, void* cscratch, hipStream_t s) {
+    if (cscratch && in.xyz != out.xyz) {
+        const CmpScratch c = cmp_carve(cscratch, B);
+        hipLaunchKernelGGL(plane_filter_kernel<false>, dim3(B), dim3(TB), 0, s, in, out, cap, axis, thr, coeff, c.params);
+        cmp_run(in, out, B, cap, PlanePred{axis == 0 ? 1 : 0, axis == 2 ? 1 : 2, axis, thr, c.params}, c, s);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(plane_filter_kernel<true>, dim3(B), dim3(TB), 0, s, in, out, cap, axis, thr, coeff, (double*)nullptr);
     return hipGetLastError();
 }
 
@@ -1022,7 +1171,8 @@ __global__ __launch_bounds__(256) void sor_knn_hard_kernel(CloudView in, int cap
     }
 }
 
-__global__ __launch_bounds__(TB) void sor_select_kernel(CloudView in, CloudOut out, int cap, double ratio, const double* mean_d) {
+template <bool COMPACT>
+__global__ __launch_bounds__(TB) void sor_select_kernel(CloudView in, CloudOut out, int cap, double ratio, const double* mean_d, double* params) {
     FRAME_VIEW();
     const double* md = mean_d + (size_t)b * cap;
     double s = 0.0;
@@ -1035,6 +1185,10 @@ __global__ __launch_bounds__(TB) void sor_select_kernel(CloudView in, CloudOut o
     const double sq = block_sum_f64(q, L);
     const double stdv = sqrt(sq / (double)(n - 1));
     const double thr = cloud_mean + ratio * stdv;
+    if (!COMPACT) {
+        if (threadIdx.x == 0) params[b * CMP_PARAMS] = thr;
+        return;
+    }
     block_compact(xyz, rgb, n, oxyz, orgb, on, cap, [=](int i, float, float, float) {
         const double v = md[i];
         return v > 0.0 && v < thr;
@@ -1124,7 +1278,8 @@ static void build_grid(CloudView in, int B, int cap, double fixed_cell, const O3
     hipLaunchKernelGGL(grid_scatter_kernel, grid, dim3(256), 0, s, in, cap, sc.cell_cnt, sc.cell_start, sc.cell_of, sc.sidx, sc.sxyz);
 }
 
-hipError_t launch_sor(CloudView in, CloudOut out, int B, int cap, int k, double ratio, void* scratch, double* mean_out, hipStream_t s) {
+hipError_t launch_sor(CloudView in, CloudOut out, int B, int cap, int k, double ratio, void* scratch, double* mean_out, void* cscratch,
+                      hipStream_t s) {
     if (k > KMAX) return hipErrorInvalidValue;
     O3dScratch sc = carve(scratch, B, cap);
     build_grid(in, B, cap, 0.0, sc, s, /*keep_meta=*/false, /*occupancy_only=*/true);
@@ -1141,15 +1296,25 @@ hipError_t launch_sor(CloudView in, CloudOut out, int B, int cap, int k, double 
         hipLaunchKernelGGL(sor_knn_kernel<KMAX>, qgrid, dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx, sc.sxyz, k, md, sc.hard_n, sc.cell_of, sc.hard_best);
         hipLaunchKernelGGL(sor_knn_hard_kernel<KMAX>, hgrid, dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx, sc.sxyz, k, md, sc.hard_n, sc.cell_of, sc.hard_best);
     }
-    hipLaunchKernelGGL(sor_select_kernel, dim3(B), dim3(TB), 0, s, in, out, cap, ratio, md);
+    if (cscratch && in.xyz != out.xyz) {
+        const CmpScratch c = cmp_carve(cscratch, B);
+        hipLaunchKernelGGL(sor_select_kernel<false>, dim3(B), dim3(TB), 0, s, in, out, cap, ratio, md, c.params);
+        cmp_run(in, out, B, cap, SorPred{md, cap, c.params}, c, s);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(sor_select_kernel<true>, dim3(B), dim3(TB), 0, s, in, out, cap, ratio, md, (double*)nullptr);
     return hipGetLastError();
 }
 
-hipError_t launch_ror(CloudView in, CloudOut out, int B, int cap, int nb, double radius, void* scratch, hipStream_t s) {
+hipError_t launch_ror(CloudView in, CloudOut out, int B, int cap, int nb, double radius, void* scratch, void* cscratch, hipStream_t s) {
     O3dScratch sc = carve(scratch, B, cap);
     build_grid(in, B, cap, radius / ROR_RINGS * (1.0 + 1e-6), sc, s);
     hipLaunchKernelGGL(ror_count_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, s, in, cap, sc.meta, sc.cell_start, sc.sidx,
                        sc.sxyz, nb, radius * radius, sc.keep);
+    if (cscratch && in.xyz != out.xyz) {
+        cmp_run(in, out, B, cap, KeepPred{sc.keep, cap}, cmp_carve(cscratch, B), s);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(keep_select_kernel, dim3(B), dim3(TB), 0, s, in, out, cap, sc.keep);
     return hipGetLastError();
 }
