@@ -57,8 +57,11 @@ __device__ __forceinline__ DirectChunk load_chunk(const DirectChunk* ptr) {
 // persistent: workgroup b walks tiles b, b + grid, ...; the (tile, chunk) sequence is one software pipeline, so the first
 // chunk of the next tile lands while the current tile's epilogue runs.
 // F16: fp16 planes, ONE fp16 weight plane, two MFMA products per product (split_fmt.hpp)
-template <int NB, int MT, bool F16>
+// N16 (Cout <= 16, NB = 1): the 32-row MFMA would spend half its rows on padding, so the products run on
+// v_mfma_f32_16x16x32 instead: K = 32 is one PAIR of taps x 16 channels, a wave's 2 x 32 pixels are four 16-pixel blocks.
+template <int NB, int MT, bool F16, bool N16 = false>
 __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectParams p) {
+    static_assert(!N16 || NB == 1, "N16 is a variant of the 32-channel kernel");
     using Cfg = DirectCfg<NB, MT>;
     constexpr int D_WI = Cfg::WI, D_WUNITS = Cfg::WUNITS, D_STAGE = Cfg::STAGE;
     constexpr int D_TH = Cfg::TH, D_HH = Cfg::HH, D_XI = Cfg::XI, D_XUNITS = Cfg::XUNITS, XS = Cfg::XS;
@@ -128,6 +131,9 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
         const int nl = 8 * r4 + 4 * fk;
         bias[r4] = nl < p.Cout ? *reinterpret_cast<const f32x4*>(p.bias + nl) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    const int c16 = lane & 15, kg16 = lane >> 4;           // N16 fragment coordinates
+    f32x4 bias16 = {0.f, 0.f, 0.f, 0.f};
+    if (N16 && 4 * kg16 < p.Cout) bias16 = *reinterpret_cast<const f32x4*>(p.bias + 4 * kg16);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     int tid = blockIdx.x;
@@ -143,6 +149,11 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][nb][r] = 0.f;
+        f32x4 acc16[MT][2];
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) acc16[a][pb] = (f32x4){0.f, 0.f, 0.f, 0.f};
         Tile nxt = cur;
         for (int c = 0; c < p.nchunks; ++c, ++g) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -153,6 +164,30 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
             const u32x4* Xl = Xh + D_XUNITS;
             const u32x4* Wh = Xl + D_XUNITS;
             const u32x4* Wl = Wh + D_WUNITS;
+            if constexpr (N16) {
+                const u32x4 z4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int tp = 0; tp < 5; ++tp) {             // tap pairs (0,1) (2,3) (4,5) (6,7) (8,-)
+                    const int tap = 2 * tp + (kg16 >> 1), oct = kg16 & 1;
+                    const bool live = tap < 9;
+                    const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;         // tap / 3, tap % 3 for tap < 10
+                    const int wi = (tap * 2 + oct) * 32 + c16;
+                    const u32x4 wh = live ? Wh[wi] : z4;
+                    const u32x4 wl = F16 ? wh : (live ? Wl[wi] : z4);
+#pragma unroll
+                    for (int a = 0; a < MT; ++a)
+#pragma unroll
+                        for (int pb = 0; pb < 2; ++pb) {
+                            const int lp = (MT * wave + a + dy) * D_HW + 16 * pb + c16 + dx;
+                            const int idx = lp * 2 + (oct ^ ((lp >> 3) & 1));
+                            const u32x4 xh = live ? Xh[idx] : z4;
+                            const u32x4 xl = live ? Xl[idx] : z4;
+#pragma unroll
+                            for (int pr = (F16 ? 1 : 0); pr < 3; ++pr)
+                                acc16[a][pb] = mfma_frag16<F16>(pr == 0 ? wl : wh, pr == 1 ? xl : xh, acc16[a][pb]);
+                        }
+                }
+            } else {
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 u32x4 xh[MT + 2], xl[MT + 2];
@@ -177,6 +212,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
                                 acc[a][nb] = mfma_frag<F16>(pr == 0 ? wl : wh, pr == 1 ? xl[a + dy] : xh[a + dy], acc[a][nb]);
                     }
             }
+            }
         }
 
         // ---- epilogue: bias + activation, split once, LDS transpose (in the stage just consumed; the other one is being
@@ -193,6 +229,42 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
             unsigned char* sl = TWO ? sh + 32 * ROW : sh;
             const int seg = lane % SEGS, prow = lane / SEGS;
             uint16_t* const out_hi = reinterpret_cast<uint16_t*>(p.out);
+            if constexpr (N16) {
+                // lane holds channels 4 kg16 .. + 3 of pixel 16 pb + c16; slab row = 16 channels (32 B) + pad per plane
+                constexpr int R16 = 32 + 16;
+                unsigned char* s16 = reinterpret_cast<unsigned char*>(lds + ((g - 1) & 1) * D_STAGE) + wave * (2 * 32 * R16);
+#pragma unroll
+                for (int a = 0; a < MT; ++a) {
+                    const int y = cur.ty0 + MT * wave + a;
+#pragma unroll
+                    for (int pb = 0; pb < 2; ++pb) {
+                        f32x4 v = acc16[a][pb] + bias16;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
+                        uint2 h, l;
+                        split4_t<F16>(v, h, l);
+                        if (4 * kg16 < p.Cout) {
+                            *reinterpret_cast<uint2*>(s16 + (16 * pb + c16) * R16 + kg16 * 8) = h;
+                            *reinterpret_cast<uint2*>(s16 + 32 * R16 + (16 * pb + c16) * R16 + kg16 * 8) = l;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    {   // 32 pixels x 2 segments of 8 channels = 64 lanes, one pass per plane
+                        const int pix = lane >> 1, sg = lane & 1;
+                        const u32x4 h = *reinterpret_cast<const u32x4*>(s16 + pix * R16 + sg * 16);
+                        const u32x4 l = *reinterpret_cast<const u32x4*>(s16 + 32 * R16 + pix * R16 + sg * 16);
+                        if (y < p.H && sg * 8 < p.Cout) {
+                            uint16_t* o = out_hi + ((size_t)(cur.img * p.H + y) * p.W + cur.tx0 + pix) * p.Cout + sg * 8;
+                            *reinterpret_cast<u32x4*>(o) = h;
+                            *reinterpret_cast<u32x4*>(o + p.out_plane) = l;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                return;
+            }
             if (MT == 2 && p.pool) {
                 // fused 2x2 max pool: vertical max across the wave's two rows (same lane), horizontal across lane pairs
                 // (pixel = lane & 31), THEN bias + activation (monotonic) on a quarter of the values
@@ -325,12 +397,15 @@ hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
     const int tiles = (p.W / D_TW) * ((p.H + th - 1) / th) * p.N;
     const dim3 grid((unsigned)(tiles < cus ? tiles : cus));
     const int nb = p.Cout <= 32 ? 1 : 2;
+    const bool n16 = p.Cout <= 16 && !p.pool && !std::getenv("SEMDEPTH_NO_N16");
     if (p.rows_per_wave != 2) return hipErrorInvalidValue;       // (8-row tiles were measured no better and are not built)
     if (p.f16) {
-        if (nb == 1) hipLaunchKernelGGL((conv_direct_kernel<1, 2, true>), grid, dim3(512), 0, s, q);
+        if (n16) hipLaunchKernelGGL((conv_direct_kernel<1, 2, true, true>), grid, dim3(512), 0, s, q);
+        else if (nb == 1) hipLaunchKernelGGL((conv_direct_kernel<1, 2, true>), grid, dim3(512), 0, s, q);
         else hipLaunchKernelGGL((conv_direct_kernel<2, 2, true>), grid, dim3(512), 0, s, q);
     } else {
-        if (nb == 1) hipLaunchKernelGGL((conv_direct_kernel<1, 2, false>), grid, dim3(512), 0, s, q);
+        if (n16) hipLaunchKernelGGL((conv_direct_kernel<1, 2, false, true>), grid, dim3(512), 0, s, q);
+        else if (nb == 1) hipLaunchKernelGGL((conv_direct_kernel<1, 2, false>), grid, dim3(512), 0, s, q);
         else hipLaunchKernelGGL((conv_direct_kernel<2, 2, false>), grid, dim3(512), 0, s, q);
     }
     return hipGetLastError();

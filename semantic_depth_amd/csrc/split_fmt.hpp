@@ -83,4 +83,11 @@ template <bool F16> __device__ __forceinline__ f32x16_t mfma_frag(u32x4s_t a, u3
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
+// one 16x16x32 MFMA (A: 16 rows x 32 k, B: 32 k x 16 columns; lane l supplies row/column l & 15, k = 8 (l >> 4) .. + 7 and
+// holds D[4 (l >> 4) + r][l & 15]) on raw 16-byte fragments
+template <bool F16> __device__ __forceinline__ f32x4_t mfma_frag16(u32x4s_t a, u32x4s_t b, f32x4_t c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
 }  // namespace sd
