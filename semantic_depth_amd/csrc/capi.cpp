@@ -567,26 +567,26 @@ static sd_status set_n(sd_handle* h, int n, int32_t** dn, hipStream_t s) {
 sd_status sd_pcl_remove_from_to(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int axis, double to_meter,
                                 float* xyz_out, uint8_t* rgb_out, int32_t* n_out, void* stream) {
     PCL_PROLOGUE();
-    HIPCHK(h, launch_filter_coord({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, F_LT_NEG, axis, to_meter, nullptr, s));
+    HIPCHK(h, launch_filter_coord({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, F_LT_NEG, axis, to_meter, h->ws + h->o_cmp, s));
     return SD_OK;
 }
 sd_status sd_pcl_threshold_complete(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int axis, double threshold,
                                     float* xyz_out, uint8_t* rgb_out, int32_t* n_out, void* stream) {
     PCL_PROLOGUE();
-    HIPCHK(h, launch_filter_coord({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, F_ABS_LT, axis, threshold, nullptr, s));
+    HIPCHK(h, launch_filter_coord({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, F_ABS_LT, axis, threshold, h->ws + h->o_cmp, s));
     return SD_OK;
 }
 sd_status sd_pcl_remove_noise_by_mad(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int axis, double threshold,
                                      float* xyz_out, uint8_t* rgb_out, int32_t* n_out, float* stats_out, void* stream) {
     PCL_PROLOGUE();
-    HIPCHK(h, launch_mad_filter({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, axis, threshold, stats_out, nullptr, s));
+    HIPCHK(h, launch_mad_filter({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, axis, threshold, stats_out, h->ws + h->o_cmp, s));
     return SD_OK;
 }
 sd_status sd_pcl_remove_noise_by_fitting_plane(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int axis, double threshold,
                                                float* xyz_out, uint8_t* rgb_out, int32_t* n_out, double* coeff_out, void* stream) {
     PCL_PROLOGUE();
     if (axis < 0 || axis > 2) return fail(h, SD_ERR_INVALID, "axis");
-    HIPCHK(h, launch_plane_filter({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, axis, threshold, coeff_out, nullptr, s));
+    HIPCHK(h, launch_plane_filter({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, axis, threshold, coeff_out, h->ws + h->o_cmp, s));
     return SD_OK;
 }
 sd_status sd_pcl_extract_pcls(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int axis, float* left_xyz, uint8_t* left_rgb,
@@ -615,14 +615,14 @@ sd_status sd_o3d_statistical_outlier_removal(sd_handle* h, const float* xyz, con
     PCL_PROLOGUE();
     if (nb_neighbors < 1 || nb_neighbors > 16) return fail(h, SD_ERR_INVALID, "nb_neighbors must be in 1..16");
     if (o3d_scratch_bytes(1, cap1) > o3d_scratch_bytes(h->max_batch, h->cap)) return fail(h, SD_ERR_INVALID, "cloud too large");
-    HIPCHK(h, launch_sor({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, nb_neighbors, std_ratio, h->ws + h->o_o3d, mean_dist_out, nullptr, s));
+    HIPCHK(h, launch_sor({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, nb_neighbors, std_ratio, h->ws + h->o_o3d, mean_dist_out, h->ws + h->o_cmp, s));
     return SD_OK;
 }
 sd_status sd_o3d_radius_outlier_removal(sd_handle* h, const float* xyz, const uint8_t* rgb, int n, int nb_points, double radius,
                                         float* xyz_out, uint8_t* rgb_out, int32_t* n_out, void* stream) {
     PCL_PROLOGUE();
     if (o3d_scratch_bytes(1, cap1) > o3d_scratch_bytes(h->max_batch, h->cap)) return fail(h, SD_ERR_INVALID, "cloud too large");
-    HIPCHK(h, launch_ror({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, nb_points, radius, h->ws + h->o_o3d, nullptr, s));
+    HIPCHK(h, launch_ror({xyz, rgb, dn}, {xyz_out, rgb_out, n_out}, 1, cap1, nb_points, radius, h->ws + h->o_o3d, h->ws + h->o_cmp, s));
     return SD_OK;
 }
 

@@ -76,16 +76,25 @@ __device__ float block_select(F val, int n, unsigned rank, Lds& L) {
             }
         }
         __syncthreads();
-        if (tid == 0) {
-            unsigned cum = 0;
-            int b = 0;
-            for (; b < 255; ++b) {
-                const unsigned c = L.hist[b];
-                if (cum + c > rank) break;
-                cum += c;
+        if (tid < 64) {            // first bin whose cumulative count exceeds rank: 4 bins per lane, shuffle scan over the wave
+            const unsigned h0 = L.hist[4 * tid], h1 = L.hist[4 * tid + 1], h2 = L.hist[4 * tid + 2], h3 = L.hist[4 * tid + 3];
+            const unsigned own = h0 + h1 + h2 + h3;
+            unsigned incl = own;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (tid >= o) incl += t; }
+            const unsigned excl = incl - own;
+            const unsigned long long hit = __ballot(incl > rank);
+            const int first = hit ? __ffsll((long long)hit) - 1 : 63;          // (rank < n always: some lane hits)
+            if (tid == first) {
+                unsigned cum = excl;
+                int b = 4 * tid;
+                if (cum + h0 > rank) { }
+                else if (cum + h0 + h1 > rank) { cum += h0; b += 1; }
+                else if (cum + h0 + h1 + h2 > rank) { cum += h0 + h1; b += 2; }
+                else { cum += h0 + h1 + h2; b += 3; }
+                L.sh[0] = (unsigned)b;
+                L.sh[1] = rank - cum;
             }
-            L.sh[0] = (unsigned)b;
-            L.sh[1] = rank - cum;
         }
         __syncthreads();
         prefix |= L.sh[0] << shift;
@@ -289,12 +298,20 @@ __device__ void block_compact(const float* __restrict__ xyz, const uint8_t* __re
 // frame's parameter record) and leave the data movement to these two kernels.
 constexpr int CMP_G = 64;            // slices (workgroups) per frame
 constexpr int CMP_PARAMS = 8;        // doubles per frame: MAD {median, mad}; plane {C0, C1, C2}; statistical filter {threshold}
-struct CmpScratch { int* blk_cnt; double* params; };
-size_t cmp_scratch_bytes(int B) { return (size_t)B * (CMP_G * sizeof(int) + CMP_PARAMS * sizeof(double)) + 512; }
+struct MedG { unsigned klo, khi, cnt, below, nan, done; float med, madv; };      // per-frame state of a multi-block median
+struct CmpScratch { int* blk_cnt; double* params; MedG* med; unsigned* medbuf; };
+size_t cmp_scratch_bytes(int B) {
+    return (size_t)B * (CMP_G * sizeof(int) + CMP_PARAMS * sizeof(double) + sizeof(MedG) + (size_t)MED_CAP * sizeof(unsigned)) + 1024;
+}
 static CmpScratch cmp_carve(void* base, int B) {
     CmpScratch c;
     c.params = reinterpret_cast<double*>(base);
-    c.blk_cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(base) + ((size_t)B * CMP_PARAMS * sizeof(double) + 255) / 256 * 256);
+    char* q = reinterpret_cast<char*>(base) + ((size_t)B * CMP_PARAMS * sizeof(double) + 255) / 256 * 256;
+    c.blk_cnt = reinterpret_cast<int*>(q);
+    q += ((size_t)B * CMP_G * sizeof(int) + 255) / 256 * 256;
+    c.med = reinterpret_cast<MedG*>(q);
+    q += ((size_t)B * sizeof(MedG) + 255) / 256 * 256;
+    c.medbuf = reinterpret_cast<unsigned*>(q);
     return c;
 }
 __device__ __forceinline__ void cmp_slice(int n, int g, int& lo, int& hi) {
@@ -423,6 +440,109 @@ hipError_t launch_filter_coord(CloudView in, CloudOut out, int B, int cap, int k
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------ multi-block median
+// block_median_fast spread over the chip: (1) one workgroup per frame samples the column and brackets the middle ranks,
+// (2) CMP_G workgroups per frame make the one pass over the column (count below the bracket, append the keys inside it to
+// a global buffer), (3) one workgroup per frame selects the order statistics from the buffer -- or, if the bracket missed,
+// runs the full single-workgroup select.  MODE 0: median of the column; MODE 1: median of |column - median| (the MAD).
+template <int MODE>
+__device__ __forceinline__ float med_value(const float* xyz, int i, int axis, float med) {
+    const float v = xyz[(size_t)i * 3 + axis];
+    return MODE == 0 ? v : fabsf(v - med);
+}
+template <int MODE>
+__global__ __launch_bounds__(TB) void med_sample_kernel(CloudView in, int cap, int axis, MedG* G) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* xyz = in.xyz + (size_t)b * cap * 3;
+    const int n = min(in.n[b], cap);
+    __shared__ Lds L;
+    __shared__ unsigned samp[MED_S];
+    const float med = MODE == 1 ? G[b].med : 0.f;
+    auto val = [=](int i) { return med_value<MODE>(xyz, i, axis, med); };
+    if (n < 4 * MED_S) {                                        // small cloud: the plain select, done here
+        const float r = block_median(val, n, L);
+        if (tid == 0) { G[b].done = 1; if (MODE == 0) G[b].med = r; else G[b].madv = r; }
+        return;
+    }
+    for (int j = tid; j < MED_S; j += TB) samp[j] = f2key(val((int)(((long)j * n) / MED_S)));
+    __syncthreads();
+    const unsigned r1 = (unsigned)((n - 1) / 2);
+    const int ts = (int)(((long)r1 * MED_S) / n);
+    const int slo = max(ts - MED_D, 0), shi = min(ts + MED_D, MED_S - 1);
+    auto sval = [&](int j) { return key2f(samp[j]); };
+    const unsigned klo = f2key(block_select(sval, MED_S, (unsigned)slo, L));
+    const unsigned khi = f2key(block_select(sval, MED_S, (unsigned)shi, L));
+    if (tid == 0) { G[b].klo = klo; G[b].khi = khi; G[b].cnt = 0; G[b].below = 0; G[b].nan = 0; G[b].done = 0; }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void med_collect_kernel(CloudView in, int cap, int axis, MedG* G, unsigned* medbuf) {
+    const int b = blockIdx.y, g = blockIdx.x;
+    if (G[b].done) return;
+    const float* xyz = in.xyz + (size_t)b * cap * 3;
+    const int n = min(in.n[b], cap);
+    const unsigned klo = G[b].klo, khi = G[b].khi;
+    const float med = MODE == 1 ? G[b].med : 0.f;
+    unsigned* buf = medbuf + (size_t)b * MED_CAP;
+    int lo, hi;
+    cmp_slice(n, g, lo, hi);
+    unsigned below = 0, nanf = 0;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+        const float v = med_value<MODE>(xyz, i, axis, med);
+        nanf |= (v != v);
+        const unsigned k = f2key(v);
+        if (k < klo) ++below;
+        else if (k <= khi) {
+            const unsigned pos = atomicAdd(&G[b].cnt, 1u);
+            if (pos < MED_CAP) buf[pos] = k;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { below += __shfl_xor(below, o); nanf |= __shfl_xor(nanf, o); }
+    if ((threadIdx.x & 63) == 0) { if (below) atomicAdd(&G[b].below, below); if (nanf) atomicOr(&G[b].nan, 1u); }
+}
+template <int MODE>
+__global__ __launch_bounds__(TB) void med_pick_kernel(CloudView in, int cap, int axis, MedG* G, const unsigned* medbuf, float* stats, double* params) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* xyz = in.xyz + (size_t)b * cap * 3;
+    const int n = min(in.n[b], cap);
+    __shared__ Lds L;
+    float r;
+    if (G[b].done) {
+        r = MODE == 0 ? G[b].med : G[b].madv;
+    } else {
+        const unsigned cnt = G[b].cnt, bel = G[b].below;
+        const unsigned r1 = (unsigned)((n - 1) / 2), r2 = (unsigned)(n / 2);
+        const float med = MODE == 1 ? G[b].med : 0.f;
+        if (G[b].nan) {
+            r = __uint_as_float(0x7fc00000u);
+        } else if (cnt > MED_CAP || r1 < bel || r2 >= bel + cnt) {            // bracket missed: exact fallback
+            r = block_median([=](int i) { return med_value<MODE>(xyz, i, axis, med); }, n, L);
+        } else {
+            const unsigned* buf = medbuf + (size_t)b * MED_CAP;
+            auto bval = [=](int j) { return key2f(buf[j]); };
+            const float a = block_select(bval, (int)cnt, r1 - bel, L);
+            r = a;
+            if (r1 != r2) r = (a + block_select(bval, (int)cnt, r2 - bel, L)) / 2.0f;
+        }
+    }
+    if (tid == 0) {
+        if (MODE == 0) {
+            G[b].med = r;
+        } else {
+            G[b].madv = r;
+            const float med = G[b].med;
+            if (stats) { stats[b * 2] = med; stats[b * 2 + 1] = r; }
+            params[b * CMP_PARAMS] = (double)med; params[b * CMP_PARAMS + 1] = (double)r;
+        }
+    }
+}
+template <int MODE>
+static void med_run(CloudView in, int B, int cap, int axis, const CmpScratch& c, float* stats, hipStream_t s) {
+    hipLaunchKernelGGL(med_sample_kernel<MODE>, dim3(B), dim3(TB), 0, s, in, cap, axis, c.med);
+    hipLaunchKernelGGL(med_collect_kernel<MODE>, dim3(CMP_G, B), dim3(256), 0, s, in, cap, axis, c.med, c.medbuf);
+    hipLaunchKernelGGL(med_pick_kernel<MODE>, dim3(B), dim3(TB), 0, s, in, cap, axis, c.med, c.medbuf, stats, c.params);
+}
+
 // ------------------------------------------------------------------------------------------ K21 MAD
 // pcl.remove_noise_by_mad + mad (pcl.py:46-81), all float32 like numpy on a float32 column:
 //   med = median(v); dev = |v - med|; MAD = median(dev); keep 0.6745f*dev/MAD < thr
@@ -448,7 +568,8 @@ __global__ __launch_bounds__(TB) void mad_filter_kernel(CloudView in, CloudOut o
 hipError_t launch_mad_filter(CloudView in, CloudOut out, int B, int cap, int axis, double thr, float* stats, void* cscratch, hipStream_t s) {
     if (cscratch && in.xyz != out.xyz) {
         const CmpScratch c = cmp_carve(cscratch, B);
-        hipLaunchKernelGGL(mad_filter_kernel<false>, dim3(B), dim3(TB), 0, s, in, out, cap, axis, (float)thr, stats, c.params);
+        med_run<0>(in, B, cap, axis, c, nullptr, s);              // median, then the median of the deviations from it
+        med_run<1>(in, B, cap, axis, c, stats, s);
         cmp_run(in, out, B, cap, MadPred{axis, (float)thr, c.params}, c, s);
         return hipGetLastError();
     }
