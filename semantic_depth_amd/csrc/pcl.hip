@@ -966,18 +966,38 @@ __global__ __launch_bounds__(TB) void grid_meta_kernel(CloudView in, int cap, do
     }
 }
 
+// runs of equal cell ids among the lanes of a wave (a pixel-ordered cloud puts neighbouring points into the same cell): one
+// atomic per run instead of one per point.  Valid lanes are a prefix of the wave.  Returns the run's first lane and length.
+__device__ __forceinline__ void cell_runs(bool valid, int c, int& first, int& len) {
+    const int lane = threadIdx.x & 63;
+    const int pc = __shfl_up(c, 1);
+    const bool start = valid && (lane == 0 || c != pc);
+    const unsigned long long starts = __ballot(start);
+    const int nvalid = __popcll(__ballot(valid));
+    const unsigned long long upto = starts & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+    first = upto ? 63 - __builtin_clzll(upto) : 0;
+    const unsigned long long after = first == 63 ? 0ull : (starts >> (first + 1));
+    const int end = after ? first + 1 + (__ffsll((long long)after) - 1) : nvalid;
+    len = end - first;
+}
+
 __global__ __launch_bounds__(256) void grid_count_kernel(CloudView in, int cap, const GridMeta* meta, int* cell_cnt, int* cell_of) {
     const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= min(in.n[b], cap)) return;
-    const GridMeta g = meta[b];
-    const float* p = in.xyz + ((size_t)b * cap + i) * 3;
-    const int cx = cell_coord((double)p[0], g.ox, g.inv, g.gx);
-    const int cy = cell_coord((double)p[1], g.oy, g.inv, g.gy);
-    const int cz = cell_coord((double)p[2], g.oz, g.inv, g.gz);
-    const int c = (cz * g.gy + cy) * g.gx + cx;
-    cell_of[(size_t)b * cap + i] = c;
-    atomicAdd(&cell_cnt[(size_t)b * GRID_CELLS + c], 1);
+    const bool valid = i < min(in.n[b], cap);
+    int c = 0;
+    if (valid) {
+        const GridMeta g = meta[b];
+        const float* p = in.xyz + ((size_t)b * cap + i) * 3;
+        const int cx = cell_coord((double)p[0], g.ox, g.inv, g.gx);
+        const int cy = cell_coord((double)p[1], g.oy, g.inv, g.gy);
+        const int cz = cell_coord((double)p[2], g.oz, g.inv, g.gz);
+        c = (cz * g.gy + cy) * g.gx + cx;
+        cell_of[(size_t)b * cap + i] = c;
+    }
+    int first, len;
+    cell_runs(valid, c, first, len);
+    if (valid && (int)(threadIdx.x & 63) == first) atomicAdd(&cell_cnt[(size_t)b * GRID_CELLS + c], len);
 }
 
 // exclusive scan of the per-frame cell counts in three parallel passes (segment sums, scan of sums, write-back)
@@ -1041,9 +1061,16 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(CloudView in, int cap
                                                            const int* cell_of, int* sidx, float* sxyz) {
     const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= min(in.n[b], cap)) return;
-    const int c = cell_of[(size_t)b * cap + i];
-    const int pos = cell_start[(size_t)b * (GRID_CELLS + 1) + c] + atomicAdd(&cell_cnt[(size_t)b * GRID_CELLS + c], 1);
+    const bool valid = i < min(in.n[b], cap);
+    const int c = valid ? cell_of[(size_t)b * cap + i] : 0;
+    int first, len;
+    cell_runs(valid, c, first, len);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (valid && lane == first) base = atomicAdd(&cell_cnt[(size_t)b * GRID_CELLS + c], len);      // the run's slots in the cell
+    base = __shfl(base, first);
+    if (!valid) return;
+    const int pos = cell_start[(size_t)b * (GRID_CELLS + 1) + c] + base + (lane - first);
     sidx[(size_t)b * cap + pos] = i;
     const float* p = in.xyz + ((size_t)b * cap + i) * 3;
     float* q = sxyz + ((size_t)b * cap + pos) * 3;
