@@ -908,14 +908,14 @@ __device__ void grid_layout(GridMeta& g, double cell) {
 
 // second look at the cell size of the statistical filter: the first grid's occupancy tells how the cloud really fills
 // space (a road cloud is a sheet, not a volume); aim at ~8 points per OCCUPIED cell, assuming occupancy ~ cell^2
-__global__ void grid_refine_kernel(CloudView in, int cap, GridMeta* meta, int B) {
+__global__ void grid_refine_kernel(CloudView in, int cap, GridMeta* meta, int B, double occ_target) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     GridMeta g = meta[b];
     const int n = min(in.n[b], cap);
     if (g.occupied > 0 && n > 0) {
         const double avg = (double)n / (double)g.occupied;
-        if (avg > 12.0) grid_layout(g, fmax(g.cell * sqrt(8.0 / avg), g.cell * 0.125));
+        if (avg > 1.5 * occ_target) grid_layout(g, fmax(g.cell * sqrt(occ_target / avg), g.cell * 0.125));
     }
     g.occupied = 0;
     meta[b] = g;
@@ -1431,7 +1431,8 @@ hipError_t launch_sor(CloudView in, CloudOut out, int B, int cap, int k, double 
     if (k > KMAX) return hipErrorInvalidValue;
     O3dScratch sc = carve(scratch, B, cap);
     build_grid(in, B, cap, 0.0, sc, s, /*keep_meta=*/false, /*occupancy_only=*/true);
-    hipLaunchKernelGGL(grid_refine_kernel, dim3((B + 63) / 64), dim3(64), 0, s, in, cap, sc.meta, B);   // re-size the cells from the
+    const double occ_target = 6.0;      // points per occupied cell (measured on the bench cloud: 4 -> 6.2 ms, 6 -> 5.35, 8 -> 5.47, 12 -> 5.86)
+    hipLaunchKernelGGL(grid_refine_kernel, dim3((B + 63) / 64), dim3(64), 0, s, in, cap, sc.meta, B, occ_target);   // re-size the cells from the
     build_grid(in, B, cap, 0.0, sc, s, /*keep_meta=*/true);                                              // measured occupancy, rebuild
     double* md = mean_out ? mean_out : sc.mean_d;
     // the top-k array is walked by every lane of a wave whenever ANY lane inserts: keep it as short as k allows
