@@ -146,6 +146,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 const bool split = p.prec != 0;
                 c.f16 = p.f16;
                 c.src0 = T(op.src[0]); c.src0_plane = PL(op.src[0]);
+                c.out_planar16 = d.planar16;
                 hipEvent_t ea = nullptr, eb = nullptr;
                 if (h->prof) {
                     if (h->prof_used == h->prof_pool.size()) {
@@ -159,6 +160,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 }
                 const bool dma = split && conv_dma_variant(c) != 0 && !std::getenv("SEMDEPTH_NO_DMA");
                 const bool stem = split && !dma && conv_stem_eligible(c);
+                if (c.out_planar16 && !stem) return fail(h, SD_ERR_STATE, "sub-planar output needs the stem conv kernel");
                 if (c.pool && !dma) return fail(h, SD_ERR_STATE, "fused pool needs the LDS-DMA conv kernel");
                 e = dma ? launch_conv_dma(c, s) : stem ? launch_conv_stem(c, s) : split ? launch_conv_split(c, s) : launch_conv_igemm(c, s);
                 if (h->prof) {

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
     // stage image: Xh[1280] Xl[1280] Wh[576] Wl[576]; X unit = [halo pixel][octet ^ ((pixel >> 3) & 1)]
     auto issue = [&](const Tile& tl, int c, int stage) {
         const DirectChunk ch = load_chunk(p.chunks + c);
-        const size_t plane = (size_t)p.Nmax * ch.H * ch.W * ch.C;      // elements
+        const size_t plane = (size_t)p.Nmax * ch.H * ch.W * (ch.pad ? ch.pad : ch.C);      // elements (pad: channels of a sub-planar tensor)
         const unsigned sbyte = lds0 + (unsigned)(stage * D_STAGE * 16);
         const uint16_t* const img_hi = reinterpret_cast<const uint16_t*>(ch.base) + (size_t)tl.img * ch.H * ch.W * ch.C;
 #pragma unroll

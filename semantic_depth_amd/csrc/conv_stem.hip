@@ -164,7 +164,9 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
                         const int pix = ps * PPP + prow;
                         const u32x4 v = *reinterpret_cast<const u32x4*>(sh + pix * ROW + seg * 16);
                         if (y < p.Hout) {
-                            uint16_t* o = out_hi + ((size_t)(cur.img * p.Hout + y) * p.Wout + cur.tx0 + pix) * p.Cout + seg * 8;
+                            const size_t px = (size_t)(cur.img * p.Hout + y) * p.Wout + cur.tx0 + pix;
+                            uint16_t* o = p.out_planar16 ? out_hi + ((size_t)(seg >> 1) * p.Nmax * p.Hout * p.Wout + px) * 16 + (seg & 1) * 8
+                                                         : out_hi + px * p.Cout + seg * 8;
                             *reinterpret_cast<u32x4*>(pl ? o + p.out_plane : o) = v;
                         }
                     }
@@ -184,6 +186,7 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
 bool conv_stem_eligible(const ConvParams& p) {
     if (!p.src0 || p.nsrc != 1 || p.Ctot != 4 || p.kh != p.kw || !(p.kh & 1) || p.kh > 7 || (p.stride != 1 && p.stride != 2)) return false;
     if ((p.Cout != 32 && p.Cout != 64) || p.CoutPad != p.Cout || p.Wout % ST_TW || p.residual || p.pool) return false;
+    if (p.out_planar16 && p.Cout % 16) return false;
     const int rw = p.stride == 1 ? 2 : 1, th = 8 * rw;
     const int ih = (th - 1) * p.stride + p.kh, iw = (ST_TW - 1) * p.stride + p.kh;
     return ih * iw <= ST_MAXPIX && !std::getenv("SEMDEPTH_NO_STEM");

@@ -46,6 +46,7 @@ struct ConvParams {
     const void* src0;  // first source tensor (hi plane) and the element offset of its lo plane: conv_stem.hip reads it directly
     size_t src0_plane;
     int f16;           // split planes are fp16 and the weights one fp16 plane (2 MFMA products): split_fmt.hpp
+    int out_planar16;  // conv_stem.hip: write the output as Cout/16 sub-planes of 16 channels (TensorDesc::planar16)
     int pool;          // conv_dma.hip: output pixels are walked in 2x2-window-major order and the epilogue max-pools each
                        // window: out is [N,Hout/2,Wout/2,Cout]
     int simple;        // one source, stride 1, no upsample, all k-tiles vec: the DMA kernel computes its gather addresses
@@ -100,7 +101,7 @@ struct DirectChunk {       // one 16-channel chunk of one source (32 bytes)
     int H, W, C;           // physical dims of the source tensor
     int up;                // 1: read through a x2 nearest-neighbour upsample
     int nvalid;            // channel octets of the chunk that exist (1..2)
-    int pad;
+    int pad;               // 0, or the tensor's channel count when the source is stored as 16-channel sub-planes (then C = 16)
 };
 static_assert(sizeof(DirectChunk) == 32, "DirectChunk must be 32 bytes");
 struct ConvDirectParams {

@@ -292,7 +292,15 @@ NetPlan build_fcn8s(int frames, int H, int W, int prec, int f16) {
     for (int s = 0; s < 5; ++s) {
         for (int j = 0; j < 3 && blocks[s][j]; ++j) {
             std::string n = blocks[s][j];
+            const int xin = x;
             x = b.conv(n, {{x, 0}}, ch[s], 3, 1, ACT_RELU, "vgg/" + n + "/filter", "vgg/" + n + "/biases");
+            // conv1_1 (stem kernel) -> conv1_2 (direct kernel): hand the 64 channels over as four 16-channel sub-planes
+            if (s == 0 && j == 1 && prec && b.p.ops.back().kind == OP_CONV_DIRECT && b.p.tensors[xin].C == 64 && W % 32 == 0 &&
+                !std::getenv("SEMDEPTH_NO_PLANAR") && !std::getenv("SEMDEPTH_NO_STEM")) {
+                b.p.tensors[xin].planar16 = 1;
+                for (auto it = b.p.tensor_by_name.begin(); it != b.p.tensor_by_name.end();)
+                    it = it->second == xin ? b.p.tensor_by_name.erase(it) : std::next(it);       // not a plain NHWC tensor any more
+            }
         }
         x = b.pool("pool" + std::to_string(s + 1), x, false);
         pools[s] = x;
@@ -569,6 +577,10 @@ void build_direct_chunks(const NetPlan& p, const OpDesc& op, const char* act_bas
             ch.H = t.H; ch.W = t.W; ch.C = t.C; ch.up = op.up[i];
             ch.nvalid = std::min(2, (t.C - c0) / 8);
             ch.pad = 0;
+            if (t.planar16) {     // sub-plane c0/16 of [C/16][Nmax][H][W][16]: pixel stride 16, `pad` carries the tensor's channel count
+                ch.base = act_base + t.offset + (size_t)(c0 / 16) * p.images * t.H * t.W * 16 * 2;
+                ch.C = 16; ch.pad = t.C;
+            }
             chunks.push_back(ch);
         }
     }

@@ -16,6 +16,9 @@ struct TensorDesc {
     int N = 0, H = 0, W = 0, C = 0;   // C = stored channels
     int Ctf = 0;                      // channels the TensorFlow graph sees (input_pre stores 4, TF sees 3)
     int fmt = 0;                      // 0: f32 NHWC; 1: split-bf16 planes (split_fmt.hpp)
+    int planar16 = 0;                 // split planes stored as C/16 sub-planes of 16 channels ([C/16][N][H][W][16] per plane): the
+                                      // producer is the stem kernel, the only consumer a direct conv, whose 16-channel halo DMA
+                                      // then reads whole 128-byte lines
     size_t bytes = 0;
     size_t offset = 0;      // byte offset in the activation arena
     int first = -1, last = -1;   // op indices (liveness)
