@@ -138,6 +138,9 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.vec = op.vec; c.vtiles = op.Kvec / 32;
                 c.simple = op.nsrc == 1 && op.vec && op.Kvec == op.Kpad && op.sstride[0] == 1 && !op.up[0] && op.k * op.k <= 64 &&
                            op.Kpad == op.k * op.k * s0.C;
+                if (!c.simple && op.nsrc == 2 && op.k == 1 && op.vec && op.Kvec == op.Kpad && !op.up[0] && !op.up[1] && op.pad == 0 &&
+                    s0.C % 32 == 0 && p.tensors[op.src[1]].C % 32 == 0 && op.Kpad == s0.C + p.tensors[op.src[1]].C)
+                    c.simple = 2;
                 c.residual = op.residual >= 0 ? T(op.residual) : nullptr;
                 c.out = T(op.dst);
                 c.act = op.act; c.m_fastest = op.m_fastest;

@@ -61,7 +61,9 @@ __device__ __forceinline__ KEntry load_kentry(const KEntry* ptr) {
 // measured -2 % (337.7 vs 344.9 fps); four waves (one per SIMD) with 64 x 128 wave tiles on the same 128 x 256 block -8 %.
 // F16: fp16 planes, ONE fp16 weight plane, two MFMA products per product (split_fmt.hpp): a k-tile then carries 4 weight
 // DMAs less per workgroup and 16 instead of 24 MFMAs per wave.
-template <int WAVES_M, int WAVES_N, int MT, int NT, bool SIMPLE, int STAGES, bool F16 = false>
+// SIMPLE = 2: the two-source 1x1 GEMM of a ResNet block tail (conv3 over its 3x3 output + projection over the block input,
+// each with its own stride): two base pointers per lane, the k-tile index selects the source.
+template <int WAVES_M, int WAVES_N, int MT, int NT, int SIMPLE, int STAGES, bool F16 = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 2 ? 2 : 1) void conv_dma_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
@@ -123,10 +125,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 2 ? 2 : 1) void c
     // SIMPLE state: pixel base pointers (tap (0,0) minus pad, channel 0 + this lane's octet), tap validity masks, and the
     // wave-uniform walk over (channel block, tap row, tap column) in k-tile order
     const uint16_t* sbase[XH];
+    const uint16_t* sbaseB[XH];                               // SIMPLE == 2: second source
     unsigned long long smask[XH];
-    size_t splane = 0;
-    int sW = 0, sC = 0, s_ty = 0, s_tx = 0, s_cb = 0;
-    if constexpr (SIMPLE) {
+    size_t splane = 0, splaneB = 0;
+    int sW = 0, sC = 0, s_ty = 0, s_tx = 0, s_cb = 0, nA = 0;
+    if constexpr (SIMPLE == 2) {
+        const KEntry eA = load_kentry(ktab);
+        nA = eA.C / 32;
+        const KEntry eB = load_kentry(ktab + nA);
+        splane = (size_t)Nmax * eA.H * eA.W * eA.C;
+        splaneB = (size_t)Nmax * eB.H * eB.W * eB.C;
+        const int stA = (eA.flags >> 4) & 3, stB = (eB.flags >> 4) & 3;
+#pragma unroll
+        for (int i = 0; i < XH; ++i) {
+            sbase[i] = reinterpret_cast<const uint16_t*>(eA.base) + ((size_t)(pimg[i] * eA.H + poy[i] * stA) * eA.W + pox[i] * stA) * eA.C + pkg[i] * 8;
+            sbaseB[i] = reinterpret_cast<const uint16_t*>(eB.base) + ((size_t)(pimg[i] * eB.H + poy[i] * stB) * eB.W + pox[i] * stB) * eB.C + pkg[i] * 8;
+            smask[i] = pok[i] ? 1ull : 0ull;
+        }
+    }
+    if constexpr (SIMPLE == 1) {
         const KEntry e0 = load_kentry(ktab);                  // (channel block 0, tap 0): base, dims, dy = dx = -pad
         sW = e0.W; sC = e0.C;
         splane = (size_t)Nmax * e0.H * e0.W * e0.C;
@@ -146,7 +163,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 2 ? 2 : 1) void c
     auto issue = [&](int kt, int stage) {
         const unsigned sbyte = ring_lds + (unsigned)(stage * STAGE_UNITS * 16);      // LDS byte address of the stage
         // ---- activations: hi plane instruction(s) then lo plane instruction(s) ----
-        if constexpr (SIMPLE) {
+        if constexpr (SIMPLE == 2) {
+            const bool first = kt < nA;
+            const int coff = (first ? kt : kt - nA) * 32;                    // elements, wave-uniform
+            const size_t pln = first ? splane : splaneB;
+#pragma unroll
+            for (int i = 0; i < XH; ++i) {
+                const bool ok = smask[i] != 0;
+                const uint16_t* px = (first ? sbase[i] : sbaseB[i]) + coff;
+                const u32x4* gh = ok ? reinterpret_cast<const u32x4*>(px) : zero;
+                const u32x4* gl = ok ? reinterpret_cast<const u32x4*>(px + pln) : zero;
+                dma16(gh, sbyte + (unsigned)((wave + NW * i) * 1024));
+                dma16(gl, sbyte + (unsigned)((4 * BM + (wave + NW * i) * 64) * 16));
+            }
+        } else if constexpr (SIMPLE == 1) {
             const int tap = s_ty * p.kw + s_tx;
             const long soff = (long)(s_ty * sW + s_tx) * sC + s_cb * 32;          // elements, wave-uniform
 #pragma unroll
@@ -357,11 +387,14 @@ template <int WM, int WN, int MT, int NT, int STAGES>
 static void launch_dma_variant(const ConvParams& p, long M, hipStream_t s) {
     const int tilesM = (int)((M + WM * MT * 32 - 1) / (WM * MT * 32)), tilesN = p.Cout / (WN * NT * 32);
     const dim3 grid((unsigned)(tilesM * tilesN)), block(64 * WM * WN);
+    const int mode = (p.dbg & 16) ? 0 : p.simple;
     if (p.f16) {
-        if (p.simple) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, true, STAGES, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
-        else hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, false, STAGES, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
-    } else if (p.simple && !(p.dbg & 16)) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, true, STAGES>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
-    else hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, false, STAGES>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+        if (mode == 2) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 2, STAGES, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+        else if (mode == 1) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 1, STAGES, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+        else hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 0, STAGES, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+    } else if (mode == 2) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 2, STAGES>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+    else if (mode == 1) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 1, STAGES>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+    else hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 0, STAGES>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
 }
 
 hipError_t launch_conv_dma(const ConvParams& p0, hipStream_t s) {

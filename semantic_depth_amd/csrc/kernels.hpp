@@ -49,7 +49,8 @@ struct ConvParams {
     int out_planar16;  // conv_stem.hip: write the output as Cout/16 sub-planes of 16 channels (TensorDesc::planar16)
     int pool;          // conv_dma.hip: output pixels are walked in 2x2-window-major order and the epilogue max-pools each
                        // window: out is [N,Hout/2,Wout/2,Cout]
-    int simple;        // one source, stride 1, no upsample, all k-tiles vec: the DMA kernel computes its gather addresses
+    int simple;        // 1: one source, stride 1, no upsample, all k-tiles vec: the DMA kernel computes its gather addresses;
+                       // 2: two-source 1x1 GEMM (ResNet conv3 + projection), per-source strides, no upsample
     int dbg;           // SEMDEPTH_DMA_DBG=16: general gather path on SIMPLE layers too (A/B switch; 0 in production)
     int m_fastest;     // block order: 1 = consecutive blocks walk M (share a weight panel), 0 = walk N
 };
