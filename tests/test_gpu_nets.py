@@ -122,3 +122,29 @@ def test_flipped_frame_symmetry_of_post_processing():
     a = eng.monodepth_forward(dev(fr))[0].cpu().numpy()
     b = eng.monodepth_forward(dev(fr[:, :, ::-1].copy()))[0].cpu().numpy()
     assert relerr(b[:, ::-1], a) < 1e-5
+
+
+@pytest.mark.parametrize("switch", ["SEMDEPTH_NO_DMA", "SEMDEPTH_NO_DIRECT", "SEMDEPTH_NO_STEM", "SEMDEPTH_NO_POOL_FUSE", "SEMDEPTH_NO_PLANAR",
+                                    "SEMDEPTH_NO_N16", "SEMDEPTH_NO_SMALLN_TILE"])
+def test_generic_kernels_behind_each_specialised_one(switch):
+    """every specialised kernel (LDS-DMA pipeline, direct conv, stem conv, fused pools, sub-plane hand-off, 16-wide MFMA,
+    tiled heads) has a generic one behind it; with the specialised one switched off the networks still meet the budget."""
+    from semantic_depth_amd.engine import Engine
+    from semantic_depth_amd import weights as Wt
+    H, W, B = 64, 128, 2
+    os.environ[switch] = "1"
+    try:
+        eng = Engine(H, W, B, "resnet50", precision="bf16x2")       # the switches are read when the plan is built / at launch
+        wf = Wt.make_fcn8s_weights(1, decoder_std=0.05, bias_std=0.1)
+        wm = Wt.make_monodepth_weights("resnet50", 2, bias_std=0.05)
+        eng.load_weights(L.SD_NET_FCN8S, wf)
+        eng.load_weights(L.SD_NET_MONODEPTH, wm)
+        fr = _frames(B, H, W, seed=5)
+        lg = eng.fcn8s_forward(dev(fr), want_logits=True)["logits"].cpu().numpy()
+        _, raw = eng.monodepth_forward(dev(fr), want_raw=True)
+    finally:
+        os.environ.pop(switch, None)
+    assert relerr(lg, nets.fcn8s_forward(fr, wf)) < TOL
+    f = fr[1].astype(np.float32) / 255
+    ref = nets.monodepth_forward(np.stack((f, np.fliplr(f)), 0), wm, "resnet50")[..., 0]
+    assert relerr(raw[1].cpu().numpy(), ref) < TOL
