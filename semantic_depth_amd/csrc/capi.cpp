@@ -179,7 +179,8 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.chunks = reinterpret_cast<const DirectChunk*>(wbase + op.tab_offset);
                 c.nchunks = op.nchunks;
                 c.pool = op.fuse_pool;
-                c.N = N; c.H = d.H << c.pool; c.W = d.W << c.pool; c.Cout = d.C;
+                c.N = N; c.H = d.H << c.pool; c.W = d.W << c.pool;
+                c.nsplit = op.nsplit; c.Cout = d.C / op.nsplit; c.Cstride = d.C; c.out_planar16 = d.planar16;
                 c.wt = reinterpret_cast<const u32x4_t*>(Wp(op.w)); c.bias = Wp(op.b);
                 c.out = T(op.dst); c.out_plane = PL(op.dst); c.act = op.act; c.Nmax = p.images;
                 c.zero16 = h->ws + h->o_misc + 256;
@@ -646,7 +647,8 @@ sd_status sd_net_tensor(sd_handle* h, sd_net net, const char* name, float* out, 
     if (numel > cap_floats) return fail(h, SD_ERR_INVALID, "output buffer too small");
     const char* abase = h->ws + (net == SD_NET_FCN8S ? h->o_fcn : h->o_mono);
     if (t.fmt)      // split-bf16 planes -> f32
-        HIPCHK(h, launch_unsplit(reinterpret_cast<const float*>(abase + t.offset), out, (long)N * t.H * t.W, t.C, t.Ctf, (size_t)p.images * t.H * t.W * t.C, p.f16, (hipStream_t)stream));
+        HIPCHK(h, launch_unsplit(reinterpret_cast<const float*>(abase + t.offset), out, (long)N * t.H * t.W, t.C, t.Ctf, (size_t)p.images * t.H * t.W * t.C,
+                                 t.planar16 ? (size_t)p.images * t.H * t.W * 16 : 0, p.f16, (hipStream_t)stream));
     else
         HIPCHK(h, hipMemcpyAsync(out, abase + t.offset, numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return SD_OK;

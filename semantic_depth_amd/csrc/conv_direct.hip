@@ -97,7 +97,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
     }
 
     // stage image: Xh[1280] Xl[1280] Wh[576] Wl[576]; X unit = [halo pixel][octet ^ ((pixel >> 3) & 1)]
-    auto issue = [&](const Tile& tl, int c, int stage) {
+    auto issue = [&](const Tile& tl, int half, int c, int stage) {
         const DirectChunk ch = load_chunk(p.chunks + c);
         const size_t plane = (size_t)p.Nmax * ch.H * ch.W * (ch.pad ? ch.pad : ch.C);      // elements (pad: channels of a sub-planar tensor)
         const unsigned sbyte = lds0 + (unsigned)(stage * D_STAGE * 16);
@@ -118,19 +118,16 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
             const int jw = wave + D_WAVES * i;
             if (jw < (F16 ? 1 : 2) * D_WI) {
                 const int pl = jw >= D_WI ? 1 : 0;
-                const u32x4* gw = p.wt + ((size_t)pl * p.nchunks + c) * D_WUNITS + (jw - pl * D_WI) * 64 + lane;
+                const u32x4* gw = p.wt + ((size_t)(2 * half + pl) * p.nchunks + c) * D_WUNITS + (jw - pl * D_WI) * 64 + lane;
                 ddma16(gw, sbyte + (unsigned)((2 * D_XUNITS + jw * 64) * 16));
             }
         }
     };
 
-    // bias of this lane's accumulator rows, once
-    f32x4 bias[4 * NB];
-#pragma unroll
-    for (int r4 = 0; r4 < 4 * NB; ++r4) {
-        const int nl = 8 * r4 + 4 * fk;
-        bias[r4] = nl < p.Cout ? *reinterpret_cast<const f32x4*>(p.bias + nl) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+    // the bias vector lives in LDS (zero past the layer's channels) and is read by the epilogue: no registers held
+    // through the product loop
+    __shared__ __attribute__((aligned(16))) float sbias[128];
+    if (threadIdx.x < 128) sbias[threadIdx.x] = (int)threadIdx.x < p.nsplit * p.Cout ? p.bias[threadIdx.x] : 0.f;
     const int c16 = lane & 15, kg16 = lane >> 4;           // N16 fragment coordinates
     f32x4 bias16 = {0.f, 0.f, 0.f, 0.f};
     if (N16 && 4 * kg16 < p.Cout) bias16 = *reinterpret_cast<const f32x4*>(p.bias + 4 * kg16);
@@ -139,9 +136,10 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
     int tid = blockIdx.x;
     if (tid >= total) return;
     Tile cur = tile_of(tid);
-    issue(cur, 0, 0);
+    issue(cur, 0, 0, 0);
     int g = 0;                                     // stages consumed so far
-    for (; tid < total; tid += gridDim.x) {
+    for (; tid < total; tid += gridDim.x)
+    for (int half = 0; half < p.nsplit; ++half) {
         f32x16 acc[MT][NB];
 #pragma unroll
         for (int a = 0; a < MT; ++a)
@@ -158,8 +156,9 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
         for (int c = 0; c < p.nchunks; ++c, ++g) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();          // stage g has landed for every wave; everyone is done with stage g-1
-            if (c + 1 < p.nchunks) issue(cur, c + 1, (g + 1) & 1);
-            else if (tid + (int)gridDim.x < total) { nxt = tile_of(tid + gridDim.x); issue(nxt, 0, (g + 1) & 1); }
+            if (c + 1 < p.nchunks) issue(cur, half, c + 1, (g + 1) & 1);
+            else if (half + 1 < p.nsplit) issue(cur, half + 1, 0, (g + 1) & 1);               // same tile, next 64 output channels
+            else if (tid + (int)gridDim.x < total) { nxt = tile_of(tid + gridDim.x); issue(nxt, 0, 0, (g + 1) & 1); }
             const u32x4* Xh = lds + (g & 1) * D_STAGE;
             const u32x4* Xl = Xh + D_XUNITS;
             const u32x4* Wh = Xl + D_XUNITS;
@@ -229,6 +228,15 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
             unsigned char* sl = TWO ? sh + 32 * ROW : sh;
             const int seg = lane % SEGS, prow = lane / SEGS;
             uint16_t* const out_hi = reinterpret_cast<uint16_t*>(p.out);
+            const int n0 = half * p.Cout;                 // first output channel of this split
+            f32x4 bias[4 * NB];
+#pragma unroll
+            for (int r4 = 0; r4 < 4 * NB; ++r4) bias[r4] = *reinterpret_cast<const f32x4*>(sbias + n0 + 8 * r4 + 4 * fk);
+            // output address of 8 channels (segment sg) of pixel px: NHWC, or 16-channel sub-planes
+            auto oaddr = [&](size_t px, size_t npix, int sg) {
+                const int ch = n0 + sg * 8;
+                return p.out_planar16 ? out_hi + ((size_t)(ch >> 4) * p.Nmax * npix + px) * 16 + (ch & 8) : out_hi + px * p.Cstride + ch;
+            };
             if constexpr (N16) {
                 // lane holds channels 4 kg16 .. + 3 of pixel 16 pb + c16; slab row = 16 channels (32 B) + pad per plane
                 constexpr int R16 = 32 + 16;
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
                         const u32x4 h = *reinterpret_cast<const u32x4*>(s16 + pix * R16 + sg * 16);
                         const u32x4 l = *reinterpret_cast<const u32x4*>(s16 + 32 * R16 + pix * R16 + sg * 16);
                         if (y < p.H && sg * 8 < p.Cout) {
-                            uint16_t* o = out_hi + ((size_t)(cur.img * p.H + y) * p.W + cur.tx0 + pix) * p.Cout + sg * 8;
+                            uint16_t* o = oaddr((size_t)(cur.img * p.H + y) * p.W + cur.tx0 + pix, (size_t)p.H * p.W, sg);
                             *reinterpret_cast<u32x4*>(o) = h;
                             *reinterpret_cast<u32x4*>(o + p.out_plane) = l;
                         }
@@ -309,7 +317,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
                         const int pix = ps * PPP + prow;
                         if (pix < 16 && yp < Hp && seg * 8 < p.Cout) {
                             const u32x4 h = *reinterpret_cast<const u32x4*>(sh + pix * ROW + seg * 16);
-                            uint16_t* o = out_hi + ((size_t)(cur.img * Hp + yp) * Wp + (cur.tx0 >> 1) + pix) * p.Cout + seg * 8;
+                            uint16_t* o = oaddr((size_t)(cur.img * Hp + yp) * Wp + (cur.tx0 >> 1) + pix, (size_t)Hp * Wp, seg);
                             if (TWO) {
                                 const u32x4 l = *reinterpret_cast<const u32x4*>(sl + pix * ROW + seg * 16);
                                 *reinterpret_cast<u32x4*>(o) = h;
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
                         u32x4 l = h;
                         if (TWO) l = *reinterpret_cast<const u32x4*>(sl + pix * ROW + seg * 16);
                         if (y < p.H && seg * 8 < p.Cout) {
-                            uint16_t* o = out_hi + ((size_t)(cur.img * p.H + y) * p.W + cur.tx0 + pix) * p.Cout + seg * 8;
+                            uint16_t* o = oaddr((size_t)(cur.img * p.H + y) * p.W + cur.tx0 + pix, (size_t)p.H * p.W, seg);
                             if (TWO) {
                                 *reinterpret_cast<u32x4*>(o) = h;
                                 *reinterpret_cast<u32x4*>(o + p.out_plane) = l;
@@ -378,12 +386,12 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
         if (p.act == ACT_RELU) epilogue(ActTag<ACT_RELU>{});
         else if (p.act == ACT_ELU) epilogue(ActTag<ACT_ELU>{});
         else epilogue(ActTag<ACT_NONE>{});
-        cur = nxt;
+        if (half + 1 == p.nsplit) cur = nxt;
     }
 }
 
 hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
-    if (p.W % D_TW || p.Cout > 64 || p.Cout % 8) return hipErrorInvalidValue;
+    if (p.W % D_TW || p.Cout > 64 || p.Cout % 8 || p.nsplit < 1 || p.nsplit > 2 || (p.nsplit == 2 && p.Cout != 64)) return hipErrorInvalidValue;
     static int cus = 0;
     if (!cus) {
         int dev = 0;
@@ -397,7 +405,7 @@ hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
     const int tiles = (p.W / D_TW) * ((p.H + th - 1) / th) * p.N;
     const dim3 grid((unsigned)(tiles < cus ? tiles : cus));
     const int nb = p.Cout <= 32 ? 1 : 2;
-    const bool n16 = p.Cout <= 16 && !p.pool && !std::getenv("SEMDEPTH_NO_N16");
+    const bool n16 = p.Cout <= 16 && p.nsplit == 1 && !p.pool && !std::getenv("SEMDEPTH_NO_N16");
     if (p.rows_per_wave != 2) return hipErrorInvalidValue;       // (8-row tiles were measured no better and are not built)
     if (p.f16) {
         if (n16) hipLaunchKernelGGL((conv_direct_kernel<1, 2, true, true>), grid, dim3(512), 0, s, q);

@@ -109,8 +109,11 @@ struct ConvDirectParams {
     const DirectChunk* chunks;   // DEVICE [nchunks]
     int nchunks;
     int N, H, W;                 // output (= logical input) dims
-    int Cout;                    // <= 32 or 64, multiple of 8
-    const u32x4_t* wt;           // [plane][chunk][tap 9][octet 2][32 or 64][8 bf16]
+    int Cout;                    // output channels PER SPLIT: <= 32 or 64, multiple of 8
+    int nsplit, Cstride;         // layers with 128 output channels run as 2 splits of 64 (same tile, one after the other);
+                                 // Cstride = channels of the output tensor
+    int out_planar16;            // write the output as 16-channel sub-planes (TensorDesc::planar16)
+    const u32x4_t* wt;           // [split][plane][chunk][tap 9][octet 2][32 or 64][8 bf16]
     const float* bias;
     float* out;                  // split planes [N,H,W,Cout]
     size_t out_plane;
@@ -148,7 +151,7 @@ hipError_t launch_pre_vgg(const uint8_t* frames, float* out, long npix, int spli
 hipError_t launch_pre_mono(const uint8_t* frames, float* out, int B, int H, int W, int split, size_t plane, hipStream_t s);      // /255 + fliplr pair
 hipError_t launch_maxpool2(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s);
 hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s);
-hipError_t launch_unsplit(const float* x, float* y, long npix, int C, int Ctf, size_t plane, int f16, hipStream_t s);  // split planes -> f32 [npix][Ctf]
+hipError_t launch_unsplit(const float* x, float* y, long npix, int C, int Ctf, size_t plane, size_t sub, int f16, hipStream_t s);  // split planes -> f32 [npix][Ctf]
 // y[n,2i+ky-1,2j+kx-1,o] += x[n,i,j,c]*w[ky,kx,o,c]; y += bias + skip   (3->3 channels; fcn8s/fcn.py:186-204)
 hipError_t launch_deconv4s2_add(const float* x, const float* w, const float* bias, const float* skip, float* y,
                                 int N, int H, int W, hipStream_t s);

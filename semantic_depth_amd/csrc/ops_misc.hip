@@ -380,18 +380,19 @@ hipError_t launch_conv_smalln(const SmallNParams& p, hipStream_t s) {
 }
 
 // split planes [npix][C] -> f32 [npix][Ctf] (introspection: sd_net_tensor); Ctf < C for zero-padded tensors
-__global__ __launch_bounds__(256) void unsplit_kernel(const float* __restrict__ x, float* __restrict__ y, long total, int C, int Ctf, size_t plane, int f16) {
+// (sub > 0: the tensor is stored as C/16 sub-planes of 16 channels, sub = elements per sub-plane, TensorDesc::planar16)
+__global__ __launch_bounds__(256) void unsplit_kernel(const float* __restrict__ x, float* __restrict__ y, long total, int C, int Ctf, size_t plane, size_t sub, int f16) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const long pix = i / Ctf;
     const int c = (int)(i - pix * Ctf);
-    const uint16_t* h = reinterpret_cast<const uint16_t*>(x) + pix * C + c;
+    const uint16_t* h = reinterpret_cast<const uint16_t*>(x) + (sub ? (size_t)(c >> 4) * sub + (size_t)pix * 16 + (c & 15) : (size_t)pix * C + c);
     if (f16) y[i] = (float)__builtin_bit_cast(_Float16, h[0]) + (float)__builtin_bit_cast(_Float16, h[plane]);
     else y[i] = __uint_as_float((unsigned)h[0] << 16) + __uint_as_float((unsigned)h[plane] << 16);
 }
-hipError_t launch_unsplit(const float* x, float* y, long npix, int C, int Ctf, size_t plane, int f16, hipStream_t s) {
+hipError_t launch_unsplit(const float* x, float* y, long npix, int C, int Ctf, size_t plane, size_t sub, int f16, hipStream_t s) {
     const long total = npix * Ctf;
-    hipLaunchKernelGGL(unsplit_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, total, C, Ctf, plane, f16);
+    hipLaunchKernelGGL(unsplit_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, total, C, Ctf, plane, sub, f16);
     return hipGetLastError();
 }
 

@@ -30,16 +30,16 @@ struct Builder {
     }
     void alias(const std::string& name, int t) { p.tensor_by_name[name] = t; }
 
-    int wslot(const std::string& name, std::initializer_list<int64_t> shape, int layout, int Kpad = 0, int CoutPad = 0, int nout = 0) {
+    int wslot(const std::string& name, std::initializer_list<int64_t> shape, int layout, int Kpad = 0, int CoutPad = 0, int nout = 0, int nsplit = 1) {
         WeightSlot s;
-        s.name = name; s.rank = (int)shape.size(); s.layout = layout; s.Kpad = Kpad; s.CoutPad = CoutPad; s.nout = nout;
+        s.name = name; s.rank = (int)shape.size(); s.layout = layout; s.Kpad = Kpad; s.CoutPad = CoutPad; s.nout = nout; s.nsplit = nsplit;
         s.f16 = p.f16;
         int i = 0;
         for (auto v : shape) s.shape[i++] = v;
         size_t n = 0;
         switch (layout) {
             case WL_IGEMM: case WL_IGEMM_SPLIT: n = (size_t)Kpad * CoutPad; break;
-            case WL_DIRECT_SPLIT: n = (size_t)Kpad * CoutPad; break;     // Kpad = nchunks * 9 * 16, CoutPad = 32 or 64
+            case WL_DIRECT_SPLIT: n = (size_t)Kpad * CoutPad * nsplit; break;     // Kpad = nchunks * 9 * 16, CoutPad = 32 or 64
             case WL_SMALLN: n = (size_t)s.shape[0] * s.shape[1] * s.shape[2] * 4; break;
             case WL_BIAS4: n = 4; break;
             default: n = 1; for (int j = 0; j < s.rank; ++j) n *= (size_t)s.shape[j];
@@ -84,7 +84,8 @@ struct Builder {
         op.Kvec = k * k * Cvec; op.CqPad = CqPad;
         op.Kpad = op.Kvec + (k * k * CqPad + 31) / 32 * 32;
         // full-resolution few-channel 3x3 layers of the split engine go to the direct (halo-tile) kernel
-        bool direct = p.prec && k == 3 && stride == 1 && (Cout <= 32 || Cout == 64) && Cout % 8 == 0 && Win % 32 == 0 && residual < 0 &&
+        const bool split128 = Cout == 128 && !std::getenv("SEMDEPTH_NO_DIRECT128");      // two 64-channel passes per tile
+        bool direct = p.prec && k == 3 && stride == 1 && (Cout <= 32 || Cout == 64 || split128) && Cout % 8 == 0 && Win % 32 == 0 && residual < 0 &&
                       !std::getenv("SEMDEPTH_NO_DIRECT");
         for (int i = 0; i < op.nsrc; ++i)
             if (p.tensors[op.src[i]].C % 8 || op.sstride[i] != 1) direct = false;
@@ -93,7 +94,8 @@ struct Builder {
             int nch = 0;
             for (int i = 0; i < op.nsrc; ++i) nch += (p.tensors[op.src[i]].C + 15) / 16;
             op.nchunks = nch;
-            op.w = wslot(wname, {k, k, Ctf, Cout}, WL_DIRECT_SPLIT, nch * 9 * 16, Cout <= 32 ? 32 : 64);
+            op.nsplit = Cout > 64 ? 2 : 1;
+            op.w = wslot(wname, {k, k, Ctf, Cout}, WL_DIRECT_SPLIT, nch * 9 * 16, Cout <= 32 ? 32 : 64, 0, op.nsplit);
             WeightSlot& ws = p.weights[op.w];
             ws.nsrc = op.nsrc;
             for (int i = 0; i < 3; ++i) { ws.srcCtf[i] = srcCtf[i]; ws.srcCpad[i] = i < op.nsrc ? p.tensors[op.src[i]].C : 0; }
@@ -213,7 +215,27 @@ struct Builder {
         return op.dst;
     }
 
+    // a tensor written by a direct conv and read only by direct convs is handed over as 16-channel sub-planes
+    // (TensorDesc::planar16): the reader's 16-channel chunk of a pixel row is then one contiguous run
+    void mark_planar() {
+        if (!p.prec || std::getenv("SEMDEPTH_NO_PLANAR")) return;
+        for (size_t ti = 0; ti < p.tensors.size(); ++ti) {
+            TensorDesc& t = p.tensors[ti];
+            if (t.C % 16 || (int)ti == p.t_output || (int)ti == p.t_input) continue;
+            bool made = false, ok = true;
+            int readers = 0;
+            for (const OpDesc& op : p.ops) {
+                if (op.dst == (int)ti) made = op.kind == OP_CONV_DIRECT;
+                bool reads = op.residual == (int)ti;
+                for (int j = 0; j < op.nsrc; ++j) reads = reads || op.src[j] == (int)ti;
+                if (reads) { ++readers; ok = ok && op.kind == OP_CONV_DIRECT && op.residual != (int)ti; }
+            }
+            if (made && ok && readers > 0) t.planar16 = 1;
+        }
+    }
+
     void finish() {
+        mark_planar();
         // liveness
         for (size_t i = 0; i < p.ops.size(); ++i) {
             const OpDesc& op = p.ops[i];
@@ -298,8 +320,6 @@ NetPlan build_fcn8s(int frames, int H, int W, int prec, int f16) {
             if (s == 0 && j == 1 && prec && b.p.ops.back().kind == OP_CONV_DIRECT && b.p.tensors[xin].C == 64 && W % 32 == 0 &&
                 !std::getenv("SEMDEPTH_NO_PLANAR") && !std::getenv("SEMDEPTH_NO_STEM")) {
                 b.p.tensors[xin].planar16 = 1;
-                for (auto it = b.p.tensor_by_name.begin(); it != b.p.tensor_by_name.end();)
-                    it = it->second == xin ? b.p.tensor_by_name.erase(it) : std::next(it);       // not a plain NHWC tensor any more
             }
         }
         x = b.pool("pool" + std::to_string(s + 1), x, false);
@@ -486,10 +506,10 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
             }
         }
     } else if (s.layout == WL_DIRECT_SPLIT) {
-        // [plane][chunk][tap 9][octet 2][CoutPad n][8]: chunk = 16 stored channels of one source
+        // [split][plane][chunk][tap 9][octet 2][CoutPad n][8]: chunk = 16 stored channels of one source
         const int64_t Ctf = s.shape[2], Cout = s.shape[3];
-        uint16_t* hi = reinterpret_cast<uint16_t*>(out.data());
-        uint16_t* lo = hi + (size_t)s.Kpad * s.CoutPad;
+        const size_t plane = (size_t)s.Kpad * s.CoutPad;
+        uint16_t* const hi0 = reinterpret_cast<uint16_t*>(out.data());
         auto bf16 = [](float v) -> uint16_t { uint32_t u; std::memcpy(&u, &v, 4); u += 0x7FFFu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
         auto bf16_to_f = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; };
         int chunk = 0, cb_tf = 0;
@@ -501,10 +521,11 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
                         const float* src = w + ((int64_t)tap * Ctf + cb_tf + c) * Cout;
                         const size_t base = (((size_t)chunk * 9 + tap) * 2 + oct) * s.CoutPad * 8 + e;
                         for (int64_t n = 0; n < Cout; ++n) {
-                            if (s.f16) { hi[base + n * 8] = f32_to_f16_rne(src[n]); continue; }
+                            uint16_t* hi = hi0 + (size_t)(n / s.CoutPad) * 2 * plane + base + (n % s.CoutPad) * 8;
+                            if (s.f16) { *hi = f32_to_f16_rne(src[n]); continue; }
                             const uint16_t h = bf16(src[n]);
-                            hi[base + n * 8] = h;
-                            lo[base + n * 8] = bf16(src[n] - bf16_to_f(h));
+                            *hi = h;
+                            hi[plane] = bf16(src[n] - bf16_to_f(h));
                         }
                     }
             cb_tf += s.srcCtf[i];

@@ -33,6 +33,7 @@ struct WeightSlot {
     int rank = 0;
     int layout = WL_RAW;
     int Kpad = 0, CoutPad = 0, nout = 0;
+    int nsplit = 1;        // WL_DIRECT_SPLIT: output channels are stored as nsplit blocks of CoutPad (128-channel layers: 2 x 64)
     int nsrc = 1, srcCtf[3] = {0, 0, 0}, srcCpad[3] = {0, 0, 0};   // WL_IGEMM: channel structure of the K axis
     int vec = 0;           // 1: K axis is ordered (32-channel block, tap, channel) instead of (tap, channel)
     int f16 = 0;           // split layouts: hi plane = fp16(w), lo plane unused (the 2-product scheme of split_fmt.hpp)
@@ -61,6 +62,7 @@ struct OpDesc {
     int K = 0, Kpad = 0, vec = 0, m_fastest = 0;
     int fuse_pool = 0;           // OP_CONV_DIRECT / OP_CONV (LDS-DMA kernel): the 2x2 max pool that follows is applied in the epilogue
     int nchunks = 0;             // OP_CONV_DIRECT: 32-channel chunks over the concatenated sources
+    int nsplit = 1;              // OP_CONV_DIRECT: passes of <= 64 output channels per tile
     int Kvec = 0, CqPad = 0;     // mixed layers: K = [vec region: (32-channel block, tap, channel)] + [quad tail: (tap, channel quads)]
     size_t tab_offset = 0, tab_bytes = 0;    // KEntry table, in the weight arena
     double flops = 0;                        // 2*M*N*K for the whole chunk
