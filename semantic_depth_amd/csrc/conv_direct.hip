@@ -74,10 +74,14 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds;      // LDS byte address
     const int frow = lane & 31, fk = lane >> 5;
 
-    struct Tile { int img, ty0, tx0; };
-    auto tile_of = [&](int tid) {
-        if ((total & 7) == 0) tid = (tid & 7) * (total >> 3) + (tid >> 3);     // neighbouring tiles (shared halos) on one XCD
+    // work item = (tile, pass of <= 64 output channels); the passes of a tile are neighbouring items
+    const int items = total * p.nsplit;
+    struct Tile { int img, ty0, tx0, half; };
+    auto tile_of = [&](int it) {
+        if ((items & 7) == 0) it = (it & 7) * (items >> 3) + (it >> 3);     // neighbouring items (shared halos) on one XCD
         Tile r;
+        int tid = it / p.nsplit;
+        r.half = it - tid * p.nsplit;
         const int bx = tid % tiles_x; tid /= tiles_x;
         r.tx0 = bx * D_TW; r.ty0 = (tid % tiles_y) * D_TH; r.img = tid / tiles_y;
         return r;
@@ -126,20 +130,20 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
 
     // the bias vector lives in LDS (zero past the layer's channels) and is read by the epilogue: no registers held
     // through the product loop
-    __shared__ __attribute__((aligned(16))) float sbias[128];
-    if (threadIdx.x < 128) sbias[threadIdx.x] = (int)threadIdx.x < p.nsplit * p.Cout ? p.bias[threadIdx.x] : 0.f;
+    __shared__ __attribute__((aligned(16))) float sbias[512];
+    sbias[threadIdx.x] = (int)threadIdx.x < p.nsplit * p.Cout ? p.bias[threadIdx.x] : 0.f;
     const int c16 = lane & 15, kg16 = lane >> 4;           // N16 fragment coordinates
     f32x4 bias16 = {0.f, 0.f, 0.f, 0.f};
     if (N16 && 4 * kg16 < p.Cout) bias16 = *reinterpret_cast<const f32x4*>(p.bias + 4 * kg16);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     int tid = blockIdx.x;
-    if (tid >= total) return;
+    if (tid >= items) return;
     Tile cur = tile_of(tid);
-    issue(cur, 0, 0, 0);
+    issue(cur, cur.half, 0, 0);
     int g = 0;                                     // stages consumed so far
-    for (; tid < total; tid += gridDim.x)
-    for (int half = 0; half < p.nsplit; ++half) {
+    for (; tid < items; tid += gridDim.x) {
+        const int half = cur.half;
         f32x16 acc[MT][NB];
 #pragma unroll
         for (int a = 0; a < MT; ++a)
@@ -157,8 +161,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();          // stage g has landed for every wave; everyone is done with stage g-1
             if (c + 1 < p.nchunks) issue(cur, half, c + 1, (g + 1) & 1);
-            else if (half + 1 < p.nsplit) issue(cur, half + 1, 0, (g + 1) & 1);               // same tile, next 64 output channels
-            else if (tid + (int)gridDim.x < total) { nxt = tile_of(tid + gridDim.x); issue(nxt, 0, 0, (g + 1) & 1); }
+            else if (tid + (int)gridDim.x < items) { nxt = tile_of(tid + gridDim.x); issue(nxt, nxt.half, 0, (g + 1) & 1); }
             const u32x4* Xh = lds + (g & 1) * D_STAGE;
             const u32x4* Xl = Xh + D_XUNITS;
             const u32x4* Wh = Xl + D_XUNITS;
@@ -386,12 +389,12 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
         if (p.act == ACT_RELU) epilogue(ActTag<ACT_RELU>{});
         else if (p.act == ACT_ELU) epilogue(ActTag<ACT_ELU>{});
         else epilogue(ActTag<ACT_NONE>{});
-        if (half + 1 == p.nsplit) cur = nxt;
+        cur = nxt;
     }
 }
 
 hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
-    if (p.W % D_TW || p.Cout > 64 || p.Cout % 8 || p.nsplit < 1 || p.nsplit > 2 || (p.nsplit == 2 && p.Cout != 64)) return hipErrorInvalidValue;
+    if (p.W % D_TW || p.Cout > 64 || p.Cout % 8 || p.nsplit < 1 || p.nsplit > 8 || (p.nsplit > 1 && p.Cout != 64)) return hipErrorInvalidValue;
     static int cus = 0;
     if (!cus) {
         int dev = 0;
@@ -403,7 +406,7 @@ hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
     if (p.pool && (p.rows_per_wave != 2 || (p.H & 1) || (p.W & 1))) return hipErrorInvalidValue;
     const int th = 8 * p.rows_per_wave;
     const int tiles = (p.W / D_TW) * ((p.H + th - 1) / th) * p.N;
-    const dim3 grid((unsigned)(tiles < cus ? tiles : cus));
+    const dim3 grid((unsigned)(tiles * p.nsplit < cus ? tiles * p.nsplit : cus));
     const int nb = p.Cout <= 32 ? 1 : 2;
     const bool n16 = p.Cout <= 16 && p.nsplit == 1 && !p.pool && !std::getenv("SEMDEPTH_NO_N16");
     if (p.rows_per_wave != 2) return hipErrorInvalidValue;       // (8-row tiles were measured no better and are not built)

@@ -110,7 +110,7 @@ struct ConvDirectParams {
     int nchunks;
     int N, H, W;                 // output (= logical input) dims
     int Cout;                    // output channels PER SPLIT: <= 32 or 64, multiple of 8
-    int nsplit, Cstride;         // layers with 128 output channels run as 2 splits of 64 (same tile, one after the other);
+    int nsplit, Cstride;         // layers with 128 / 256 output channels run as 2 / 4 passes of 64 per tile (work item = tile x pass);
                                  // Cstride = channels of the output tensor
     int out_planar16;            // write the output as 16-channel sub-planes (TensorDesc::planar16)
     const u32x4_t* wt;           // [split][plane][chunk][tap 9][octet 2][32 or 64][8 bf16]

@@ -84,7 +84,12 @@ struct Builder {
         op.Kvec = k * k * Cvec; op.CqPad = CqPad;
         op.Kpad = op.Kvec + (k * k * CqPad + 31) / 32 * 32;
         // full-resolution few-channel 3x3 layers of the split engine go to the direct (halo-tile) kernel
-        const bool split128 = Cout == 128 && !std::getenv("SEMDEPTH_NO_DIRECT128");      // two 64-channel passes per tile
+        // 128 .. 512 output channels: 2 .. 8 passes of 64 per tile (256 and more only where an image has enough tiles: the
+        // choice must not depend on the batch)
+        const char* mp = std::getenv("SEMDEPTH_DIRECT_MINPIX");
+        const int64_t minpix = mp ? std::atoll(mp) : 512;
+        const bool split128 = (Cout == 128 && !std::getenv("SEMDEPTH_NO_DIRECT128")) ||
+                              ((Cout == 256 || Cout == 512) && (int64_t)Hin * Win >= minpix);
         bool direct = p.prec && k == 3 && stride == 1 && (Cout <= 32 || Cout == 64 || split128) && Cout % 8 == 0 && Win % 32 == 0 && residual < 0 &&
                       !std::getenv("SEMDEPTH_NO_DIRECT");
         for (int i = 0; i < op.nsrc; ++i)
@@ -94,7 +99,7 @@ struct Builder {
             int nch = 0;
             for (int i = 0; i < op.nsrc; ++i) nch += (p.tensors[op.src[i]].C + 15) / 16;
             op.nchunks = nch;
-            op.nsplit = Cout > 64 ? 2 : 1;
+            op.nsplit = Cout > 64 ? Cout / 64 : 1;
             op.w = wslot(wname, {k, k, Ctf, Cout}, WL_DIRECT_SPLIT, nch * 9 * 16, Cout <= 32 ? 32 : 64, 0, op.nsplit);
             WeightSlot& ws = p.weights[op.w];
             ws.nsrc = op.nsrc;
