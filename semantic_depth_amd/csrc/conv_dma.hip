@@ -64,7 +64,7 @@ __device__ __forceinline__ KEntry load_kentry(const KEntry* ptr) {
 // SIMPLE = 2: the two-source 1x1 GEMM of a ResNet block tail (conv3 over its 3x3 output + projection over the block input,
 // each with its own stride): two base pointers per lane, the k-tile index selects the source.
 template <int WAVES_M, int WAVES_N, int MT, int NT, int SIMPLE, int STAGES, bool F16 = false>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 2 ? 2 : 1) void conv_dma_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
     constexpr int STAGE_UNITS = 8 * (BM + BN);                // 16-B units: Xh [4][BM] | Xl [4][BM] | Wh [4][BN] | Wl [4][BN]
@@ -377,6 +377,8 @@ int conv_dma_variant(const ConvParams& p) {
     const long M = (long)p.N * p.Hout * p.Wout;
     const long thr = p.pool ? 0 : 96;     // tiles needed: the DMA pipeline at half occupancy still beats the register-staged
                                           // kernel (a fused pool exists only here: such layers always take this kernel)
+    static const bool big = std::getenv("SEMDEPTH_NO_DMA_BIG") == nullptr;
+    if (big && !p.pool && p.Cout % 256 == 0 && ((M + 255) / 256) * (p.Cout / 256) >= 512) return 5;     // 256 x 256, two stages
     if (p.Cout % 256 == 0 && ((M + 127) / 128) * (p.Cout / 256) >= thr) return 1;     // 128 x 256
     if (p.Cout % 128 == 0 && ((M + 255) / 256) * (p.Cout / 128) >= thr) return 2;     // 256 x 128
     if (p.Cout % 128 != 0 && ((M + 255) / 256) * (p.Cout / 64) >= thr) return 3;      // 256 x 64
@@ -406,6 +408,7 @@ hipError_t launch_conv_dma(const ConvParams& p0, hipStream_t s) {
     if (v == 1) launch_dma_variant<2, 4, 2, 2, 3>(p, M, s);
     else if (v == 2) launch_dma_variant<4, 2, 2, 2, 3>(p, M, s);
     else if (v == 3) launch_dma_variant<4, 2, 2, 1, 3>(p, M, s);
+    else if (v == 5) launch_dma_variant<2, 4, 4, 2, 2>(p, M, s);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -415,12 +418,14 @@ const char* conv_dma_kernel_name(const ConvParams& p) {
         switch (conv_dma_variant(p)) {
             case 1: return "conv_dma_f16w_kernel<2,4,2,2>";
             case 2: return "conv_dma_f16w_kernel<4,2,2,2>";
+            case 5: return "conv_dma_f16w_kernel<2,4,4,2>";
             default: return "conv_dma_f16w_kernel<4,2,2,1>";
         }
     }
     switch (conv_dma_variant(p)) {
         case 1: return "conv_dma_kernel<2,4,2,2>";
         case 2: return "conv_dma_kernel<4,2,2,2>";
+        case 5: return "conv_dma_kernel<2,4,4,2>";
         default: return "conv_dma_kernel<4,2,2,1>";
     }
 }
