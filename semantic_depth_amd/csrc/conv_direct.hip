@@ -60,10 +60,13 @@ __device__ __forceinline__ DirectChunk load_chunk(const DirectChunk* ptr) {
 // N16 (Cout <= 16, NB = 1): the 32-row MFMA would spend half its rows on padding, so the products run on
 // v_mfma_f32_16x16x32 instead: K = 32 is one PAIR of taps x 16 channels, a wave's 2 x 32 pixels are four 16-pixel blocks.
 template <int NB, int MT, bool F16, bool N16 = false>
-__global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectParams p) {
+__global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_kernel(const ConvDirectParams p) {
     static_assert(!N16 || NB == 1, "N16 is a variant of the 32-channel kernel");
     using Cfg = DirectCfg<NB, MT>;
-    constexpr int D_WI = Cfg::WI, D_WUNITS = Cfg::WUNITS, D_STAGE = Cfg::STAGE;
+    // weights: a (plane, chunk) block in memory is [tap][octet][32 NB][8]; the LDS image is the same, except N16, which keeps
+    // only the 16 output channels it multiplies ([tap][octet][16][8], 288 units in 5 DMA instructions)
+    constexpr int D_GW = Cfg::WUNITS;
+    constexpr int D_WI = N16 ? 5 : Cfg::WI, D_WUNITS = N16 ? 320 : Cfg::WUNITS, D_STAGE = 2 * Cfg::XUNITS + 2 * D_WUNITS;
     constexpr int D_TH = Cfg::TH, D_HH = Cfg::HH, D_XI = Cfg::XI, D_XUNITS = Cfg::XUNITS, XS = Cfg::XS;
     __shared__ __attribute__((aligned(16))) u32x4 lds[2 * D_STAGE];
     const int t = threadIdx.x, lane = t & 63;
@@ -122,16 +125,17 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
             const int jw = wave + D_WAVES * i;
             if (jw < (F16 ? 1 : 2) * D_WI) {
                 const int pl = jw >= D_WI ? 1 : 0;
-                const u32x4* gw = p.wt + ((size_t)(2 * half + pl) * p.nchunks + c) * D_WUNITS + (jw - pl * D_WI) * 64 + lane;
-                ddma16(gw, sbyte + (unsigned)((2 * D_XUNITS + jw * 64) * 16));
+                const int u = (jw - pl * D_WI) * 64 + lane;
+                const u32x4* gw = p.wt + ((size_t)(2 * half + pl) * p.nchunks + c) * D_GW + (N16 ? (u >> 4) * 32 + (u & 15) : u);
+                ddma16(N16 && u >= 288 ? zero : gw, sbyte + (unsigned)((2 * D_XUNITS + jw * 64) * 16));
             }
         }
     };
 
     // the bias vector lives in LDS (zero past the layer's channels) and is read by the epilogue: no registers held
     // through the product loop
-    __shared__ __attribute__((aligned(16))) float sbias[512];
-    sbias[threadIdx.x] = (int)threadIdx.x < p.nsplit * p.Cout ? p.bias[threadIdx.x] : 0.f;
+    __shared__ __attribute__((aligned(16))) float sbias[N16 ? 4 : 512];
+    if constexpr (!N16) sbias[threadIdx.x] = (int)threadIdx.x < p.nsplit * p.Cout ? p.bias[threadIdx.x] : 0.f;
     const int c16 = lane & 15, kg16 = lane >> 4;           // N16 fragment coordinates
     f32x4 bias16 = {0.f, 0.f, 0.f, 0.f};
     if (N16 && 4 * kg16 < p.Cout) bias16 = *reinterpret_cast<const f32x4*>(p.bias + 4 * kg16);
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
                     const int tap = 2 * tp + (kg16 >> 1), oct = kg16 & 1;
                     const bool live = tap < 9;
                     const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;         // tap / 3, tap % 3 for tap < 10
-                    const int wi = (tap * 2 + oct) * 32 + c16;
+                    const int wi = (tap * 2 + oct) * 16 + c16;
                     const u32x4 wh = live ? Wh[wi] : z4;
                     const u32x4 wl = F16 ? wh : (live ? Wl[wi] : z4);
 #pragma unroll
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const ConvDirectPar
             const int n0 = half * p.Cout;                 // first output channel of this split
             f32x4 bias[4 * NB];
 #pragma unroll
-            for (int r4 = 0; r4 < 4 * NB; ++r4) bias[r4] = *reinterpret_cast<const f32x4*>(sbias + n0 + 8 * r4 + 4 * fk);
+            for (int r4 = 0; r4 < 4 * NB; ++r4) bias[r4] = *reinterpret_cast<const f32x4*>(sbias + (N16 ? 0 : n0 + 8 * r4 + 4 * fk));
             // output address of 8 channels (segment sg) of pixel px: NHWC, or 16-channel sub-planes
             auto oaddr = [&](size_t px, size_t npix, int sg) {
                 const int ch = n0 + sg * 8;
@@ -404,18 +408,24 @@ hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
     }
     ConvDirectParams q = p;
     if (p.pool && (p.rows_per_wave != 2 || (p.H & 1) || (p.W & 1))) return hipErrorInvalidValue;
-    const int th = 8 * p.rows_per_wave;
-    const int tiles = (p.W / D_TW) * ((p.H + th - 1) / th) * p.N;
-    const dim3 grid((unsigned)(tiles * p.nsplit < cus ? tiles * p.nsplit : cus));
+    if (p.rows_per_wave != 2) return hipErrorInvalidValue;       // (8-row tiles of the 32/64-channel kernels were measured no better and are not built)
     const int nb = p.Cout <= 32 ? 1 : 2;
     const bool n16 = p.Cout <= 16 && p.nsplit == 1 && !p.pool && !std::getenv("SEMDEPTH_NO_N16");
-    if (p.rows_per_wave != 2) return hipErrorInvalidValue;       // (8-row tiles were measured no better and are not built)
+    // N16 layers (full-resolution decoder tail: two chunks of little arithmetic per tile) are bound by the DMA latency of
+    // a two-stage ring: 8-row tiles, 64 KiB of LDS, TWO workgroups per CU cover each other's waits
+    const bool mt1 = n16 && !std::getenv("SEMDEPTH_NO_N16_MT1");
+    const int th = mt1 ? 8 : 16;
+    const int tiles = (p.W / D_TW) * ((p.H + th - 1) / th) * p.N * p.nsplit;
+    const int slots = cus * (mt1 ? 2 : 1);
+    const dim3 grid((unsigned)(tiles < slots ? tiles : slots));
     if (p.f16) {
-        if (n16) hipLaunchKernelGGL((conv_direct_kernel<1, 2, true, true>), grid, dim3(512), 0, s, q);
+        if (mt1) hipLaunchKernelGGL((conv_direct_kernel<1, 1, true, true>), grid, dim3(512), 0, s, q);
+        else if (n16) hipLaunchKernelGGL((conv_direct_kernel<1, 2, true, true>), grid, dim3(512), 0, s, q);
         else if (nb == 1) hipLaunchKernelGGL((conv_direct_kernel<1, 2, true>), grid, dim3(512), 0, s, q);
         else hipLaunchKernelGGL((conv_direct_kernel<2, 2, true>), grid, dim3(512), 0, s, q);
     } else {
-        if (n16) hipLaunchKernelGGL((conv_direct_kernel<1, 2, false, true>), grid, dim3(512), 0, s, q);
+        if (mt1) hipLaunchKernelGGL((conv_direct_kernel<1, 1, false, true>), grid, dim3(512), 0, s, q);
+        else if (n16) hipLaunchKernelGGL((conv_direct_kernel<1, 2, false, true>), grid, dim3(512), 0, s, q);
         else if (nb == 1) hipLaunchKernelGGL((conv_direct_kernel<1, 2, false>), grid, dim3(512), 0, s, q);
         else hipLaunchKernelGGL((conv_direct_kernel<2, 2, false>), grid, dim3(512), 0, s, q);
     }
