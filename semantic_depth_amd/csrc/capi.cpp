@@ -163,7 +163,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 }
                 const bool dma = split && conv_dma_variant(c) != 0 && !std::getenv("SEMDEPTH_NO_DMA");
                 const bool stem = split && !dma && conv_stem_eligible(c);
-                if (c.out_planar16 && !stem) return fail(h, SD_ERR_STATE, "sub-planar output needs the stem conv kernel");
+                if (c.out_planar16 && !stem && !dma) return fail(h, SD_ERR_STATE, "sub-planar output needs the LDS-DMA or the stem conv kernel");
                 if (c.pool && !dma) return fail(h, SD_ERR_STATE, "fused pool needs the LDS-DMA conv kernel");
                 e = dma ? launch_conv_dma(c, s) : stem ? launch_conv_stem(c, s) : split ? launch_conv_split(c, s) : launch_conv_igemm(c, s);
                 if (h->prof) {
@@ -211,6 +211,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.wt = Wp(op.w); c.bias = Wp(op.b); c.out = T(op.dst); c.act = op.act;
                 c.in_split = FMT(op.src[0]) != 0; c.out_split = FMT(op.dst) != 0; c.in_plane = PL(op.src[0]); c.out_plane = PL(op.dst);
                 c.f16 = p.f16;
+                c.in_sub = s0.planar16 ? (size_t)p.images * s0.H * s0.W * 16 : 0;
                 c.out_c = p.tensors[op.dst].C;
                 c.zero16 = h->ws + h->o_misc + 256;
                 e = launch_conv_smalln(c, s);

@@ -284,6 +284,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
         constexpr int SEGS = NT * 4, PPP = 64 / SEGS;
         const int seg = lane % SEGS, prow = lane / SEGS;
         uint16_t* const out_hi = reinterpret_cast<uint16_t*>(p.out);
+        // 8 channels from channel ch of output pixel px: NHWC, or 16-channel sub-planes (TensorDesc::planar16)
+        const size_t osub = p.out_plane / p.Cout * 16;
+        auto oaddr = [&](size_t px, int ch) {
+            return p.out_planar16 ? out_hi + (size_t)(ch >> 4) * osub + px * 16 + (ch & 8) : out_hi + px * p.Cout + ch;
+        };
         const int m0 = bm0 + wm0, n0 = bn0 + wn0;
         if (p.pool) {
             // fused 2x2 max pool: the four pixels of a window are four consecutive accumulator columns = lanes 4j..4j+3;
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
                     if (pix < 8 && mo < M) {
                         const u32x4 h = *reinterpret_cast<const u32x4*>(sh + pix * ROW + seg * 16);
                         const u32x4 l = *reinterpret_cast<const u32x4*>(sl + pix * ROW + seg * 16);
-                        uint16_t* o = out_hi + (size_t)(mo >> 2) * p.Cout + n0 + seg * 8;
+                        uint16_t* o = oaddr((size_t)(mo >> 2), n0 + seg * 8);
                         *reinterpret_cast<u32x4*>(o) = h;
                         *reinterpret_cast<u32x4*>(o + p.out_plane) = l;
                     }
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
                 const u32x4 h = *reinterpret_cast<const u32x4*>(sh + pix * ROW + seg * 16);
                 const u32x4 l = *reinterpret_cast<const u32x4*>(sl + pix * ROW + seg * 16);
                 if (mo < M) {
-                    uint16_t* o = out_hi + (size_t)mo * p.Cout + n0 + seg * 8;
+                    uint16_t* o = oaddr((size_t)mo, n0 + seg * 8);
                     *reinterpret_cast<u32x4*>(o) = h;
                     *reinterpret_cast<u32x4*>(o + p.out_plane) = l;
                 }
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
 int conv_dma_variant(const ConvParams& p) {
     if (!p.vec || !p.zero16 || p.Cout % 64 || p.Kpad < 64) return 0;
     const long M = (long)p.N * p.Hout * p.Wout;
-    const long thr = p.pool ? 0 : 96;     // tiles needed: the DMA pipeline at half occupancy still beats the register-staged
+    const long thr = (p.pool || p.out_planar16) ? 0 : 96;     // tiles needed: the DMA pipeline at half occupancy still beats the register-staged
                                           // kernel (a fused pool exists only here: such layers always take this kernel)
     static const bool big = std::getenv("SEMDEPTH_NO_DMA_BIG") == nullptr;
     if (big && !p.pool && p.Cout % 256 == 0 && ((M + 255) / 256) * (p.Cout / 256) >= 512) return 5;     // 256 x 256, two stages

@@ -131,6 +131,8 @@ struct SmallNParams {
     int in_split, out_split;       // activation formats (split_fmt.hpp); out_split needs nout == 2
     int out_c;                     // stored channels of a split output (2, or 8 = zero-padded octet for the direct conv)
     size_t in_plane, out_plane;    // element offset of the lo plane
+    size_t in_sub;                 // > 0: the input is stored as C/16 sub-planes of 16 channels, in_sub elements each
+                                   // (TensorDesc::planar16; tiled kernel only)
     int N, H, W, C;
     int k;              // 1 or 3 (stride 1, zero pad (k-1)/2)
     int nout;           // computed output channels (<= 4)
@@ -142,6 +144,7 @@ struct SmallNParams {
     int f16;            // split planes (in and out) are fp16 instead of bf16
 };
 hipError_t launch_conv_smalln(const SmallNParams& p, hipStream_t s);
+bool conv_smalln_tiled(int in_split, int k, int W, int C, int nout);   // the LDS-tiled kernel takes this layer (it alone reads sub-planar inputs)
 
 // ---------------------------------------------------------------------------------------------
 // misc network ops (ops_misc.hip)

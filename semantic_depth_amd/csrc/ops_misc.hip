@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256) void conv_smalln_tile_kernel(const SmallNParam
     const int ty0 = (bid % tiles_y) * SN_TH;
     const int img = bid / tiles_y;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)X;
-    const uint16_t* const img_hi = reinterpret_cast<const uint16_t*>(p.x) + (size_t)img * p.H * p.W * p.C;
+    const int pstride = p.in_sub ? 16 : p.C;                     // elements per pixel in one (sub-)plane
+    const uint16_t* const img_hi = reinterpret_cast<const uint16_t*>(p.x) + (size_t)img * p.H * p.W * pstride;
     const int row = t >> 5, col = t & 31;
     float acc[NOUT];
 #pragma unroll
@@ -297,7 +298,8 @@ __global__ __launch_bounds__(256) void conv_smalln_tile_kernel(const SmallNParam
             const int ry = pix / SN_HW, rx = pix - ry * SN_HW;
             const int gy = ty0 - 1 + ry, gx = tx0 - 1 + rx;
             const bool ok = pix < SN_HH * SN_HW && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && oct < nvalid;
-            const uint16_t* src = img_hi + (pl ? p.in_plane : (size_t)0) + ((size_t)gy * p.W + gx) * p.C + c0 + oct * 8;
+            const uint16_t* src = img_hi + (pl ? p.in_plane : (size_t)0) + ((size_t)gy * p.W + gx) * pstride +
+                                  (p.in_sub ? (size_t)(c0 >> 4) * p.in_sub : (size_t)c0) + oct * 8;
             sn_dma16(ok ? (const void*)src : p.zero16, lds0 + (unsigned)(j * 1024));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -371,7 +373,12 @@ static void launch_smalln_t(const SmallNParams& p, hipStream_t s) {
         hipLaunchKernelGGL(conv_smalln_wave_kernel<IN_SPLIT>, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, p);
     }
 }
+bool conv_smalln_tiled(int in_split, int k, int W, int C, int nout) {
+    return in_split && k == 3 && W % SN_TW == 0 && C % 8 == 0 && nout <= 2 && (size_t)9 * C * 4 * nout <= 24576 &&
+           !std::getenv("SEMDEPTH_NO_SMALLN_TILE");
+}
 hipError_t launch_conv_smalln(const SmallNParams& p, hipStream_t s) {
+    if (p.in_sub && !(conv_smalln_tiled(p.in_split, p.k, p.W, p.C, p.nout) && p.zero16)) return hipErrorInvalidValue;   // sub-planes: tiled kernel only
     if (p.out_split && (p.nout != 2 || p.k * p.k * p.C > 2048)) return hipErrorInvalidValue;
     if (p.in_split && p.f16) launch_smalln_t<2>(p, s);
     else if (p.in_split) launch_smalln_t<1>(p, s);

@@ -220,20 +220,28 @@ struct Builder {
         return op.dst;
     }
 
-    // a tensor written by a direct conv and read only by direct convs is handed over as 16-channel sub-planes
-    // (TensorDesc::planar16): the reader's 16-channel chunk of a pixel row is then one contiguous run
+    // a tensor written by a direct conv (or by a conv that always takes the LDS-DMA kernel) and read only by direct convs and
+    // LDS-tiled few-channel heads is handed over as 16-channel sub-planes (TensorDesc::planar16): the reader's 16-channel
+    // chunk of a pixel row is then one contiguous run instead of 32 bytes out of every pixel's line
     void mark_planar() {
         if (!p.prec || std::getenv("SEMDEPTH_NO_PLANAR")) return;
+        const bool wide = !std::getenv("SEMDEPTH_NO_PLANAR_WIDE");
         for (size_t ti = 0; ti < p.tensors.size(); ++ti) {
             TensorDesc& t = p.tensors[ti];
             if (t.C % 16 || (int)ti == p.t_output || (int)ti == p.t_input) continue;
             bool made = false, ok = true;
             int readers = 0;
             for (const OpDesc& op : p.ops) {
-                if (op.dst == (int)ti) made = op.kind == OP_CONV_DIRECT;
+                if (op.dst == (int)ti)
+                    made = op.kind == OP_CONV_DIRECT ||
+                           (wide && op.kind == OP_CONV && op.vec && op.Kvec == op.Kpad && t.C % 64 == 0 && op.Kpad >= 64 &&
+                            !std::getenv("SEMDEPTH_NO_DMA"));
                 bool reads = op.residual == (int)ti;
                 for (int j = 0; j < op.nsrc; ++j) reads = reads || op.src[j] == (int)ti;
-                if (reads) { ++readers; ok = ok && op.kind == OP_CONV_DIRECT && op.residual != (int)ti; }
+                if (!reads) continue;
+                ++readers;
+                const bool head = wide && op.kind == OP_SMALLN && conv_smalln_tiled(1, op.k, t.W, t.C, op.nout);
+                ok = ok && (op.kind == OP_CONV_DIRECT || head) && op.residual != (int)ti;
             }
             if (made && ok && readers > 0) t.planar16 = 1;
         }
