@@ -382,7 +382,7 @@ int conv_dma_variant(const ConvParams& p) {
     const long M = (long)p.N * p.Hout * p.Wout;
     const long thr = (p.pool || p.out_planar16) ? 0 : 96;     // tiles needed: the DMA pipeline at half occupancy still beats the register-staged
                                           // kernel (a fused pool exists only here: such layers always take this kernel)
-    static const bool big = std::getenv("SEMDEPTH_NO_DMA_BIG") == nullptr;
+    const bool big = std::getenv("SEMDEPTH_NO_DMA_BIG") == nullptr;
     if (big && !p.pool && p.Cout % 256 == 0 && ((M + 255) / 256) * (p.Cout / 256) >= 512) return 5;     // 256 x 256, two stages
     if (p.Cout % 256 == 0 && ((M + 127) / 128) * (p.Cout / 256) >= thr) return 1;     // 128 x 256
     if (p.Cout % 128 == 0 && ((M + 255) / 256) * (p.Cout / 128) >= thr) return 2;     // 256 x 128

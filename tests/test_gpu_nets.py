@@ -125,14 +125,17 @@ def test_flipped_frame_symmetry_of_post_processing():
 
 
 @pytest.mark.parametrize("switch", ["SEMDEPTH_NO_DMA", "SEMDEPTH_NO_DIRECT", "SEMDEPTH_NO_STEM", "SEMDEPTH_NO_POOL_FUSE", "SEMDEPTH_NO_PLANAR",
-                                    "SEMDEPTH_NO_N16", "SEMDEPTH_NO_SMALLN_TILE"])
+                                    "SEMDEPTH_NO_N16", "SEMDEPTH_NO_SMALLN_TILE", "SEMDEPTH_NO_DIRECT128", "SEMDEPTH_NO_N16_MT1",
+                                    "SEMDEPTH_NO_PLANAR_WIDE", "SEMDEPTH_DIRECT_MINPIX=1000000000"])
 def test_generic_kernels_behind_each_specialised_one(switch):
-    """every specialised kernel (LDS-DMA pipeline, direct conv, stem conv, fused pools, sub-plane hand-off, 16-wide MFMA,
-    tiled heads) has a generic one behind it; with the specialised one switched off the networks still meet the budget."""
+    """every specialised kernel (LDS-DMA pipeline, direct conv and its multi-pass form for 128..512 output channels, stem
+    conv, fused pools, sub-plane hand-off, 16-wide MFMA and its 8-row tiles, tiled heads) has a generic one behind it; with
+    the specialised one switched off the networks still meet the budget."""
     from semantic_depth_amd.engine import Engine
     from semantic_depth_amd import weights as Wt
     H, W, B = 64, 128, 2
-    os.environ[switch] = "1"
+    switch, _, val = switch.partition("=")
+    os.environ[switch] = val or "1"
     try:
         eng = Engine(H, W, B, "resnet50", precision="bf16x2")       # the switches are read when the plan is built / at launch
         wf = Wt.make_fcn8s_weights(1, decoder_std=0.05, bias_std=0.1)
@@ -148,3 +151,31 @@ def test_generic_kernels_behind_each_specialised_one(switch):
     f = fr[1].astype(np.float32) / 255
     ref = nets.monodepth_forward(np.stack((f, np.fliplr(f)), 0), wm, "resnet50")[..., 0]
     assert relerr(raw[1].cpu().numpy(), ref) < TOL
+
+
+def test_256x256_block_of_the_dma_pipeline_is_bit_identical_to_the_128x256_one():
+    """the LDS-DMA conv kernel takes layers with >= 512 blocks of 256 x 256 outputs in that block shape (two LDS stages)
+    instead of 128 x 256 (three): same k order and product order per output, so the network outputs must not change by a
+    bit.  256 x 512 frames, 8 of them: the ResNet block tails from res2 on have enough blocks."""
+    from semantic_depth_amd.engine import Engine
+    from semantic_depth_amd import weights as Wt
+    H, W, B = 256, 512, 8
+    wm = Wt.make_monodepth_weights("resnet50", 4, bias_std=0.05)
+    fr = dev(_frames(B, H, W, seed=21))
+    outs = []
+    for off in (False, True):
+        if off:
+            os.environ["SEMDEPTH_NO_DMA_BIG"] = "1"
+        try:
+            eng = Engine(H, W, B, "resnet50", precision="bf16x2")
+            eng.load_weights(L.SD_NET_MONODEPTH, wm)
+            eng.profile(True)
+            _, raw = eng.monodepth_forward(fr, want_raw=True)
+            kernels = {b["kernel"] for b in eng.profile_read()}
+            eng.profile(False)
+        finally:
+            os.environ.pop("SEMDEPTH_NO_DMA_BIG", None)
+        assert any("<2,4,4,2>" in k for k in kernels) == (not off), kernels
+        outs.append(raw.clone())
+        del eng
+    assert torch.equal(outs[0], outs[1])
