@@ -181,6 +181,8 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.pool = op.fuse_pool;
                 c.N = N; c.H = d.H << c.pool; c.W = d.W << c.pool;
                 c.nsplit = op.nsplit; c.Cout = d.C / op.nsplit; c.Cstride = d.C; c.out_planar16 = d.planar16;
+                c.all_up = 1;
+                for (int i = 0; i < op.nsrc; ++i) c.all_up = c.all_up && op.up[i] == 1;
                 c.wt = reinterpret_cast<const u32x4_t*>(Wp(op.w)); c.bias = Wp(op.b);
                 c.out = T(op.dst); c.out_plane = PL(op.dst); c.act = op.act; c.Nmax = p.images;
                 c.zero16 = h->ws + h->o_misc + 256;

@@ -32,9 +32,13 @@ constexpr int D_WAVES = 8;
 // MT = 2 halves the halo and weight traffic per pixel; MT = 1 keeps the source footprint of the workgroups of one XCD
 // inside its 4 MiB L2 when a source pixel is wider than one 16-channel chunk (each chunk pass touches only 32 B of a
 // pixel's 128-B line, so a line evicted between passes is fetched from the fabric again).
-template <int NB, int MT> struct DirectCfg {
+// UP: every source is read through a x2 nearest-neighbour upsample (the upconv layers): the LDS tile then holds the
+// (HH/2 + 1) x 18 SOURCE pixels under the halo instead of their HH x 34 replicas (a quarter of the DMA instructions and
+// bytes); halo pixel (hy, hx) reads source pixel ((hy + 1) >> 1, (hx + 1) >> 1) of the tile (tile origins are even).
+template <int NB, int MT, bool UP = false> struct DirectCfg {
     static constexpr int TH = 8 * MT, HH = TH + 2;
-    static constexpr int XI = (HH * D_HW * 2 + 63) / 64;      // DMA instructions per halo plane (2 slots per pixel)
+    static constexpr int SH = UP ? HH / 2 + 1 : HH, SW = UP ? D_HW / 2 + 1 : D_HW;      // stored tile
+    static constexpr int XI = (SH * SW * 2 + 63) / 64;        // DMA instructions per halo plane (2 slots per pixel)
     static constexpr int XUNITS = XI * 64;
     static constexpr int XS = (2 * XI + D_WAVES - 1) / D_WAVES;    // X-DMA slots per wave
     static constexpr int WI = 9 * NB;                    // DMA instructions per weight plane
@@ -59,14 +63,19 @@ __device__ __forceinline__ DirectChunk load_chunk(const DirectChunk* ptr) {
 // F16: fp16 planes, ONE fp16 weight plane, two MFMA products per product (split_fmt.hpp)
 // N16 (Cout <= 16, NB = 1): the 32-row MFMA would spend half its rows on padding, so the products run on
 // v_mfma_f32_16x16x32 instead: K = 32 is one PAIR of taps x 16 channels, a wave's 2 x 32 pixels are four 16-pixel blocks.
-template <int NB, int MT, bool F16, bool N16 = false>
+template <int NB, int MT, bool F16, bool N16 = false, bool UP = false>
 __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_kernel(const ConvDirectParams p) {
     static_assert(!N16 || NB == 1, "N16 is a variant of the 32-channel kernel");
-    using Cfg = DirectCfg<NB, MT>;
+    using Cfg = DirectCfg<NB, MT, UP>;
+    constexpr int S_HH = Cfg::SH, S_HW = Cfg::SW;
+    // LDS pixel slot of halo pixel (hy, hx)
+    auto hpix = [](int hy, int hx) { return UP ? ((hy + 1) >> 1) * S_HW + ((hx + 1) >> 1) : hy * S_HW + hx; };
     // weights: a (plane, chunk) block in memory is [tap][octet][32 NB][8]; the LDS image is the same, except N16, which keeps
     // only the 16 output channels it multiplies ([tap][octet][16][8], 288 units in 5 DMA instructions)
     constexpr int D_GW = Cfg::WUNITS;
-    constexpr int D_WI = N16 ? 5 : Cfg::WI, D_WUNITS = N16 ? 320 : Cfg::WUNITS, D_STAGE = 2 * Cfg::XUNITS + 2 * D_WUNITS;
+    constexpr int D_WI = N16 ? 5 : Cfg::WI, D_WUNITS = N16 ? 320 : Cfg::WUNITS;
+    constexpr int SLAB16 = D_WAVES * 2 * 32 * 48 / 16;       // the N16 epilogue's transposition slabs live in a consumed stage
+    constexpr int D_STAGE = (N16 && 2 * Cfg::XUNITS + 2 * D_WUNITS < SLAB16) ? SLAB16 : 2 * Cfg::XUNITS + 2 * D_WUNITS;
     constexpr int D_TH = Cfg::TH, D_HH = Cfg::HH, D_XI = Cfg::XI, D_XUNITS = Cfg::XUNITS, XS = Cfg::XS;
     __shared__ __attribute__((aligned(16))) u32x4 lds[2 * D_STAGE];
     const int t = threadIdx.x, lane = t & 63;
@@ -99,8 +108,8 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
         const int u = (j - (j >= D_XI ? D_XI : 0)) * 64 + lane;      // (slots with j >= 2 XI are never issued)
         const int pix = u >> 1;
         const int oct = (u & 1) ^ ((pix >> 3) & 1);
-        const int ry = pix / D_HW, rx = pix - ry * D_HW;
-        geo[i] = ry | (rx << 8) | (oct << 16) | ((pix < D_HH * D_HW ? 1 : 0) << 17);
+        const int ry = pix / S_HW, rx = pix - ry * S_HW;
+        geo[i] = ry | (rx << 8) | (oct << 16) | ((pix < S_HH * S_HW ? 1 : 0) << 17);
     }
 
     // stage image: Xh[1280] Xl[1280] Wh[576] Wl[576]; X unit = [halo pixel][octet ^ ((pixel >> 3) & 1)]
@@ -114,9 +123,12 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
             const int j = wave + D_WAVES * i;
             if (j >= 2 * D_XI) continue;
             const int ry = geo[i] & 0xff, rx = (geo[i] >> 8) & 0xff, oct = (geo[i] >> 16) & 1;
-            const int gy = tl.ty0 - 1 + ry, gx = tl.tx0 - 1 + rx;
-            const bool ok = (geo[i] >> 17) && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && oct < ch.nvalid;
-            const unsigned off = (unsigned)(((gy >> ch.up) * ch.W + (gx >> ch.up)) * ch.C + oct * 8);
+            // UP: source coordinates directly (an output-resolution pixel is outside the image exactly when its source pixel is)
+            const int gy = (UP ? (tl.ty0 >> 1) : tl.ty0) - 1 + ry, gx = (UP ? (tl.tx0 >> 1) : tl.tx0) - 1 + rx;
+            const bool ok = (geo[i] >> 17) && (unsigned)gy < (unsigned)(UP ? ch.H : p.H) && (unsigned)gx < (unsigned)(UP ? ch.W : p.W) &&
+                            oct < ch.nvalid;
+            const unsigned off = UP ? (unsigned)((gy * ch.W + gx) * ch.C + oct * 8)
+                                    : (unsigned)(((gy >> ch.up) * ch.W + (gx >> ch.up)) * ch.C + oct * 8);
             const uint16_t* src = (j >= D_XI ? img_hi + plane : img_hi) + off;
             ddma16(ok ? reinterpret_cast<const u32x4*>(src) : zero, sbyte + (unsigned)(j * 1024));
         }
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                     for (int a = 0; a < MT; ++a)
 #pragma unroll
                         for (int pb = 0; pb < 2; ++pb) {
-                            const int lp = (MT * wave + a + dy) * D_HW + 16 * pb + c16 + dx;
+                            const int lp = hpix(MT * wave + a + dy, 16 * pb + c16 + dx);
                             const int idx = lp * 2 + (oct ^ ((lp >> 3) & 1));
                             const u32x4 xh = live ? Xh[idx] : z4;
                             const u32x4 xl = live ? Xl[idx] : z4;
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                 u32x4 xh[MT + 2], xl[MT + 2];
 #pragma unroll
                 for (int r = 0; r < MT + 2; ++r) {
-                    const int lp = (MT * wave + r) * D_HW + frow + dx;
+                    const int lp = hpix(MT * wave + r, frow + dx);
                     const int idx = lp * 2 + (fk ^ ((lp >> 3) & 1));
                     xh[r] = Xh[idx];
                     xl[r] = Xl[idx];
@@ -247,6 +259,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
             if constexpr (N16) {
                 // lane holds channels 4 kg16 .. + 3 of pixel 16 pb + c16; slab row = 16 channels (32 B) + pad per plane
                 constexpr int R16 = 32 + 16;
+                static_assert(D_WAVES * 2 * 32 * R16 <= D_STAGE * 16, "N16 epilogue slabs must fit one stage");
                 unsigned char* s16 = reinterpret_cast<unsigned char*>(lds + ((g - 1) & 1) * D_STAGE) + wave * (2 * 32 * R16);
 #pragma unroll
                 for (int a = 0; a < MT; ++a) {
@@ -413,22 +426,32 @@ hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
     const bool n16 = p.Cout <= 16 && p.nsplit == 1 && !p.pool && !std::getenv("SEMDEPTH_NO_N16");
     // N16 layers (full-resolution decoder tail: two chunks of little arithmetic per tile) are bound by the DMA latency of
     // a two-stage ring: 8-row tiles, 64 KiB of LDS, TWO workgroups per CU cover each other's waits
-    const bool mt1 = n16 && !std::getenv("SEMDEPTH_NO_N16_MT1");
+    // every source behind a x2 upsample: source-resolution halo tiles (48 KiB of LDS for N16 with 16-row tiles: they stay)
+    const bool up = p.all_up && !(p.H & 1) && !(p.W & 1) && !std::getenv("SEMDEPTH_NO_UPTILE");
+    const bool mt1 = n16 && !up && !std::getenv("SEMDEPTH_NO_N16_MT1");
     const int th = mt1 ? 8 : 16;
     const int tiles = (p.W / D_TW) * ((p.H + th - 1) / th) * p.N * p.nsplit;
-    const int slots = cus * (mt1 ? 2 : 1);
-    const dim3 grid((unsigned)(tiles < slots ? tiles : slots));
+    // persistent grid: as many workgroups as the instantiation keeps resident (1-3 per CU, by LDS and registers)
+#define SD_DIRECT_(NB_, MT_, F16_, N16_, UP_) \
+    do { static int per_cu = 0; \
+         if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_direct_kernel<NB_, MT_, F16_, N16_, UP_>, 512, 0) != hipSuccess || per_cu < 1)) per_cu = 1; \
+         const int slots = cus * per_cu; \
+         const dim3 grid((unsigned)(tiles < slots ? tiles : slots)); \
+         hipLaunchKernelGGL((conv_direct_kernel<NB_, MT_, F16_, N16_, UP_>), grid, dim3(512), 0, s, q); } while (0)
+#define SD_DIRECT(NB_, MT_, F16_, N16_) do { if (up) SD_DIRECT_(NB_, MT_, F16_, N16_, true); else SD_DIRECT_(NB_, MT_, F16_, N16_, false); } while (0)
     if (p.f16) {
-        if (mt1) hipLaunchKernelGGL((conv_direct_kernel<1, 1, true, true>), grid, dim3(512), 0, s, q);
-        else if (n16) hipLaunchKernelGGL((conv_direct_kernel<1, 2, true, true>), grid, dim3(512), 0, s, q);
-        else if (nb == 1) hipLaunchKernelGGL((conv_direct_kernel<1, 2, true>), grid, dim3(512), 0, s, q);
-        else hipLaunchKernelGGL((conv_direct_kernel<2, 2, true>), grid, dim3(512), 0, s, q);
+        if (mt1) SD_DIRECT(1, 1, true, true);
+        else if (n16) SD_DIRECT(1, 2, true, true);
+        else if (nb == 1) SD_DIRECT(1, 2, true, false);
+        else SD_DIRECT(2, 2, true, false);
     } else {
-        if (mt1) hipLaunchKernelGGL((conv_direct_kernel<1, 1, false, true>), grid, dim3(512), 0, s, q);
-        else if (n16) hipLaunchKernelGGL((conv_direct_kernel<1, 2, false, true>), grid, dim3(512), 0, s, q);
-        else if (nb == 1) hipLaunchKernelGGL((conv_direct_kernel<1, 2, false>), grid, dim3(512), 0, s, q);
-        else hipLaunchKernelGGL((conv_direct_kernel<2, 2, false>), grid, dim3(512), 0, s, q);
+        if (mt1) SD_DIRECT(1, 1, false, true);
+        else if (n16) SD_DIRECT(1, 2, false, true);
+        else if (nb == 1) SD_DIRECT(1, 2, false, false);
+        else SD_DIRECT(2, 2, false, false);
     }
+#undef SD_DIRECT_
+#undef SD_DIRECT
     return hipGetLastError();
 }
 

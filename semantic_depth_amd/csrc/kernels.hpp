@@ -113,6 +113,7 @@ struct ConvDirectParams {
     int nsplit, Cstride;         // layers with 128 / 256 output channels run as 2 / 4 passes of 64 per tile (work item = tile x pass);
                                  // Cstride = channels of the output tensor
     int out_planar16;            // write the output as 16-channel sub-planes (TensorDesc::planar16)
+    int all_up;                  // every chunk has up == 1 (upconv layers): the kernel keeps source-resolution halo tiles
     const u32x4_t* wt;           // [split][plane][chunk][tap 9][octet 2][32 or 64][8 bf16]
     const float* bias;
     float* out;                  // split planes [N,H,W,Cout]

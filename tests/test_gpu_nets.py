@@ -126,7 +126,7 @@ def test_flipped_frame_symmetry_of_post_processing():
 
 @pytest.mark.parametrize("switch", ["SEMDEPTH_NO_DMA", "SEMDEPTH_NO_DIRECT", "SEMDEPTH_NO_STEM", "SEMDEPTH_NO_POOL_FUSE", "SEMDEPTH_NO_PLANAR",
                                     "SEMDEPTH_NO_N16", "SEMDEPTH_NO_SMALLN_TILE", "SEMDEPTH_NO_DIRECT128", "SEMDEPTH_NO_N16_MT1",
-                                    "SEMDEPTH_NO_PLANAR_WIDE", "SEMDEPTH_DIRECT_MINPIX=1000000000"])
+                                    "SEMDEPTH_NO_PLANAR_WIDE", "SEMDEPTH_NO_UPTILE", "SEMDEPTH_DIRECT_MINPIX=1000000000"])
 def test_generic_kernels_behind_each_specialised_one(switch):
     """every specialised kernel (LDS-DMA pipeline, direct conv and its multi-pass form for 128..512 output channels, stem
     conv, fused pools, sub-plane hand-off, 16-wide MFMA and its 8-row tiles, tiled heads) has a generic one behind it; with
