@@ -181,6 +181,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.pool = op.fuse_pool;
                 c.N = N; c.H = d.H << c.pool; c.W = d.W << c.pool;
                 c.nsplit = op.nsplit; c.Cout = d.C / op.nsplit; c.Cstride = d.C; c.out_planar16 = d.planar16;
+                c.nreal = (d.Ctf > 0 && d.Ctf < d.C) ? d.Ctf : 0;
                 c.all_up = 1;
                 for (int i = 0; i < op.nsrc; ++i) c.all_up = c.all_up && op.up[i] == 1;
                 c.wt = reinterpret_cast<const u32x4_t*>(Wp(op.w)); c.bias = Wp(op.b);

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
     if constexpr (!N16) sbias[threadIdx.x] = (int)threadIdx.x < p.nsplit * p.Cout ? p.bias[threadIdx.x] : 0.f;
     const int c16 = lane & 15, kg16 = lane >> 4;           // N16 fragment coordinates
     f32x4 bias16 = {0.f, 0.f, 0.f, 0.f};
-    if (N16 && 4 * kg16 < p.Cout) bias16 = *reinterpret_cast<const f32x4*>(p.bias + 4 * kg16);
+    if (N16 && 4 * kg16 < (p.nreal ? p.nreal : p.Cout)) bias16 = *reinterpret_cast<const f32x4*>(p.bias + 4 * kg16);      // (bias slots are padded to 4)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     int tid = blockIdx.x;
@@ -269,6 +269,10 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                         f32x4 v = acc16[a][pb] + bias16;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
+                        if (p.nreal) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = 4 * kg16 + r < p.nreal ? v[r] : 0.f;
+                        }
                         uint2 h, l;
                         split4_t<F16>(v, h, l);
                         if (4 * kg16 < p.Cout) {
@@ -405,12 +409,14 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
         };
         if (p.act == ACT_RELU) epilogue(ActTag<ACT_RELU>{});
         else if (p.act == ACT_ELU) epilogue(ActTag<ACT_ELU>{});
+        else if (N16 && p.act == ACT_SIGMOID03) epilogue(ActTag<ACT_SIGMOID03>{});
         else epilogue(ActTag<ACT_NONE>{});
         cur = nxt;
     }
 }
 
 hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
+    if ((p.act == ACT_SIGMOID03 || p.nreal) && (p.Cout > 16 || p.nsplit != 1 || p.pool || std::getenv("SEMDEPTH_NO_N16"))) return hipErrorInvalidValue;
     if (p.W % D_TW || p.Cout > 64 || p.Cout % 8 || p.nsplit < 1 || p.nsplit > 8 || (p.nsplit > 1 && p.Cout != 64)) return hipErrorInvalidValue;
     static int cus = 0;
     if (!cus) {

@@ -87,6 +87,7 @@ template <int ACT> struct ActTag { static constexpr int value = ACT; };
 template <int ACT> __device__ __forceinline__ float act_split(float v) {
     if (ACT == 1) return fmaxf(v, 0.f);
     if (ACT == 2) return fast_elu_split(v);
+    if (ACT == 3) return 0.3f * (1.0f / (1.0f + expf(-v)));      // as smalln_act (ops_misc.hip)
     return v;
 }
 template <int ACT> __device__ __forceinline__ float act_f32(float v) {
@@ -113,6 +114,8 @@ struct ConvDirectParams {
     int nsplit, Cstride;         // layers with 128 / 256 output channels run as 2 / 4 passes of 64 per tile (work item = tile x pass);
                                  // Cstride = channels of the output tensor
     int out_planar16;            // write the output as 16-channel sub-planes (TensorDesc::planar16)
+    int nreal;                   // > 0: only the first nreal of the Cout stored channels are real, the rest are written as zeros
+                                 // (disparity heads: 2 channels in a zero-padded octet; N16 kernel)
     int all_up;                  // every chunk has up == 1 (upconv layers): the kernel keeps source-resolution halo tiles
     const u32x4_t* wt;           // [split][plane][chunk][tap 9][octet 2][32 or 64][8 bf16]
     const float* bias;

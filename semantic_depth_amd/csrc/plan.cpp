@@ -173,6 +173,25 @@ struct Builder {
         OpDesc op;
         op.kind = OP_SMALLN; op.name = name; op.nsrc = 1; op.src[0] = src; op.k = k; op.pad = (k - 1) / 2; op.act = act; op.nout = nout;
         const TensorDesc& t = p.tensors[src];
+        // a 3x3 head whose output feeds the next iconv (disp4..disp2, written as one zero-padded octet per pixel) is a direct
+        // conv on the 16-wide MFMA: its two real output channels ride in a 16-column weight image
+        if (feeds_conv && p.prec && k == 3 && t.W % 32 == 0 && t.C % 8 == 0 && nout <= 8 && nout == cout_tf &&
+            !std::getenv("SEMDEPTH_NO_DIRECT") && !std::getenv("SEMDEPTH_NO_N16") && !std::getenv("SEMDEPTH_NO_MFMA_HEADS")) {
+            op.kind = OP_CONV_DIRECT; op.stride = 1;
+            op.nchunks = (t.C + 15) / 16;
+            op.nsplit = 1;
+            op.w = wslot(wname, {k, k, t.C, cout_tf}, WL_DIRECT_SPLIT, op.nchunks * 9 * 16, 32, 0, 1);
+            WeightSlot& ws = p.weights[op.w];
+            ws.nsrc = 1; ws.srcCtf[0] = t.Ctf ? t.Ctf : t.C; ws.srcCpad[0] = t.C;
+            op.b = wslot(bname, {cout_tf}, WL_BIAS4, 0, 0, nout);
+            op.dst = tensor(name, t.N, t.H, t.W, 8);
+            p.tensors[op.dst].Ctf = nout;
+            op.tab_bytes = (size_t)op.nchunks * sizeof(DirectChunk);
+            op.K = k * k * t.C;
+            op.flops = 2.0 * t.N * t.H * t.W * nout * k * k * t.C;
+            push(op);
+            return op.dst;
+        }
         op.w = wslot(wname, {k, k, t.C, cout_tf}, WL_SMALLN, 0, 0, nout);
         op.b = wslot(bname, {cout_tf}, WL_BIAS4, 0, 0, nout);
         // a disparity map that feeds the next iconv is stored as ONE zero-padded channel octet per pixel in the split
