@@ -179,3 +179,27 @@ def test_256x256_block_of_the_dma_pipeline_is_bit_identical_to_the_128x256_one()
         outs.append(raw.clone())
         del eng
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("H,W,B,enc", [(512, 1024, 2, "resnet50"), (384, 1280, 2, "resnet50"), (512, 1024, 1, "vgg")])
+def test_full_size_split_engine_matches_the_exact_f32_engine(H, W, B, enc):
+    """BASELINE.json's frame size is out of the CPU oracle's reach, so the split-bf16 engine (direct conv passes,
+    source-resolution upconv tiles, sub-plane hand-off, 256 x 256 DMA blocks, ...) is held against the exact f32 engine
+    (one generic f32-MFMA kernel, itself checked against the oracle at small sizes above): logits and raw disparities agree
+    to the split format's precision, an order of magnitude inside the 1e-3 budget."""
+    from semantic_depth_amd.engine import Engine
+    from semantic_depth_amd import weights as Wt
+    wf = Wt.make_fcn8s_weights(1, decoder_std=0.05, bias_std=0.1)
+    wm = Wt.make_monodepth_weights(enc, 2, bias_std=0.05)
+    fr = dev(_frames(B, H, W, seed=H + W))
+    res = {}
+    for prec in ("f32", "bf16x2"):
+        eng = Engine(H, W, B, enc, precision=prec)
+        eng.load_weights(L.SD_NET_FCN8S, wf)
+        eng.load_weights(L.SD_NET_MONODEPTH, wm)
+        lg = eng.fcn8s_forward(fr, want_logits=True)["logits"].clone()
+        _, raw = eng.monodepth_forward(fr, want_raw=True)
+        res[prec] = (lg.cpu().numpy(), raw.clone().cpu().numpy())
+        del eng
+    assert relerr(res["bf16x2"][0], res["f32"][0]) < 1e-4
+    assert relerr(res["bf16x2"][1], res["f32"][1]) < 1e-4
