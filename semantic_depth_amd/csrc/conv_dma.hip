@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
     constexpr int NDMA = XI + WPW;                            // DMA instructions per wave per tile (6; F16: 4 or 5)
     constexpr int EPI_ROW = NT * 64 + 16;
     static_assert(NW * 2 * 32 * EPI_ROW <= STAGES * STAGE_UNITS * 16, "epilogue slabs fit in the ring");
-    static_assert((8 * BM / 64) % (2 * NW) == 0 && (8 * BN / 64) % NW == 0, "whole DMA instructions per wave and plane");
+    static_assert((8 * BM / 64) % (2 * NW) == 0 && ((8 * BN / 64) % NW == 0 || NW % (8 * BN / 64 / 2) == 0), "whole DMA instructions per wave and plane (fewer weight instructions than waves: duplicate fetches)");
     __shared__ __attribute__((aligned(16))) u32x4 ring[STAGES * STAGE_UNITS];
 
     const int t = threadIdx.x, lane = t & 63;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
 
 // which layers take the DMA pipeline: vec layers with Cout a multiple of 64 and enough tiles to occupy the chip
 int conv_dma_variant(const ConvParams& p) {
-    if (!p.vec || !p.zero16 || p.Cout % 64 || p.Kpad < 64) return 0;
+    if (!p.vec || !p.zero16 || p.Cout % 32 || p.Kpad < 64) return 0;
     const long M = (long)p.N * p.Hout * p.Wout;
     const long thr = (p.pool || p.out_planar16) ? 0 : 96;     // tiles needed: the DMA pipeline at half occupancy still beats the register-staged
                                           // kernel (a fused pool exists only here: such layers always take this kernel)
@@ -386,7 +386,8 @@ int conv_dma_variant(const ConvParams& p) {
     if (big && !p.pool && p.Cout % 256 == 0 && ((M + 255) / 256) * (p.Cout / 256) >= 512) return 5;     // 256 x 256, two stages
     if (p.Cout % 256 == 0 && ((M + 127) / 128) * (p.Cout / 256) >= thr) return 1;     // 128 x 256
     if (p.Cout % 128 == 0 && ((M + 255) / 256) * (p.Cout / 128) >= thr) return 2;     // 256 x 128
-    if (p.Cout % 128 != 0 && ((M + 255) / 256) * (p.Cout / 64) >= thr) return 3;      // 256 x 64
+    if (p.Cout % 64 == 0 && p.Cout % 128 != 0 && ((M + 255) / 256) * (p.Cout / 64) >= thr) return 3;      // 256 x 64
+    if (p.Cout == 32 && !p.pool && !p.out_planar16 && (M + 255) / 256 >= thr && !std::getenv("SEMDEPTH_NO_DMA32")) return 4;      // 256 x 32 (monodepth-vgg conv1b)
     return 0;
 }
 
@@ -413,6 +414,7 @@ hipError_t launch_conv_dma(const ConvParams& p0, hipStream_t s) {
     if (v == 1) launch_dma_variant<2, 4, 2, 2, 3>(p, M, s);
     else if (v == 2) launch_dma_variant<4, 2, 2, 2, 3>(p, M, s);
     else if (v == 3) launch_dma_variant<4, 2, 2, 1, 3>(p, M, s);
+    else if (v == 4) launch_dma_variant<8, 1, 1, 1, 3>(p, M, s);
     else if (v == 5) launch_dma_variant<2, 4, 4, 2, 2>(p, M, s);
     else return hipErrorInvalidValue;
     return hipGetLastError();
@@ -423,6 +425,7 @@ const char* conv_dma_kernel_name(const ConvParams& p) {
         switch (conv_dma_variant(p)) {
             case 1: return "conv_dma_f16w_kernel<2,4,2,2>";
             case 2: return "conv_dma_f16w_kernel<4,2,2,2>";
+            case 4: return "conv_dma_f16w_kernel<8,1,1,1>";
             case 5: return "conv_dma_f16w_kernel<2,4,4,2>";
             default: return "conv_dma_f16w_kernel<4,2,2,1>";
         }
@@ -430,6 +433,7 @@ const char* conv_dma_kernel_name(const ConvParams& p) {
     switch (conv_dma_variant(p)) {
         case 1: return "conv_dma_kernel<2,4,2,2>";
         case 2: return "conv_dma_kernel<4,2,2,2>";
+        case 4: return "conv_dma_kernel<8,1,1,1>";
         case 5: return "conv_dma_kernel<2,4,4,2>";
         default: return "conv_dma_kernel<4,2,2,1>";
     }
