@@ -133,8 +133,52 @@ __global__ __launch_bounds__(256) void maxpool3z_kernel(const float* __restrict_
         }
     store4<SPLIT>(y, plane_out, i, m);
 }
+// split planes with C % 8 == 0: one thread per (output pixel, channel octet), 16-byte loads per plane and tap
+template <bool F16>
+__global__ __launch_bounds__(256) void maxpool3z_oct_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C8,
+                                                            size_t plane_in, size_t plane_out) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    long total = (long)N * Ho * Wo * C8;
+    if (i >= total) return;
+    int c = (int)(i % C8);
+    long r = i / C8;
+    int ox = (int)(r % Wo); r /= Wo;
+    int oy = (int)(r % Ho);
+    int n = (int)(r / Ho);
+    const u32x4_t* const xh = reinterpret_cast<const u32x4_t*>(x);
+    const u32x4_t* const xl = reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(x) + plane_in);
+    f32x4 m0 = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, m1 = m0;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            int iy = 2 * oy - 1 + dy, ix = 2 * ox - 1 + dx;
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;   // the padding is ZERO and takes part in the max (upstream quirk)
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                const long q = (((long)n * H + iy) * W + ix) * C8 + c;
+                const u32x4_t h = xh[q], l = xl[q];
+                v0 = recon4_t<F16>(uint2{h[0], h[1]}, uint2{l[0], l[1]});
+                v1 = recon4_t<F16>(uint2{h[2], h[3]}, uint2{l[2], l[3]});
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { m0[j] = fmaxf(m0[j], v0[j]); m1[j] = fmaxf(m1[j], v1[j]); }
+        }
+    uint2 h0, l0, h1, l1;
+    split4_t<F16>(m0, h0, l0);
+    split4_t<F16>(m1, h1, l1);
+    reinterpret_cast<u32x4_t*>(y)[i] = (u32x4_t){h0.x, h0.y, h1.x, h1.y};
+    reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(y) + plane_out)[i] = (u32x4_t){l0.x, l0.y, l1.x, l1.y};
+}
 hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    if (split && C % 8 == 0) {
+        const long tot8 = (long)N * Ho * Wo * (C / 8);
+        const dim3 g8((unsigned)((tot8 + 255) / 256));
+        if (split == 2) hipLaunchKernelGGL(maxpool3z_oct_kernel<true>, g8, dim3(256), 0, s, x, y, N, H, W, C / 8, plane_in, plane_out);
+        else hipLaunchKernelGGL(maxpool3z_oct_kernel<false>, g8, dim3(256), 0, s, x, y, N, H, W, C / 8, plane_in, plane_out);
+        return hipGetLastError();
+    }
     long total = (long)N * Ho * Wo * (C / 4);
     const dim3 grid((unsigned)((total + 255) / 256));
     if (split == 2) hipLaunchKernelGGL(maxpool3z_kernel<2>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
