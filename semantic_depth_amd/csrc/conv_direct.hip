@@ -1,13 +1,17 @@
-// Direct 3x3 stride-1 convolution for the full-resolution, few-channel layers of the split-bf16 engine
-// (monodepth decoder levels 1-2: Cout <= 32, sources of 8..64 channels, optional x2 nearest-neighbour upsample, concat).
+// Direct 3x3 stride-1 convolution of the split engines: every such layer whose width is a multiple of 32 (VGG conv1_2..conv5_3,
+// the ResNet 3x3 layers, the whole monodepth decoder incl. the disparity heads 4..2), with optional x2 nearest-neighbour
+// upsample and concatenated sources.
 //
-// For these layers an im2col GEMM is bound by the gather, not by the MFMA: every activation would be fetched nine times
-// (once per tap) for only 32 output channels.  Here a workgroup (8 waves) owns a 16 x 32 pixel output tile and, per
-// 16-channel chunk of the input, DMAs the 18 x 34 pixel HALO TILE once into LDS (32 B per pixel and plane, octet slot
-// XOR-swizzled by (pixel >> 3) & 1 on the source side so the shifted ds_read_b128 fragment reads stay conflict free)
-// together with the chunk's 9 x 16 x 32 weights; the nine taps read their shifted MFMA fragments straight out of the halo
-// tile, each input row fragment serving three taps.  Two 58 KiB stages: the DMA of chunk c+1 runs under the MFMAs of chunk c,
-// one barrier per chunk.  Each wave: 2 rows x 32 pixels x 32 channels, 3 x v_mfma_f32_32x32x16_bf16 per product.
+// An im2col GEMM fetches every activation nine times (once per tap).  Here a workgroup (8 waves) owns a 16 x 32 pixel
+// output tile and, per 16-channel chunk of the input, DMAs the 18 x 34 pixel HALO TILE once into LDS (32 B per pixel and
+// plane, octet slot XOR-swizzled by (pixel >> 3) & 1 on the source side so the shifted ds_read_b128 fragment reads stay
+// conflict free) together with the chunk's 9 x 16 x 64 weights; the nine taps read their shifted MFMA fragments straight
+// out of the halo tile, each input row fragment serving three taps: 89 B of LDS-DMA per MFMA against 170-256 B of the
+// im2col blocks of conv_dma.hip.  Two stages: the DMA of chunk c+1 runs under the MFMAs of chunk c, one barrier per chunk.
+// Each wave: 2 rows x 32 pixels x 64 channels, 3 x v_mfma_f32_32x32x16_bf16 per product.  Layers with more than 64 output
+// channels are passes of 64 (work item = tile x pass).  Variants: NB = 1 (<= 32 channels), N16 (<= 16 channels on the
+// 16-wide MFMA, 8-row tiles with two workgroups per CU), UP (all sources upsampled: source-resolution LDS tile), fused
+// 2x2 max pool, sub-planar (16-channel planes) sources and outputs.
 #include <cstdlib>
 #include "kernels.hpp"
 #include "split_fmt.hpp"

@@ -7,8 +7,9 @@
 // meets at ONE barrier:
 //      wait(tile t landed) ; barrier ; issue DMA(tile t+2) ; 16 ds_read + 24 MFMA on stage t%3
 // (stage (t+2)%3 was last read in iteration t-1, which every wave finished before this barrier).
-// 8 waves; block 128x256 (Cout % 256 == 0), 256x128 (Cout % 128 == 0) or 256x64 (Cout = 64); 3 x 40-48 KiB of LDS, one
-// workgroup per CU.
+// 8 waves; block 256x256 in TWO 64-KiB stages (layers with >= 512 such blocks: 170 B of DMA per MFMA, half the barriers), else
+// 128x256 (Cout % 256 == 0), 256x128 (Cout % 128 == 0), 256x64 or 256x32 with 3 x 36-48 KiB stages; one workgroup per CU.
+// (3x3 stride-1 layers of widths that are multiples of 32 never come here: conv_direct.hip.)
 // Out-of-image taps and pixels beyond M read a 16-byte zero page, so zero padding costs no branch in the pipeline.
 // Gather granularity: four consecutive lanes fetch the four 16-byte octets of ONE pixel (64 contiguous bytes per plane),
 // so a wave-instruction touches 16 cache lines instead of 64; the LDS image is therefore [pixel][octet] and the octet
