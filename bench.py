@@ -207,6 +207,15 @@ def main():
                        "tflops": round(b["flops"] / (b["ms"] * 1e-3) / 1e12, 2)} for b in buckets if b["launches"]],
     }
 
+    # second roofline: the fusion / back-projection stage is HBM-bound.  Algorithmic bytes of the stage as it runs
+    # here: read disp_pp (4 B) + two masks (2 B) + the frame (3 B) per pixel, write 15 B (xyz f32 + rgb u8) per gathered point.
+    n_pts = float(out["fuse"]["n_road"].sum().item()) + (float(out["fuse"]["n_fence"].sum().item()) if out["fuse"].get("n_fence") is not None else 0.0)
+    fuse_bytes = B * H * W * 9.0 + 15.0 * n_pts
+    fuse_gbs = fuse_bytes / (stage_ms[2] * 1e-3) / 1e9 if stage_ms[2] > 0 else 0.0
+    fusion_roofline = {"bound": "hbm", "achieved": round(fuse_gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(fuse_gbs / 8000.0, 4),
+                       "traffic": None, "kernel": "fuse_count_kernel + fuse_write_kernel (to3D stage of the last step, torch events)",
+                       "algorithmic_bytes_per_frame": round(fuse_bytes / B), "stage_us_per_frame": round(stage_ms[2] * 1e3 / B, 2)}
+
     # ------------------------------------------------------------------ CPU baseline: the oracle on this box's host cores
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
@@ -223,7 +232,7 @@ def main():
                    "stage_ms_last_step": {"seg": round(stage_ms[0], 2), "disp": round(stage_ms[1], 2), "to3D": round(stage_ms[2], 2),
                                           "road": round(stage_ms[3], 2)},
                    "road_fraction": round(road_frac, 4), "n_road_mean": float(recs["n_road"].mean()), "found": int(recs["found"].sum())},
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "fusion_roofline": fusion_roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(line), flush=True)
     if world > 1:
