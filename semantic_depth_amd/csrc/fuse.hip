@@ -8,6 +8,7 @@
 //   scan   : one workgroup per frame, exclusive scan over the frame's block counts   (tiny)
 //   write  : recompute the per-pixel record, rank inside the block with wave ballots, write at base + rank
 // Row-major order of points3D[mask] (semantic_depth.py:183-187) is preserved exactly.
+#include <cstdlib>
 #include "kernels.hpp"
 
 namespace sd {
@@ -117,6 +118,11 @@ __global__ __launch_bounds__(256) void fuse_write_kernel(const FuseParams p, int
     uint8_t c0 = 0, c1 = 0, c2 = 0;
     if (in) {
         const size_t gi = (size_t)b * npix + i;
+        if (p.road) r = p.road[gi] != 0;
+        if (p.fence) f = p.fence[gi] != 0;
+    }
+    if (in && (p.dense || r || f)) {       // the point is only needed where it is stored (three f64 divisions per pixel)
+        const size_t gi = (size_t)b * npix + i;
         const int y = i / p.W, x = i - y * p.W;
         const CamDev cam = p.cams[b];
         // disparity = disp_pp * multiplier in float32 (semantic_depth.py:145; seq:146)
@@ -136,9 +142,7 @@ __global__ __launch_bounds__(256) void fuse_write_kernel(const FuseParams p, int
             float* dp = p.dense + gi * 3;
             dp[0] = X; dp[1] = Y; dp[2] = Z;
         }
-        if (p.road) r = p.road[gi] != 0;
-        if (p.fence) f = p.fence[gi] != 0;
-        if (p.frames) {               // colours = cv2.cvtColor(frame, BGR2RGB), semantic_depth.py:161
+        if (p.frames && (r || f)) {               // colours = cv2.cvtColor(frame, BGR2RGB), semantic_depth.py:161
             const uint8_t* fp = p.frames + gi * 3;
             c0 = fp[2]; c1 = fp[1]; c2 = fp[0];
         }
@@ -170,10 +174,117 @@ __global__ __launch_bounds__(256) void fuse_write_kernel(const FuseParams p, int
     }
 }
 
+// ---- four pixels per thread (W % 4 == 0): 16-byte disparity loads, 4-byte mask loads, 12 bytes of frame per thread; a block
+//      is 1024 consecutive pixels.  Same row-major output order: thread order = pixel order, and a thread's four pixels are
+//      written in order.  Wave prefix of the 0..4 per-lane counts from three ballots (one per bit of the count).
+__device__ __forceinline__ int nz_bytes(unsigned v) { return ((v & 0xffu) != 0) + ((v & 0xff00u) != 0) + ((v & 0xff0000u) != 0) + ((v & 0xff000000u) != 0); }
+__device__ __forceinline__ void wave_prefix_total(int c, int lane, int& prefix, int& total) {
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long b0 = __ballot(c & 1), b1 = __ballot(c & 2), b2 = __ballot(c & 4);
+    prefix = __popcll(b0 & below) + 2 * __popcll(b1 & below) + 4 * __popcll(b2 & below);
+    total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+}
+__global__ __launch_bounds__(256) void fuse_count4_kernel(const uint8_t* __restrict__ road, const uint8_t* __restrict__ fence,
+                                                          int npix, int nblk, int32_t* __restrict__ blk_counts) {
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const int i4 = blk * 256 + threadIdx.x;                   // pixel quad
+    int cr = 0, cf = 0;
+    if (i4 * 4 < npix) {
+        if (road) cr = nz_bytes(reinterpret_cast<const unsigned*>(road + (size_t)b * npix)[i4]);
+        if (fence) cf = nz_bytes(reinterpret_cast<const unsigned*>(fence + (size_t)b * npix)[i4]);
+    }
+    __shared__ int wr[4], wf[4];
+    int pr_, tr, pf_, tf;
+    wave_prefix_total(cr, threadIdx.x & 63, pr_, tr);
+    wave_prefix_total(cf, threadIdx.x & 63, pf_, tf);
+    if ((threadIdx.x & 63) == 0) { wr[threadIdx.x >> 6] = tr; wf[threadIdx.x >> 6] = tf; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t* o = blk_counts + ((size_t)b * nblk + blk) * 2;
+        o[0] = wr[0] + wr[1] + wr[2] + wr[3];
+        o[1] = wf[0] + wf[1] + wf[2] + wf[3];
+    }
+}
+__global__ __launch_bounds__(256) void fuse_write4_kernel(const FuseParams p, int npix, int nblk) {
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const int i4 = blk * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool in = i4 * 4 < npix;
+    unsigned mr4 = 0, mf4 = 0;
+    if (in) {
+        if (p.road) mr4 = reinterpret_cast<const unsigned*>(p.road + (size_t)b * npix)[i4];
+        if (p.fence) mf4 = reinterpret_cast<const unsigned*>(p.fence + (size_t)b * npix)[i4];
+    }
+    const int cr = nz_bytes(mr4), cf = nz_bytes(mf4);
+    int pre_r, tot_r, pre_f, tot_f;
+    wave_prefix_total(cr, lane, pre_r, tot_r);
+    wave_prefix_total(cf, lane, pre_f, tot_f);
+    __shared__ int wr[4], wf[4];
+    if (lane == 0) { wr[wave] = tot_r; wf[wave] = tot_f; }
+    __syncthreads();
+    if (!in || (!p.dense && !cr && !cf)) return;              // (no barrier below)
+    const int32_t* off = p.blk_offsets + ((size_t)b * nblk + blk) * 2;
+    int pos_r = off[0] + pre_r, pos_f = off[1] + pre_f;
+    for (int w = 0; w < wave; ++w) { pos_r += wr[w]; pos_f += wf[w]; }
+    const size_t g4 = (size_t)b * npix + (size_t)i4 * 4;
+    const int i = i4 * 4, y = i / p.W, x0 = i - y * p.W;
+    const CamDev cam = p.cams[b];
+    const float4 dq = *reinterpret_cast<const float4*>(p.disp_pp + g4);
+    const float dv[4] = {dq.x, dq.y, dq.z, dq.w};
+    unsigned fw[3] = {0u, 0u, 0u};
+    if (p.frames) {
+        const unsigned* fp = reinterpret_cast<const unsigned*>(p.frames + g4 * 3);
+        fw[0] = fp[0]; fw[1] = fp[1]; fw[2] = fp[2];
+    }
+    const double* q = cam.q;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool r = (mr4 >> (8 * k)) & 0xffu, f = (mf4 >> (8 * k)) & 0xffu;
+        if (!p.dense && !r && !f) continue;
+        // disparity = disp_pp * multiplier in float32 (semantic_depth.py:145; seq:146); cv2.reprojectImageTo3D [UPSTREAM OpenCV
+        // 4.x]: homg = Q*(x,y,d,1) in double, left to right; numerators narrowed to float, divided by the double W, narrowed again
+        const float dpx = dv[k] * cam.mult;
+        const double xd = (double)(x0 + k), yd = (double)y, d = (double)dpx;
+        const double Wh = ((q[12] * xd + q[13] * yd) + q[14] * d) + q[15];
+        const double n0 = ((q[0] * xd + q[1] * yd) + q[2] * d) + q[3];
+        const double n1 = ((q[4] * xd + q[5] * yd) + q[6] * d) + q[7];
+        const double n2 = ((q[8] * xd + q[9] * yd) + q[10] * d) + q[11];
+        const float X = (float)((double)(float)n0 / Wh), Y = (float)((double)(float)n1 / Wh), Z = (float)((double)(float)n2 / Wh);
+        if (p.dense) { float* dp = p.dense + (g4 + k) * 3; dp[0] = X; dp[1] = Y; dp[2] = Z; }
+        // bytes 3k .. 3k+2 of the 12 frame bytes: B, G, R -> colours = cv2.cvtColor(frame, BGR2RGB), semantic_depth.py:161
+        const unsigned long long lo64 = ((unsigned long long)fw[1] << 32) | fw[0], hi64 = ((unsigned long long)fw[2] << 32) | fw[1];
+        const unsigned bgr = k < 2 ? (unsigned)(lo64 >> (24 * k)) : (unsigned)(hi64 >> (24 * k - 32));
+        const uint8_t c0 = (uint8_t)(bgr >> 16), c1 = (uint8_t)(bgr >> 8), c2 = (uint8_t)bgr;
+        if (r && p.road_xyz) {
+            if (pos_r < p.cap) {
+                float* o = p.road_xyz + ((size_t)b * p.cap + pos_r) * 3;
+                o[0] = X; o[1] = Y; o[2] = Z;
+                if (p.road_rgb) { uint8_t* c = p.road_rgb + ((size_t)b * p.cap + pos_r) * 3; c[0] = c0; c[1] = c1; c[2] = c2; }
+            }
+            ++pos_r;
+        }
+        if (f && p.fence_xyz) {
+            if (pos_f < p.cap) {
+                float* o = p.fence_xyz + ((size_t)b * p.cap + pos_f) * 3;
+                o[0] = X; o[1] = Y; o[2] = Z;
+                if (p.fence_rgb) { uint8_t* c = p.fence_rgb + ((size_t)b * p.cap + pos_f) * 3; c[0] = c0; c[1] = c1; c[2] = c2; }
+            }
+            ++pos_f;
+        }
+    }
+}
+
 hipError_t launch_fuse(const FuseParams& p, hipStream_t s) {
     const int npix = p.H * p.W;
-    const int nblk = (npix + 255) / 256;
     const bool gather = p.road_xyz || p.fence_xyz;
+    if (p.W % 4 == 0 && gather && !std::getenv("SEMDEPTH_NO_FUSE4")) {          // four pixels per thread, 1024 per block
+        const int nblk4 = (npix + 1023) / 1024;
+        hipLaunchKernelGGL(fuse_count4_kernel, dim3(nblk4, p.B), dim3(256), 0, s, p.road, p.fence, npix, nblk4, p.blk_counts);
+        hipLaunchKernelGGL(fuse_scan_kernel, dim3(p.B), dim3(1024), 0, s, p.blk_counts, p.blk_offsets, nblk4, p.n_road, p.n_fence);
+        hipLaunchKernelGGL(fuse_write4_kernel, dim3(nblk4, p.B), dim3(256), 0, s, p, npix, nblk4);
+        return hipGetLastError();
+    }
+    const int nblk = (npix + 255) / 256;
     if (gather) {
         hipLaunchKernelGGL(fuse_count_kernel, dim3(nblk, p.B), dim3(256), 0, s, p.road, p.fence, npix, nblk, p.blk_counts);
         hipLaunchKernelGGL(fuse_scan_kernel, dim3(p.B), dim3(1024), 0, s, p.blk_counts, p.blk_offsets, nblk, p.n_road, p.n_fence);

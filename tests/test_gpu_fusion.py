@@ -40,7 +40,11 @@ def _fuse_ref(dp, road, fence, frame, cam):
     return fusion.fuse(dp, road, fence, frame, **cam)
 
 
-def test_fuse_matches_oracle_small(eng_small):
+@pytest.mark.parametrize("one_pixel_per_thread", [False, True])
+def test_fuse_matches_oracle_small(eng_small, one_pixel_per_thread, monkeypatch):
+    """both forms of the gather: four pixels per thread (widths that are multiples of 4) and the generic one behind it"""
+    if one_pixel_per_thread:
+        monkeypatch.setenv("SEMDEPTH_NO_FUSE4", "1")
     e = eng_small
     scenes = [pipeline.synthetic_scene(128, 256, seed=s, f=250.0, fences=True) for s in (3, 4, 5)]
     cams = [Camera(**s[4]) for s in scenes]
