@@ -1186,7 +1186,49 @@ __global__ __launch_bounds__(256) void sor_knn_kernel(CloudView in, int cap, con
     top.init(kk);
     const int rall = max(g.gx, max(g.gy, g.gz));
     bool done = false;
-    for (int r = 0; r <= SOR_RSOFT && !done; ++r) {
+    // shells 0 and 1 (every query visits them: the bound of shell 0 is zero): the cell ranges of all ten runs -- the own cell,
+    // eight face rows, the two end cells of the centre row -- are fetched FIRST, so the search pays one gather latency for
+    // them instead of one per row
+    {
+        int t0[11], t1[11];
+#pragma unroll
+        for (int i = 0; i < 11; ++i) { t0[i] = 0; t1[i] = 0; }
+        {
+            const int rb = (cz * g.gy + cy) * g.gx;
+            t0[0] = st[rb + cx]; t1[0] = st[rb + cx + 1];
+            if (cx - 1 >= 0) { t0[9] = st[rb + cx - 1]; t1[9] = t0[0]; }
+            if (cx + 1 < g.gx) { t0[10] = t1[0]; t1[10] = st[rb + cx + 2]; }
+        }
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.gx - 1);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            if (i == 4) continue;
+            const int z = cz + i / 3 - 1, y = cy + i % 3 - 1;
+            if (z < 0 || z >= g.gz || y < 0 || y >= g.gy) continue;
+            const int rb = (z * g.gy + y) * g.gx;
+            const int slot = i < 4 ? i + 1 : i;
+            t0[slot] = st[rb + x0]; t1[slot] = st[rb + x1 + 1];
+        }
+        visit_points(pts, qx, qy, qz, t0[0], t1[0], [&](double d) { top.push(d); });       // shell 0
+        if (top.kth <= 0.0 || rall == 0) done = true;      // (the bound of shell 0 is zero)
+        if (!done) {
+            // shell 1 in the order of the generic walk below: (dz, dy) rows ascending, centre row = its two end cells
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                if (i == 4) {
+                    visit_points(pts, qx, qy, qz, t0[9], t1[9], [&](double d) { top.push(d); });
+                    visit_points(pts, qx, qy, qz, t0[10], t1[10], [&](double d) { top.push(d); });
+                } else {
+                    const int slot = i < 4 ? i + 1 : i;
+                    visit_points(pts, qx, qy, qz, t0[slot], t1[slot], [&](double d) { top.push(d); });
+                }
+            }
+            const double bound = g.cell * (1.0 - 1e-9);
+            if (top.kth <= bound * bound) done = true;
+            if (1 >= rall) done = true;
+        }
+    }
+    for (int r = 2; r <= SOR_RSOFT && !done; ++r) {
         for (int dz = -r; dz <= r; ++dz) {
             double zmin = 0.0, zmax;
             if (r >= 2 && cz + dz >= 0 && cz + dz < g.gz) axis_bounds(qz, g.oz, g.cell, cz + dz, g.gz, zmin, zmax);
