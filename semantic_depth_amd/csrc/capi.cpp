@@ -203,7 +203,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 e = launch_conv_direct(c, s);
                 if (h->prof) {
                     hipEventRecord(eb, s);
-                    h->prof_recs.push_back({p.f16 ? "conv_direct_f16w_kernel" : "conv_direct_kernel", op.flops * N / p.images, ea, eb, op.name.c_str(), N * c.H * c.W, d.C, op.K});
+                    h->prof_recs.push_back({conv_direct_kernel_name(c), op.flops * N / p.images, ea, eb, op.name.c_str(), N * c.H * c.W, d.C, op.K});
                 }
                 break;
             }

@@ -465,4 +465,13 @@ hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// label of the instantiation family launch_conv_direct picks (profiling buckets): 64-channel passes, <= 32 channels, or the
+// 16-wide MFMA form
+const char* conv_direct_kernel_name(const ConvDirectParams& p) {
+    const bool n16 = p.Cout <= 16 && p.nsplit == 1 && !p.pool && !std::getenv("SEMDEPTH_NO_N16");
+    if (n16) return p.f16 ? "conv_direct_f16w_kernel<1,n16>" : "conv_direct_kernel<1,n16>";
+    if (p.Cout <= 32) return p.f16 ? "conv_direct_f16w_kernel<1,2>" : "conv_direct_kernel<1,2>";
+    return p.f16 ? "conv_direct_f16w_kernel<2,2>" : "conv_direct_kernel<2,2>";
+}
+
 }  // namespace sd

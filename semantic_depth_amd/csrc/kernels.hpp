@@ -128,6 +128,7 @@ struct ConvDirectParams {
     int pool;                    // 1: fused 2x2 stride-2 max pool, out is [N,H/2,W/2,Cout] (needs rows_per_wave == 2)
 };
 hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s);
+const char* conv_direct_kernel_name(const ConvDirectParams& p);
 
 // small-N convolution (N <= 4 output channels: score 1x1 convs, monodepth disparity heads)
 struct SmallNParams {

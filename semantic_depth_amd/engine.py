@@ -252,9 +252,9 @@ class Engine:
 
     def profile_read(self):
         """[{kernel, launches, ms, flops}] per conv-engine instantiation since the last read (synchronises)."""
-        buf = (L.sd_profile_bucket * 16)()
+        buf = (L.sd_profile_bucket * 32)()
         n = C.c_int()
-        L.check(self.lib, self.h, self.lib.sd_profile_read(self.h, buf, 16, C.byref(n)), "sd_profile_read")
+        L.check(self.lib, self.h, self.lib.sd_profile_read(self.h, buf, 32, C.byref(n)), "sd_profile_read")
         return [dict(kernel=b.kernel.decode(), launches=int(b.launches), ms=float(b.ms), flops=float(b.flops)) for b in buf[:n.value]]
 
     def flops_per_image(self, net: int) -> float:
