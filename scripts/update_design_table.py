@@ -9,7 +9,7 @@ rb, rf, rm = b['roofline'], f['roofline'], m['roofline']
 tr = json.load(open('profiles/r01_pmc_conv_traffic.json'))['all_conv']['hbm_bytes_per_launch']
 big = [k for k in rb['by_kernel'] if '4,4,2' in k['kernel']][0]['tflops']
 fr = b['fusion_roofline']
-tbl = f'''| fused frames/s, 1 MI355X | **{b['value']:.1f}** ({b['ms_per_step']:.1f} ms / 32 frames; 403-420 across the pool's boxes) | {f['value']:.1f} ({f['ms_per_step']:.1f} ms) | {m['value']:.1f} ({m['ms_per_step']:.1f} ms) |
+tbl = f'''| fused frames/s, 1 MI355X | **{b['value']:.1f}** ({b['ms_per_step']:.1f} ms / 32 frames; 403-422 across the pool's boxes, ±0.2 % run to run on one box) | {f['value']:.1f} ({f['ms_per_step']:.1f} ms) | {m['value']:.1f} ({m['ms_per_step']:.1f} ms) |
 | stage ms per 32 frames: seg / disp / to3D / road | {st(b)} | {st(f)} | {st(m)} |
 | conv engine, algorithmic TF/s (HIP events, all launches) | {rb['achieved']:.1f} = **{100*rb['frac']:.1f} %** of 833 ({100*rb['achieved']/604:.1f} % of the 604 TF/s the chip sustains with random operands) | {rf['achieved']:.1f} = **{100*rf['frac']:.1f} %** of 157.3 | {rm['achieved']:.1f} = {100*rm['frac']:.1f} % of {rm['peak']:.0f} (flop-weighted peak: 2-product kernels at 1250) |
 | dominant kernel | `{rb['dominant']['kernel']}` (64-channel passes of the direct kernel): {rb['dominant']['achieved']:.1f} TF/s = {100*rb['dominant']['achieved']/833.3:.1f} % over {rb['dominant']['launches']} launches (isolated: conv4_3 499, conv5_3 507, conv3_3 475, conv1_2 392); its <= 32-channel and 16-wide forms (decoder levels 1-2, disparity heads) {' / '.join(str(k['tflops']) for k in rb['by_kernel'] if 'conv_direct' in k['kernel'] and k['kernel'] != rb['dominant']['kernel'])}; `conv_dma_kernel<2,4,4,2>` {big:.1f} (fc6 485) | `conv_igemm_kernel<2,2,4,4,true>`: {rf['dominant']['achieved']:.1f} TF/s = {100*rf['dominant']['achieved']/157.3:.1f} % | |
