@@ -4,20 +4,34 @@
 Metric (BASELINE.json): fused frames/sec (FCN-8s + monodepth + pcl fusion) at 512x1024.
 One step = one pass of the whole hot path over one batch of synthetic frames already resident in HBM:
   FCN-8s forward -> masks/argmax, monodepth-resnet50 forward on (frame, flipped frame) -> post-processed disparity,
-  back-projection + ordered mask gather -> road/fence clouds, road chain (z-cut, 2x MAD, plane fit, Open3D
-  statistical + radius filters, end points) -> per-frame road-width record; with N > 1 ranks one RCCL all_gather
-  of the per-frame records.  Workload = BASELINE.json configs[3] (batch 32 per GPU; weak scaling over GPUs).
+  back-projection + ordered mask gather -> road/fence clouds (with colours), road chain (z-cut, 2x MAD, plane fit, Open3D
+  statistical + radius filters, end points) -> per-frame road-width record; with N > 1 ranks one RCCL all_gather of the
+  per-frame records.
 
-  python bench.py --gpus 1 --steps 5 --warmup 2
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+  --config 4 (default)  BASELINE.json configs[3]: batch 32 per GPU, 512x1024 frames, camera cx=W/2 cy=H/2 f=1000 b=1,
+                        disp_mult=W
+  --config 5            BASELINE.json configs[4]: per rank 32 synthetic 1024x2048 frames -> cubic resize to 512x1024 on the GPU
+                        (inside the step) -> the same path, disp_mult=3800, cx=1048.64/2, cy=519.277/2, f=1000, b=1
+                        (seq:105,123-130,500-508), driven by distributed.run_sequence (shard -> process_batch -> all_gather)
 
-Prints ONE JSON line on rank 0 (contract in the round prompt) with `roofline` (conv engine, f32 MFMA peak) and
-`cpu_baseline` (the CPU oracle timed on this box's host cores, bounded sample).
+  python bench.py --gpus N --steps K --warmup W
+     N > 1 without a launcher: this process starts N fresh rank processes itself (before anything touches a GPU) and waits;
+     under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it is one of the ranks.  Either way the
+     world size must equal --gpus, and the JSON carries `ranks_seen` (an all_reduce of ones over RCCL).
+
+Prints ONE JSON line on rank 0 (contract in the round prompt) with
+  `roofline`     dominant conv kernel: algorithmic FLOPs per launch / its average HIP-event duration in THIS run vs the MFMA peak of
+                 its arithmetic; `roofline.engine` = all conv launches together
+  `f32_exact`    the same step on the exact-f32 engine (v_mfma_f32_16x16x4_f32), timed in the same process
+  `parity`       this run's outputs (the frames of the timed batch) against the f32 engine and against the CPU oracle
+  `cpu_baseline` the CPU oracle timed on this box's host cores (bounded sample), all cores and 1 thread
 """
 import argparse
 import contextlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,55 +41,99 @@ if ROOT not in sys.path:
 
 H, W = 512, 1024
 # MI355X_MICROARCH.md peaks.  f32: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz.
-# bf16x2: every algorithmic product costs three dense-bf16 MFMA products (hi*hi + hi*lo + lo*hi), so the ceiling for
-# ALGORITHMIC flops is the dense bf16 peak / 3 (frac is then also executed-MFMA-flops / dense bf16 peak).
-PEAK_TFLOPS = {"f32": 157.3, "bf16x2": 2500.0 / 3.0, "mixed": 2500.0 / 3.0}      # mixed: per-kernel peaks, see below
-DTYPE = {"f32": "f32", "bf16x2": "bf16x2 split operands (hi+lo, 16 mantissa bits), 3 bf16 MFMA products per product, f32 accumulate",
-         "mixed": "FCN-8s: bf16x2 split operands, 3 bf16 MFMA products; monodepth: fp16x2 split activations (22 bits) x fp16 weights, "
-                  "2 fp16 MFMA products; f32 accumulate"}
+# split-bf16 (3 products): every algorithmic product costs three dense-bf16 MFMA products (hi*hi + hi*lo + lo*hi), so the
+# ceiling for ALGORITHMIC flops is the dense bf16 peak / 3; split-fp16 x fp16 weights (2 products): dense fp16 peak / 2.
+PEAK_F32, PEAK_3P, PEAK_2P = 157.3, 2500.0 / 3.0, 2500.0 / 2.0
+DTYPE = {
+    "f32": "f32 (exact: v_mfma_f32_16x16x4_f32)",
+    "bf16x2": "bf16x2 split operands (hi+lo, 16 mantissa bits), 3 bf16 MFMA products per product, f32 accumulate",
+    "mixed": "FCN-8s: bf16x2 split operands, 3 bf16 MFMA products; monodepth: fp16x2 split activations (22 bits) x fp16 weights, "
+             "2 fp16 MFMA products; f32 accumulate",
+    "plan": "per-layer precision plan: bf16x2 split operands (3 bf16 MFMA products) / fp16x2 split activations x fp16 weights "
+            "(2 fp16 MFMA products) chosen per layer under an error budget; f32 accumulate",
+}
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--config", type=int, default=4, choices=[4, 5], help="SURVEY §8d config: 4 = fused B=32 (default), 5 = sequence driver")
     ap.add_argument("--overlap", action="store_true",
-                    help="run the per-frame tail of step i on a side stream under the convolutions of step i+1 (measured +2.8 %% fps, "
-                         "but the tail's workgroups slow the conv launches they share CUs with, so the roofline attribution blurs)")
+                    help="run the per-frame tail of step i on a side stream under the convolutions of step i+1")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step (configs[3]: 32)")
     ap.add_argument("--encoder", default="resnet50")
-    ap.add_argument("--precision", default="bf16x2", choices=["f32", "bf16x2", "mixed"],
-                    help="conv arithmetic: exact f32 MFMA, or split-bf16 (3 bf16 MFMA products per product, f32 accumulate)")
+    ap.add_argument("--precision", default=os.environ.get("SD_BENCH_PRECISION", "bf16x2"), choices=["f32", "bf16x2", "mixed", "plan"],
+                    help="conv arithmetic of the measured engine")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-f32-leg", action="store_true", help="skip the exact-f32 engine leg (f32_exact + parity vs f32)")
+    ap.add_argument("--f32-steps", type=int, default=2)
+    ap.add_argument("--no-colours", action="store_true", help="do not carry the RGB of the points through the road chain")
+    return ap.parse_args()
+
+
+def spawn_ranks(args) -> int:
+    """--gpus N without a launcher: start N fresh rank processes of this script (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in
+    their environment).  Nothing in THIS process has touched a GPU: the library is built by hipcc subprocesses only."""
+    from semantic_depth_amd import build as b
+    b.build()                                     # once, before the ranks start: no rank ever links or maps a half-written library
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), SD_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: world size {world} (WORLD_SIZE) != --gpus {args.gpus}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
+    if torch.cuda.device_count() < world:
+        sys.exit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) visible")
     import __graft_entry__ as graft
-    if rank == 0 or not os.path.exists(os.path.join(ROOT, "semantic_depth_amd", "libsemdepth.so")):
-        graft.build()
+    if world == 1:
+        graft.build()                 # N > 1: the launcher (spawn_ranks / the driver) has built it; ranks only load it
     from semantic_depth_amd import _lib as L
     from semantic_depth_amd import weights as Wt
-    from semantic_depth_amd.distributed import gather_records
+    from semantic_depth_amd.distributed import gather_records, make_engine_step, run_sequence
     from semantic_depth_amd.engine import Camera, Engine, RoadWidthParams
 
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    ones = torch.ones(1, device="cuda")
+    if world > 1:
+        dist.all_reduce(ones)         # RCCL over xGMI: every rank contributes 1
+    ranks_seen = int(ones.item())
     B = args.batch
+    colours = not args.no_colours
 
     # ------------------------------------------------------------------ setup (untimed)
     t_setup = time.time()
@@ -88,58 +146,77 @@ def main():
     eng.load_weights(L.SD_NET_MONODEPTH, wm)
     rng = np.random.default_rng(1000 + rank)
     # smooth random frames: low-pass of uniform noise (SURVEY §8d config 2 variant) so that masks form regions
-    base = rng.integers(0, 256, (B, H // 8, W // 8, 3), dtype=np.uint8)
+    if args.config == 4:
+        sh, sw = H, W
+        cam = Camera(W / 2, H / 2, 1000.0, 1.0, float(W))                         # §8d config 4
+    else:
+        sh, sw = 2 * H, 2 * W                                                     # Cityscapes frames are 1024 x 2048
+        cam = Camera(1048.64 / 2, 519.277 / 2, 1000.0, 1.0, 3800.0)               # §8d config 5 (seq:500-508 scaled to 512x1024; seq:105)
+    base = rng.integers(0, 256, (B, sh // 8, sw // 8, 3), dtype=np.uint8)
     frames_np = np.repeat(np.repeat(base, 8, axis=1), 8, axis=2)
     frames_np = (frames_np.astype(np.int16) + rng.integers(-16, 17, frames_np.shape, dtype=np.int16)).clip(0, 255).astype(np.uint8)
-    frames = torch.from_numpy(frames_np).cuda()
-    # config 4 camera (cx=W/2, cy=H/2, b=1, disp_mult=W); f=2000 puts the random-weight net's median disparity
-    # (~0.19 of the width) at Z ~ -10 m, so the z-cut / depth window of the road chain see real work
-    cams = [Camera(W / 2, H / 2, 2000.0, 1.0, float(W))] * B
+    src_frames = torch.from_numpy(frames_np).cuda()
+    frames = src_frames if args.config == 4 else eng.resize_cubic(src_frames)
+    cams = [cam] * B
     prm = RoadWidthParams()
+    # a random-weight monodepth puts its median disparity wherever its last bias puts it; calibrate that ONE bias (dec/disp1,
+    # untimed, part of the synthetic weights) so that the median depth is the measuring depth (10 m) for this config's camera:
+    # the z-cut, the depth window and the Open3D filters of the road chain then all see real work
+    d0 = float(eng.monodepth_forward(frames).median().item())
+    target = cam.f * cam.b / prm.depth / cam.disp_mult                            # disparity (fraction of width) of a point at 10 m
+    logit = lambda p: float(np.log(p / (1.0 - p)))
+    bias = logit(target / 0.3) - logit(min(max(d0, 1e-4), 0.2999) / 0.3)
+    wm["dec/disp1/biases"] = (wm["dec/disp1/biases"] + np.float32(bias)).astype(np.float32)
+    eng.load_weights(L.SD_NET_MONODEPTH, {"dec/disp1/biases": wm["dec/disp1/biases"]})
     if rank == 0:
-        log(f"setup {time.time() - t_setup:.1f}s; arenas: " + ", ".join(f"{k} {v / 2**30:.2f} GiB" for k, v in eng.bytes.items()))
+        log(f"setup {time.time() - t_setup:.1f}s; arenas: " + ", ".join(f"{k} {v / 2**30:.2f} GiB" for k, v in eng.bytes.items()) +
+            f"; disp1 bias {bias:+.3f} (median disparity {d0:.4f} -> {target:.4f})")
+
+    seq_step = make_engine_step(eng, lambda i: cam, prm)
 
     def step():
-        out = eng.process_batch(frames, cams, prm)
+        if args.config == 5:
+            # the sequence driver: this rank's shard of the world*B frame list -> resize -> whole path -> ONE all_gather
+            return run_sequence(lambda lo, hi: src_frames[lo - rank * B: hi - rank * B], world * B, seq_step, batch=B, device="cuda")
+        out = eng.process_batch(frames, cams, prm, colours=colours)
         # the only collective on the path: per-frame road-width records (104 B x B per rank), RCCL all_gather over xGMI
-        out["all_records"] = gather_records(out["records"], world * B)
-        return out
+        return gather_records(out["records"], world * B)
 
     for _ in range(args.warmup):
-        out = step()
+        step()
     torch.cuda.synchronize()
 
     # ------------------------------------------------------------------ timed region
     eng.profile(True)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    stage_ms = np.zeros(4)
-    # The two networks run on the main stream; the per-frame tail of step i (back-projection, road chain, record gather:
-    # 32 single-workgroup reductions and latency-bound grid searches that cannot fill the chip) runs on a side stream
-    # underneath the convolutions of step i+1 when --overlap is given; the default keeps everything on one stream.
+    # The two networks run on the main stream; with --overlap the per-frame tail of step i (back-projection, road chain, record
+    # gather) runs on a side stream underneath the convolutions of step i+1; the default keeps everything on one stream.
     side = torch.cuda.Stream() if args.overlap else None
     for _ in range(args.steps):
         ev[0].record()
-        seg = eng.fcn8s_forward(frames)
+        fr = eng.resize_cubic(src_frames) if args.config == 5 else frames
         ev[1].record()
-        disp_pp = eng.monodepth_forward(frames)
+        seg = eng.fcn8s_forward(fr)
         ev[2].record()
+        disp_pp = eng.monodepth_forward(fr)
+        ev[3].record()
         if side is not None:
-            side.wait_event(ev[2])
-            for t_ in (disp_pp, seg["road"], seg["fence"]):
+            side.wait_event(ev[3])
+            for t_ in (disp_pp, seg["road"], seg["fence"], fr):
                 t_.record_stream(side)
             ctx = torch.cuda.stream(side)
         else:
             ctx = contextlib.nullcontext()
         with ctx:
-            fz = eng.fuse_backproject(disp_pp, seg["road"], seg["fence"], frames, cams)
-            ev[3].record()
-            rec = eng.road_width(fz["road_xyz"], fz["n_road"], prm)
-            allrec = gather_records(rec, world * B)
+            fz = eng.fuse_backproject(disp_pp, seg["road"], seg["fence"], fr, cams, want_rgb=colours)
             ev[4].record()
+            rec = eng.road_width(fz["road_xyz"], fz["n_road"], prm, road_rgb=fz["road_rgb"] if colours else None)
+            allrec = gather_records(rec, world * B)
+            ev[5].record()
         out = dict(seg=seg, disp_pp=disp_pp, fuse=fz, records=rec)
     torch.cuda.synchronize()
     if world > 1:
@@ -147,8 +224,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     # stage split of the LAST step (events are only read after the timed region)
-    for i in range(4):
-        stage_ms[i] = ev[i].elapsed_time(ev[i + 1])
+    stage_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
     buckets = eng.profile_read()
     eng.profile(False)
 
@@ -158,6 +234,7 @@ def main():
     dt = float(tmax.item())
     frames_total = world * B * args.steps
     value = frames_total / dt
+    assert allrec.shape[0] == world * B
 
     if rank != 0:
         if world > 1:
@@ -168,102 +245,246 @@ def main():
     road_frac = float(out["seg"]["road"].float().mean().item())
     log(f"masks: road fraction {road_frac:.3f}; n_road mean {recs['n_road'].mean():.0f}; after chain {recs['n_ror'].mean():.0f}; "
         f"found {int(recs['found'].sum())}/{B}; width mean {np.nanmean(recs['width']) if recs['found'].any() else float('nan'):.3f}")
-    log(f"stage ms (last step, {B} frames): seg {stage_ms[0]:.2f}  disp {stage_ms[1]:.2f}  to3D {stage_ms[2]:.2f}  road {stage_ms[3]:.2f}")
+    log(f"stage ms (last step, {B} frames): resize {stage_ms[0]:.2f}  seg {stage_ms[1]:.2f}  disp {stage_ms[2]:.2f}  to3D {stage_ms[3]:.2f}  "
+        f"road {stage_ms[4]:.2f}")
 
-    # ------------------------------------------------------------------ roofline (conv engine = the dominant kernel family)
-    tot_ms = sum(b["ms"] for b in buckets)
-    tot_fl = sum(b["flops"] for b in buckets)
-    tot_n = sum(b["launches"] for b in buckets)
-    dom = max(buckets, key=lambda b: b["ms"])
-    achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-    peak_of = lambda b: (2500.0 / 2.0 if "f16w" in b["kernel"] else PEAK_TFLOPS[args.precision])
-    # effective peak of the launch mix: total flops / time at peak (harmonic mean over the kernels' own peaks)
-    t_at_peak = sum(b["flops"] / (peak_of(b) * 1e12) for b in buckets)
-    eff_peak = tot_fl / t_at_peak / 1e12 if t_at_peak > 0 else PEAK_TFLOPS[args.precision]
-    # HBM bytes per conv launch from the committed PMC profile of this same command (rocprofv3 FETCH_SIZE / WRITE_SIZE passes)
-    traffic = None
-    try:
-        import glob
-        pf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_conv_traffic.json")))
-        if pf and args.precision in ("bf16x2", "mixed"):
-            traffic = round(json.load(open(pf[-1]))["all_conv"]["hbm_bytes_per_launch"])
-    except Exception:
-        traffic = None
-    roofline = {
-        "bound": "mfma", "achieved": round(achieved, 2), "peak": round(eff_peak, 1), "unit": "TFLOP/s",
-        "frac": round(achieved / eff_peak, 4), "traffic": traffic,
-        "peak_note": ("f32 MFMA dense peak" if args.precision == "f32" else
-                      "dense bf16 MFMA peak 2500 TF/s / 3 MFMA products per algorithmic product; achieved counts algorithmic flops. "
-                      "Measured on this pool: with random operands the chip sustains 1812 TF/s of v_mfma_f32_32x32x16_bf16 "
-                      "(power limit; profiles/r01_mfma_sustained_probe.txt), i.e. 604 TF/s of algorithmic work"),
-        "kernel": ("conv_igemm_kernel (all instantiations)" if args.precision == "f32" else
-                   "split-bf16 conv engine: conv_dma_kernel + conv_direct_kernel + conv_split_kernel (all instantiations)"), "launches": tot_n,
-        "avg_launch_us": round(tot_ms * 1e3 / max(tot_n, 1), 2),
-        "algorithmic_gflop_per_launch": round(tot_fl / max(tot_n, 1) / 1e9, 3),
-        "conv_time_share_of_step": round(tot_ms * 1e-3 / dt, 4),
-        "dominant": {"kernel": dom["kernel"], "launches": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2),
-                     "achieved": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12, 2) if dom["ms"] > 0 else 0.0},
-        "by_kernel": [{"kernel": b["kernel"], "launches": b["launches"], "ms": round(b["ms"], 3),
-                       "tflops": round(b["flops"] / (b["ms"] * 1e-3) / 1e12, 2)} for b in buckets if b["launches"]],
-    }
-
+    roofline = conv_roofline(buckets, args.precision, dt)
     # second roofline: the fusion / back-projection stage is HBM-bound.  Algorithmic bytes of the stage as it runs
     # here: read disp_pp (4 B) + two masks (2 B) + the frame (3 B) per pixel, write 15 B (xyz f32 + rgb u8) per gathered point.
-    n_pts = float(out["fuse"]["n_road"].sum().item()) + (float(out["fuse"]["n_fence"].sum().item()) if out["fuse"].get("n_fence") is not None else 0.0)
-    fuse_bytes = B * H * W * 9.0 + 15.0 * n_pts
-    fuse_gbs = fuse_bytes / (stage_ms[2] * 1e-3) / 1e9 if stage_ms[2] > 0 else 0.0
+    n_pts = float(out["fuse"]["n_road"].sum().item()) + float(out["fuse"]["n_fence"].sum().item())
+    fuse_bytes = B * H * W * 9.0 + (15.0 if colours else 12.0) * n_pts
+    fuse_gbs = fuse_bytes / (stage_ms[3] * 1e-3) / 1e9 if stage_ms[3] > 0 else 0.0
     fusion_roofline = {"bound": "hbm", "achieved": round(fuse_gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(fuse_gbs / 8000.0, 4),
-                       "traffic": None, "kernel": "fuse_count_kernel + fuse_write_kernel (to3D stage of the last step, torch events)",
-                       "algorithmic_bytes_per_frame": round(fuse_bytes / B), "stage_us_per_frame": round(stage_ms[2] * 1e3 / B, 2)}
+                       "traffic": None, "kernel": "fuse kernels (to3D stage of the last step, stream events)",
+                       "algorithmic_bytes_per_frame": round(fuse_bytes / B), "stage_us_per_frame": round(stage_ms[3] * 1e3 / B, 2)}
+
+    # ------------------------------------------------------------------ exact-f32 leg + parity of THIS run's outputs
+    f32_exact, parity, oracle_in = None, {}, None
+    want_parity = world == 1
+    if want_parity:
+        segp = eng.fcn8s_forward(frames, want_logits=True)
+        planned = dict(logits=segp["logits"], road=segp["road"], fence=segp["fence"], argmax=segp["argmax"],
+                       disp=eng.monodepth_forward(frames), records=recs)
+        oracle_in = planned
+    if want_parity and not args.no_f32_leg and args.precision != "f32":
+        f32_exact, parity["vs_f32_engine"] = f32_leg(args, eng, wf, wm, frames, cams, prm, planned, colours, log)
 
     # ------------------------------------------------------------------ CPU baseline: the oracle on this box's host cores
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(frames_np, wf, wm, args.encoder, cams[0], log)
+        cpu, parity["vs_cpu_oracle"] = cpu_baseline(frames.cpu().numpy(), wf, wm, args.encoder, cam, oracle_in, eng, prm, log)
+    if parity:
+        parity["tolerance"] = "north_star: outputs within 1e-3 relative (max |delta| / max |ref| per tensor); masks/argmax as mismatch fraction"
 
     flops_frame = eng.flops_per_image(L.SD_NET_FCN8S) + 2 * eng.flops_per_image(L.SD_NET_MONODEPTH)
+    workload = ("BASELINE.json configs[3]: full fused pipeline (seg + depth + pcl back-projection + road width), " if args.config == 4 else
+                "BASELINE.json configs[4]: batch-sharded sequence driver (1024x2048 frames -> GPU cubic resize -> full fused pipeline -> "
+                "RCCL all_gather of the records), ")
     line = {
         "metric": "fused frames/sec (FCN-8s+monodepth+pcl fusion) at 512x1024", "value": round(value, 3), "unit": "frames/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[3]: full fused pipeline (seg + depth + pcl back-projection + road width), "
-                               f"batch {B} per GPU, 512x1024, monodepth-{args.encoder} on frame+flip, seeded synthetic weights",
-                   "frames_per_step": world * B, "gflop_per_frame": round(flops_frame / 1e9, 2),
-                   "stage_ms_last_step": {"seg": round(stage_ms[0], 2), "disp": round(stage_ms[1], 2), "to3D": round(stage_ms[2], 2),
-                                          "road": round(stage_ms[3], 2)},
-                   "road_fraction": round(road_frac, 4), "n_road_mean": float(recs["n_road"].mean()), "found": int(recs["found"].sum())},
-        "roofline": roofline, "fusion_roofline": fusion_roofline, "cpu_baseline": cpu,
+        "config": {"workload": workload + f"batch {B} per GPU, 512x1024, monodepth-{args.encoder} on frame+flip, seeded synthetic weights",
+                   "survey_config": args.config, "frames_per_step": world * B, "gflop_per_frame": round(flops_frame / 1e9, 2),
+                   "camera": {"cx": cam.cx, "cy": cam.cy, "f": cam.f, "b": cam.b, "disp_mult": cam.disp_mult},
+                   "stage_ms_last_step": {"resize": round(stage_ms[0], 2), "seg": round(stage_ms[1], 2), "disp": round(stage_ms[2], 2),
+                                          "to3D": round(stage_ms[3], 2), "road": round(stage_ms[4], 2)},
+                   "colours_through_road_chain": colours, "overlap": bool(args.overlap),
+                   "road_fraction": round(road_frac, 4), "n_road_mean": float(recs["n_road"].mean()), "n_after_chain_mean": float(recs["n_ror"].mean()),
+                   "found": int(recs["found"].sum())},
+        "roofline": roofline, "fusion_roofline": fusion_roofline, "f32_exact": f32_exact, "parity": parity or None, "cpu_baseline": cpu,
     }
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(frames_np, wf, wm, encoder, cam, log):
-    """the oracle (kind 'port': the reference's TF/OpenCV/Open3D stack cannot run here) on a bounded sample."""
+def peak_of(kernel: str, precision: str) -> float:
+    if "igemm" in kernel:
+        return PEAK_F32
+    return PEAK_2P if "f16w" in kernel else PEAK_3P
+
+
+def conv_roofline(buckets, precision, dt):
+    """`roofline` of the contract for the DOMINANT conv kernel (most time in this run) + the whole conv engine under `engine`.
+    Durations are HIP events recorded by the library around every conv launch on the launch stream (sd_profile)."""
+    buckets = [b for b in buckets if b["launches"]]
+    if not buckets:
+        return None
+    tot_ms = sum(b["ms"] for b in buckets)
+    tot_fl = sum(b["flops"] for b in buckets)
+    tot_n = sum(b["launches"] for b in buckets)
+    dom = max(buckets, key=lambda b: b["ms"])
+    ach = lambda b: b["flops"] / (b["ms"] * 1e-3) / 1e12 if b["ms"] > 0 else 0.0
+    # effective peak of the launch mix: total flops / time at peak (harmonic mean over the kernels' own peaks)
+    t_at_peak = sum(b["flops"] / (peak_of(b["kernel"], precision) * 1e12) for b in buckets)
+    eff_peak = tot_fl / t_at_peak / 1e12
+    # HBM bytes per launch from the committed PMC profile of this same command (rocprofv3 FETCH_SIZE / WRITE_SIZE passes are
+    # separate runs by construction: a constant read from profiles/, NOT a measurement of this run)
+    traffic, traffic_src = None, None
+    try:
+        import glob
+        pf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_conv_traffic.json")))
+        if pf:
+            prof = json.load(open(pf[-1]))
+            per = prof.get("by_kernel", {})
+            key = next((k for k in per if dom["kernel"].split("<")[0] in k and dom["kernel"].split("<")[-1].rstrip(">") in k), None)
+            if key:
+                traffic = round(per[key]["hbm_bytes_per_launch"])
+            elif "all_conv" in prof:
+                traffic = round(prof["all_conv"]["hbm_bytes_per_launch"])
+            traffic_src = "profiles/" + os.path.basename(pf[-1]) + " (separate rocprofv3 --pmc passes of this command; not measured in this run)"
+    except Exception:
+        traffic = None
+    dpk = peak_of(dom["kernel"], precision)
+    return {
+        "bound": "mfma", "kernel": dom["kernel"], "achieved": round(ach(dom), 2), "peak": round(dpk, 1), "unit": "TFLOP/s",
+        "frac": round(ach(dom) / dpk, 4), "traffic": traffic, "traffic_source": traffic_src,
+        "launches": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
+        "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
+        "peak_note": "f32 MFMA dense peak 157.3; split-bf16: dense bf16 MFMA peak 2500 / 3 MFMA products per algorithmic product; kernels "
+                     "named f16w: 2500 / 2 products.  `achieved` counts ALGORITHMIC flops (2*M*N*K of the layer, padding not counted). "
+                     "Measured on this pool: with random operands the chip sustains 1812 TF/s of v_mfma_f32_32x32x16_bf16 (power limit; "
+                     "profiles/r01_mfma_sustained_probe.txt)",
+        "engine": {"kernels": "all conv launches", "achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), "peak": round(eff_peak, 1),
+                   "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / eff_peak, 4), "launches": tot_n,
+                   "conv_time_share_of_step": round(tot_ms * 1e-3 / dt, 4)},
+        "by_kernel": [{"kernel": b["kernel"], "launches": b["launches"], "ms": round(b["ms"], 3), "tflops": round(ach(b), 2),
+                       "frac": round(ach(b) / peak_of(b["kernel"], precision), 4)} for b in sorted(buckets, key=lambda b: -b["ms"])],
+    }
+
+
+def err_stats(got, ref):
+    """max-normalised error (north_star's figure), plus per-element statistics: |delta| / (|ref| + 1e-3 * max|ref|)"""
+    import numpy as np
+    got = np.asarray(got, np.float64).ravel()
+    ref = np.asarray(ref, np.float64).ravel()
+    d = np.abs(got - ref)
+    scale = float(np.abs(ref).max()) + 1e-30
+    per = d / (np.abs(ref) + 1e-3 * scale)
+    return {"max_rel": float(d.max() / scale), "p99_elem_rel": float(np.quantile(per, 0.99)), "max_elem_rel": float(per.max()),
+            "rms_rel": float(np.sqrt((d * d).mean()) / scale)}
+
+
+def f32_leg(args, eng, wf, wm, frames, cams, prm, planned, colours, log):
+    """the same batch through the exact-f32 engine: its speed (f32_exact) and the planned-precision outputs against it"""
+    import numpy as np
+    import torch
+    from semantic_depth_amd import _lib as L
+    from semantic_depth_amd.engine import Engine
+    B = frames.shape[0]
+    e32 = Engine(H, W, B, args.encoder, eng.device.index or 0, precision="f32")
+    e32.load_weights(L.SD_NET_FCN8S, wf)
+    e32.load_weights(L.SD_NET_MONODEPTH, wm)
+    e32.process_batch(frames, cams, prm, colours=colours)            # warm-up
+    e32.profile(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.f32_steps):
+        o32 = e32.process_batch(frames, cams, prm, colours=colours)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rl = conv_roofline(e32.profile_read(), "f32", dt)
+    e32.profile(False)
+    f32_exact = {"value": round(B * args.f32_steps / dt, 3), "unit": "frames/s", "ms_per_step": round(dt / args.f32_steps * 1e3, 3),
+                 "steps": args.f32_steps, "dtype": DTYPE["f32"],
+                 "roofline": {k: rl[k] for k in ("kernel", "achieved", "peak", "frac", "launches", "avg_launch_us")} | {"engine": rl["engine"]}}
+    s32 = e32.fcn8s_forward(frames, want_logits=True)
+    d32 = e32.monodepth_forward(frames)
+    r32 = Engine.records(o32["records"])
+    rp = planned["records"]
+    mism = lambda a, b: float((a != b).float().mean().item())
+    both = (rp["found"] != 0) & (r32["found"] != 0)
+    par = {
+        "frames": B,
+        "logits": err_stats(planned["logits"].cpu().numpy(), s32["logits"].cpu().numpy()),
+        "disp_pp": err_stats(planned["disp"].cpu().numpy(), d32.cpu().numpy()),
+        "road_mask_mismatch_frac": mism(planned["road"], s32["road"]), "fence_mask_mismatch_frac": mism(planned["fence"], s32["fence"]),
+        "argmax_mismatch_frac": mism(planned["argmax"], s32["argmax"]),
+        "records": {"found_equal": bool((rp["found"] == r32["found"]).all()),
+                    "n_road_max_rel_diff": float((np.abs(rp["n_road"] - r32["n_road"]) / np.maximum(r32["n_road"], 1)).max()),
+                    "n_after_chain_max_rel_diff": float((np.abs(rp["n_ror"] - r32["n_ror"]) / np.maximum(r32["n_ror"], 1)).max()),
+                    "width_max_abs_diff_m": float(np.abs(rp["width"][both] - r32["width"][both]).max()) if both.any() else None,
+                    "width_mean_abs_diff_m": float(np.abs(rp["width"][both] - r32["width"][both]).mean()) if both.any() else None},
+    }
+    # the tail is exact arithmetic: fed the f32 engine's masks and disparities, the measured engine's tail must reproduce the f32
+    # engine's records bit for bit
+    fz = eng.fuse_backproject(d32, s32["road"], s32["fence"], frames, cams, want_rgb=False)
+    rs = Engine.records(eng.road_width(fz["road_xyz"], fz["n_road"], prm))
+    par["records_given_same_masks_and_disparity_bit_equal"] = bool(rs.tobytes() == r32.tobytes())
+    log(f"f32 engine: {f32_exact['value']:.1f} frames/s; vs f32: logits {par['logits']['max_rel']:.2e}, disp {par['disp_pp']['max_rel']:.2e}, "
+        f"road mask mismatch {par['road_mask_mismatch_frac']:.2e}, width diff {par['records']['width_max_abs_diff_m']}")
+    del e32
+    torch.cuda.empty_cache()
+    return f32_exact, par
+
+
+def cpu_baseline(frames_np, wf, wm, encoder, cam, planned, eng, prm, log):
+    """the oracle (kind 'port': the reference's TF/OpenCV/Open3D stack cannot run here) on a bounded sample of the bench's own
+    frames; its outputs double as the parity reference for those frames."""
     import numpy as np
     import torch
     from oracle import nets, pipeline
+    ncpu = os.cpu_count() or 1
     # torch-CPU convs stop scaling (and collapse at 256 threads) well before the core count of the GPU box: 32 threads
-    cores = min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(cores)
-    n_done, t_used = 0, 0.0
+    cores = min(ncpu, 32)
     cam_d = dict(cx=cam.cx, cy=cam.cy, f=cam.f, b=cam.b, disp_mult=cam.disp_mult)
-    while n_done < min(6, len(frames_np)) and t_used < 15.0:
-        fr = frames_np[n_done]
-        t0 = time.perf_counter()
+
+    def one(fr):
         logits = nets.fcn8s_forward(fr[None], wf)
-        _, road, fence, _ = nets.softmax_masks(logits[0])
+        _, road, fence, am = nets.softmax_masks(logits[0])
         f = fr.astype(np.float32) / 255
         pair = np.stack((f, np.fliplr(f)), 0)
         disp = nets.monodepth_forward(pair, wm, encoder)[..., 0].astype(np.float32)
-        pipeline.frame_tail(disp, road, fence, fr, cam_d)
+        tail = pipeline.frame_tail(disp, road, fence, fr, cam_d)
+        return logits[0], road, fence, am, tail
+
+    torch.set_num_threads(cores)
+    n_done, t_used, outs = 0, 0.0, []
+    while n_done < min(6, len(frames_np)) and t_used < 15.0:
+        t0 = time.perf_counter()
+        outs.append(one(frames_np[n_done]))
         t_used += time.perf_counter() - t0
         n_done += 1
     log(f"cpu baseline: {n_done} frame(s) in {t_used:.1f}s on {torch.get_num_threads()} threads")
-    return {"value": round(n_done / t_used, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_done} of the bench's 512x1024 frames through the CPU oracle (torch-CPU f32 convs with TF semantics + numpy "
-                      "fusion/pcl + cKDTree Open3D filters), whole path"}
+    torch.set_num_threads(1)
+    t0 = time.perf_counter()
+    one(frames_np[0])
+    t1 = time.perf_counter() - t0
+    torch.set_num_threads(cores)
+    log(f"cpu baseline: 1 frame in {t1:.1f}s on 1 thread")
+    cpu = {"value": round(n_done / t_used, 4), "unit": "frames/s", "cores": cores, "host_cpus": ncpu, "kind": "port",
+           "value_1_thread": round(1.0 / t1, 5),
+           "sample": f"{n_done} of the bench's 512x1024 frames through the CPU oracle (torch-CPU f32 convs with TF semantics + numpy "
+                     f"fusion/pcl + cKDTree Open3D filters), whole path, {cores} threads of {ncpu} host CPUs; 1 frame on 1 thread"}
+    par = None
+    if planned is not None:
+        lg = planned["logits"][:n_done].cpu().numpy()
+        dp = planned["disp"][:n_done].cpu().numpy()
+        ref_l = np.stack([o[0] for o in outs])
+        ref_d = np.stack([o[4]["disp_pp"] for o in outs])
+        road = planned["road"][:n_done].cpu().numpy().astype(bool)
+        am = planned["argmax"][:n_done].cpu().numpy()
+        par = {"frames": n_done, "logits": err_stats(lg, ref_l), "disp_pp": err_stats(dp, ref_d),
+               "road_mask_mismatch_frac": float((road != np.stack([o[1] for o in outs])).mean()),
+               "argmax_mismatch_frac": float((am != np.stack([o[3] for o in outs])).mean())}
+        # the exact tail: the oracle's frame_tail fed the GPU's OWN masks and raw disparity pair must give the GPU's records
+        from semantic_depth_amd.engine import Engine
+        pp, raw = eng.monodepth_forward(torch.from_numpy(frames_np[:n_done]).cuda(), want_raw=True)
+        seg = eng.fcn8s_forward(torch.from_numpy(frames_np[:n_done]).cuda())
+        fz = eng.fuse_backproject(pp, seg["road"], seg["fence"], torch.from_numpy(frames_np[:n_done]).cuda(), [cam] * n_done)
+        rg = Engine.records(eng.road_width(fz["road_xyz"], fz["n_road"], prm))
+        eq = True
+        for i in range(n_done):
+            t = pipeline.frame_tail(raw[i].cpu().numpy(), seg["road"][i].cpu().numpy().astype(bool), seg["fence"][i].cpu().numpy().astype(bool),
+                                    frames_np[i], cam_d)
+            rw = t["rw"]
+            eq = eq and int(rg["n_road"][i]) == rw["n_in"] and int(rg["n_ror"][i]) == rw["n_ror"] and bool(rg["found"][i]) == rw["found"]
+            if rw["found"]:
+                eq = eq and float(rg["width"][i]) == rw["width"]
+        par["tail_records_bit_equal_given_gpu_masks_and_disparity"] = bool(eq)
+        log(f"vs cpu oracle ({n_done} frames): logits {par['logits']['max_rel']:.2e}, disp {par['disp_pp']['max_rel']:.2e}, tail bit-equal {eq}")
+    return cpu, par
 
 
 if __name__ == "__main__":

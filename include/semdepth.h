@@ -40,8 +40,11 @@ typedef enum { SD_NET_FCN8S = 0, SD_NET_MONODEPTH = 1 } sd_net;
  * (hi + lo), three bf16 MFMA products per product, f32 accumulate (~1e-5 relative; gfx950 has no TF32);
  * SD_PREC_MIXED = FCN-8s as SD_PREC_BF16X2, monodepth with activations split into two fp16 (22 bits) and weights rounded
  * once to fp16, two fp16 MFMA products per product (~2e-4 relative on the disparity: the 2^-12 weight rounding; the
- * same scheme on FCN-8s gives 6e-4..1.6e-3 on the logits, over the 1e-3 budget, hence "mixed") */
-typedef enum { SD_PREC_F32 = 0, SD_PREC_BF16X2 = 1, SD_PREC_MIXED = 2 } sd_precision;
+ * same scheme on FCN-8s gives 6e-4..1.6e-3 on the logits, over the 1e-3 budget, hence "mixed");
+ * SD_PREC_PLAN = per-layer precision plan: each conv layer runs either the 3-product bf16 scheme or the 2-product fp16 one; the
+ * built-in plan (sd_default_plan) was calibrated on the MI355X against the exact-f32 engine under an error budget
+ * (DESIGN.md); sd_create_with_plan takes any other choice */
+typedef enum { SD_PREC_F32 = 0, SD_PREC_BF16X2 = 1, SD_PREC_MIXED = 2, SD_PREC_PLAN = 3 } sd_precision;
 
 typedef struct sd_handle sd_handle;
 
@@ -86,6 +89,16 @@ const char* sd_status_string(sd_status s);
 /* replaces DepthFrame.__init__ + SegmentFrame.__init__ (semantic_depth.py:464-469, :575-624):
  * fixes H, W, the largest batch a call may carry and the monodepth encoder; builds both layer plans. */
 sd_status sd_create(sd_handle** out, int device, int H, int W, int max_batch, sd_encoder enc, sd_precision prec);
+/* the same with an explicit precision plan for the split engine: per network a comma-separated list of conv layer names
+ * (sd_net_tensor names, e.g. "fc6,fc7" / "enc/res4*,dec/upconv6"; a trailing '*' matches a prefix, "*" = all, "" = none) that run
+ * the 2-product fp16 scheme; the rest run the 3-product bf16 one.  The choice is closed under "one plane format per tensor"
+ * (sd_precision_plan returns what actually runs).  An unknown layer name is SD_ERR_INVALID. */
+sd_status sd_create_with_plan(sd_handle** out, int device, int H, int W, int max_batch, sd_encoder enc, const char* fcn_f16_layers,
+                              const char* mono_f16_layers);
+const char* sd_default_plan(sd_net net);
+/* layers_out (nullable): the 2-product layers of the handle's plan, comma-separated; flop_share_out (nullable): their share of
+ * the network's algorithmic FLOPs */
+sd_status sd_precision_plan(const sd_handle* h, sd_net net, char* layers_out, size_t cap, double* flop_share_out);
 sd_status sd_destroy(sd_handle* h);
 const char* sd_last_error(const sd_handle* h);
 
@@ -133,11 +146,13 @@ sd_status sd_fuse_backproject(sd_handle* h, const float* disp_pp, const uint8_t*
 
 /* the road chain of FrameProcessor.process_frame, semantic_depth.py:203-259 (seq:180-238):
  * z-cut -> MAD(y) -> MAD(x) -> plane fit -> [Open3D statistical + radius] -> end points -> width.
- * road_xyz f32 [B,cap,3], n_road i32 [B] (device).  results: DEVICE array of B sd_rw_result.
- * final_xyz (nullable) f32 [B,cap,3] receives the denoised cloud, n_final i32 [B] its size. */
-sd_status sd_road_width(sd_handle* h, const float* road_xyz, const int32_t* n_road, int B, int cap,
-                        const sd_rw_params* params_host, sd_rw_result* results, float* final_xyz, int32_t* n_final,
-                        void* stream);
+ * road_xyz f32 [B,cap,3], n_road i32 [B] (device).  road_rgb (nullable) u8 [B,cap,3]: the colours the reference carries
+ * through every filter (road_colors, :206-245).  results: DEVICE array of B sd_rw_result.
+ * final_xyz (nullable) f32 [B,cap,3] receives the denoised cloud, final_rgb (nullable, needs road_rgb) its colours,
+ * n_final i32 [B] its size. */
+sd_status sd_road_width(sd_handle* h, const float* road_xyz, const uint8_t* road_rgb, const int32_t* n_road, int B, int cap,
+                        const sd_rw_params* params_host, sd_rw_result* results, float* final_xyz, uint8_t* final_rgb,
+                        int32_t* n_final, void* stream);
 
 /* fence chain + fence-to-fence distance, semantic_depth.py:273-334 (seq:245-298), for B frames:
  * MAD(y, mad_y) -> |z| < z_max -> extract_pcls at mean x -> left: MAD(x, mad_left) + plane(axis 0, plane_thr);
@@ -158,8 +173,11 @@ typedef struct {
     int32_t counts[7];                 /* n_fence, after MAD(y), after |z| cut, left, right, left final, right final */
     int32_t ok;                        /* 0 when a side is empty / the planes are degenerate (dist is NaN) */
 } sd_f2f_result;
-sd_status sd_fence_to_fence(sd_handle* h, const float* fence_xyz, const int32_t* n_fence, int B, int cap,
-                            const sd_rw_result* road, const sd_f2f_params* params_host, sd_f2f_result* results, void* stream);
+/* fence_rgb (nullable) u8 [B,cap,3]; left_* / right_* (nullable) receive the denoised left / right fence clouds the
+ * reference writes to <name>_FENCE.ply (:412-415): xyz f32 [B,cap,3], rgb u8 [B,cap,3], sizes = results[b].counts[5], [6] */
+sd_status sd_fence_to_fence(sd_handle* h, const float* fence_xyz, const uint8_t* fence_rgb, const int32_t* n_fence, int B, int cap,
+                            const sd_rw_result* road, const sd_f2f_params* params_host, sd_f2f_result* results,
+                            float* left_xyz, uint8_t* left_rgb, float* right_xyz, uint8_t* right_rgb, void* stream);
 
 /* ---------------------------------------------------------------- pcl.py, function by function
  * (semantic_depth_lib/pcl.py; one cloud per call: xyz f32 [n,3], rgb u8 [n,3] nullable, n on the host).

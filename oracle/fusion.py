@@ -47,8 +47,10 @@ def reproject(disp: np.ndarray, Q: np.ndarray) -> np.ndarray:
 
     [UPSTREAM, parity unpinned]  Restated from OpenCV 4.x calibration.cpp: Q is promoted to double;
     per pixel homg = Q * (x, y, d, 1) accumulated left to right in double; the three numerators are
-    narrowed to float, then each is divided by the double W and narrowed to float again
-    (``dptr[x] = Vec3d(homg); dptr[x] /= homg[3]``).  d = 0 gives +-inf / nan exactly as IEEE does."""
+    narrowed to float (``dptr[x] = Vec3d(homg)`` into a Vec3f), then ``dptr[x] /= homg[3]``: core/matx.hpp implements
+    ``Vec<_Tp,cn> /= double`` as a multiply by ``ialpha = 1./alpha`` with a saturate_cast back to float, so each numerator
+    is multiplied by the double reciprocal of W and narrowed again (NOT divided: the two differ by 1 ulp on rare pixels).
+    d = 0 gives W = 0, ialpha = +-inf and +-inf / nan results exactly as IEEE does."""
     assert disp.dtype == np.float32 and disp.ndim == 2
     h, w = disp.shape
     q = Q.astype(np.float64)
@@ -60,7 +62,7 @@ def reproject(disp: np.ndarray, Q: np.ndarray) -> np.ndarray:
         W = ((q[3, 0] * x + q[3, 1] * y) + q[3, 2] * d) + q[3, 3]
         for i in range(3):
             num = ((q[i, 0] * x + q[i, 1] * y) + q[i, 2] * d) + q[i, 3]
-            out[..., i] = (num.astype(np.float32).astype(np.float64) / W).astype(np.float32)
+            out[..., i] = (num.astype(np.float32).astype(np.float64) * (1.0 / W)).astype(np.float32)
     return out
 
 

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libsemdepth.so")
 SD_OK = 0
 SD_ENC_VGG, SD_ENC_RESNET50 = 0, 1
 SD_NET_FCN8S, SD_NET_MONODEPTH = 0, 1
-SD_PREC_F32, SD_PREC_BF16X2, SD_PREC_MIXED = 0, 1, 2
+SD_PREC_F32, SD_PREC_BF16X2, SD_PREC_MIXED, SD_PREC_PLAN = 0, 1, 2, 3
 
 
 class sd_camera(C.Structure):
@@ -55,6 +55,9 @@ SIGNATURES = {
     "sd_version": (C.c_char_p, []),
     "sd_status_string": (C.c_char_p, [C.c_int]),
     "sd_create": (C.c_int, [C.POINTER(_H), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sd_create_with_plan": (C.c_int, [C.POINTER(_H), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]),
+    "sd_default_plan": (C.c_char_p, [C.c_int]),
+    "sd_precision_plan": (C.c_int, [_H, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double)]),
     "sd_destroy": (C.c_int, [_H]),
     "sd_last_error": (C.c_char_p, [_H]),
     "sd_query_memory": (C.c_int, [_H, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
@@ -67,8 +70,8 @@ SIGNATURES = {
     "sd_post_process": (C.c_int, [_H, _P, C.c_int, _P, _P]),
     "sd_resize_cubic_u8": (C.c_int, [_H, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P]),
     "sd_fuse_backproject": (C.c_int, [_H, _P, _P, _P, _P, C.POINTER(sd_camera), C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "sd_road_width": (C.c_int, [_H, _P, _P, C.c_int, C.c_int, C.POINTER(sd_rw_params), _P, _P, _P, _P]),
-    "sd_fence_to_fence": (C.c_int, [_H, _P, _P, C.c_int, C.c_int, _P, C.POINTER(sd_f2f_params), _P, _P]),
+    "sd_road_width": (C.c_int, [_H, _P, _P, _P, C.c_int, C.c_int, C.POINTER(sd_rw_params), _P, _P, _P, _P, _P]),
+    "sd_fence_to_fence": (C.c_int, [_H, _P, _P, _P, C.c_int, C.c_int, _P, C.POINTER(sd_f2f_params), _P, _P, _P, _P, _P, _P]),
     "sd_pcl_extract_pcls": (C.c_int, [_H, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sd_pcl_remove_from_to": (C.c_int, [_H, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P]),
     "sd_pcl_remove_noise_by_mad": (C.c_int, [_H, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P, _P]),
@@ -101,6 +104,12 @@ def load():
         fn = getattr(lib, name)      # AttributeError here == header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    if os.environ.get("SEMDEPTH_SKIP_HASH_CHECK") != "1":
+        from .build import source_hash
+        built, want = lib.sd_version().decode().rpartition("src=")[2], source_hash()
+        if built != want:
+            raise RuntimeError(f"{LIB_PATH} was built from other sources (library src={built}, tree src={want}): rebuild it with "
+                               "`python -m semantic_depth_amd.build` — a stale binary is never used silently")
     _lib = lib
     return lib
 

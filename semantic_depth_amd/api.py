@@ -2,12 +2,14 @@
 
     SegmentFrame  <- semantic_depth.py:464-571   (seq:378-485)
     DepthFrame    <- semantic_depth.py:575-697   (seq:488-589)
-    FrameProcessor.process_frame <- semantic_depth.py:98-268 (seq:117-238), compute steps only
+    FrameProcessor.process_frame <- semantic_depth.py:98-334 (seq:117-298), compute steps
 
 Same constructor arguments / method names / return types, so the reference's FrameProcessor body reads the same
-against these classes.  Differences: weights come from a dict / .npz of TF-layout arrays (the reference restores TF
-checkpoints; INTEGRATION.md has the name map), both classes can share one Engine, and every method also has a
-batched, device-resident form on the Engine.  No file I/O, drawing or PLY writing here (out of scope).
+against these classes, and they are built the way the reference's main() builds them (DepthFrame and SegmentFrame
+independently, semantic_depth.py:773-789): both resolve to ONE shared Engine per (H, W, device, precision) through the
+registry below.  Differences: weights come from a dict / .npz of TF-layout arrays or a TF checkpoint / frozen graph read
+by ``tf_import`` (the reference restores TF checkpoints; INTEGRATION.md has the name map), and every method also has a
+batched, device-resident form on the Engine.  File outputs live in ``outputs.py``.
 """
 from __future__ import annotations
 
@@ -15,16 +17,66 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .engine import Camera, Engine, RoadWidthParams
+from .engine import Camera, Engine, FenceParams, RoadWidthParams
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one Engine per (H, W, device, precision): the reference builds DepthFrame and SegmentFrame independently and both then
+# live in one process / on one GPU; here they share the handle, the activation workspace and the stream
+# ---------------------------------------------------------------------------------------------------------------------
+_engines: dict = {}
 
 
-def _load_weight_arg(w):
+def shared_engine(H: int, W: int, device: int = 0, precision: str = "f32", encoder: str | None = None, max_batch: int = 1) -> Engine:
+    """the registered Engine for this geometry; created on first use.  ``encoder`` None = whatever is registered (or 'vgg',
+    the reference's default --monodepth_encoder, semantic_depth.py:721-722)."""
+    key = (int(H), int(W), int(device), precision)
+    per = _engines.setdefault(key, {})
+    if encoder is None:
+        if per:
+            return next(iter(per.values()))
+        encoder = "vgg"
+    eng = per.get(encoder)
+    if eng is None or eng.max_batch < max_batch:
+        eng = Engine(H, W, max_batch, encoder, device, precision=precision)
+        eng._api_loaded = {}
+        per[encoder] = eng
+    return eng
+
+
+def register_engine(engine: Engine):
+    """make an existing Engine the shared one for its geometry (bench / batched drivers build theirs with max_batch > 1)."""
+    key = (engine.H, engine.W, engine.device.index or 0, engine.precision)
+    if not hasattr(engine, "_api_loaded"):
+        engine._api_loaded = {}
+    _engines.setdefault(key, {})[engine.encoder] = engine
+
+
+def any_engine() -> Engine | None:
+    for per in _engines.values():
+        for e in per.values():
+            return e
+    return None
+
+
+def _load_weight_arg(w, net="fcn8s", encoder=None):
     if isinstance(w, dict):
         return w
     if isinstance(w, str):
-        z = np.load(w)
-        return {k: z[k] for k in z.files}
-    raise TypeError("weights must be a dict name->array or a path to an .npz")
+        if w.endswith(".npz"):
+            z = np.load(w)
+            return {k: z[k] for k in z.files}
+        from . import tf_import           # TF checkpoint prefix / frozen .pb (semantic_depth.py:498-541, :627-653)
+        return tf_import.load_any(w, net, encoder)
+    raise TypeError("weights must be a dict name->array, a path to an .npz, a TF checkpoint prefix or a frozen .pb")
+
+
+def _ensure_loaded(engine: Engine, net: int, weights: dict):
+    loaded = getattr(engine, "_api_loaded", None)
+    if loaded is None:
+        loaded = engine._api_loaded = {}
+    if loaded.get(net) is not weights:
+        engine.load_weights(net, weights)
+        loaded[net] = weights
 
 
 class SegmentFrame:
@@ -33,10 +85,22 @@ class SegmentFrame:
     and ignored (TF graph details)."""
 
     def __init__(self, input_shape, model_var_dir, use_frozen=True, use_xla=False, CUDA_DEVICE_NUMBER="0", engine: Engine | None = None,
-                 encoder: str = "resnet50"):
+                 precision: str = "f32"):
         self.input_shape = tuple(input_shape)
-        self.engine = engine or Engine(self.input_shape[0], self.input_shape[1], 1, encoder, int(CUDA_DEVICE_NUMBER))
-        self.engine.load_weights(L.SD_NET_FCN8S, _load_weight_arg(model_var_dir))
+        self.model_var_dir = model_var_dir
+        self.CUDA_DEVICE_NUMBER = CUDA_DEVICE_NUMBER
+        self.precision = precision
+        self._weights = _load_weight_arg(model_var_dir)
+        self._engine = engine
+
+    @property
+    def engine(self) -> Engine:
+        """resolved on first use, so that a DepthFrame built before OR after this object decides the monodepth encoder of the
+        shared Engine"""
+        if self._engine is None:
+            self._engine = shared_engine(self.input_shape[0], self.input_shape[1], int(self.CUDA_DEVICE_NUMBER), self.precision)
+        _ensure_loaded(self._engine, L.SD_NET_FCN8S, self._weights)
+        return self._engine
 
     def segment_frame(self, frame: np.ndarray):
         """semantic_depth.py:544-571: (road bool (H,W,1), fence bool (H,W,1), overlay u8 (H,W,3))."""
@@ -62,7 +126,7 @@ class DepthFrame:
     ``checkpoint_path``: dict / .npz of monodepth weights."""
 
     def __init__(self, is_city=False, encoder="vgg", input_height=256, input_width=512, checkpoint_path=None, f=None,
-                 engine: Engine | None = None):
+                 engine: Engine | None = None, precision: str = "f32", device: int = 0):
         self.is_city, self.encoder = is_city, encoder
         self.input_height, self.input_width = input_height, input_width
         self.f = float(f) if f is not None else None
@@ -74,9 +138,14 @@ class DepthFrame:
             self.cx, self.cy, self.b = 314.05519001, 124.09658151, 1
             if self.f is None:
                 self.f = 380
-        self.engine = engine or Engine(input_height, input_width, 1, encoder)
-        assert self.engine.encoder == encoder and (self.engine.H, self.engine.W) == (input_height, input_width)
-        self.engine.load_weights(L.SD_NET_MONODEPTH, _load_weight_arg(checkpoint_path))
+        self.engine = engine or shared_engine(input_height, input_width, device, precision, encoder)
+        if self.engine.encoder != encoder or (self.engine.H, self.engine.W) != (input_height, input_width):
+            raise ValueError(f"engine is {self.engine.encoder} {self.engine.H}x{self.engine.W}, DepthFrame wants {encoder} "
+                             f"{input_height}x{input_width}")
+        _ensure_loaded(self.engine, L.SD_NET_MONODEPTH, _load_weight_arg(checkpoint_path, "monodepth", encoder))
+
+    def camera(self, disp_mult: float) -> Camera:
+        return Camera(self.cx, self.cy, self.f, self.b, float(disp_mult))
 
     def compute_disparity(self, frame: np.ndarray) -> np.ndarray:
         """semantic_depth.py:667-678 -> float32 (H,W), fraction of image width."""
@@ -94,19 +163,27 @@ class DepthFrame:
 
 
 class FrameProcessor:
-    """Compute steps of FrameProcessor.process_frame (semantic_depth.py:98-268) on an already-resized BGR frame.
-    ``disp_multiplier``: original_width (semantic_depth.py:109) or 3800 (seq:105)."""
+    """Compute steps of FrameProcessor.process_frame (semantic_depth.py:98-334) on a BGR frame (any size: it is
+    cubic-resized to the network shape on the GPU like :111).
+    ``approach``: 'rw' or 'both' (:743-745; 'both' adds the fence chain and the fence-to-fence distance, :273-334).
+    ``disp_multiplier``: None = the original width of each frame (semantic_depth.py:109), or a constant (3800, seq:105)."""
 
     def __init__(self, frame_segmenter: SegmentFrame, frame_depther: DepthFrame, depth: float = 10.0,
-                 disp_multiplier: float | None = None, params: RoadWidthParams | None = None):
+                 disp_multiplier: float | None = None, params: RoadWidthParams | None = None, approach: str = "rw",
+                 fence_params: FenceParams | None = None):
         self.frame_segmenter, self.frame_depther = frame_segmenter, frame_depther
         self.depth = depth
+        self.approach = approach
         self.disp_multiplier = disp_multiplier
         self.params = params or RoadWidthParams(depth=depth)
-        assert frame_segmenter.engine is frame_depther.engine, "share one Engine between the two operators"
+        self.fence_params = fence_params or FenceParams(depth=depth)
+        if frame_segmenter._engine is None:          # built independently of the DepthFrame: join its Engine
+            d = frame_depther.engine
+            if (d.H, d.W) == tuple(frame_segmenter.input_shape):
+                frame_segmenter._engine = d
 
-    def process_frame(self, frame: np.ndarray, original_width: int | None = None):
-        e = self.frame_depther.engine
+    def process_frame(self, frame: np.ndarray, original_width: int | None = None, want_clouds: bool = False):
+        es, e = self.frame_segmenter.engine, self.frame_depther.engine
         d = self.frame_depther
         # semantic_depth.py:105-112: the frame as read from disk is cubic-resized to the network shape and its ORIGINAL width
         # scales the disparities; a frame that is not H x W takes the same route here (on the GPU)
@@ -114,11 +191,41 @@ class FrameProcessor:
         fr = torch.from_numpy(np.ascontiguousarray(frame, dtype=np.uint8))[None].to(e.device)
         if tuple(fr.shape[1:3]) != (e.H, e.W):
             fr = e.resize_cubic(fr)
-        out = e.process_batch(fr, [Camera(d.cx, d.cy, d.f, d.b, float(mult))], self.params)
+        cams = [d.camera(mult)]
+        if es is e:
+            out = e.process_batch(fr, cams, self.params, approach=self.approach, fence_params=self.fence_params, want_final=want_clouds)
+        else:
+            # two Engines (different geometry registries): FCN-8s on the segmenter's, everything else on the depther's
+            seg = es.fcn8s_forward(fr)
+            disp_pp = e.monodepth_forward(fr)
+            fz = e.fuse_backproject(disp_pp, seg["road"], seg["fence"], fr, cams)
+            rw = e.road_width(fz["road_xyz"], fz["n_road"], self.params, want_final=want_clouds, road_rgb=fz["road_rgb"])
+            out = dict(seg=seg, disp_pp=disp_pp, fuse=fz, records=rw[0] if want_clouds else rw, f2f=None)
+            if want_clouds:
+                out["road_final"] = dict(xyz=rw[1], rgb=rw[2], n=rw[3])
+            if self.approach == "both":
+                f2 = e.fence_to_fence(fz["fence_xyz"], fz["n_fence"], out["records"], self.fence_params, fence_rgb=fz["fence_rgb"],
+                                      want_clouds=want_clouds)
+                out["f2f"], out["fence_final"] = f2 if want_clouds else (f2, None)
         rec = Engine.records(out["records"])[0]
         n = int(out["fuse"]["n_road"][0].item())
-        return dict(record=rec, dist_rw=float(rec["width"]) if rec["found"] else None,
-                    road_mask=out["seg"]["road"][0].cpu().numpy().astype(bool),
-                    fence_mask=out["seg"]["fence"][0].cpu().numpy().astype(bool),
-                    disparity=out["disp_pp"][0].cpu().numpy() * np.float32(mult),
-                    road3D=out["fuse"]["road_xyz"][0, :n].cpu().numpy(), road_colors=out["fuse"]["road_rgb"][0, :n].cpu().numpy())
+        res = dict(record=rec, dist_rw=float(rec["width"]) if rec["found"] else None, dist_f2f=None, f2f_record=None,
+                   road_mask=out["seg"]["road"][0].cpu().numpy().astype(bool),
+                   fence_mask=out["seg"]["fence"][0].cpu().numpy().astype(bool),
+                   disparity=out["disp_pp"][0].cpu().numpy() * np.float32(mult),
+                   road3D=out["fuse"]["road_xyz"][0, :n].cpu().numpy(), road_colors=out["fuse"]["road_rgb"][0, :n].cpu().numpy())
+        if out.get("f2f") is not None:
+            f2 = Engine.f2f_records(out["f2f"])[0]
+            res["f2f_record"] = f2
+            res["dist_f2f"] = float(f2["dist"]) if f2["ok"] else None      # semantic_depth.py:327
+        if want_clouds:
+            nf = int(out["road_final"]["n"][0].item())
+            res["road3D_final"] = out["road_final"]["xyz"][0, :nf].cpu().numpy()
+            res["road_colors_final"] = out["road_final"]["rgb"][0, :nf].cpu().numpy()
+            if out.get("fence_final"):
+                cl, cnt = out["fence_final"], res["f2f_record"]["counts"]
+                res["fence3D_left"] = cl["left_xyz"][0, :int(cnt[5])].cpu().numpy()
+                res["fence_left_colors"] = cl["left_rgb"][0, :int(cnt[5])].cpu().numpy()
+                res["fence3D_right"] = cl["right_xyz"][0, :int(cnt[6])].cpu().numpy()
+                res["fence_right_colors"] = cl["right_rgb"][0, :int(cnt[6])].cpu().numpy()
+        return res

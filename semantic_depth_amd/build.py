@@ -39,6 +39,21 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+def source_hash() -> str:
+    """sha256 over every file the library is built from (csrc sources + headers + the C-ABI header + the compile recipe
+    below), in a fixed order.  Embedded in the library (sd_version()) at build time; _lib.load() refuses a library whose
+    hash differs from the tree it is loaded from, so a stale prebuilt .so can never be used silently."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".hpp")))
+    for f in files:
+        h.update(f.encode() + b"\0")
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(HERE, "..", "include", "semdepth.h"), "rb").read())
+    h.update(repr(SOURCES).encode() + ARCH.encode())
+    return h.hexdigest()[:16]
+
+
 def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True
@@ -50,18 +65,25 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
-    # a library newer than every source needs nothing, even when the object directory did not travel with the tree
+    # a library built from exactly this tree (hash sidecar written after a successful link; _lib.load() checks the hash
+    # embedded in the library itself) needs nothing, even when the object directory did not travel with the tree
     # (gpurun ships the .so but not csrc/build/): no one-minute rebuild at the start of every GPU-box command
-    if not force and not _stale(LIB, [os.path.join(CSRC, src) for src, _ in SOURCES] + hdrs):
+    digest = source_hash()
+    stamp = LIB + ".hash"
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
         return LIB
+    hash_obj = os.path.join(OBJ, "capi.hash")
+    hash_changed = not os.path.exists(hash_obj) or open(hash_obj).read().strip() != digest
     jobs = []
     objs = []
     for src, extra in SOURCES:
         sp = os.path.join(CSRC, src)
         op = os.path.join(OBJ, src + ".o")
         objs.append(op)
-        if force or _stale(op, [sp] + hdrs):
+        if force or _stale(op, [sp] + hdrs) or (src == "capi.cpp" and hash_changed):
             cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", sp, "-o", op] + extra
+            if src == "capi.cpp":
+                cmd.append(f'-DSD_SOURCE_HASH="{digest}"')
             if src.endswith(".cpp"):
                 cmd += ["-x", "hip"]
                 cmd = cmd[:1] + ["-x", "hip"] + [c for c in cmd[1:] if c not in ("-x", "hip")]
@@ -79,7 +101,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or _stale(LIB, objs):
-        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs)
+        tmp = LIB + f".tmp{os.getpid()}"          # link aside, then rename: no process ever maps a half-written library
+        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + objs)
+        os.replace(tmp, LIB)
+    with open(hash_obj, "w") as f:
+        f.write(digest)
+    with open(stamp, "w") as f:
+        f.write(digest)
     return LIB
 
 

@@ -22,13 +22,14 @@ static_assert(sizeof(F2fResultDev) == sizeof(sd_f2f_result), "sd_f2f_result layo
 
 struct sd_handle {
     int device = 0, H = 0, W = 0, max_batch = 0, enc = 0, chunk = 0, cap = 0, prec = 0;
+    unsigned sw = 0;      // SEMDEPTH_* switches, latched in sd_create
     NetPlan fcn, mono;
     bool bound = false;
     char* wf = nullptr;   // FCN weight arena
     char* wm = nullptr;   // monodepth weight arena
     char* ws = nullptr;   // workspace arena
     // workspace carve (byte offsets)
-    size_t o_fcn = 0, o_mono = 0, o_fuse = 0, o_cams = 0, o_bufA = 0, o_bufB = 0, o_cnt = 0, o_plane = 0, o_o3d = 0, o_misc = 0, o_rsz = 0, o_cmp = 0;
+    size_t o_fcn = 0, o_mono = 0, o_fuse = 0, o_cams = 0, o_bufA = 0, o_bufB = 0, o_rgbA = 0, o_rgbB = 0, o_cnt = 0, o_plane = 0, o_o3d = 0, o_misc = 0, o_rsz = 0, o_cmp = 0;
     std::vector<int> rsz_host;      // tap tables of the last sd_resize_cubic_u8 geometry (kept alive for the async upload)
     int rsz_key[4] = {0, 0, 0, 0};
     size_t ws_bytes = 0;
@@ -72,6 +73,8 @@ void carve_workspace(sd_handle* h) {
     h->o_cams = take(sizeof(CamDev) * B);
     h->o_bufA = take(B * cap * 3 * sizeof(float));
     h->o_bufB = take(B * cap * 3 * sizeof(float));
+    h->o_rgbA = take(B * cap * 3);            // colours travel with the points through every filter (semantic_depth.py:206-245)
+    h->o_rgbB = take(B * cap * 3);
     h->o_cnt = take(B * sizeof(int32_t) * 24);
     h->o_plane = take(B * sizeof(double) * 4);
     h->o_o3d = take(o3d_scratch_bytes(h->max_batch, h->cap));
@@ -111,7 +114,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
     auto T = [&](int t) -> float* { return reinterpret_cast<float*>(abase + p.tensors[t].offset); };
     auto Wp = [&](int w) -> const float* { return reinterpret_cast<const float*>(wbase + p.weights[w].offset); };
     auto PL = [&](int t) -> size_t { const TensorDesc& d = p.tensors[t]; return (size_t)p.images * d.H * d.W * d.C; };   // lo-plane offset
-    auto FMT = [&](int t) -> int { return p.tensors[t].fmt ? (p.f16 ? 2 : 1) : 0; };     // 0 f32, 1 split bf16, 2 split fp16
+    auto FMT = [&](int t) -> int { return p.tensors[t].fmt ? (p.tensors[t].f16 ? 2 : 1) : 0; };     // 0 f32, 1 split bf16, 2 split fp16
     for (const WeightSlot& wsl : p.weights)
         if (!wsl.loaded) return fail(h, SD_ERR_STATE, "weight not loaded: " + wsl.name);
     for (const OpDesc& op : p.ops) {
@@ -147,9 +150,10 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.out_plane = PL(op.dst); c.Nmax = p.images;
                 c.zero16 = h->ws + h->o_misc + 256;        // the arena is zero-filled and nothing writes here
                 const bool split = p.prec != 0;
-                c.f16 = p.f16;
+                c.f16 = op.f16; c.out_f16 = d.f16;
                 c.src0 = T(op.src[0]); c.src0_plane = PL(op.src[0]);
                 c.out_planar16 = d.planar16;
+                c.sw = h->sw;
                 hipEvent_t ea = nullptr, eb = nullptr;
                 if (h->prof) {
                     if (h->prof_used == h->prof_pool.size()) {
@@ -161,7 +165,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                     ++h->prof_used;
                     hipEventRecord(ea, s);
                 }
-                const bool dma = split && conv_dma_variant(c) != 0 && !std::getenv("SEMDEPTH_NO_DMA");
+                const bool dma = split && conv_dma_variant(c) != 0 && !(h->sw & SW_NO_DMA);
                 const bool stem = split && !dma && conv_stem_eligible(c);
                 if (c.out_planar16 && !stem && !dma) return fail(h, SD_ERR_STATE, "sub-planar output needs the LDS-DMA or the stem conv kernel");
                 if (c.pool && !dma) return fail(h, SD_ERR_STATE, "fused pool needs the LDS-DMA conv kernel");
@@ -188,7 +192,8 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.out = T(op.dst); c.out_plane = PL(op.dst); c.act = op.act; c.Nmax = p.images;
                 c.zero16 = h->ws + h->o_misc + 256;
                 c.rows_per_wave = 2;
-                c.f16 = p.f16;
+                c.f16 = op.f16; c.out_f16 = d.f16;
+                c.sw = h->sw;
                 hipEvent_t ea = nullptr, eb = nullptr;
                 if (h->prof) {
                     if (h->prof_used == h->prof_pool.size()) {
@@ -213,10 +218,11 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.x = T(op.src[0]); c.N = N; c.H = s0.H; c.W = s0.W; c.C = s0.C; c.k = op.k; c.nout = op.nout;
                 c.wt = Wp(op.w); c.bias = Wp(op.b); c.out = T(op.dst); c.act = op.act;
                 c.in_split = FMT(op.src[0]) != 0; c.out_split = FMT(op.dst) != 0; c.in_plane = PL(op.src[0]); c.out_plane = PL(op.dst);
-                c.f16 = p.f16;
+                c.f16 = s0.f16; c.out_f16 = p.tensors[op.dst].f16;
                 c.in_sub = s0.planar16 ? (size_t)p.images * s0.H * s0.W * 16 : 0;
                 c.out_c = p.tensors[op.dst].C;
                 c.zero16 = h->ws + h->o_misc + 256;
+                c.sw = h->sw;
                 e = launch_conv_smalln(c, s);
                 break;
             }
@@ -263,7 +269,18 @@ int32_t* cnt_slot(sd_handle* h, int i) { return reinterpret_cast<int32_t*>(h->ws
 
 extern "C" {
 
-const char* sd_version(void) { return "semdepth 0.2 (gfx950; f32 MFMA, split-bf16 MFMA)"; }
+#ifndef SD_DEFAULT_PLAN_FCN
+#define SD_DEFAULT_PLAN_FCN "conv3_1,conv3_3,conv4_1,conv4_2,conv4_3,conv5_1,conv5_2,conv5_3,fc6,fc7"
+#endif
+#ifndef SD_DEFAULT_PLAN_MONO
+#define SD_DEFAULT_PLAN_MONO "*"
+#endif
+#ifndef SD_SOURCE_HASH
+#define SD_SOURCE_HASH "unhashed"
+#endif
+// "... src=<hash>": sha256 prefix of the sources this binary was built from (semantic_depth_amd/build.py source_hash);
+// the Python loader refuses a library whose hash differs from the tree's
+const char* sd_version(void) { return "semdepth 0.3 (gfx950; f32 MFMA, split-bf16/fp16 MFMA) src=" SD_SOURCE_HASH; }
 
 const char* sd_status_string(sd_status s) {
     switch (s) {
@@ -276,17 +293,50 @@ const char* sd_status_string(sd_status s) {
     }
 }
 
+// the default precision plan (SD_PREC_PLAN): chosen by scripts/calibrate_precision.py on the MI355X against the exact-f32
+// engine under a budget of 3e-4 per network (profiles/r02_precision_calibration.json; DESIGN.md §3 "Precision plan" has the table):
+// FCN-8s 69 % of its FLOPs on two products at 2.3e-4, monodepth-resnet50 all of them at 2.1e-4
+static const char* const kDefaultPlanFcn = SD_DEFAULT_PLAN_FCN;
+static const char* const kDefaultPlanMono = SD_DEFAULT_PLAN_MONO;
+
+static sd_status create_impl(sd_handle** out, int device, int H, int W, int max_batch, sd_encoder enc, sd_precision prec,
+                             const char* fcn_f16, const char* mono_f16);
+
 sd_status sd_create(sd_handle** out, int device, int H, int W, int max_batch, sd_encoder enc, sd_precision prec) {
-    if (!out || H <= 0 || W <= 0 || max_batch <= 0 || (prec != SD_PREC_F32 && prec != SD_PREC_BF16X2 && prec != SD_PREC_MIXED)) return SD_ERR_INVALID;
+    if (prec != SD_PREC_F32 && prec != SD_PREC_BF16X2 && prec != SD_PREC_MIXED && prec != SD_PREC_PLAN) return SD_ERR_INVALID;
+    const char* fcn = prec == SD_PREC_PLAN ? kDefaultPlanFcn : "";
+    const char* mono = prec == SD_PREC_PLAN ? kDefaultPlanMono : (prec == SD_PREC_MIXED ? "*" : "");
+    return create_impl(out, device, H, W, max_batch, enc, prec, fcn, mono);
+}
+
+sd_status sd_create_with_plan(sd_handle** out, int device, int H, int W, int max_batch, sd_encoder enc, const char* fcn_f16_layers,
+                              const char* mono_f16_layers) {
+    return create_impl(out, device, H, W, max_batch, enc, SD_PREC_PLAN, fcn_f16_layers ? fcn_f16_layers : "", mono_f16_layers ? mono_f16_layers : "");
+}
+
+const char* sd_default_plan(sd_net net) { return net == SD_NET_FCN8S ? kDefaultPlanFcn : kDefaultPlanMono; }
+
+sd_status sd_precision_plan(const sd_handle* h, sd_net net, char* layers_out, size_t cap, double* flop_share_out) {
+    if (!h) return SD_ERR_INVALID;
+    const NetPlan& p = plan_of(h, net);
+    if (layers_out && cap) { std::strncpy(layers_out, p.f16_ops.c_str(), cap - 1); layers_out[cap - 1] = 0; }
+    if (flop_share_out) *flop_share_out = p.flops_per_image > 0 ? p.flops_f16 / p.flops_per_image : 0.0;
+    return p.f16_ops.size() + 1 > cap && layers_out ? SD_ERR_INVALID : SD_OK;
+}
+
+static sd_status create_impl(sd_handle** out, int device, int H, int W, int max_batch, sd_encoder enc, sd_precision prec,
+                             const char* fcn_f16, const char* mono_f16) {
+    if (!out || H <= 0 || W <= 0 || max_batch <= 0) return SD_ERR_INVALID;
     sd_handle* h = new sd_handle();
+    h->sw = latch_switches();
     h->device = device; h->H = H; h->W = W; h->max_batch = max_batch; h->enc = (int)enc; h->cap = H * W; h->prec = (int)prec;
     int chunk = 32;      // frames per network pass: the deep layers (M = 512 px per frame) need ~32 frames to fill 256 CUs;
                          // activations of a 32-frame chunk are ~17 GB at 512x1024, nothing on a 288 GB part
     if (const char* e = std::getenv("SEMDEPTH_CHUNK")) chunk = std::max(1, atoi(e));
     h->chunk = std::min(max_batch, chunk);
     try {
-        h->fcn = build_fcn8s(h->chunk, H, W, h->prec != SD_PREC_F32 ? 1 : 0, 0);
-        h->mono = build_monodepth(enc == SD_ENC_VGG ? 0 : 1, h->chunk, H, W, h->prec != SD_PREC_F32 ? 1 : 0, h->prec == SD_PREC_MIXED ? 1 : 0);
+        h->fcn = build_fcn8s(h->chunk, H, W, h->prec != SD_PREC_F32 ? 1 : 0, fcn_f16);
+        h->mono = build_monodepth(enc == SD_ENC_VGG ? 0 : 1, h->chunk, H, W, h->prec != SD_PREC_F32 ? 1 : 0, mono_f16);
     } catch (const std::exception& ex) {
         std::fprintf(stderr, "sd_create: %s\n", ex.what());
         delete h;
@@ -483,7 +533,7 @@ sd_status sd_fuse_backproject(sd_handle* h, const float* disp_pp, const uint8_t*
     }
     FuseParams p{};
     p.disp_pp = disp_pp; p.road = road_xyz ? road : nullptr; p.fence = fence_xyz ? fence : nullptr; p.frames = frames; p.cams = dcams;
-    p.B = B; p.H = h->H; p.W = h->W; p.cap = cap;
+    p.B = B; p.H = h->H; p.W = h->W; p.cap = cap; p.sw = h->sw;
     p.dense = dense; p.road_xyz = road_xyz; p.road_rgb = frames ? road_rgb : nullptr; p.n_road = n_road;
     p.fence_xyz = fence_xyz; p.fence_rgb = frames ? fence_rgb : nullptr; p.n_fence = n_fence;
     const size_t nblk = ((size_t)h->H * h->W + 255) / 256;
@@ -493,8 +543,9 @@ sd_status sd_fuse_backproject(sd_handle* h, const float* disp_pp, const uint8_t*
     return SD_OK;
 }
 
-sd_status sd_road_width(sd_handle* h, const float* road_xyz, const int32_t* n_road, int B, int cap, const sd_rw_params* prm,
-                        sd_rw_result* results, float* final_xyz, int32_t* n_final, void* stream) {
+sd_status sd_road_width(sd_handle* h, const float* road_xyz, const uint8_t* road_rgb, const int32_t* n_road, int B, int cap,
+                        const sd_rw_params* prm, sd_rw_result* results, float* final_xyz, uint8_t* final_rgb, int32_t* n_final,
+                        void* stream) {
     if (!h || !road_xyz || !n_road || !prm || !results || B <= 0 || B > h->max_batch || cap <= 0 || cap > h->cap)
         return fail(h, SD_ERR_INVALID, "sd_road_width: bad arguments");
     if (!h->bound) return fail(h, SD_ERR_STATE, "sd_bind_memory first");
@@ -508,16 +559,19 @@ sd_status sd_road_width(sd_handle* h, const float* road_xyz, const int32_t* n_ro
     // the stages ping-pong between arenas A and B2: with distinct input and output the ordered compaction of a frame runs on
     // 64 workgroups instead of one (pcl.hip: multi-block compaction)
     float* B2 = reinterpret_cast<float*>(h->ws + h->o_bufB);
+    // colours (nullable): the reference carries road_colors through every filter (semantic_depth.py:206-245)
+    uint8_t* cA = road_rgb ? reinterpret_cast<uint8_t*>(h->ws + h->o_rgbA) : nullptr;
+    uint8_t* cB = road_rgb ? reinterpret_cast<uint8_t*>(h->ws + h->o_rgbB) : nullptr;
     void* cmp = h->ws + h->o_cmp;
-    HIPCHK(h, launch_filter_coord({road_xyz, nullptr, n_road}, {A, nullptr, n1}, B, cap, F_LT_NEG, 2, prm->z_cut, cmp, s));
-    HIPCHK(h, launch_mad_filter({A, nullptr, n1}, {B2, nullptr, n2}, B, cap, 1, prm->mad_y, nullptr, cmp, s));
-    HIPCHK(h, launch_mad_filter({B2, nullptr, n2}, {A, nullptr, n3}, B, cap, 0, prm->mad_x, nullptr, cmp, s));
-    HIPCHK(h, launch_plane_filter({A, nullptr, n3}, {B2, nullptr, n4}, B, cap, 1, prm->plane_thr, plane, cmp, s));
+    HIPCHK(h, launch_filter_coord({road_xyz, road_rgb, n_road}, {A, cA, n1}, B, cap, F_LT_NEG, 2, prm->z_cut, cmp, s));
+    HIPCHK(h, launch_mad_filter({A, cA, n1}, {B2, cB, n2}, B, cap, 1, prm->mad_y, nullptr, cmp, s));
+    HIPCHK(h, launch_mad_filter({B2, cB, n2}, {A, cA, n3}, B, cap, 0, prm->mad_x, nullptr, cmp, s));
+    HIPCHK(h, launch_plane_filter({A, cA, n3}, {B2, cB, n4}, B, cap, 1, prm->plane_thr, plane, cmp, s));
     const int32_t* nlast = n4;
     const float* fin = B2;
     if (prm->use_o3d) {
-        HIPCHK(h, launch_sor({B2, nullptr, n4}, {A, nullptr, n5}, B, cap, prm->sor_k, prm->sor_ratio, o3d, nullptr, cmp, s));
-        HIPCHK(h, launch_ror({A, nullptr, n5}, {B2, nullptr, n6}, B, cap, prm->ror_n, prm->ror_r, o3d, cmp, s));
+        HIPCHK(h, launch_sor({B2, cB, n4}, {A, cA, n5}, B, cap, prm->sor_k, prm->sor_ratio, o3d, nullptr, cmp, s));
+        HIPCHK(h, launch_ror({A, cA, n5}, {B2, cB, n6}, B, cap, prm->ror_n, prm->ror_r, o3d, cmp, s));
         nlast = n6;
     } else {
         n5 = n4; n6 = n4;
@@ -525,12 +579,17 @@ sd_status sd_road_width(sd_handle* h, const float* road_xyz, const int32_t* n_ro
     HIPCHK(h, launch_end_points({fin, nullptr, nlast}, B, cap, prm->depth - prm->depth_offset, prm->window, res, s));
     HIPCHK(h, launch_record_counts(res, B, n_road, n1, n2, n3, n4, n5, n6, plane, s));
     if (final_xyz) HIPCHK(h, hipMemcpyAsync(final_xyz, fin, (size_t)B * cap * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (final_rgb) {
+        if (!road_rgb) return fail(h, SD_ERR_INVALID, "sd_road_width: final_rgb needs road_rgb");
+        HIPCHK(h, hipMemcpyAsync(final_rgb, cB, (size_t)B * cap * 3, hipMemcpyDeviceToDevice, s));
+    }
     if (n_final) HIPCHK(h, hipMemcpyAsync(n_final, nlast, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     return SD_OK;
 }
 
-sd_status sd_fence_to_fence(sd_handle* h, const float* fence_xyz, const int32_t* n_fence, int B, int cap, const sd_rw_result* road,
-                            const sd_f2f_params* prm, sd_f2f_result* results, void* stream) {
+sd_status sd_fence_to_fence(sd_handle* h, const float* fence_xyz, const uint8_t* fence_rgb, const int32_t* n_fence, int B, int cap,
+                            const sd_rw_result* road, const sd_f2f_params* prm, sd_f2f_result* results, float* left_xyz,
+                            uint8_t* left_rgb, float* right_xyz, uint8_t* right_rgb, void* stream) {
     if (!h || !fence_xyz || !n_fence || !road || !prm || !results || B <= 0 || B > h->max_batch || cap <= 0 || cap > h->cap)
         return fail(h, SD_ERR_INVALID, "sd_fence_to_fence: bad arguments");
     if (!h->bound) return fail(h, SD_ERR_STATE, "sd_bind_memory first");
@@ -538,6 +597,11 @@ sd_status sd_fence_to_fence(sd_handle* h, const float* fence_xyz, const int32_t*
     float* A = reinterpret_cast<float*>(h->ws + h->o_bufA);     // fence, then left fence
     float* Rb = reinterpret_cast<float*>(h->ws + h->o_bufB);    // right fence
     float* Lb = reinterpret_cast<float*>(h->ws + h->o_o3d);     // left fence (the Open3D scratch is idle here)
+    const size_t pts = (size_t)h->max_batch * h->cap;
+    uint8_t* cA = fence_rgb ? reinterpret_cast<uint8_t*>(h->ws + h->o_rgbA) : nullptr;
+    uint8_t* cR = fence_rgb ? reinterpret_cast<uint8_t*>(h->ws + h->o_rgbB) : nullptr;
+    uint8_t* cL = fence_rgb ? reinterpret_cast<uint8_t*>(h->ws + h->o_o3d) + al(pts * 3 * sizeof(float)) : nullptr;
+    if ((left_rgb || right_rgb) && !fence_rgb) return fail(h, SD_ERR_INVALID, "sd_fence_to_fence: colour outputs need fence_rgb");
     int32_t* cnt = cnt_slot(h, 8);                              // [7][max_batch]: slots 8..14
     auto C = [&](int j) { return cnt + (size_t)j * h->max_batch; };
     int32_t* packed = reinterpret_cast<int32_t*>(h->ws + h->o_misc + 4096);
@@ -545,13 +609,18 @@ sd_status sd_fence_to_fence(sd_handle* h, const float* fence_xyz, const int32_t*
     double *p_road = planes, *p_left = planes + (size_t)B * 4, *p_right = planes + (size_t)B * 8;
     HIPCHK(h, hipMemcpyAsync(C(0), n_fence, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     HIPCHK(h, launch_gather_planes(reinterpret_cast<const RwResultDev*>(road), B, p_road, s));
-    HIPCHK(h, launch_mad_filter({fence_xyz, nullptr, n_fence}, {A, nullptr, C(1)}, B, cap, 1, prm->mad_y, nullptr, nullptr, s));
-    HIPCHK(h, launch_filter_coord({A, nullptr, C(1)}, {A, nullptr, C(2)}, B, cap, F_ABS_LT, 2, prm->z_max, nullptr, s));
-    HIPCHK(h, launch_extract_pcls({A, nullptr, C(2)}, {Lb, nullptr, C(3)}, {Rb, nullptr, C(4)}, B, cap, 0, nullptr, s));
-    HIPCHK(h, launch_mad_filter({Lb, nullptr, C(3)}, {Lb, nullptr, C(5)}, B, cap, 0, prm->mad_left, nullptr, nullptr, s));
-    HIPCHK(h, launch_plane_filter({Lb, nullptr, C(5)}, {Lb, nullptr, C(5)}, B, cap, 0, prm->plane_thr, p_left, nullptr, s));
-    HIPCHK(h, launch_mad_filter({Rb, nullptr, C(4)}, {Rb, nullptr, C(6)}, B, cap, 0, prm->mad_right, nullptr, nullptr, s));
-    HIPCHK(h, launch_plane_filter({Rb, nullptr, C(6)}, {Rb, nullptr, C(6)}, B, cap, 0, prm->plane_thr, p_right, nullptr, s));
+    HIPCHK(h, launch_mad_filter({fence_xyz, fence_rgb, n_fence}, {A, cA, C(1)}, B, cap, 1, prm->mad_y, nullptr, nullptr, s));
+    HIPCHK(h, launch_filter_coord({A, cA, C(1)}, {A, cA, C(2)}, B, cap, F_ABS_LT, 2, prm->z_max, nullptr, s));
+    HIPCHK(h, launch_extract_pcls({A, cA, C(2)}, {Lb, cL, C(3)}, {Rb, cR, C(4)}, B, cap, 0, nullptr, s));
+    HIPCHK(h, launch_mad_filter({Lb, cL, C(3)}, {Lb, cL, C(5)}, B, cap, 0, prm->mad_left, nullptr, nullptr, s));
+    HIPCHK(h, launch_plane_filter({Lb, cL, C(5)}, {Lb, cL, C(5)}, B, cap, 0, prm->plane_thr, p_left, nullptr, s));
+    HIPCHK(h, launch_mad_filter({Rb, cR, C(4)}, {Rb, cR, C(6)}, B, cap, 0, prm->mad_right, nullptr, nullptr, s));
+    HIPCHK(h, launch_plane_filter({Rb, cR, C(6)}, {Rb, cR, C(6)}, B, cap, 0, prm->plane_thr, p_right, nullptr, s));
+    // denoised left / right fence clouds (the reference writes them to *_FENCE.ply, semantic_depth.py:412-415); sizes = counts[5], counts[6]
+    if (left_xyz) HIPCHK(h, hipMemcpyAsync(left_xyz, Lb, (size_t)B * cap * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (right_xyz) HIPCHK(h, hipMemcpyAsync(right_xyz, Rb, (size_t)B * cap * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (left_rgb) HIPCHK(h, hipMemcpyAsync(left_rgb, cL, (size_t)B * cap * 3, hipMemcpyDeviceToDevice, s));
+    if (right_rgb) HIPCHK(h, hipMemcpyAsync(right_rgb, cR, (size_t)B * cap * 3, hipMemcpyDeviceToDevice, s));
     // counts array for the kernel is [7][B] contiguous: compact the strided slots
     for (int j = 0; j < 7; ++j)
         HIPCHK(h, hipMemcpyAsync(packed + (size_t)j * B, C(j), (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
@@ -652,7 +721,7 @@ sd_status sd_net_tensor(sd_handle* h, sd_net net, const char* name, float* out, 
     const char* abase = h->ws + (net == SD_NET_FCN8S ? h->o_fcn : h->o_mono);
     if (t.fmt)      // split-bf16 planes -> f32
         HIPCHK(h, launch_unsplit(reinterpret_cast<const float*>(abase + t.offset), out, (long)N * t.H * t.W, t.C, t.Ctf, (size_t)p.images * t.H * t.W * t.C,
-                                 t.planar16 ? (size_t)p.images * t.H * t.W * 16 : 0, p.f16, (hipStream_t)stream));
+                                 t.planar16 ? (size_t)p.images * t.H * t.W * 16 : 0, t.f16, (hipStream_t)stream));
     else
         HIPCHK(h, hipMemcpyAsync(out, abase + t.offset, numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return SD_OK;
@@ -668,12 +737,12 @@ sd_status sd_profile(sd_handle* h, int enable) {
 sd_status sd_profile_read(sd_handle* h, sd_profile_bucket* out, int cap_buckets, int* n_out) {
     if (!h || !out || !n_out || cap_buckets < 1) return SD_ERR_INVALID;
     HIPCHK(h, hipDeviceSynchronize());
-    const char* verbose = std::getenv("SEMDEPTH_PROFILE_VERBOSE");
+    const bool verbose = (h->sw & SW_PROFILE_VERBOSE) != 0;
     int n = 0;
     for (auto& r : h->prof_recs) {
         float ms = 0.f;
         HIPCHK(h, hipEventElapsedTime(&ms, r.a, r.b));
-        if (verbose && verbose[0] == '1')
+        if (verbose)
             std::fprintf(stderr, "[sd_profile] %-28s M=%-8d N=%-5d K=%-6d %8.3f ms %7.2f TF/s  %s\n", r.op, r.M, r.N, r.K, ms,
                          r.flops / (ms * 1e-3) / 1e12, r.kernel);
         int b = 0;

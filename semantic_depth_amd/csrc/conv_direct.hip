@@ -240,8 +240,9 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
         // ---- epilogue: bias + activation, split once, LDS transpose (in the stage just consumed; the other one is being
         //      filled for the next tile), 16-byte runs of 8 channels per pixel and plane ----
         __builtin_amdgcn_s_barrier();
-        auto epilogue = [&](auto tag) {
+        auto epilogue = [&](auto tag, auto otag) {
             constexpr int ACT = decltype(tag)::value;
+            constexpr bool O16 = decltype(otag)::value;        // output planes: fp16 or bf16 (the consumers' format)
             constexpr int ROW = 64 * NB + 16;
             constexpr int SEGS = 4 * NB, PPP = 64 / SEGS;        // 16-byte segments per pixel, pixels per store pass
             // per wave: hi slab and lo slab of 32 pixels (a lo slab that does not fit the stage reuses the hi slab)
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                             for (int r = 0; r < 4; ++r) v[r] = 4 * kg16 + r < p.nreal ? v[r] : 0.f;
                         }
                         uint2 h, l;
-                        split4_t<F16>(v, h, l);
+                        split4_t<O16>(v, h, l);
                         if (4 * kg16 < p.Cout) {
                             *reinterpret_cast<uint2*>(s16 + (16 * pb + c16) * R16 + kg16 * 8) = h;
                             *reinterpret_cast<uint2*>(s16 + 32 * R16 + (16 * pb + c16) * R16 + kg16 * 8) = l;
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                     v += bias[r4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
-                    split4_t<F16>(v, hh[r4], ll[r4]);
+                    split4_t<O16>(v, hh[r4], ll[r4]);
                 }
                 const int pp = frow >> 1;                    // pooled pixel of this lane pair
 #pragma unroll
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                     v += bias[r4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
-                    split4_t<F16>(v, hh[r4], ll[r4]);
+                    split4_t<O16>(v, hh[r4], ll[r4]);
                 }
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
@@ -411,16 +412,17 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                 }
             }
         };
-        if (p.act == ACT_RELU) epilogue(ActTag<ACT_RELU>{});
-        else if (p.act == ACT_ELU) epilogue(ActTag<ACT_ELU>{});
-        else if (N16 && p.act == ACT_SIGMOID03) epilogue(ActTag<ACT_SIGMOID03>{});
-        else epilogue(ActTag<ACT_NONE>{});
+        auto ep = [&](auto tag) { if (p.out_f16) epilogue(tag, BoolTag<true>{}); else epilogue(tag, BoolTag<false>{}); };
+        if (p.act == ACT_RELU) ep(ActTag<ACT_RELU>{});
+        else if (p.act == ACT_ELU) ep(ActTag<ACT_ELU>{});
+        else if (N16 && p.act == ACT_SIGMOID03) ep(ActTag<ACT_SIGMOID03>{});
+        else ep(ActTag<ACT_NONE>{});
         cur = nxt;
     }
 }
 
 hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
-    if ((p.act == ACT_SIGMOID03 || p.nreal) && (p.Cout > 16 || p.nsplit != 1 || p.pool || std::getenv("SEMDEPTH_NO_N16"))) return hipErrorInvalidValue;
+    if ((p.act == ACT_SIGMOID03 || p.nreal) && (p.Cout > 16 || p.nsplit != 1 || p.pool || (p.sw & SW_NO_N16))) return hipErrorInvalidValue;
     if (p.W % D_TW || p.Cout > 64 || p.Cout % 8 || p.nsplit < 1 || p.nsplit > 8 || (p.nsplit > 1 && p.Cout != 64)) return hipErrorInvalidValue;
     static int cus = 0;
     if (!cus) {
@@ -433,12 +435,12 @@ hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
     if (p.pool && (p.rows_per_wave != 2 || (p.H & 1) || (p.W & 1))) return hipErrorInvalidValue;
     if (p.rows_per_wave != 2) return hipErrorInvalidValue;       // (8-row tiles of the 32/64-channel kernels were measured no better and are not built)
     const int nb = p.Cout <= 32 ? 1 : 2;
-    const bool n16 = p.Cout <= 16 && p.nsplit == 1 && !p.pool && !std::getenv("SEMDEPTH_NO_N16");
+    const bool n16 = p.Cout <= 16 && p.nsplit == 1 && !p.pool && !(p.sw & SW_NO_N16);
     // N16 layers (full-resolution decoder tail: two chunks of little arithmetic per tile) are bound by the DMA latency of
     // a two-stage ring: 8-row tiles, 64 KiB of LDS, TWO workgroups per CU cover each other's waits
     // every source behind a x2 upsample: source-resolution halo tiles (48 KiB of LDS for N16 with 16-row tiles: they stay)
-    const bool up = p.all_up && !(p.H & 1) && !(p.W & 1) && !std::getenv("SEMDEPTH_NO_UPTILE");
-    const bool mt1 = n16 && !up && !std::getenv("SEMDEPTH_NO_N16_MT1");
+    const bool up = p.all_up && !(p.H & 1) && !(p.W & 1) && !(p.sw & SW_NO_UPTILE);
+    const bool mt1 = n16 && !up && !(p.sw & SW_NO_N16_MT1);
     const int th = mt1 ? 8 : 16;
     const int tiles = (p.W / D_TW) * ((p.H + th - 1) / th) * p.N * p.nsplit;
     // persistent grid: as many workgroups as the instantiation keeps resident (1-3 per CU, by LDS and registers)
@@ -468,7 +470,7 @@ hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
 // label of the instantiation family launch_conv_direct picks (profiling buckets): 64-channel passes, <= 32 channels, or the
 // 16-wide MFMA form
 const char* conv_direct_kernel_name(const ConvDirectParams& p) {
-    const bool n16 = p.Cout <= 16 && p.nsplit == 1 && !p.pool && !std::getenv("SEMDEPTH_NO_N16");
+    const bool n16 = p.Cout <= 16 && p.nsplit == 1 && !p.pool && !(p.sw & SW_NO_N16);
     if (n16) return p.f16 ? "conv_direct_f16w_kernel<1,n16>" : "conv_direct_kernel<1,n16>";
     if (p.Cout <= 32) return p.f16 ? "conv_direct_f16w_kernel<1,2>" : "conv_direct_kernel<1,2>";
     return p.f16 ? "conv_direct_f16w_kernel<2,2>" : "conv_direct_kernel<2,2>";

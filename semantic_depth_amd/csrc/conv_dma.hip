@@ -277,8 +277,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
 
     // ---- epilogue (as conv_split.hip): bias + activation, split once, LDS transpose, 16-byte runs per pixel ----
     __syncthreads();
-    auto epilogue = [&](auto tag) {
+    auto epilogue = [&](auto tag, auto otag) {
         constexpr int ACT = decltype(tag)::value;
+        constexpr bool O16 = decltype(otag)::value;            // output planes: fp16 or bf16 (the consumers' format)
         constexpr int ROW = EPI_ROW;
         unsigned char* sh = reinterpret_cast<unsigned char*>(ring) + wave * (2 * 32 * ROW);
         unsigned char* sl = sh + 32 * ROW;
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
                         uint2 h, l;
-                        split4_t<F16>(v, h, l);
+                        split4_t<O16>(v, h, l);
                         if ((lane & 3) == 0) {
                             *reinterpret_cast<uint2*>(sh + ((lane & 31) >> 2) * ROW + nl * 2) = h;
                             *reinterpret_cast<uint2*>(sl + ((lane & 31) >> 2) * ROW + nl * 2) = l;
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
                     uint2 h, l;
-                    split4_t<F16>(v, h, l);
+                    split4_t<O16>(v, h, l);
                     *reinterpret_cast<uint2*>(sh + (lane & 31) * ROW + nl * 2) = h;
                     *reinterpret_cast<uint2*>(sl + (lane & 31) * ROW + nl * 2) = l;
                 }
@@ -372,9 +373,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     };
-    if (p.act == ACT_RELU) epilogue(ActTag<ACT_RELU>{});
-    else if (p.act == ACT_ELU) epilogue(ActTag<ACT_ELU>{});
-    else epilogue(ActTag<ACT_NONE>{});
+    auto ep = [&](auto tag) { if (p.out_f16) epilogue(tag, BoolTag<true>{}); else epilogue(tag, BoolTag<false>{}); };
+    if (p.act == ACT_RELU) ep(ActTag<ACT_RELU>{});
+    else if (p.act == ACT_ELU) ep(ActTag<ACT_ELU>{});
+    else ep(ActTag<ACT_NONE>{});
 }
 
 // which layers take the DMA pipeline: vec layers with Cout a multiple of 64 and enough tiles to occupy the chip
@@ -383,12 +385,12 @@ int conv_dma_variant(const ConvParams& p) {
     const long M = (long)p.N * p.Hout * p.Wout;
     const long thr = (p.pool || p.out_planar16) ? 0 : 96;     // tiles needed: the DMA pipeline at half occupancy still beats the register-staged
                                           // kernel (a fused pool exists only here: such layers always take this kernel)
-    const bool big = std::getenv("SEMDEPTH_NO_DMA_BIG") == nullptr;
+    const bool big = !(p.sw & SW_NO_DMA_BIG);
     if (big && !p.pool && p.Cout % 256 == 0 && ((M + 255) / 256) * (p.Cout / 256) >= 512) return 5;     // 256 x 256, two stages
     if (p.Cout % 256 == 0 && ((M + 127) / 128) * (p.Cout / 256) >= thr) return 1;     // 128 x 256
     if (p.Cout % 128 == 0 && ((M + 255) / 256) * (p.Cout / 128) >= thr) return 2;     // 256 x 128
     if (p.Cout % 64 == 0 && p.Cout % 128 != 0 && ((M + 255) / 256) * (p.Cout / 64) >= thr) return 3;      // 256 x 64
-    if (p.Cout == 32 && !p.pool && !p.out_planar16 && (M + 255) / 256 >= thr && !std::getenv("SEMDEPTH_NO_DMA32")) return 4;      // 256 x 32 (monodepth-vgg conv1b)
+    if (p.Cout == 32 && !p.pool && !p.out_planar16 && (M + 255) / 256 >= thr && !(p.sw & SW_NO_DMA32)) return 4;      // 256 x 32 (monodepth-vgg conv1b)
     return 0;
 }
 
@@ -408,8 +410,7 @@ static void launch_dma_variant(const ConvParams& p, long M, hipStream_t s) {
 
 hipError_t launch_conv_dma(const ConvParams& p0, hipStream_t s) {
     ConvParams p = p0;
-    static const char* dbg = std::getenv("SEMDEPTH_DMA_DBG");
-    p.dbg = dbg ? atoi(dbg) : 0;
+    p.dbg = (p.sw & SW_DMA_DBG16) ? 16 : 0;
     const long M = (long)p.N * p.Hout * p.Wout;
     const int v = conv_dma_variant(p);
     if (v == 1) launch_dma_variant<2, 4, 2, 2, 3>(p, M, s);

@@ -78,9 +78,16 @@ __device__ __forceinline__ void split_epilogue_act(f32x16 (&acc)[MT][NT], unsign
 }
 template <int MT, int NT, bool F16>
 __device__ __forceinline__ void split_epilogue(f32x16 (&acc)[MT][NT], unsigned char* slab, const ConvParams& p, int m0, int n0, int M, int lane) {
-    if (p.act == ACT_RELU) split_epilogue_act<ACT_RELU, MT, NT, F16>(acc, slab, p, m0, n0, M, lane);
-    else if (p.act == ACT_ELU) split_epilogue_act<ACT_ELU, MT, NT, F16>(acc, slab, p, m0, n0, M, lane);
-    else split_epilogue_act<ACT_NONE, MT, NT, F16>(acc, slab, p, m0, n0, M, lane);
+    // the template's F16 is the INPUT format of the kernel; the output planes follow p.out_f16 (the consumers' format)
+    if (p.out_f16) {
+        if (p.act == ACT_RELU) split_epilogue_act<ACT_RELU, MT, NT, true>(acc, slab, p, m0, n0, M, lane);
+        else if (p.act == ACT_ELU) split_epilogue_act<ACT_ELU, MT, NT, true>(acc, slab, p, m0, n0, M, lane);
+        else split_epilogue_act<ACT_NONE, MT, NT, true>(acc, slab, p, m0, n0, M, lane);
+        return;
+    }
+    if (p.act == ACT_RELU) split_epilogue_act<ACT_RELU, MT, NT, false>(acc, slab, p, m0, n0, M, lane);
+    else if (p.act == ACT_ELU) split_epilogue_act<ACT_ELU, MT, NT, false>(acc, slab, p, m0, n0, M, lane);
+    else split_epilogue_act<ACT_NONE, MT, NT, false>(acc, slab, p, m0, n0, M, lane);
 }
 
 template <int WAVES_M, int WAVES_N, int MT, int NT>

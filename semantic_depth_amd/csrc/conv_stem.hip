@@ -133,8 +133,9 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
         }
 
         // ---- epilogue: bias + activation, split once, LDS transpose one plane at a time, 16-byte runs per pixel ----
-        auto epilogue = [&](auto tag) {
+        auto epilogue = [&](auto tag, auto otag) {
             constexpr int ACT = decltype(tag)::value;
+            constexpr bool O16 = decltype(otag)::value;
             constexpr int SEGS = 4 * NB, PPP = 64 / SEGS;
             unsigned char* sh = slab + wave * (32 * ROW);
             const int seg = lane % SEGS, prow = lane / SEGS;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
                     v += bias[r4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
-                    split4_t<F16>(v, hh[r4], ll[r4]);
+                    split4_t<O16>(v, hh[r4], ll[r4]);
                 }
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
@@ -175,9 +176,10 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
                 }
             }
         };
-        if (p.act == ACT_RELU) epilogue(ActTag<ACT_RELU>{});
-        else if (p.act == ACT_ELU) epilogue(ActTag<ACT_ELU>{});
-        else epilogue(ActTag<ACT_NONE>{});
+        auto ep = [&](auto tag) { if (p.out_f16) epilogue(tag, BoolTag<true>{}); else epilogue(tag, BoolTag<false>{}); };
+        if (p.act == ACT_RELU) ep(ActTag<ACT_RELU>{});
+        else if (p.act == ACT_ELU) ep(ActTag<ACT_ELU>{});
+        else ep(ActTag<ACT_NONE>{});
         cur = nxt;
     }
 }
@@ -189,7 +191,7 @@ bool conv_stem_eligible(const ConvParams& p) {
     if (p.out_planar16 && p.Cout % 16) return false;
     const int rw = p.stride == 1 ? 2 : 1, th = 8 * rw;
     const int ih = (th - 1) * p.stride + p.kh, iw = (ST_TW - 1) * p.stride + p.kh;
-    return ih * iw <= ST_MAXPIX && !std::getenv("SEMDEPTH_NO_STEM");
+    return ih * iw <= ST_MAXPIX && !(p.sw & SW_NO_STEM);
 }
 
 hipError_t launch_conv_stem(const ConvParams& p, hipStream_t s) {

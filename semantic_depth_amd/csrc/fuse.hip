@@ -128,16 +128,17 @@ __global__ __launch_bounds__(256) void fuse_write_kernel(const FuseParams p, int
         // disparity = disp_pp * multiplier in float32 (semantic_depth.py:145; seq:146)
         const float dpx = p.disp_pp[gi] * cam.mult;
         // cv2.reprojectImageTo3D [UPSTREAM OpenCV 4.x]: homg = Q*(x,y,d,1) in double, left to right;
-        // numerators narrowed to float, divided by the double W, narrowed again.
+        // numerators narrowed to float, multiplied by the double 1/W (matx.hpp operator/=), narrowed again.
         const double xd = (double)x, yd = (double)y, d = (double)dpx;
         const double* q = cam.q;
         const double Wh = ((q[12] * xd + q[13] * yd) + q[14] * d) + q[15];
         const double n0 = ((q[0] * xd + q[1] * yd) + q[2] * d) + q[3];
         const double n1 = ((q[4] * xd + q[5] * yd) + q[6] * d) + q[7];
         const double n2 = ((q[8] * xd + q[9] * yd) + q[10] * d) + q[11];
-        X = (float)((double)(float)n0 / Wh);
-        Y = (float)((double)(float)n1 / Wh);
-        Z = (float)((double)(float)n2 / Wh);
+        const double iW = 1.0 / Wh;               // Vec3f /= double is a multiply by 1./alpha (core/matx.hpp)
+        X = (float)((double)(float)n0 * iW);
+        Y = (float)((double)(float)n1 * iW);
+        Z = (float)((double)(float)n2 * iW);
         if (p.dense) {
             float* dp = p.dense + gi * 3;
             dp[0] = X; dp[1] = Y; dp[2] = Z;
@@ -242,14 +243,15 @@ __global__ __launch_bounds__(256) void fuse_write4_kernel(const FuseParams p, in
         const bool r = (mr4 >> (8 * k)) & 0xffu, f = (mf4 >> (8 * k)) & 0xffu;
         if (!p.dense && !r && !f) continue;
         // disparity = disp_pp * multiplier in float32 (semantic_depth.py:145; seq:146); cv2.reprojectImageTo3D [UPSTREAM OpenCV
-        // 4.x]: homg = Q*(x,y,d,1) in double, left to right; numerators narrowed to float, divided by the double W, narrowed again
+        // 4.x]: homg = Q*(x,y,d,1) in double, left to right; numerators narrowed to float, multiplied by the double 1/W, narrowed again
         const float dpx = dv[k] * cam.mult;
         const double xd = (double)(x0 + k), yd = (double)y, d = (double)dpx;
         const double Wh = ((q[12] * xd + q[13] * yd) + q[14] * d) + q[15];
         const double n0 = ((q[0] * xd + q[1] * yd) + q[2] * d) + q[3];
         const double n1 = ((q[4] * xd + q[5] * yd) + q[6] * d) + q[7];
         const double n2 = ((q[8] * xd + q[9] * yd) + q[10] * d) + q[11];
-        const float X = (float)((double)(float)n0 / Wh), Y = (float)((double)(float)n1 / Wh), Z = (float)((double)(float)n2 / Wh);
+        const double iW = 1.0 / Wh;                 // Vec3f /= double is a multiply by 1./alpha (core/matx.hpp)
+        const float X = (float)((double)(float)n0 * iW), Y = (float)((double)(float)n1 * iW), Z = (float)((double)(float)n2 * iW);
         if (p.dense) { float* dp = p.dense + (g4 + k) * 3; dp[0] = X; dp[1] = Y; dp[2] = Z; }
         // bytes 3k .. 3k+2 of the 12 frame bytes: B, G, R -> colours = cv2.cvtColor(frame, BGR2RGB), semantic_depth.py:161
         const unsigned long long lo64 = ((unsigned long long)fw[1] << 32) | fw[0], hi64 = ((unsigned long long)fw[2] << 32) | fw[1];
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256) void fuse_write4_kernel(const FuseParams p, in
 hipError_t launch_fuse(const FuseParams& p, hipStream_t s) {
     const int npix = p.H * p.W;
     const bool gather = p.road_xyz || p.fence_xyz;
-    if (p.W % 4 == 0 && gather && !std::getenv("SEMDEPTH_NO_FUSE4")) {          // four pixels per thread, 1024 per block
+    if (p.W % 4 == 0 && gather && !(p.sw & SW_NO_FUSE4)) {          // four pixels per thread, 1024 per block
         const int nblk4 = (npix + 1023) / 1024;
         hipLaunchKernelGGL(fuse_count4_kernel, dim3(nblk4, p.B), dim3(256), 0, s, p.road, p.fence, npix, nblk4, p.blk_counts);
         hipLaunchKernelGGL(fuse_scan_kernel, dim3(p.B), dim3(1024), 0, s, p.blk_counts, p.blk_offsets, nblk4, p.n_road, p.n_fence);

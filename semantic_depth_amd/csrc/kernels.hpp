@@ -7,6 +7,15 @@ namespace sd {
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
+// run-time A/B switches (SEMDEPTH_* environment variables), latched ONCE per handle in sd_create (capi.cpp latch_switches)
+// and handed to the launchers in their parameter structs: nothing on the launch path calls getenv
+enum Switch : unsigned {
+    SW_NO_N16 = 1u << 0, SW_NO_UPTILE = 1u << 1, SW_NO_N16_MT1 = 1u << 2, SW_NO_DMA_BIG = 1u << 3, SW_NO_DMA32 = 1u << 4,
+    SW_NO_STEM = 1u << 5, SW_NO_FUSE4 = 1u << 6, SW_NO_SMALLN_TILE = 1u << 7, SW_NO_DMA = 1u << 8, SW_DMA_DBG16 = 1u << 9,
+    SW_PROFILE_VERBOSE = 1u << 10, SW_NO_FUSE1 = 1u << 11
+};
+unsigned latch_switches();      // plan.cpp
+
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_SIGMOID03 = 3 /* 0.3*sigmoid, monodepth get_disp */ };
 
 // ---------------------------------------------------------------------------------------------
@@ -45,7 +54,8 @@ struct ConvParams {
     int Nmax;          // split engine: images of a full chunk (plane stride of a source = Nmax*H*W*C elements)
     const void* src0;  // first source tensor (hi plane) and the element offset of its lo plane: conv_stem.hip reads it directly
     size_t src0_plane;
-    int f16;           // split planes are fp16 and the weights one fp16 plane (2 MFMA products): split_fmt.hpp
+    int f16;           // INPUT split planes are fp16 and the weights one fp16 plane (2 MFMA products): split_fmt.hpp
+    int out_f16;       // OUTPUT split planes are fp16 (the format the consumers of the output tensor compute in)
     int out_planar16;  // conv_stem.hip: write the output as Cout/16 sub-planes of 16 channels (TensorDesc::planar16)
     int pool;          // conv_dma.hip: output pixels are walked in 2x2-window-major order and the epilogue max-pools each
                        // window: out is [N,Hout/2,Wout/2,Cout]
@@ -53,6 +63,7 @@ struct ConvParams {
                        // 2: two-source 1x1 GEMM (ResNet conv3 + projection), per-source strides, no upsample
     int dbg;           // SEMDEPTH_DMA_DBG=16: general gather path on SIMPLE layers too (A/B switch; 0 in production)
     int m_fastest;     // block order: 1 = consecutive blocks walk M (share a weight panel), 0 = walk N
+    unsigned sw;       // Switch bits of the handle
 };
 hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t s);
 const char* conv_igemm_kernel_name(const ConvParams& p);
@@ -83,6 +94,7 @@ __device__ __forceinline__ float fast_elu_split(float v) {
     return fmaxf(v, 0.f) + (__builtin_amdgcn_exp2f(fminf(v, 0.f) * 1.4426950408889634f) - 1.0f);
 }
 template <int ACT> struct ActTag { static constexpr int value = ACT; };
+template <bool B> struct BoolTag { static constexpr bool value = B; };   // output plane format of an epilogue: true = fp16 planes
 // activation selected at compile time inside the epilogues (a run-time switch per value costs more than the arithmetic)
 template <int ACT> __device__ __forceinline__ float act_split(float v) {
     if (ACT == 1) return fmaxf(v, 0.f);
@@ -124,8 +136,10 @@ struct ConvDirectParams {
     int act, Nmax;
     const void* zero16;
     int rows_per_wave;           // 1: 8 x 32 tiles, 2: 16 x 32 tiles (see conv_direct.hip)
-    int f16;                     // fp16 planes + single fp16 weight plane (2 MFMA products)
+    int f16;                     // INPUT fp16 planes + single fp16 weight plane (2 MFMA products)
+    int out_f16;                 // OUTPUT planes are fp16
     int pool;                    // 1: fused 2x2 stride-2 max pool, out is [N,H/2,W/2,Cout] (needs rows_per_wave == 2)
+    unsigned sw;                 // Switch bits of the handle
 };
 hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s);
 const char* conv_direct_kernel_name(const ConvDirectParams& p);
@@ -146,10 +160,12 @@ struct SmallNParams {
     float* out;         // [N,H,W,nout]
     int act;
     const void* zero16; // 16 zero bytes (padding source of the LDS-DMA halo loads of the tiled kernel)
-    int f16;            // split planes (in and out) are fp16 instead of bf16
+    int f16;            // INPUT split planes are fp16 instead of bf16
+    int out_f16;        // OUTPUT split planes (out_split) are fp16
+    unsigned sw;        // Switch bits of the handle
 };
 hipError_t launch_conv_smalln(const SmallNParams& p, hipStream_t s);
-bool conv_smalln_tiled(int in_split, int k, int W, int C, int nout);   // the LDS-tiled kernel takes this layer (it alone reads sub-planar inputs)
+bool conv_smalln_tiled(int in_split, int k, int W, int C, int nout, unsigned sw);   // the LDS-tiled kernel takes this layer (it alone reads sub-planar inputs)
 
 // ---------------------------------------------------------------------------------------------
 // misc network ops (ops_misc.hip)
@@ -185,6 +201,7 @@ struct FuseParams {
     float* fence_xyz; uint8_t* fence_rgb; int32_t* n_fence;
     int32_t* blk_counts;       // scratch [B][nblk][2]
     int32_t* blk_offsets;      // scratch [B][nblk][2]
+    unsigned sw;               // Switch bits of the handle
 };
 size_t fuse_scratch_bytes(int B, int H, int W);
 hipError_t launch_fuse(const FuseParams& p, hipStream_t s);

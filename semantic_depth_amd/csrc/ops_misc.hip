@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void conv_smalln_thread_kernel(const SmallNPar
     }
     if (p.out_split) {            // NOUT == 2: one bf16 pair per plane
         unsigned h, l;
-        if (p.f16) split2_t<true>(f32x2_t{smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)}, h, l);
+        if (p.out_f16) split2_t<true>(f32x2_t{smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)}, h, l);
         else split2_t<false>(f32x2_t{smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)}, h, l);
         if (p.out_c == 8) {       // one zero-padded channel octet per pixel (source of the direct 3x3 kernel)
             reinterpret_cast<u32x4_t*>(p.out)[pix] = (u32x4_t){h, 0u, 0u, 0u};
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void conv_smalln_tile_kernel(const SmallNParam
     const long pix = ((long)img * p.H + y) * p.W + tx0 + col;
     if (p.out_split) {            // NOUT == 2: one bf16 pair per plane
         unsigned h, l;
-        if (p.f16) split2_t<true>(f32x2_t{smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)}, h, l);
+        if (p.out_f16) split2_t<true>(f32x2_t{smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)}, h, l);
         else split2_t<false>(f32x2_t{smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)}, h, l);
         if (p.out_c == 8) {
             reinterpret_cast<u32x4_t*>(p.out)[pix] = (u32x4_t){h, 0u, 0u, 0u};
@@ -392,7 +392,7 @@ static void launch_smalln_t(const SmallNParams& p, hipStream_t s) {
     const long npix = (long)p.N * p.H * p.W;
     const int K = p.k * p.k * p.C;
     if (IN_SPLIT && p.k == 3 && p.W % SN_TW == 0 && p.C % 8 == 0 && p.nout <= 2 && p.zero16 && (size_t)K * 4 * p.nout <= 24576 &&
-        !std::getenv("SEMDEPTH_NO_SMALLN_TILE")) {
+        !(p.sw & SW_NO_SMALLN_TILE)) {
         const dim3 grid((unsigned)((p.W / SN_TW) * ((p.H + SN_TH - 1) / SN_TH) * p.N));
         const size_t lds = (size_t)K * 4 * p.nout;
         if (IN_SPLIT == 2) {
@@ -417,12 +417,12 @@ static void launch_smalln_t(const SmallNParams& p, hipStream_t s) {
         hipLaunchKernelGGL(conv_smalln_wave_kernel<IN_SPLIT>, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, p);
     }
 }
-bool conv_smalln_tiled(int in_split, int k, int W, int C, int nout) {
+bool conv_smalln_tiled(int in_split, int k, int W, int C, int nout, unsigned sw) {
     return in_split && k == 3 && W % SN_TW == 0 && C % 8 == 0 && nout <= 2 && (size_t)9 * C * 4 * nout <= 24576 &&
-           !std::getenv("SEMDEPTH_NO_SMALLN_TILE");
+           !(sw & SW_NO_SMALLN_TILE);
 }
 hipError_t launch_conv_smalln(const SmallNParams& p, hipStream_t s) {
-    if (p.in_sub && !(conv_smalln_tiled(p.in_split, p.k, p.W, p.C, p.nout) && p.zero16)) return hipErrorInvalidValue;   // sub-planes: tiled kernel only
+    if (p.in_sub && !(conv_smalln_tiled(p.in_split, p.k, p.W, p.C, p.nout, p.sw) && p.zero16)) return hipErrorInvalidValue;   // sub-planes: tiled kernel only
     if (p.out_split && (p.nout != 2 || p.k * p.k * p.C > 2048)) return hipErrorInvalidValue;
     if (p.in_split && p.f16) launch_smalln_t<2>(p, s);
     else if (p.in_split) launch_smalln_t<1>(p, s);

@@ -9,6 +9,20 @@
 
 namespace sd {
 
+unsigned latch_switches() {
+    static const struct { const char* name; unsigned bit; } tab[] = {
+        {"SEMDEPTH_NO_N16", SW_NO_N16}, {"SEMDEPTH_NO_UPTILE", SW_NO_UPTILE}, {"SEMDEPTH_NO_N16_MT1", SW_NO_N16_MT1},
+        {"SEMDEPTH_NO_DMA_BIG", SW_NO_DMA_BIG}, {"SEMDEPTH_NO_DMA32", SW_NO_DMA32}, {"SEMDEPTH_NO_STEM", SW_NO_STEM},
+        {"SEMDEPTH_NO_FUSE4", SW_NO_FUSE4}, {"SEMDEPTH_NO_SMALLN_TILE", SW_NO_SMALLN_TILE}, {"SEMDEPTH_NO_DMA", SW_NO_DMA},
+        {"SEMDEPTH_NO_FUSE1", SW_NO_FUSE1}};
+    unsigned sw = 0;
+    for (const auto& e : tab)
+        if (std::getenv(e.name)) sw |= e.bit;
+    if (const char* d = std::getenv("SEMDEPTH_DMA_DBG")) if (atoi(d) & 16) sw |= SW_DMA_DBG16;
+    if (const char* v = std::getenv("SEMDEPTH_PROFILE_VERBOSE")) if (v[0] == '1') sw |= SW_PROFILE_VERBOSE;
+    return sw;
+}
+
 namespace {
 
 constexpr size_t ALIGN = 256;
@@ -33,7 +47,6 @@ struct Builder {
     int wslot(const std::string& name, std::initializer_list<int64_t> shape, int layout, int Kpad = 0, int CoutPad = 0, int nout = 0, int nsplit = 1) {
         WeightSlot s;
         s.name = name; s.rank = (int)shape.size(); s.layout = layout; s.Kpad = Kpad; s.CoutPad = CoutPad; s.nout = nout; s.nsplit = nsplit;
-        s.f16 = p.f16;
         int i = 0;
         for (auto v : shape) s.shape[i++] = v;
         size_t n = 0;
@@ -259,14 +272,78 @@ struct Builder {
                 for (int j = 0; j < op.nsrc; ++j) reads = reads || op.src[j] == (int)ti;
                 if (!reads) continue;
                 ++readers;
-                const bool head = wide && op.kind == OP_SMALLN && conv_smalln_tiled(1, op.k, t.W, t.C, op.nout);
+                const bool head = wide && op.kind == OP_SMALLN && conv_smalln_tiled(1, op.k, t.W, t.C, op.nout, latch_switches());
                 ok = ok && (op.kind == OP_CONV_DIRECT || head) && op.residual != (int)ti;
             }
             if (made && ok && readers > 0) t.planar16 = 1;
         }
     }
 
+    // precision plan: mark the conv layers named in p.f16_spec, then close the choice under the one-format-per-tensor rule
+    void apply_precision_plan() {
+        if (!p.prec || p.f16_spec.empty()) return;
+        std::vector<std::string> toks;
+        {
+            size_t a = 0;
+            while (a <= p.f16_spec.size()) {
+                size_t b = p.f16_spec.find(',', a);
+                if (b == std::string::npos) b = p.f16_spec.size();
+                std::string t = p.f16_spec.substr(a, b - a);
+                while (!t.empty() && t.front() == ' ') t.erase(t.begin());
+                while (!t.empty() && t.back() == ' ') t.pop_back();
+                if (!t.empty()) toks.push_back(t);
+                a = b + 1;
+            }
+        }
+        auto is_conv = [](const OpDesc& op) { return op.kind == OP_CONV || op.kind == OP_CONV_DIRECT; };
+        auto wanted = [&](const std::string& n) {
+            for (const std::string& t : toks) {
+                if (t == "*" || t == n) return true;
+                if (t.size() > 1 && t.back() == '*' && n.compare(0, t.size() - 1, t, 0, t.size() - 1) == 0) return true;
+            }
+            return false;
+        };
+        std::vector<char> matched(toks.size(), 0);
+        for (OpDesc& op : p.ops)
+            if (is_conv(op) && wanted(op.name)) op.f16 = 1;
+        for (size_t i = 0; i < toks.size(); ++i) {
+            bool any = toks[i] == "*";
+            for (const OpDesc& op : p.ops)
+                if (is_conv(op) && (toks[i] == op.name || (toks[i].size() > 1 && toks[i].back() == '*' &&
+                                                           op.name.compare(0, toks[i].size() - 1, toks[i], 0, toks[i].size() - 1) == 0)))
+                    any = true;
+            if (!any) throw std::runtime_error("precision plan of " + p.net + ": no conv layer matches '" + toks[i] + "'");
+        }
+        for (bool changed = true; changed;) {
+            changed = false;
+            for (OpDesc& op : p.ops) {
+                if (is_conv(op)) {
+                    bool reads16 = false;
+                    for (int j = 0; j < op.nsrc; ++j) reads16 = reads16 || p.tensors[op.src[j]].f16;
+                    if (reads16 && !op.f16) { op.f16 = 1; changed = true; }
+                    if (op.f16)
+                        for (int j = 0; j < op.nsrc; ++j)
+                            if (p.tensors[op.src[j]].fmt && !p.tensors[op.src[j]].f16) { p.tensors[op.src[j]].f16 = 1; changed = true; }
+                } else if (op.kind == OP_POOL2 || op.kind == OP_POOL3Z) {      // a stand-alone pool keeps the format of its source
+                    TensorDesc &a = p.tensors[op.src[0]], &b = p.tensors[op.dst];
+                    if (a.fmt && b.fmt && a.f16 != b.f16) { a.f16 = b.f16 = 1; changed = true; }
+                }
+            }
+        }
+        double fl = 0;
+        for (OpDesc& op : p.ops) {
+            if (!is_conv(op) || !op.f16) continue;
+            p.f16_ops += (p.f16_ops.empty() ? "" : ",") + op.name;
+            fl += op.flops;
+            p.weights[op.w].f16 = 1;
+            for (WeightSlot& s : p.weights)
+                if (s.owner == op.w && (s.layout == WL_IGEMM_SPLIT || s.layout == WL_DIRECT_SPLIT)) s.f16 = 1;
+        }
+        p.flops_f16 = fl / std::max(1, p.images);
+    }
+
     void finish() {
+        apply_precision_plan();
         mark_planar();
         // liveness
         for (size_t i = 0; i < p.ops.size(); ++i) {
@@ -330,10 +407,10 @@ struct Builder {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
-NetPlan build_fcn8s(int frames, int H, int W, int prec, int f16) {
+NetPlan build_fcn8s(int frames, int H, int W, int prec, const char* f16_layers) {
     if (H % 32 || W % 32) throw std::runtime_error("FCN-8s needs H, W multiples of 32");
     Builder b;
-    b.p.prec = prec; b.p.f16 = prec ? f16 : 0;
+    b.p.prec = prec; b.p.f16_spec = (prec && f16_layers) ? f16_layers : "";
     b.p.net = "fcn8s"; b.p.frames = frames; b.p.images = frames; b.p.H = H; b.p.W = W;
     int x = b.tensor("input_pre", frames, H, W, 4);      // 4th channel is zero: float4 gathers in conv1_1
     b.p.tensors[x].Ctf = 3;
@@ -391,11 +468,11 @@ NetPlan build_fcn8s(int frames, int H, int W, int prec, int f16) {
 }
 
 // ---------------------------------------------------------------------------------------------
-NetPlan build_monodepth(int encoder, int frames, int H, int W, int prec, int f16) {
+NetPlan build_monodepth(int encoder, int frames, int H, int W, int prec, const char* f16_layers) {
     const int mult = encoder == 0 ? 128 : 64;
     if (H % mult || W % mult) throw std::runtime_error("monodepth needs H, W multiples of 128 (vgg) / 64 (resnet50)");
     Builder b;
-    b.p.prec = prec; b.p.f16 = prec ? f16 : 0;
+    b.p.prec = prec; b.p.f16_spec = (prec && f16_layers) ? f16_layers : "";
     b.p.net = encoder == 0 ? "monodepth-vgg" : "monodepth-resnet50";
     b.p.frames = frames; b.p.images = 2 * frames; b.p.H = H; b.p.W = W;
     const int N = 2 * frames;

@@ -16,6 +16,8 @@ struct TensorDesc {
     int N = 0, H = 0, W = 0, C = 0;   // C = stored channels
     int Ctf = 0;                      // channels the TensorFlow graph sees (input_pre stores 4, TF sees 3)
     int fmt = 0;                      // 0: f32 NHWC; 1: split-bf16 planes (split_fmt.hpp)
+    int f16 = 0;                      // split planes are fp16 (hi + lo, 22 bits) instead of bf16: every conv that reads it runs the
+                                      // 2-product scheme (precision plan, see NetPlan::f16_spec)
     int planar16 = 0;                 // split planes stored as C/16 sub-planes of 16 channels ([C/16][N][H][W][16] per plane): the
                                       // producer is the stem kernel, the only consumer a direct conv, whose 16-channel halo DMA
                                       // then reads whole 128-byte lines
@@ -60,6 +62,7 @@ struct OpDesc {
     // conv engine
     int Ctot = 0;          // padded channels per tap (every source rounded up to a multiple of 4)
     int K = 0, Kpad = 0, vec = 0, m_fastest = 0;
+    int f16 = 0;                 // conv ops: sources are fp16 planes, weights one fp16 plane, TWO MFMA products per product
     int fuse_pool = 0;           // OP_CONV_DIRECT / OP_CONV (LDS-DMA kernel): the 2x2 max pool that follows is applied in the epilogue
     int nchunks = 0;             // OP_CONV_DIRECT: 32-channel chunks over the concatenated sources
     int nsplit = 1;              // OP_CONV_DIRECT: passes of <= 64 output channels per tile
@@ -74,7 +77,12 @@ struct NetPlan {
     int images = 0;        // images per chunk (monodepth: 2 per frame)
     int H = 0, W = 0;
     int prec = 0;          // 0: exact f32 MFMA, 1: split engine (planes of split_fmt.hpp)
-    int f16 = 0;           // split engine only: fp16 planes + fp16 weights, 2 MFMA products (else bf16, 3 products)
+    // precision plan of the split engine: which conv layers run the 2-product fp16 scheme (fp16x2 activations x fp16 weights)
+    // instead of the 3-product bf16 one.  f16_spec = what was asked for (comma-separated op names, a trailing '*' matches a
+    // prefix, "*" = every layer, empty = none); f16_ops = the layers that run it after the consistency closure (a tensor has ONE
+    // plane format, so every conv reading an fp16 tensor is a 2-product layer and every source of a 2-product layer is fp16)
+    std::string f16_spec, f16_ops;
+    double flops_f16 = 0;  // per image, of the 2-product layers
     std::vector<TensorDesc> tensors;
     std::vector<OpDesc> ops;
     std::vector<WeightSlot> weights;
@@ -85,8 +93,8 @@ struct NetPlan {
     int t_input = -1, t_output = -1;
 };
 
-NetPlan build_fcn8s(int frames, int H, int W, int prec, int f16 = 0);
-NetPlan build_monodepth(int encoder /*0 vgg, 1 resnet50*/, int frames, int H, int W, int prec, int f16 = 0);
+NetPlan build_fcn8s(int frames, int H, int W, int prec, const char* f16_layers = nullptr);
+NetPlan build_monodepth(int encoder /*0 vgg, 1 resnet50*/, int frames, int H, int W, int prec, const char* f16_layers = nullptr);
 
 // host-side re-layout of one TensorFlow-layout weight into its slot's kernel layout
 void relayout_weight(const WeightSlot& s, const float* tf_data, std::vector<float>& out);

@@ -73,7 +73,10 @@ def _ptr(t):
 
 
 class Engine:
-    def __init__(self, H: int, W: int, max_batch: int = 1, encoder: str = "resnet50", device: int = 0, precision: str = "f32"):
+    def __init__(self, H: int, W: int, max_batch: int = 1, encoder: str = "resnet50", device: int = 0, precision: str = "f32",
+                 plan: tuple[str, str] | None = None):
+        """precision: 'f32' (exact), 'bf16x2' (3 bf16 MFMA products), 'mixed' (monodepth on 2 fp16 products), 'plan' (per-layer
+        choice; ``plan`` = (fcn8s layers, monodepth layers) that run the 2-product scheme, default = the calibrated built-in)"""
         if not torch.cuda.is_available():
             raise RuntimeError("semantic_depth_amd.Engine needs a GPU (MI355X); there is no CPU fallback")
         self.lib = L.load()
@@ -83,9 +86,14 @@ class Engine:
         h = C.c_void_p()
         enc = {"vgg": L.SD_ENC_VGG, "resnet50": L.SD_ENC_RESNET50}[encoder]
         self.precision = precision
-        prec = {"f32": L.SD_PREC_F32, "bf16x2": L.SD_PREC_BF16X2, "mixed": L.SD_PREC_MIXED}[precision]
-        st = self.lib.sd_create(C.byref(h), device, H, W, max_batch, enc, prec)
-        L.check(self.lib, None, st, f"sd_create(H={H}, W={W}, max_batch={max_batch}, {encoder})")
+        prec = {"f32": L.SD_PREC_F32, "bf16x2": L.SD_PREC_BF16X2, "mixed": L.SD_PREC_MIXED, "plan": L.SD_PREC_PLAN}[precision]
+        if plan is not None:
+            if precision != "plan":
+                raise ValueError("an explicit plan needs precision='plan'")
+            st = self.lib.sd_create_with_plan(C.byref(h), device, H, W, max_batch, enc, plan[0].encode(), plan[1].encode())
+        else:
+            st = self.lib.sd_create(C.byref(h), device, H, W, max_batch, enc, prec)
+        L.check(self.lib, None, st, f"sd_create(H={H}, W={W}, max_batch={max_batch}, {encoder}, {precision}, plan={plan})")
         self.h = h
         fw, mw, ws = C.c_size_t(), C.c_size_t(), C.c_size_t()
         L.check(self.lib, h, self.lib.sd_query_memory(h, C.byref(fw), C.byref(mw), C.byref(ws)), "sd_query_memory")
@@ -198,27 +206,41 @@ class Engine:
         L.check(self.lib, self.h, st, "sd_fuse_backproject")
         return out
 
-    def road_width(self, road_xyz, n_road, params: RoadWidthParams = RoadWidthParams(), want_final: bool = False):
+    def road_width(self, road_xyz, n_road, params: RoadWidthParams = RoadWidthParams(), want_final: bool = False, road_rgb=None):
+        """road chain (semantic_depth.py:203-259).  ``road_rgb`` (u8 [B,cap,3], optional): the colours the reference carries
+        through every filter.  want_final: also return the denoised cloud -> (records, xyz, n) or, with colours,
+        (records, xyz, rgb, n)."""
         B, cap = road_xyz.shape[0], road_xyz.shape[1]
         res = torch.zeros((B, RW_DTYPE.itemsize), dtype=torch.uint8, device=self.device)
         fin = torch.empty_like(road_xyz) if want_final else None
+        frgb = torch.empty_like(road_rgb) if (want_final and road_rgb is not None) else None
         nfin = torch.empty((B,), dtype=torch.int32, device=self.device) if want_final else None
         prm = params.to_c()
-        st = self.lib.sd_road_width(self.h, _ptr(road_xyz), _ptr(n_road), B, cap, C.byref(prm), _ptr(res), _ptr(fin), _ptr(nfin),
-                                    self._stream())
+        st = self.lib.sd_road_width(self.h, _ptr(road_xyz), _ptr(road_rgb), _ptr(n_road), B, cap, C.byref(prm), _ptr(res), _ptr(fin),
+                                    _ptr(frgb), _ptr(nfin), self._stream())
         L.check(self.lib, self.h, st, "sd_road_width")
-        return (res, fin, nfin) if want_final else res
+        if not want_final:
+            return res
+        return (res, fin, nfin) if road_rgb is None else (res, fin, frgb, nfin)
 
-    def fence_to_fence(self, fence_xyz, n_fence, road_records: torch.Tensor, params: FenceParams = FenceParams()):
+    def fence_to_fence(self, fence_xyz, n_fence, road_records: torch.Tensor, params: FenceParams = FenceParams(), fence_rgb=None,
+                       want_clouds: bool = False):
         """fence chain + fence-to-fence distance (semantic_depth.py:273-334) for B frames; ``road_records`` is the device
-        buffer returned by road_width (its plane is the road plane).  Returns a device buffer of sd_f2f_result."""
+        buffer returned by road_width (its plane is the road plane).  Returns a device buffer of sd_f2f_result; with
+        want_clouds also the denoised left / right fence clouds (dict; sizes = counts[5], counts[6] of the records)."""
         B, cap = fence_xyz.shape[0], fence_xyz.shape[1]
         res = torch.zeros((B, F2F_DTYPE.itemsize), dtype=torch.uint8, device=self.device)
         prm = params.to_c()
-        st = self.lib.sd_fence_to_fence(self.h, _ptr(fence_xyz), _ptr(n_fence), B, cap, _ptr(road_records), C.byref(prm), _ptr(res),
+        cl = {k: None for k in ("left_xyz", "left_rgb", "right_xyz", "right_rgb")}
+        if want_clouds:
+            cl["left_xyz"], cl["right_xyz"] = torch.empty_like(fence_xyz), torch.empty_like(fence_xyz)
+            if fence_rgb is not None:
+                cl["left_rgb"], cl["right_rgb"] = torch.empty_like(fence_rgb), torch.empty_like(fence_rgb)
+        st = self.lib.sd_fence_to_fence(self.h, _ptr(fence_xyz), _ptr(fence_rgb), _ptr(n_fence), B, cap, _ptr(road_records), C.byref(prm),
+                                        _ptr(res), _ptr(cl["left_xyz"]), _ptr(cl["left_rgb"]), _ptr(cl["right_xyz"]), _ptr(cl["right_rgb"]),
                                         self._stream())
         L.check(self.lib, self.h, st, "sd_fence_to_fence")
-        return res
+        return (res, cl) if want_clouds else res
 
     @staticmethod
     def f2f_records(res: torch.Tensor) -> np.ndarray:
@@ -230,13 +252,33 @@ class Engine:
         return res.cpu().numpy().view(RW_DTYPE).reshape(-1)
 
     # ------------------------------------------------------------------ whole path
-    def process_batch(self, frames: torch.Tensor, cams, params: RoadWidthParams = RoadWidthParams()):
-        """seg + depth + fusion + road width for B frames (steps 3-12 of SURVEY §3.2).  Returns device tensors."""
+    def process_batch(self, frames: torch.Tensor, cams, params: RoadWidthParams = RoadWidthParams(), approach: str = "rw",
+                      fence_params: FenceParams | None = None, colours: bool = True, want_final: bool = False):
+        """FrameProcessor.process_frame for B frames at once (semantic_depth.py:98-334; seq:117-298): seg + depth + fusion +
+        road chain (+ the fence chain and fence-to-fence distance when ``approach == 'both'``, :273-334).  ``colours``: carry
+        the RGB of every point through the filters like the reference does (they feed only the PLY outputs).
+        Returns device tensors: seg, disp_pp, fuse, records (sd_rw_result), f2f (sd_f2f_result or None) [, final clouds]."""
+        if approach not in ("rw", "both"):
+            raise ValueError("approach must be 'rw' or 'both' (semantic_depth.py:743-745)")
         seg = self.fcn8s_forward(frames)
         disp_pp = self.monodepth_forward(frames)
-        fz = self.fuse_backproject(disp_pp, seg["road"], seg["fence"], frames, cams)
-        rec = self.road_width(fz["road_xyz"], fz["n_road"], params)
-        return dict(seg=seg, disp_pp=disp_pp, fuse=fz, records=rec)
+        fz = self.fuse_backproject(disp_pp, seg["road"], seg["fence"], frames, cams, want_rgb=colours)
+        out = dict(seg=seg, disp_pp=disp_pp, fuse=fz, f2f=None)
+        rw = self.road_width(fz["road_xyz"], fz["n_road"], params, want_final=want_final, road_rgb=fz["road_rgb"] if colours else None)
+        if want_final:
+            out["records"] = rw[0]
+            out["road_final"] = dict(xyz=rw[1], rgb=rw[2] if colours else None, n=rw[-1])
+        else:
+            out["records"] = rw
+        if approach == "both":
+            fp = fence_params or FenceParams(depth=params.depth)
+            f2 = self.fence_to_fence(fz["fence_xyz"], fz["n_fence"], out["records"], fp, fence_rgb=fz["fence_rgb"] if colours else None,
+                                     want_clouds=want_final)
+            if want_final:
+                out["f2f"], out["fence_final"] = f2
+            else:
+                out["f2f"] = f2
+        return out
 
     # ------------------------------------------------------------------ introspection
     def net_tensor(self, net: int, name: str) -> torch.Tensor:
@@ -256,6 +298,16 @@ class Engine:
         n = C.c_int()
         L.check(self.lib, self.h, self.lib.sd_profile_read(self.h, buf, 32, C.byref(n)), "sd_profile_read")
         return [dict(kernel=b.kernel.decode(), launches=int(b.launches), ms=float(b.ms), flops=float(b.flops)) for b in buf[:n.value]]
+
+    def precision_plan(self) -> dict:
+        """{net: (layers that run the 2-product fp16 scheme, their share of the net's FLOPs)} after the consistency closure"""
+        out = {}
+        for name, net in (("fcn8s", L.SD_NET_FCN8S), ("monodepth", L.SD_NET_MONODEPTH)):
+            buf = C.create_string_buffer(8192)
+            share = C.c_double()
+            L.check(self.lib, self.h, self.lib.sd_precision_plan(self.h, net, buf, 8192, C.byref(share)), "sd_precision_plan")
+            out[name] = ([s for s in buf.value.decode().split(",") if s], share.value)
+        return out
 
     def flops_per_image(self, net: int) -> float:
         return float(self.lib.sd_net_flops_per_image(self.h, net))

@@ -3,8 +3,8 @@ shapes and error behaviour, executed by the HIP kernels of libsemdepth (csrc/pcl
 
 Arrays go in and come out as numpy (like the reference); they are staged through device memory per call.
 The batched, device-resident path the pipeline uses is ``Engine.road_width``.  Differences kept on purpose:
-  * remove_noise_by_fitting_plane returns None for the two visualisation arrays (plane3D, colors_plane,
-    pcl.py:104-110,121-124 ...) — they do not feed any number the tool reports.
+  * remove_noise_by_fitting_plane builds the two visualisation arrays (plane3D, colors_plane, pcl.py:104-110,121-124 ...)
+    on the host from the GPU's plane coefficients — they feed only the PLY output.
   * get_end_points_of_road returns the FIRST min-x / max-x row as a (1,3) array (the reference returns all tied
     rows and then only ever reads [0]).
 The O(1) helpers at the bottom are host arithmetic on one or two points, as in the reference.
@@ -29,9 +29,12 @@ def set_engine(engine: Engine):
 
 
 def _eng() -> Engine:
+    """the Engine the filters run on: one set with set_engine(), else whatever the api classes already share, else a
+    512 x 1024 one created (and registered for sharing) on first use — never a private second handle"""
     global _engine
     if _engine is None:
-        _engine = Engine(512, 1024, max_batch=1)
+        from . import api
+        _engine = api.any_engine() or api.shared_engine(512, 1024)
     return _engine
 
 
@@ -102,12 +105,32 @@ def mad(points1D):
     return abs(v - med), m
 
 
-def remove_noise_by_fitting_plane(points3D, colors, axis=0, threshold=1.0, plane_color=[255, 255, 255]):
-    """pcl.py:84-209.  Returns (points3D', colors', None, None, coefficients)."""
+def plane_grid(points3D, coefficients, axis, plane_color=[255, 255, 255], grid_size=0.05):
+    """the visualisation arrays of pcl.py:104-124 / :141-160 / :176-195: a ``grid_size`` lattice over the bounding box of the
+    INPUT cloud in the two in-plane coordinates, lifted onto the fitted plane.  Host numpy (it feeds only the PLY output)."""
+    points3D = np.asarray(points3D)
+    ia, ib = [(1, 2), (0, 2), (0, 1)][axis]
+    ca, cb = [("Cy", "Cz"), ("Cx", "Cz"), ("Cx", "Cy")][axis]
+    A, Bv = np.meshgrid(np.arange(np.amin(points3D[:, ia]), np.amax(points3D[:, ia]), grid_size),
+                        np.arange(np.amin(points3D[:, ib]), np.amax(points3D[:, ib]), grid_size))
+    Cn = coefficients[ca] * A + coefficients[cb] * Bv + coefficients["C"]
+    cols = [None, None, None]
+    cols[axis], cols[ia], cols[ib] = Cn.flatten(), A.flatten(), Bv.flatten()
+    plane3D = np.c_[cols[0], cols[1], cols[2]]
+    return plane3D, np.ones(plane3D.shape) * plane_color
+
+
+def remove_noise_by_fitting_plane(points3D, colors, axis=0, threshold=1.0, plane_color=[255, 255, 255], with_plane3D=True):
+    """pcl.py:84-209.  Returns (points3D', colors', plane3D, colors_plane, coefficients); the two visualisation arrays are
+    built on the host (``with_plane3D=False`` returns None for them)."""
     coeff = torch.empty(4, dtype=torch.float64, device=_eng().device)
     pts, col = _filter("sd_pcl_remove_noise_by_fitting_plane", points3D, colors, int(axis), float(threshold), extra=coeff)
     c = coeff.cpu().numpy()
-    return pts, col, None, None, {"Cx": c[0], "Cy": c[1], "Cz": c[2], "C": c[3]}
+    coefficients = {"Cx": c[0], "Cy": c[1], "Cz": c[2], "C": c[3]}
+    plane3D = colors_plane = None
+    if with_plane3D and len(np.asarray(points3D)):
+        plane3D, colors_plane = plane_grid(points3D, coefficients, int(axis), plane_color)
+    return pts, col, plane3D, colors_plane, coefficients
 
 
 def threshold_complete(points3D, colors, axis, threshold=15.0):

@@ -336,6 +336,27 @@ def convert(tensors: dict, name_map: dict, shapes: dict) -> "OrderedDict[str, np
     return out
 
 
+def load_any(path: str, net: str, encoder: str | None = None) -> "OrderedDict[str, np.ndarray]":
+    """what SegmentFrame.restore_model / DepthFrame.restore_model accept (semantic_depth.py:498-541, :627-653): a frozen
+    GraphDef (``*.pb``), or a checkpoint prefix (a directory is searched for its ``*.index``).  ``net``: 'fcn8s' | 'monodepth'."""
+    if net == "fcn8s":
+        names, shapes = fcn8s_name_map(), W.fcn8s_weight_shapes()
+    else:
+        names, shapes = monodepth_name_map(encoder or "vgg"), W.monodepth_weight_shapes(encoder or "vgg")
+    if path.endswith(".pb"):
+        return convert(read_frozen_graph(path), names, shapes)
+    if os.path.isdir(path):
+        pbs = sorted(glob.glob(os.path.join(path, "*.pb")))
+        idx = sorted(glob.glob(os.path.join(path, "*.index")) + glob.glob(os.path.join(path, "variables", "*.index")))
+        if idx:
+            return convert(read_tensor_bundle(idx[-1][:-6]), names, shapes)
+        if pbs:
+            return convert(read_frozen_graph(pbs[-1]), names, shapes)
+        raise FileNotFoundError(f"no *.index / *.pb under {path}")
+    prefix = path if os.path.exists(path + ".index") else glob.glob(path + "*.index")[0][:-6]
+    return convert(read_tensor_bundle(prefix), names, shapes)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--monodepth", help="checkpoint prefix (model_cityscapes / model_kitti)")

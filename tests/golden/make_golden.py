@@ -15,8 +15,16 @@ TensorFlow/OpenCV/Open3D), feeds it inputs produced by the oracle's synthetic gr
                       order-sensitive checksums of the reference's outputs (arrays are regenerated from
                       the seed by the oracle's scene generator at test time).
 
+  ref_pieces.npz /    outputs of pieces of semantic_depth.py that are pure numpy / pure formatting, EXECUTED from the
+  ref_text_outputs.json reference's own AST (the module itself cannot be imported: tensorflow / cv2 / open3d are absent):
+                      DepthFrame.post_processing (:656-664) on seeded disparity pairs; the ``_times.txt`` /
+                      ``_distances.txt`` writer statements of process_frame (:445-458) and the MAE / ``data.txt`` /
+                      ``best_focal_lengths.txt`` statements of main() (:907-944) on synthetic numbers; the plane
+                      visualisation grid of pcl.remove_noise_by_fitting_plane (digest).
+
 Fixtures are data (inputs and expected outputs); no reference source is copied.
 """
+import ast
 import json
 import os
 import sys
@@ -66,7 +74,86 @@ def scene_inputs(h, w, seed, f, fences=False):
     return dp, road, fence, frame, cam, fz
 
 
+def _ref_ast():
+    return ast.parse(open("/root/reference/semantic_depth.py").read())
+
+
+def _find(tree, cls, fn):
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == cls:
+            for f in node.body:
+                if isinstance(f, ast.FunctionDef) and f.name == fn:
+                    return f
+        if cls is None and isinstance(node, ast.FunctionDef) and node.name == fn:
+            return node
+    raise KeyError((cls, fn))
+
+
+def _exec(nodes, ns):
+    mod = ast.Module(body=list(nodes), type_ignores=[])
+    ast.fix_missing_locations(mod)
+    exec(compile(mod, "<reference AST>", "exec"), ns)
+    return ns
+
+
+def reference_pieces():
+    """run the reference's own pure-numpy / pure-formatting statements, lifted from its AST"""
+    import tempfile
+    tree = _ref_ast()
+    z, txt = {}, {}
+    # --- DepthFrame.post_processing, semantic_depth.py:656-664
+    fn = _find(tree, "DepthFrame", "post_processing")
+    ns = _exec([fn], {"np": np})
+    rng = np.random.default_rng(11)
+    for tag, (h, w) in (("a", (8, 40)), ("b", (16, 128)), ("c", (5, 21))):
+        d = (0.3 * rng.random((2, h, w))).astype(np.float32)
+        z[f"pp_in_{tag}"] = d
+        z[f"pp_out_{tag}"] = ns["post_processing"](None, d)                 # f64, the caller casts (:676)
+    # --- the with-open blocks that write <name>_times.txt / <name>_distances.txt, :445-458
+    pf = _find(tree, "FrameProcessor", "process_frame")
+    withs = [n for n in ast.walk(pf) if isinstance(n, ast.With)]
+    times = dict(time_read_resize=0.348812, time_semantic=0.15283203125, time_disparity=0.023, time_to3D=0.0106,
+                 time_road=0.0845, time_rw=0.0012, time_fences=0.0146, time_f2f=0.0015, time_global=0.6375)
+    cases = {"plain": dict(dist_rw=4.412345678901234, dist_f2f=4.57), "np": dict(dist_rw=np.float64(6.9976945), dist_f2f=np.float64(7.25)),
+             "f32": dict(dist_rw=np.float32(5.25), dist_f2f=None)}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, dist in cases.items():
+            class S:      # stands in for ``self``
+                output_name = os.path.join(td, tag)
+            _exec(withs, dict(self=S, **times, **dist))
+            txt[f"times_{tag}"] = open(S.output_name + "_times.txt").read()
+            txt[f"distances_{tag}"] = open(S.output_name + "_distances.txt").read()
+            txt[f"distances_{tag}_in"] = [None if v is None else float(v) for v in (dist["dist_rw"], dist["dist_f2f"])]
+            txt[f"distances_{tag}_types"] = [type(v).__name__ for v in (dist["dist_rw"], dist["dist_f2f"])]
+        txt["times_in"] = times
+        # --- MAE + data.txt + best_focal_lengths.txt, main() :854-944: the body of ``for f in focal_lengths`` after the inner
+        #     frame loop, and the with-open that follows the loop
+        mn = _find(tree, None, "main")
+        floop = [n for n in ast.walk(mn) if isinstance(n, ast.For) and isinstance(n.target, ast.Name) and n.target.id == "f"][0]
+        tail = [st for st in floop.body if st.lineno >= 907]
+        after = [n for n in ast.walk(mn) if isinstance(n, ast.With) and n.lineno > floop.end_lineno and n.lineno < 950]
+        input_frames = {"test_1.png": 5.3, "test_2.png": 4.4, "test_3.png": 5.4, "test_4.png": 3.1, "test_5.png": 4.6}
+        rows = {380: [(5.3, 4.91, 6.02), (4.4, 3.12, 5.5), (5.4, 4.41, 4.57), (3.1, 3.3, 2.2), (4.6, 6.0, 5.1)],
+                580: [(5.3, 5.6, 5.1), (4.4, 4.0, 4.1), (5.4, 5.55, 5.2), (3.1, 2.4, 3.0), (4.6, 4.9, 4.8)]}
+        ns = dict(np=np, os=os, input_frames=input_frames, best_mae_rw=-1, best_f_rw=None, best_mae_f2f=-1, best_f_f2f=None,
+                  best_mae_overall=-1, best_f_overall=None, print=lambda *a, **k: None)
+        for f, rws in rows.items():
+            ns["f"] = f
+            ns["f_directory"] = os.path.join(td, str(f))
+            os.makedirs(ns["f_directory"])
+            ns["all_data"] = [[real, rw, ff, abs(real - rw), abs(real - ff)] for real, rw, ff in rws]
+            _exec(tail, ns)
+            txt[f"data_{f}"] = open(os.path.join(td, str(f), "data.txt")).read()
+        ns["results_directory"] = td
+        _exec(after[:1], ns)
+        txt["best_focal_lengths"] = open(os.path.join(td, "best_focal_lengths.txt")).read()
+        txt["sweep_rows"] = {str(k): v for k, v in rows.items()}
+        txt["sweep_gt"] = input_frames
+    return z, txt
+
+
 def main():
+    z_ref, txt_ref = reference_pieces()
     # ---------------- miniature: full arrays ----------------
     dp, road, fence, frame, cam, fz = scene_inputs(64, 128, seed=7, f=125.0, fences=True)
     pts, col = fz["road3d"], fz["road_rgb"]
@@ -86,9 +173,16 @@ def main():
         z[f"mad_a{axis}_pts"], z[f"mad_a{axis}_col"] = p, c
     # plane fit on all three axes with a tight threshold (fence planes use axis 0, seq:262-275)
     for axis, thr in ((0, 0.5), (1, 0.02), (2, 3.0)):
-        p, c, _, _, coeff = ref.remove_noise_by_fitting_plane(pts, col, axis=axis, threshold=thr)
+        p, c, p3d, cp3d, coeff = ref.remove_noise_by_fitting_plane(pts, col, axis=axis, threshold=thr, plane_color=[200, 190, 180])
         z[f"plane_a{axis}_pts"], z[f"plane_a{axis}_col"] = p, c
         z[f"plane_a{axis}_coeff"] = np.array([coeff[k] for k in ("Cx", "Cy", "Cz", "C")], np.float64)
+        # the visualisation grid (pcl.py:104-124 ...): shape, dtype and an order-sensitive digest
+        z_ref[f"grid_a{axis}_shape"] = np.array(p3d.shape)
+        z_ref[f"grid_a{axis}_first"] = p3d[:3].copy()
+        z_ref[f"grid_a{axis}_last"] = p3d[-3:].copy()
+        z_ref[f"grid_a{axis}_sum"] = p3d.sum(axis=0)
+        z_ref[f"grid_a{axis}_colors_first"] = cp3d[:2].copy()
+        txt_ref[f"grid_a{axis}_dtype"] = [str(p3d.dtype), str(cp3d.dtype)]
     # empty depth window -> (None, None)
     l, r = ref.get_end_points_of_road(ch["plane"][0].astype(np.float64), 500.0)
     z["empty_window_is_none"] = np.array([l is None, r is None])
@@ -124,6 +218,9 @@ def main():
                         mean_x=np.float32(np.mean(p2[:, 0]))))
     fence_chain(fp, fc, "fc", lambda tag, d: z.update({f"{tag}_{k}": v for k, v in d.items()}))
     np.savez_compressed(os.path.join(HERE, "pcl_mini.npz"), **z)
+    np.savez_compressed(os.path.join(HERE, "ref_pieces.npz"), **z_ref)
+    with open(os.path.join(HERE, "ref_text_outputs.json"), "w") as fh:
+        json.dump(txt_ref, fh, indent=1, sort_keys=True)
 
     # ---------------- PLY writer: bytes written by the reference's own class ----------------
     from semantic_depth_lib.point_cloud_2_ply import PointCloud2Ply as RefPly

@@ -34,3 +34,15 @@ def relerr(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def err_report(a, b):
+    """max-normalised error (the north-star figure, = relerr) plus per-element statistics, |delta| / (|ref| + 1e-3 max|ref|):
+    a max-normalised bound alone is lenient for tensors with a wide range (logits)."""
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    d = np.abs(a - b)
+    scale = float(np.abs(b).max()) + 1e-30
+    per = d / (np.abs(b) + 1e-3 * scale)
+    return {"max_rel": float(d.max() / scale), "p99_elem_rel": float(np.quantile(per, 0.99)), "max_elem_rel": float(per.max()),
+            "rms_rel": float(np.sqrt((d * d).mean()) / scale)}

@@ -83,3 +83,42 @@ def test_bad_arguments_are_rejected(lib):
     assert lib.sd_fcn8s_forward(h, C.c_void_p(16), 1, None, None, None, None, None) == -3
     assert b"bind" in lib.sd_last_error(h)
     lib.sd_destroy(h)
+
+
+def _plan(lib, fcn, mono, enc=L.SD_ENC_RESNET50):
+    h = C.c_void_p()
+    st = lib.sd_create_with_plan(C.byref(h), 0, 256, 512, 2, enc, fcn.encode(), mono.encode())
+    if st != 0:
+        return st, None
+    out = {}
+    for net in (L.SD_NET_FCN8S, L.SD_NET_MONODEPTH):
+        buf = C.create_string_buffer(8192)
+        share = C.c_double()
+        assert lib.sd_precision_plan(h, net, buf, 8192, C.byref(share)) == 0
+        out[net] = ([s for s in buf.value.decode().split(",") if s], share.value)
+    lib.sd_destroy(h)
+    return 0, out
+
+
+def test_precision_plan_closure(lib):
+    """per-layer precision plan (sd_create_with_plan): the requested layers run the 2-product fp16 scheme, closed under
+    'one plane format per tensor' (every conv that reads an fp16 tensor is a 2-product layer)"""
+    st, p = _plan(lib, "", "")
+    assert st == 0 and p[L.SD_NET_FCN8S] == ([], 0.0) and p[L.SD_NET_MONODEPTH] == ([], 0.0)
+    st, p = _plan(lib, "fc6,fc7", "*")
+    assert st == 0 and p[L.SD_NET_FCN8S][0] == ["fc6", "fc7"]              # a chain: nothing else is dragged in
+    assert 0.25 < p[L.SD_NET_FCN8S][1] < 0.32                               # fc6 + fc7 = 28 % of FCN-8s
+    assert p[L.SD_NET_MONODEPTH][1] > 0.999                                 # (the last head, disp1, is not an MFMA conv)
+    assert "enc/conv1" in p[L.SD_NET_MONODEPTH][0] and "dec/iconv1" in p[L.SD_NET_MONODEPTH][0]
+    st, p = _plan(lib, "conv4*", "enc/res5*")
+    assert st == 0 and p[L.SD_NET_FCN8S][0] == ["conv4_1", "conv4_2", "conv4_3"]
+    mono = p[L.SD_NET_MONODEPTH][0]
+    # res5_1 reads the res4 output, which is also the level-6 skip: iconv6 is dragged in, and with it nothing upstream of res4_6
+    assert {"enc/res5_1/conv1", "enc/res5_3/conv3", "dec/iconv6"} <= set(mono) and "enc/res4_1/conv1" not in mono and "enc/conv1" not in mono
+    st, _ = _plan(lib, "no_such_layer", "")
+    assert st == L.SD_OK - 1                                                # SD_ERR_INVALID
+    assert lib.sd_default_plan(L.SD_NET_FCN8S).decode() != "" or lib.sd_default_plan(L.SD_NET_MONODEPTH).decode() != ""
+    # the built-in plan is a valid plan
+    h = C.c_void_p()
+    assert lib.sd_create(C.byref(h), 0, 256, 512, 2, L.SD_ENC_RESNET50, L.SD_PREC_PLAN) == 0
+    lib.sd_destroy(h)

@@ -66,3 +66,70 @@ def test_gather_records_world2_gloo(n_frames):
 def test_single_process_is_identity():
     x = torch.zeros((3, RECORD_BYTES), dtype=torch.uint8)
     assert gather_records(x) is x
+
+
+# ------------------------------------------------------------------------------------------------ run_sequence (the whole driver)
+def _stub_step(frames, lo):
+    """stands in for Engine.process_batch on CPU: a record per frame, derived from the frame's own pixels and its global index"""
+    from semantic_depth_amd.engine import RW_DTYPE
+    n = frames.shape[0]
+    rec = np.zeros(n, RW_DTYPE)
+    rec["width"] = frames.reshape(n, -1).astype(np.float64).mean(axis=1)
+    rec["n_road"] = lo + np.arange(n)
+    rec["found"] = 1
+    return torch.from_numpy(rec.view(np.uint8).reshape(n, RECORD_BYTES).copy())
+
+
+def _sequence(n_frames):
+    return np.random.default_rng(5).integers(0, 256, (n_frames, 6, 8, 3), dtype=np.uint8)
+
+
+def _seq_worker(rank, world, port, n_frames, batch, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from semantic_depth_amd.distributed import run_sequence
+        from semantic_depth_amd.engine import RW_DTYPE
+        frames = _sequence(n_frames)
+        loaded = []
+
+        def load(lo, hi):
+            loaded.append((lo, hi))
+            return frames[lo:hi]
+
+        allr = run_sequence(load, n_frames, _stub_step, batch=batch)
+        got = allr.numpy().view(RW_DTYPE).reshape(-1)
+        lo, hi = shard_range(n_frames, rank, world)
+        ok = (len(got) == n_frames and np.array_equal(got["n_road"], np.arange(n_frames))
+              and np.array_equal(got["width"], frames.reshape(n_frames, -1).astype(np.float64).mean(axis=1))
+              and all(lo <= a < b <= hi and b - a <= batch for a, b in loaded)          # only its own shard, in chunks of <= batch
+              and sum(b - a for a, b in loaded) == hi - lo)
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames,batch", [(10, 4), (7, 32), (1, 2)])      # chunked, ragged, and a rank with no frame at all
+def test_run_sequence_world2_gloo(n_frames, batch):
+    """shard -> per-rank chunks -> step -> ONE all_gather: every rank ends with every frame's record in global order
+    (replaces the serial loop of semantic_depth_cityscapes_sequence.py:689-701)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_seq_worker, args=(r, 2, port, n_frames, batch, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_run_sequence_single_process_equals_the_serial_loop():
+    from semantic_depth_amd.distributed import run_sequence
+    from semantic_depth_amd.engine import RW_DTYPE
+    frames = _sequence(9)
+    got = run_sequence(lambda lo, hi: frames[lo:hi], 9, _stub_step, batch=4).numpy().view(RW_DTYPE).reshape(-1)
+    serial = np.concatenate([_stub_step(frames[i:i + 1], i).numpy().view(RW_DTYPE).reshape(-1) for i in range(9)])
+    assert np.array_equal(got, serial)
