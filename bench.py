@@ -68,7 +68,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step (configs[3]: 32)")
     ap.add_argument("--encoder", default="resnet50")
-    ap.add_argument("--precision", default=os.environ.get("SD_BENCH_PRECISION", "bf16x2"), choices=["f32", "bf16x2", "mixed", "plan"],
+    ap.add_argument("--precision", default=os.environ.get("SD_BENCH_PRECISION", "plan"), choices=["f32", "bf16x2", "mixed", "plan"],
                     help="conv arithmetic of the measured engine")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the exact-f32 engine leg (f32_exact + parity vs f32)")
@@ -117,8 +117,15 @@ def main():
     if torch.cuda.device_count() < world:
         sys.exit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) visible")
     import __graft_entry__ as graft
-    if world == 1:
-        graft.build()                 # N > 1: the launcher (spawn_ranks / the driver) has built it; ranks only load it
+    from semantic_depth_amd import build as sd_build
+    if world == 1 or rank == 0:
+        graft.build()                 # returns at once when the library matches the tree (hash stamp); links aside + renames
+    else:                             # N > 1: local rank 0 (or the launcher) builds; the others wait for a library of THIS tree
+        t_wait = time.time()
+        while not (os.path.exists(sd_build.LIB + ".hash") and open(sd_build.LIB + ".hash").read().strip() == sd_build.source_hash()):
+            if time.time() - t_wait > 900:
+                sys.exit("bench.py: libsemdepth.so was not built within 15 min")
+            time.sleep(1.0)
     from semantic_depth_amd import _lib as L
     from semantic_depth_amd import weights as Wt
     from semantic_depth_amd.distributed import gather_records, make_engine_step, run_sequence

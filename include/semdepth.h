@@ -130,6 +130,12 @@ sd_status sd_monodepth_forward(sd_handle* h, const uint8_t* frames, int B, float
 sd_status sd_resize_cubic_u8(sd_handle* h, const uint8_t* src, int B, int src_h, int src_w, int channels, uint8_t* dst, int dst_h,
                              int dst_w, void* stream);
 
+/* HOST helper of the frame reader that replaces cv2.imread (semantic_depth.py:105; seq:123): reconstructs the scanlines of an
+ * inflated 8-bit non-interlaced PNG (filter byte + width*channels bytes per row; channels 1 gray, 2 gray+alpha, 3 RGB, 4 RGBA)
+ * and writes OpenCV's IMREAD_COLOR layout, u8 [height,width,3] BGR (alpha dropped, gray replicated).  Both pointers are HOST
+ * memory; no handle, no GPU (semantic_depth_amd/frame_io.py inflates with zlib and calls this from a thread pool). */
+sd_status sd_png_unfilter_bgr(const uint8_t* filtered_host, int height, int width, int channels, uint8_t* bgr_out_host);
+
 /* DepthFrame.post_processing alone, semantic_depth.py:656-664: disp_raw f32 [B,2,H,W] -> disp_pp f32 [B,H,W] */
 sd_status sd_post_process(sd_handle* h, const float* disp_raw, int B, float* disp_pp, void* stream);
 

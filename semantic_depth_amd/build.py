@@ -28,6 +28,7 @@ SOURCES = [
     ("pcl.hip", ["-ffp-contract=off"]),
     ("plan.cpp", []),
     ("capi.cpp", []),
+    ("host_png.cpp", []),
 ]
 HEADERS = ["kernels.hpp", "plan.hpp", "split_fmt.hpp", os.path.join("..", "..", "include", "semdepth.h")]
 

@@ -116,9 +116,39 @@ def _snappy(b: bytes) -> bytes:
     return bytes(out)
 
 
+# --------------------------------------------------------------------------------------------- CRC-32C (Castagnoli), LevelDB masking
+_CRC_TABLE = None
+
+
+def crc32c(data: bytes, crc: int = 0) -> int:
+    """CRC-32C as LevelDB / TensorFlow compute it (reflected polynomial 0x82F63B78; RFC 3720 B.4 has the test vectors)"""
+    global _CRC_TABLE
+    if _CRC_TABLE is None:
+        tab = []
+        for i in range(256):
+            c = i
+            for _ in range(8):
+                c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+            tab.append(c)
+        _CRC_TABLE = tab
+    c = crc ^ 0xFFFFFFFF
+    tab = _CRC_TABLE
+    for b in data:
+        c = tab[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def crc_mask(crc: int) -> int:
+    """leveldb::crc32c::Mask — the form stored in block trailers and in BundleEntryProto.crc32c"""
+    return (((crc >> 15) | (crc << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
 # --------------------------------------------------------------------------------------------- LevelDB table
 def _read_block(buf: bytes, off: int, size: int) -> bytes:
     data, ctype = buf[off:off + size], buf[off + size]
+    stored = struct.unpack_from("<I", buf, off + size + 1)[0]
+    if stored != 0 and stored != crc_mask(crc32c(buf[off:off + size + 1])):      # trailer: type byte + masked crc32c(block | type)
+        raise ValueError(f"table block at {off}: crc mismatch (file damaged)")      # (0 = written without a checksum)
     if ctype == 1:
         data = _snappy(data)
     elif ctype != 0:
@@ -215,13 +245,13 @@ def write_tensor_bundle(prefix: str, tensors: dict, block_entries: int = 7) -> N
         chunk = items[i:i + block_entries]
         b = block(chunk)
         index.append((chunk[-1][0], _put_varint(len(f)) + _put_varint(len(b))))
-        f += b + b"\x00" + b"\x00\x00\x00\x00"                     # type 0 + (unchecked) crc
+        f += b + b"\x00" + struct.pack("<I", crc_mask(crc32c(b + b"\x00")))      # trailer: type 0 + masked crc32c
     meta = block([])
     meta_h = _put_varint(len(f)) + _put_varint(len(meta))
-    f += meta + b"\x00" + b"\x00\x00\x00\x00"
+    f += meta + b"\x00" + struct.pack("<I", crc_mask(crc32c(meta + b"\x00")))
     ib = block(index, restart_every=1)
     idx_h = _put_varint(len(f)) + _put_varint(len(ib))
-    f += ib + b"\x00" + b"\x00\x00\x00\x00"
+    f += ib + b"\x00" + struct.pack("<I", crc_mask(crc32c(ib + b"\x00")))
     footer = meta_h + idx_h
     f += footer + b"\x00" * (40 - len(footer)) + struct.pack("<Q", _MAGIC)
     open(prefix + ".index", "wb").write(bytes(f))

@@ -1,0 +1,28 @@
+"""CPU: bench.py's own multi-GPU launcher.  `python bench.py --gpus N` with no WORLD_SIZE starts N fresh rank processes (before
+anything touches a GPU); under a launcher the world size must equal --gpus.  No GPU here, so the ranks stop at their first
+check — which is exactly what this pins: N ranks were started with the right environment, and a mismatch is refused."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_gpus_n_spawns_n_ranks():
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+    assert r.returncode != 0                                   # no GPU in this container: both ranks refuse to run
+    assert r.stderr.count("--gpus 2 but only 0 GPU(s) visible") == 2, r.stderr[-2000:]
+    assert r.stdout.strip() == ""                              # and nobody printed a result line
+
+
+def test_world_size_must_equal_gpus():
+    r = _run(["--gpus", "4"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "world size 2 (WORLD_SIZE) != --gpus 4" in r.stderr
+    r = _run(["--gpus", "1"], {"WORLD_SIZE": "8", "RANK": "3", "LOCAL_RANK": "3"})
+    assert r.returncode != 0 and "world size 8 (WORLD_SIZE) != --gpus 1" in r.stderr

@@ -1,0 +1,107 @@
+"""CPU: the frame reader that replaces cv2.imread (semantic_depth.py:105): PNG decode through zlib +
+libsemdepth's host-side scanline reconstruction, against PIL's decoder and against files written with every PNG filter type."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as graft
+from semantic_depth_amd import frame_io, outputs
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    graft.build()
+
+
+def _chunk(tag, data):
+    return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+
+def _filter_rows(img, ftype):
+    """PNG encoder side of filter types 0..4 (spec §9.2), written independently of the decoder under test"""
+    h, w, ch = img.shape
+    rows = img.reshape(h, w * ch).astype(np.int32)
+    out = bytearray()
+    prev = np.zeros(w * ch, np.int32)
+    for y in range(h):
+        cur = rows[y]
+        left = np.concatenate([np.zeros(ch, np.int32), cur[:-ch]])
+        upleft = np.concatenate([np.zeros(ch, np.int32), prev[:-ch]])
+        ft = ftype if ftype < 5 else y % 5
+        if ft == 0:
+            f = cur
+        elif ft == 1:
+            f = cur - left
+        elif ft == 2:
+            f = cur - prev
+        elif ft == 3:
+            f = cur - ((left + prev) >> 1)
+        else:
+            p = left + prev - upleft
+            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+            f = cur - pred
+        out += bytes([ft]) + (f & 0xFF).astype(np.uint8).tobytes()
+        prev = cur
+    return bytes(out)
+
+
+def _png(img, ctype, ftype, split_idat=False):
+    h, w, ch = img.shape
+    z = zlib.compress(_filter_rows(img, ftype), 6)
+    idat = _chunk(b"IDAT", z) if not split_idat else _chunk(b"IDAT", z[:len(z) // 2]) + _chunk(b"IDAT", z[len(z) // 2:])
+    return b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)) + _chunk(b"tEXt", b"k\0v") + idat + _chunk(b"IEND", b"")
+
+
+@pytest.mark.parametrize("ftype", [0, 1, 2, 3, 4, 5])          # 5 = a different filter on every row
+def test_every_filter_type_rgb_and_rgba(ftype):
+    rng = np.random.default_rng(ftype)
+    rgb = rng.integers(0, 256, (19, 23, 3), dtype=np.uint8)
+    assert np.array_equal(frame_io.decode_png(_png(rgb, 2, ftype, split_idat=ftype == 5)), rgb[..., ::-1])
+    rgba = rng.integers(0, 256, (7, 11, 4), dtype=np.uint8)
+    assert np.array_equal(frame_io.decode_png(_png(rgba, 6, ftype)), rgba[..., 2::-1])
+    gray = rng.integers(0, 256, (9, 5, 1), dtype=np.uint8)
+    assert np.array_equal(frame_io.decode_png(_png(gray, 0, ftype)), np.repeat(gray, 3, axis=2))
+
+
+def test_against_pil_and_round_trip_with_the_writer(tmp_path):
+    rng = np.random.default_rng(3)
+    # a smooth image (what real encoders pick Paeth / Sub / Up for) + noise
+    yy, xx = np.mgrid[0:120, 0:200]
+    img = np.stack([(yy * 2 + xx) % 256, (xx * 3) % 256, (yy + 2 * xx) % 256], -1).astype(np.uint8) ^ rng.integers(0, 8, (120, 200, 3), dtype=np.uint8)
+    p = str(tmp_path / "frame.png")
+    outputs.write_png(p, img)                                  # BGR in, like cv2.imwrite
+    assert np.array_equal(frame_io.imread(p), img)             # BGR out, like cv2.imread
+    PIL = pytest.importorskip("PIL.Image")
+    q = str(tmp_path / "pil.png")
+    PIL.fromarray(img[..., ::-1]).save(q, optimize=True)       # PIL chooses its own (adaptive) filters
+    assert np.array_equal(frame_io.imread(q), img)
+    assert np.array_equal(np.asarray(PIL.open(p).convert("RGB")), img[..., ::-1])
+    pal = PIL.fromarray(img[..., ::-1]).quantize(200)          # > 16 colours: an 8-bit palette image
+    pal.save(str(tmp_path / "pal.png"))
+    assert np.array_equal(frame_io.imread(str(tmp_path / "pal.png")), np.asarray(pal.convert("RGB"))[..., ::-1])
+
+
+def test_rejects_what_it_does_not_decode(tmp_path):
+    with pytest.raises(ValueError):
+        frame_io.decode_png(b"\xff\xd8\xff\xe0 not a png")
+    bad = bytearray(_png(np.zeros((4, 4, 3), np.uint8), 2, 0))
+    bad[8 + 8 + 8] = 16                                        # bit depth 16
+    with pytest.raises(ValueError, match="unsupported"):
+        frame_io.decode_png(bytes(bad))
+
+
+def test_frame_feeder_batches_in_order(tmp_path):
+    rng = np.random.default_rng(1)
+    frames = rng.integers(0, 256, (7, 16, 24, 3), dtype=np.uint8)
+    paths = []
+    for i, f in enumerate(frames):
+        paths.append(outputs.write_png(str(tmp_path / f"stuttgart_{i:06d}.png"), f))
+    got, los = [], []
+    for dev, lo in frame_io.FrameFeeder(sorted(paths), batch=3, device="cpu", workers=4):
+        got.append(dev.numpy().copy()); los.append(lo)
+    assert los == [0, 3, 6] and [g.shape[0] for g in got] == [3, 3, 1]
+    assert np.array_equal(np.concatenate(got), frames)

@@ -81,3 +81,98 @@ def test_fcn8s_frozen_to_slots(tmp_path):
         bad = dict(small); bad["vgg/conv1_1/filter"] = np.zeros((3, 3, 3, 63), np.float32)
         T.write_frozen_graph(p, {nm[s]: a for s, a in bad.items()})
         T.convert(T.read_frozen_graph(p), nm, shapes)
+
+
+# ------------------------------------------------------------------------------------------------ public vectors / an independent writer
+def test_crc32c_public_vectors():
+    """RFC 3720 appendix B.4 (iSCSI CRC-32C examples) and the classic check value"""
+    assert T.crc32c(b"123456789") == 0xE3069283
+    assert T.crc32c(bytes(32)) == 0x8A9136AA
+    assert T.crc32c(b"\xff" * 32) == 0x62A8AB43
+    assert T.crc32c(bytes(range(32))) == 0x46DD794E
+    assert T.crc32c(bytes(range(31, -1, -1))) == 0x113FDB5C
+    # leveldb::crc32c::Mask: rotate right by 15, add 0xa282ead8
+    c = T.crc32c(b"foo")
+    assert T.crc_mask(c) == ((((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF) and T.crc_mask(c) != c
+    assert T.crc32c(b"6789", T.crc32c(b"12345")) == 0xE3069283          # incremental form
+
+
+def _crc32c_bitwise(data):
+    c = 0xFFFFFFFF
+    for b in data:
+        c ^= b
+        for _ in range(8):
+            c = (c >> 1) ^ (0x82F63B78 & -(c & 1))
+    return c ^ 0xFFFFFFFF
+
+
+def test_reader_against_a_table_assembled_from_the_format_description(tmp_path):
+    """An index file put together here, byte by byte, from LevelDB's table_format.md / TensorFlow's tensor_bundle.proto — NOT
+    with the module's writer: prefix-compressed keys with restart interval 2, one block snappy-compressed (type 1, literal
+    elements only), real masked CRC-32C trailers from an independent bitwise CRC, a two-level index."""
+    import struct
+    vi = T._put_varint
+
+    def msg(*fields):           # (number, wire type, value)
+        out = b""
+        for n, wt, v in fields:
+            out += vi((n << 3) | wt)
+            out += vi(v) if wt == 0 else vi(len(v)) + v
+        return out
+
+    a = np.arange(24, dtype=np.float32).reshape(2, 3, 4) * 0.5
+    b = np.array([7, -9], np.int32)
+    data = a.tobytes() + b.tobytes()
+    shape = lambda s: b"".join(msg((2, 2, msg((1, 0, d)))) for d in s)
+    entries = [(b"", msg((1, 0, 1), (2, 0, 0))),                                                   # BundleHeaderProto
+               (b"model/a/weights", msg((1, 0, 1), (2, 2, shape(a.shape)), (3, 0, 0), (4, 0, 0), (5, 0, a.nbytes))),
+               (b"model/b/weights", msg((1, 0, 3), (2, 2, shape(b.shape)), (3, 0, 0), (4, 0, a.nbytes), (5, 0, b.nbytes)))]
+
+    def block(items, interval):
+        out, restarts, prev = b"", [], b""
+        for i, (k, v) in enumerate(items):
+            sh = 0
+            if i % interval == 0:
+                restarts.append(len(out))
+            else:
+                while sh < min(len(k), len(prev)) and k[sh] == prev[sh]:
+                    sh += 1
+            out += vi(sh) + vi(len(k) - sh) + vi(len(v)) + k[sh:] + v
+            prev = k
+        return out + b"".join(struct.pack("<I", r) for r in restarts) + struct.pack("<I", len(restarts))
+
+    def snappy_literals(raw):   # varint length, then literal elements of <= 60 bytes (tag = (len-1) << 2)
+        out = vi(len(raw))
+        for i in range(0, len(raw), 60):
+            piece = raw[i:i + 60]
+            out += bytes([(len(piece) - 1) << 2]) + piece
+        return out
+
+    f = b""
+    handles = []
+    for items, compress in ((entries[:2], False), (entries[2:], True)):
+        raw = block(items, 2)
+        body, ctype = (snappy_literals(raw), 1) if compress else (raw, 0)
+        handles.append((items[-1][0], vi(len(f)) + vi(len(body))))
+        f += body + bytes([ctype]) + struct.pack("<I", T.crc_mask(_crc32c_bitwise(body + bytes([ctype]))))
+    meta = block([], 1)
+    meta_h = vi(len(f)) + vi(len(meta))
+    f += meta + b"\x00" + struct.pack("<I", T.crc_mask(_crc32c_bitwise(meta + b"\x00")))
+    idx = block(handles, 1)
+    idx_h = vi(len(f)) + vi(len(idx))
+    f += idx + b"\x00" + struct.pack("<I", T.crc_mask(_crc32c_bitwise(idx + b"\x00")))
+    footer = meta_h + idx_h
+    f += footer + bytes(40 - len(footer)) + struct.pack("<Q", 0xDB4775248B80FB57)
+    prefix = str(tmp_path / "hand")
+    open(prefix + ".index", "wb").write(f)
+    open(prefix + ".data-00000-of-00001", "wb").write(data)
+    got = T.read_tensor_bundle(prefix)
+    assert list(got) == ["model/a/weights", "model/b/weights"]
+    assert got["model/a/weights"].dtype == np.float32 and np.array_equal(got["model/a/weights"], a)
+    assert got["model/b/weights"].dtype == np.int32 and np.array_equal(got["model/b/weights"], b)
+    # a flipped payload bit is caught by the block checksum
+    bad = bytearray(f)
+    bad[5] ^= 0x10
+    open(prefix + ".index", "wb").write(bytes(bad))
+    with pytest.raises(ValueError, match="crc"):
+        T.read_tensor_bundle(prefix)
