@@ -121,7 +121,9 @@ sd_status sd_fcn8s_forward(sd_handle* h, const uint8_t* frames, int B, float* lo
 
 /* DepthFrame.compute_disparity, semantic_depth.py:667-678 (seq:568-579), for B frames: /255, (frame, fliplr(frame))
  * pair through monodepth, disp_left_est[0], post_processing (:656-664).  disp_pp: f32 [B,H,W] in fraction of
- * image width.  disp_raw (nullable): f32 [B,2,H,W] = the net's channel-0 output for frame and flipped frame. */
+ * image width.  disp_raw (nullable): f32 [B,2,H,W] = the net's channel-0 output for frame and flipped frame.
+ * disp_pp may be NULL when the post-processing is left to sd_postprocess_fuse_backproject (needs B <= the handle's pass size of
+ * 32 frames, or disp_raw). */
 sd_status sd_monodepth_forward(sd_handle* h, const uint8_t* frames, int B, float* disp_pp, float* disp_raw, void* stream);
 
 /* Input stage, semantic_depth.py:111 / seq:128: cv2.resize(frame, (dst_w, dst_h), interpolation=cv2.INTER_CUBIC) for B
@@ -149,6 +151,15 @@ sd_status sd_fuse_backproject(sd_handle* h, const float* disp_pp, const uint8_t*
                               const uint8_t* frames, const sd_camera* cams_host, int B, int cap, float* points_dense,
                               float* road_xyz, uint8_t* road_rgb, int32_t* n_road, float* fence_xyz, uint8_t* fence_rgb,
                               int32_t* n_fence, void* stream);
+
+/* DepthFrame.post_processing (:656-664) + the above in ONE pass over the pixels: the raw pair is read once, disp_pp_out
+ * (f32 [B,H,W], required) is written once and never re-read, both clouds are gathered in the same launch (decoupled look-back
+ * compaction).  disp_raw f32 [B,2,H,W], or NULL = the raw output of the handle's last sd_monodepth_forward (B <= 32 frames).
+ * Same results as sd_post_process followed by sd_fuse_backproject, bit for bit. */
+sd_status sd_postprocess_fuse_backproject(sd_handle* h, const float* disp_raw, float* disp_pp_out, const uint8_t* road_mask,
+                                          const uint8_t* fence_mask, const uint8_t* frames, const sd_camera* cams_host, int B, int cap,
+                                          float* road_xyz, uint8_t* road_rgb, int32_t* n_road, float* fence_xyz, uint8_t* fence_rgb,
+                                          int32_t* n_fence, void* stream);
 
 /* the road chain of FrameProcessor.process_frame, semantic_depth.py:203-259 (seq:180-238):
  * z-cut -> MAD(y) -> MAD(x) -> plane fit -> [Open3D statistical + radius] -> end points -> width.

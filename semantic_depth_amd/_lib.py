@@ -71,6 +71,7 @@ SIGNATURES = {
     "sd_post_process": (C.c_int, [_H, _P, C.c_int, _P, _P]),
     "sd_resize_cubic_u8": (C.c_int, [_H, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P]),
     "sd_fuse_backproject": (C.c_int, [_H, _P, _P, _P, _P, C.POINTER(sd_camera), C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sd_postprocess_fuse_backproject": (C.c_int, [_H, _P, _P, _P, _P, _P, C.POINTER(sd_camera), C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "sd_road_width": (C.c_int, [_H, _P, _P, _P, C.c_int, C.c_int, C.POINTER(sd_rw_params), _P, _P, _P, _P, _P]),
     "sd_fence_to_fence": (C.c_int, [_H, _P, _P, _P, C.c_int, C.c_int, _P, C.POINTER(sd_f2f_params), _P, _P, _P, _P, _P, _P]),
     "sd_pcl_extract_pcls": (C.c_int, [_H, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -23,13 +23,15 @@ static_assert(sizeof(F2fResultDev) == sizeof(sd_f2f_result), "sd_f2f_result layo
 struct sd_handle {
     int device = 0, H = 0, W = 0, max_batch = 0, enc = 0, chunk = 0, cap = 0, prec = 0;
     unsigned sw = 0;      // SEMDEPTH_* switches, latched in sd_create
+    unsigned fuse_epoch = 0;   // epoch of the look-back words in the one-pass fuse scratch (0: scratch must be zeroed first)
+    int last_mono_frames = 0;  // frames of the last sd_monodepth_forward whose raw pair is still in the activation arena (0: none / chunked)
     NetPlan fcn, mono;
     bool bound = false;
     char* wf = nullptr;   // FCN weight arena
     char* wm = nullptr;   // monodepth weight arena
     char* ws = nullptr;   // workspace arena
     // workspace carve (byte offsets)
-    size_t o_fcn = 0, o_mono = 0, o_fuse = 0, o_cams = 0, o_bufA = 0, o_bufB = 0, o_rgbA = 0, o_rgbB = 0, o_cnt = 0, o_plane = 0, o_o3d = 0, o_misc = 0, o_rsz = 0, o_cmp = 0;
+    size_t o_fcn = 0, o_mono = 0, o_fuse = 0, o_fuse1 = 0, o_cams = 0, o_bufA = 0, o_bufB = 0, o_rgbA = 0, o_rgbB = 0, o_cnt = 0, o_plane = 0, o_o3d = 0, o_misc = 0, o_rsz = 0, o_cmp = 0;
     std::vector<int> rsz_host;      // tap tables of the last sd_resize_cubic_u8 geometry (kept alive for the async upload)
     int rsz_key[4] = {0, 0, 0, 0};
     size_t ws_bytes = 0;
@@ -70,6 +72,7 @@ void carve_workspace(sd_handle* h) {
     h->o_fcn = take(h->fcn.act_bytes);
     h->o_mono = take(h->mono.act_bytes);
     h->o_fuse = take(fuse_scratch_bytes(h->max_batch, h->H, h->W));
+    h->o_fuse1 = take(fuse_onepass_scratch_bytes(h->max_batch, h->H, h->W));
     h->o_cams = take(sizeof(CamDev) * B);
     h->o_bufA = take(B * cap * 3 * sizeof(float));
     h->o_bufB = take(B * cap * 3 * sizeof(float));
@@ -499,7 +502,9 @@ sd_status sd_post_process(sd_handle* h, const float* disp_raw, int B, float* dis
 }
 
 sd_status sd_monodepth_forward(sd_handle* h, const uint8_t* frames, int B, float* disp_pp, float* disp_raw, void* stream) {
-    if (!h || !frames || !disp_pp || B <= 0 || B > h->max_batch) return fail(h, SD_ERR_INVALID, "sd_monodepth_forward: bad arguments");
+    if (!h || !frames || B <= 0 || B > h->max_batch) return fail(h, SD_ERR_INVALID, "sd_monodepth_forward: bad arguments");
+    if (!disp_pp && B > h->chunk && !disp_raw)
+        return fail(h, SD_ERR_INVALID, "sd_monodepth_forward: disp_pp may be NULL only when the raw pair survives (B <= chunk) or disp_raw is given");
     if (!h->bound) return fail(h, SD_ERR_STATE, "sd_bind_memory first");
     const size_t npix = (size_t)h->H * h->W;
     hipStream_t s = (hipStream_t)stream;
@@ -509,17 +514,18 @@ sd_status sd_monodepth_forward(sd_handle* h, const uint8_t* frames, int B, float
         const int nb = std::min(h->chunk, B - b0);
         sd_status st = run_plan(h, SD_NET_MONODEPTH, frames + (size_t)b0 * npix * 3, nb, nullptr, s);
         if (st != SD_OK) return st;
-        HIPCHK(h, launch_post_process(raw, disp_pp + (size_t)b0 * npix, nb, h->H, h->W, s));
+        if (disp_pp) HIPCHK(h, launch_post_process(raw, disp_pp + (size_t)b0 * npix, nb, h->H, h->W, s));
         if (disp_raw)
             HIPCHK(h, hipMemcpyAsync(disp_raw + (size_t)b0 * 2 * npix, raw, (size_t)nb * 2 * npix * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
+    h->last_mono_frames = B <= h->chunk ? B : 0;
     return SD_OK;
 }
 
-sd_status sd_fuse_backproject(sd_handle* h, const float* disp_pp, const uint8_t* road, const uint8_t* fence, const uint8_t* frames,
-                              const sd_camera* cams, int B, int cap, float* dense, float* road_xyz, uint8_t* road_rgb,
-                              int32_t* n_road, float* fence_xyz, uint8_t* fence_rgb, int32_t* n_fence, void* stream) {
-    if (!h || !disp_pp || !cams || B <= 0 || B > h->max_batch || cap <= 0) return fail(h, SD_ERR_INVALID, "sd_fuse_backproject: bad arguments");
+static sd_status fuse_impl(sd_handle* h, const float* disp_pp, const float* disp_raw, float* pp_out, const uint8_t* road, const uint8_t* fence,
+                           const uint8_t* frames, const sd_camera* cams, int B, int cap, float* dense, float* road_xyz, uint8_t* road_rgb,
+                           int32_t* n_road, float* fence_xyz, uint8_t* fence_rgb, int32_t* n_fence, void* stream) {
+    if (!h || (!disp_pp && !disp_raw) || !cams || B <= 0 || B > h->max_batch || cap <= 0) return fail(h, SD_ERR_INVALID, "sd_fuse_backproject: bad arguments");
     if (!h->bound) return fail(h, SD_ERR_STATE, "sd_bind_memory first");
     if ((road_xyz && (!road || !n_road)) || (fence_xyz && (!fence || !n_fence)))
         return fail(h, SD_ERR_INVALID, "sd_fuse_backproject: a cloud output needs its mask and its counter");
@@ -539,8 +545,40 @@ sd_status sd_fuse_backproject(sd_handle* h, const float* disp_pp, const uint8_t*
     const size_t nblk = ((size_t)h->H * h->W + 255) / 256;
     p.blk_counts = reinterpret_cast<int32_t*>(h->ws + h->o_fuse);
     p.blk_offsets = p.blk_counts + (size_t)h->max_batch * nblk * 2;
+    // one-pass form: look-back words + tickets; the words carry an epoch, so the scratch is zeroed only every 1023 launches
+    p.disp_raw = disp_raw; p.pp_out = pp_out;
+    // (layout of fuse_onepass_scratch_bytes: the look-back words of max_batch frames, then the tickets)
+    p.lb_state = reinterpret_cast<unsigned long long*>(h->ws + h->o_fuse1);
+    p.lb_ticket = reinterpret_cast<int32_t*>(h->ws + h->o_fuse1 + (fuse_onepass_scratch_bytes(h->max_batch, h->H, h->W) - 256 - (size_t)h->max_batch * 4));
+    if (h->fuse_epoch == 0 || h->fuse_epoch >= 1023) {
+        HIPCHK(h, hipMemsetAsync(h->ws + h->o_fuse1, 0, fuse_onepass_scratch_bytes(h->max_batch, h->H, h->W), s));
+        h->fuse_epoch = 0;
+    }
+    p.epoch = ++h->fuse_epoch;
     HIPCHK(h, launch_fuse(p, s));
     return SD_OK;
+}
+
+sd_status sd_fuse_backproject(sd_handle* h, const float* disp_pp, const uint8_t* road, const uint8_t* fence, const uint8_t* frames,
+                              const sd_camera* cams, int B, int cap, float* dense, float* road_xyz, uint8_t* road_rgb,
+                              int32_t* n_road, float* fence_xyz, uint8_t* fence_rgb, int32_t* n_fence, void* stream) {
+    if (!disp_pp) return fail(h, SD_ERR_INVALID, "sd_fuse_backproject: bad arguments");
+    return fuse_impl(h, disp_pp, nullptr, nullptr, road, fence, frames, cams, B, cap, dense, road_xyz, road_rgb, n_road, fence_xyz, fence_rgb,
+                     n_fence, stream);
+}
+
+sd_status sd_postprocess_fuse_backproject(sd_handle* h, const float* disp_raw, float* disp_pp_out, const uint8_t* road, const uint8_t* fence,
+                                          const uint8_t* frames, const sd_camera* cams, int B, int cap, float* road_xyz, uint8_t* road_rgb,
+                                          int32_t* n_road, float* fence_xyz, uint8_t* fence_rgb, int32_t* n_fence, void* stream) {
+    if (!h || !disp_pp_out) return fail(h, SD_ERR_INVALID, "sd_postprocess_fuse_backproject: bad arguments");
+    if (!disp_raw) {            // the raw pair of the handle's last sd_monodepth_forward, still in the activation arena
+        if (h->last_mono_frames < B || B > h->chunk)
+            return fail(h, SD_ERR_STATE, "sd_postprocess_fuse_backproject: no raw disparities of a monodepth pass of >= B frames in the arena");
+        const NetPlan& p = h->mono;
+        disp_raw = reinterpret_cast<const float*>(h->ws + h->o_mono + p.tensors[p.t_output].offset);
+    }
+    return fuse_impl(h, nullptr, disp_raw, disp_pp_out, road, fence, frames, cams, B, cap, nullptr, road_xyz, road_rgb, n_road, fence_xyz,
+                     fence_rgb, n_fence, stream);
 }
 
 sd_status sd_road_width(sd_handle* h, const float* road_xyz, const uint8_t* road_rgb, const int32_t* n_road, int B, int cap,

@@ -276,9 +276,262 @@ __global__ __launch_bounds__(256) void fuse_write4_kernel(const FuseParams p, in
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// ONE pass (SURVEY K16-K19 in a single launch): flip-pair post-processing (when the raw pair is given), back-projection, and
+// the ordered gather of both clouds by decoupled look-back -- each block of 8 x 1024 pixels counts its masks first and publishes
+// its (road, fence) counts in one 8-byte word, resolves its exclusive prefix from its predecessors' words while it post-processes
+// its first sub-tile, and then writes every masked pixel at prefix + rank (thread order == pixel order, so a wave writes one
+// contiguous run per class).  The next sub-tile's loads are in flight while the current one is processed.
+//   * blocks take a TICKET per frame instead of trusting blockIdx order: every lower-numbered block is then already
+//     running, so the look-back cannot wait on a block that was never scheduled (HIP promises no dispatch order)
+//   * a look-back word is one naturally aligned 8-byte granule written by ONE relaxed agent-scope store and read by relaxed
+//     agent-scope loads (L1-bypassing): data and flag cannot tear, no fence is needed (MI355X_MICROARCH.md, granule hand-off)
+//   * words carry the launch's epoch, so the scratch is not cleared between launches; the last ticket holder re-arms the ticket
+//   * measured (scripts/fuse_bench.py, 32 frames, 451 MB algorithmic): 173 us against 62 + 15 + 5 + 100 us of the four launches it
+//     replaces.  PMC: 51 % of the wave cycles wait on memory, 23 % issue; the stage is bound by the ~640 VALU + 25 scattered
+//     store instructions per pixel quad, not by HBM (2.6 of 8 TB/s).  Rejected variants, same speed within 5 %: staging each
+//     sub-tile's points in LDS and writing them as coalesced dword runs (165 us), 1024- / 4096-pixel blocks (252 / 170 us: the
+//     ticket + look-back cost per block shows below 4096 pixels), closed forms for the interior columns / the sparse Q (kept:
+//     they are exact, but the f64 arithmetic was not the limiter).
+#ifndef SD_F1_SUB
+#define SD_F1_SUB 8
+#endif
+#ifndef SD_F1_WAVES
+#define SD_F1_WAVES 4
+#endif
+constexpr int F1_SUB = SD_F1_SUB;                       // sub-tiles of 1024 pixels (256 threads x 4 pixels) per block
+constexpr int F1_PIX = 1024 * F1_SUB;           // pixels per block: one ticket, one look-back, one published word
+__device__ __forceinline__ unsigned long long f1_pack(unsigned epoch, unsigned flag, unsigned r, unsigned f) {
+    return ((unsigned long long)epoch << 54) | ((unsigned long long)flag << 52) | ((unsigned long long)r << 26) | (unsigned long long)f;
+}
+size_t fuse_onepass_scratch_bytes(int B, int H, int W) {
+    const size_t nblk = ((size_t)H * W + F1_PIX - 1) / F1_PIX;
+    return (size_t)B * nblk * 8 + (size_t)B * 4 + 256;
+}
+bool fuse_onepass_eligible(const FuseParams& p) {
+    return p.W % 4 == 0 && (p.H * p.W) % 4 == 0 && !p.dense && (p.road_xyz || p.fence_xyz) && p.lb_state && p.lb_ticket && p.epoch &&
+           (size_t)p.H * p.W < (1u << 26) && !(p.sw & SW_NO_FUSE1);
+}
+
+struct F1Quad { float4 L, R; unsigned fw[3]; };
+__device__ __forceinline__ F1Quad f1_load(const FuseParams& p, int b, int npix, int i4, bool in, unsigned masks) {
+    F1Quad qd;
+    qd.L = qd.R = make_float4(0.f, 0.f, 0.f, 0.f);
+    qd.fw[0] = qd.fw[1] = qd.fw[2] = 0u;
+    if (!in) return qd;
+    const int i = i4 * 4, y = i / p.W, x0 = i - y * p.W;
+    if (p.disp_raw) {
+        qd.L = *reinterpret_cast<const float4*>(p.disp_raw + ((size_t)(2 * b) * p.H + y) * p.W + x0);
+        qd.R = *reinterpret_cast<const float4*>(p.disp_raw + ((size_t)(2 * b + 1) * p.H + y) * p.W + (p.W - 4 - x0));   // R[W-1-x0-3 .. W-1-x0]
+    } else {
+        qd.L = *reinterpret_cast<const float4*>(p.disp_pp + (size_t)b * npix + i);
+    }
+    if (p.frames && masks) {
+        const unsigned* fp = reinterpret_cast<const unsigned*>(p.frames + ((size_t)b * npix + (size_t)i) * 3);
+        qd.fw[0] = fp[0]; qd.fw[1] = fp[1]; qd.fw[2] = fp[2];
+    }
+    return qd;
+}
+
+__global__ __launch_bounds__(256, SD_F1_WAVES) void fuse_onepass_kernel(const FuseParams p, int npix, int nblk) {
+    const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    __shared__ int s_blk, wr[F1_SUB][4], wf[F1_SUB][4], s_excl[2];
+    if (t == 0) s_blk = atomicAdd(&p.lb_ticket[b], 1);
+    __syncthreads();
+    const int blk = s_blk;
+    const unsigned* const road4 = (p.road && p.road_xyz) ? reinterpret_cast<const unsigned*>(p.road + (size_t)b * npix) : nullptr;
+    const unsigned* const fence4 = (p.fence && p.fence_xyz) ? reinterpret_cast<const unsigned*>(p.fence + (size_t)b * npix) : nullptr;
+    const int q0 = blk * F1_SUB * 256 + t;                      // first pixel quad of this thread; sub-tile u: q0 + 256 u
+    // ---- pass 1 over the masks only: the block's counts are what the successors wait for ----
+    for (int u = 0; u < F1_SUB; ++u) {
+        const int i4 = q0 + 256 * u;
+        unsigned mr = 0, mf = 0;
+        if (i4 * 4 < npix) { if (road4) mr = road4[i4]; if (fence4) mf = fence4[i4]; }
+        int pr, tr, pf, tf;
+        wave_prefix_total(nz_bytes(mr), lane, pr, tr);
+        wave_prefix_total(nz_bytes(mf), lane, pf, tf);
+        if (lane == 0) { wr[u][wave] = tr; wf[u][wave] = tf; }
+    }
+    __syncthreads();
+    int blk_r = 0, blk_f = 0;
+    for (int u = 0; u < F1_SUB; ++u) {
+        blk_r += wr[u][0] + wr[u][1] + wr[u][2] + wr[u][3];
+        blk_f += wf[u][0] + wf[u][1] + wf[u][2] + wf[u][3];
+    }
+    unsigned long long* const st = p.lb_state + (size_t)b * nblk;
+    if (t == 0) {                                              // publish: block 0 knows its inclusive prefix at once
+        __hip_atomic_store(&st[blk], f1_pack(p.epoch, blk == 0 ? 2u : 1u, (unsigned)blk_r, (unsigned)blk_f), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        if (blk == 0) { s_excl[0] = 0; s_excl[1] = 0; }
+    }
+    const CamDev cam = p.cams[b];
+    const double* q = cam.q;
+    const bool sparse_q = q[0] == 1.0 && q[1] == 0.0 && q[2] == 0.0 && q[4] == 0.0 && q[5] == -1.0 && q[6] == 0.0 && q[8] == 0.0 && q[9] == 0.0 &&
+                          q[10] == 0.0 && q[12] == 0.0 && q[13] == 0.0 && q[15] == 0.0;
+    // columns x with l_mask(x) == 0 and r_mask(x) == 0 exactly (ramp_l saturates at 0 from 20 (l - 0.05) >= 1 on): the interior of the image
+    int mid_lo = p.W, mid_hi = -1;
+    {
+        const double step = 1.0 / (double)(p.W - 1);
+        int lo = (int)(0.1 * (p.W - 1)) - 2;
+        lo = lo < 0 ? 0 : lo;
+        while (lo < p.W && !(ramp_l(lo, p.W, step) == 0.0)) ++lo;          // first column whose left ramp is exactly 0
+        mid_lo = lo; mid_hi = p.W - 1 - lo;                                   // r_mask is the mirror image
+    }
+    const float inv_w = 1.0f / (float)p.W;
+    int ex_r = 0, ex_f = 0;
+    // ---- pass 2, per sub-tile: post-process, back-project the masked pixels, stage them in output order, write contiguous runs;
+    //      the next sub-tile's loads are in flight meanwhile.  The look-back is resolved after the first sub-tile's arithmetic. ----
+    unsigned nmr = 0, nmf = 0;
+    if (q0 * 4 < npix) { if (road4) nmr = road4[q0]; if (fence4) nmf = fence4[q0]; }
+    F1Quad nxt = f1_load(p, b, npix, q0, q0 * 4 < npix, nmr | nmf);
+    for (int u = 0; u < F1_SUB; ++u) {
+        const int i4 = q0 + 256 * u;
+        const bool in = i4 * 4 < npix;
+        const int i = i4 * 4;
+        int y = (int)((float)i * inv_w);                         // row of the quad: float estimate, then exact correction (i < 2^26)
+        y -= (y * p.W > i); y += ((y + 1) * p.W <= i); y -= (y * p.W > i);
+        if (!in) y = 0;
+        const int x0 = i - y * p.W;
+        const F1Quad cur = nxt;
+        const unsigned mr = nmr, mf = nmf;
+        if (u + 1 < F1_SUB) {
+            const int j4 = i4 + 256;
+            nmr = nmf = 0;
+            if (j4 * 4 < npix) { if (road4) nmr = road4[j4]; if (fence4) nmf = fence4[j4]; }
+            nxt = f1_load(p, b, npix, j4, j4 * 4 < npix, nmr | nmf);
+        }
+        float dv[4];
+        if (p.disp_raw) {
+            // DepthFrame.post_processing, semantic_depth.py:656-664 (as post_process_kernel): L at x, R at W-1-x of the flipped pass
+            const float Lv[4] = {cur.L.x, cur.L.y, cur.L.z, cur.L.w}, Rv[4] = {cur.R.w, cur.R.z, cur.R.y, cur.R.x};
+            const double step = 1.0 / (double)(p.W - 1);
+            // both ramps are exactly 0 between the two 10 %-wide margins: the blend is then 0*L + 0*R + 1*m = m bit for bit (for
+            // finite L, R; anything else takes the general expression)
+            const bool interior = x0 >= mid_lo && x0 + 3 <= mid_hi;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = x0 + k;
+                const float m = 0.5f * (Lv[k] + Rv[k]);
+                if (interior && fabsf(m) < INFINITY) { dv[k] = m; continue; }
+                const double lm = ramp_l(x, p.W, step), rm = ramp_l(p.W - 1 - x, p.W, step);
+                dv[k] = (float)((rm * (double)Lv[k] + lm * (double)Rv[k]) + ((1.0 - lm) - rm) * (double)m);
+            }
+            if (in) *reinterpret_cast<float4*>(p.pp_out + (size_t)b * npix + i) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+        } else {
+            dv[0] = cur.L.x; dv[1] = cur.L.y; dv[2] = cur.L.z; dv[3] = cur.L.w;
+        }
+        float X[4], Y[4], Z[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            X[k] = Y[k] = Z[k] = 0.f;
+            if (!(((mr | mf) >> (8 * k)) & 0xffu)) continue;
+            // disparity = disp_pp * multiplier in float32 (semantic_depth.py:145; seq:146); cv2.reprojectImageTo3D as fuse_write_kernel
+            const float dpx = dv[k] * cam.mult;
+            const double xd = (double)(x0 + k), yd = (double)y, d = (double)dpx;
+            double Wh, n0, n1, n2;
+            if (sparse_q && fabsf(dpx) < INFINITY) {
+                // Q of make_cam ([1 0 0 -cx; 0 -1 0 cy; 0 0 0 -f; 0 0 1/b 0]) and a finite disparity: the zero products and the
+                // additions of +0.0 of the general expression below drop out without changing a bit
+                Wh = 0.0 + q[14] * d;
+                n0 = xd + q[3];
+                n1 = (0.0 - yd) + q[7];
+                n2 = q[11];
+            } else {
+                Wh = ((q[12] * xd + q[13] * yd) + q[14] * d) + q[15];
+                n0 = ((q[0] * xd + q[1] * yd) + q[2] * d) + q[3];
+                n1 = ((q[4] * xd + q[5] * yd) + q[6] * d) + q[7];
+                n2 = ((q[8] * xd + q[9] * yd) + q[10] * d) + q[11];
+            }
+            const double iW = 1.0 / Wh;                         // Vec3f /= double is a multiply by 1./alpha (core/matx.hpp)
+            X[k] = (float)((double)(float)n0 * iW); Y[k] = (float)((double)(float)n1 * iW); Z[k] = (float)((double)(float)n2 * iW);
+        }
+        if (u == 0) {
+            // ---- decoupled look-back by wave 0: exclusive prefix of this block ----
+            if (wave == 0 && blk > 0) {
+                int look = blk - 1;
+                unsigned sum_r = 0, sum_f = 0;
+                while (true) {
+                    const int idx = look - lane;
+                    unsigned long long w = idx >= 0 ? __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : f1_pack(p.epoch, 2u, 0u, 0u);
+                    unsigned flag = (unsigned)(w >> 54) == p.epoch ? (unsigned)((w >> 52) & 3u) : 0u;
+                    const unsigned long long incl = __ballot(flag == 2u), notready = __ballot(flag == 0u);
+                    const int first_incl = incl ? __ffsll((long long)incl) - 1 : 64;
+                    const unsigned long long needed = first_incl < 64 ? ((first_incl == 63 ? ~0ull : ((2ull << first_incl) - 1ull))) : ~0ull;
+                    if (notready & needed) { __builtin_amdgcn_s_sleep(2); continue; }
+                    unsigned r = lane <= first_incl ? (unsigned)((w >> 26) & 0x3ffffffu) : 0u, f = lane <= first_incl ? (unsigned)(w & 0x3ffffffu) : 0u;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) { r += __shfl_xor(r, o); f += __shfl_xor(f, o); }
+                    sum_r += r; sum_f += f;
+                    if (first_incl < 64) break;
+                    look -= 64;
+                }
+                if (lane == 0) {
+                    s_excl[0] = (int)sum_r; s_excl[1] = (int)sum_f;
+                    __hip_atomic_store(&st[blk], f1_pack(p.epoch, 2u, sum_r + (unsigned)blk_r, sum_f + (unsigned)blk_f), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __syncthreads();
+            ex_r = s_excl[0]; ex_f = s_excl[1];
+            if (blk == nblk - 1 && t == 0) {                    // the last ticket: totals, and re-arm the ticket for the next launch
+                if (p.n_road) p.n_road[b] = ex_r + blk_r;
+                if (p.n_fence) p.n_fence[b] = ex_f + blk_f;
+                p.lb_ticket[b] = 0;
+            }
+        }
+        int pre_r, pre_f, tr_, tf_;
+        wave_prefix_total(nz_bytes(mr), lane, pre_r, tr_);
+        wave_prefix_total(nz_bytes(mf), lane, pre_f, tf_);
+        const int cnt_r = p.road_xyz ? wr[u][0] + wr[u][1] + wr[u][2] + wr[u][3] : 0;
+        const int cnt_f = p.fence_xyz ? wf[u][0] + wf[u][1] + wf[u][2] + wf[u][3] : 0;
+        if (cnt_r + cnt_f == 0) continue;                       // (uniform over the block)
+        // write each masked pixel at (exclusive prefix of the block) + (sub-tiles before) + (rank inside the sub-tile): thread order ==
+        // pixel order, so the lanes of a wave write one contiguous run per class
+#pragma unroll
+        for (int cls = 0; cls < 2; ++cls) {
+            const int cnt = cls ? cnt_f : cnt_r;
+            if (cnt == 0) continue;
+            float* oxyz = cls ? p.fence_xyz : p.road_xyz;
+            uint8_t* orgb = cls ? p.fence_rgb : p.road_rgb;
+            const unsigned m4 = cls ? mf : mr;
+            int pos = (cls ? ex_f + pre_f : ex_r + pre_r);
+            for (int w = 0; w < wave; ++w) pos += cls ? wf[u][w] : wr[u][w];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!((m4 >> (8 * k)) & 0xffu)) continue;
+                if (pos < p.cap) {
+                    float* o = oxyz + ((size_t)b * p.cap + pos) * 3;
+                    o[0] = X[k]; o[1] = Y[k]; o[2] = Z[k];
+                    if (orgb) {
+                        // bytes 3k .. 3k+2 of the 12 frame bytes: B, G, R -> colours = cv2.cvtColor(frame, BGR2RGB), semantic_depth.py:161
+                        const unsigned long long lo64 = ((unsigned long long)cur.fw[1] << 32) | cur.fw[0], hi64 = ((unsigned long long)cur.fw[2] << 32) | cur.fw[1];
+                        const unsigned bgr = k < 2 ? (unsigned)(lo64 >> (24 * k)) : (unsigned)(hi64 >> (24 * k - 32));
+                        uint8_t* c = orgb + ((size_t)b * p.cap + pos) * 3;
+                        c[0] = (uint8_t)(bgr >> 16); c[1] = (uint8_t)(bgr >> 8); c[2] = (uint8_t)bgr;
+                    }
+                }
+                ++pos;
+            }
+            if (cls) ex_f += cnt; else ex_r += cnt;
+        }
+    }
+}
+
 hipError_t launch_fuse(const FuseParams& p, hipStream_t s) {
     const int npix = p.H * p.W;
     const bool gather = p.road_xyz || p.fence_xyz;
+    if (fuse_onepass_eligible(p)) {
+        const int nblk = (npix + F1_PIX - 1) / F1_PIX;
+        hipLaunchKernelGGL(fuse_onepass_kernel, dim3(nblk, p.B), dim3(256), 0, s, p, npix, nblk);
+        return hipGetLastError();
+    }
+    if (p.disp_raw) {           // the three-launch forms read a post-processed map
+        hipError_t e = launch_post_process(p.disp_raw, p.pp_out, p.B, p.H, p.W, s);
+        if (e != hipSuccess) return e;
+        FuseParams q = p;
+        q.disp_pp = p.pp_out; q.disp_raw = nullptr;
+        return launch_fuse(q, s);
+    }
     if (p.W % 4 == 0 && gather && !(p.sw & SW_NO_FUSE4)) {          // four pixels per thread, 1024 per block
         const int nblk4 = (npix + 1023) / 1024;
         hipLaunchKernelGGL(fuse_count4_kernel, dim3(nblk4, p.B), dim3(256), 0, s, p.road, p.fence, npix, nblk4, p.blk_counts);

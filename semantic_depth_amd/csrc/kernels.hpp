@@ -202,7 +202,15 @@ struct FuseParams {
     int32_t* blk_counts;       // scratch [B][nblk][2]
     int32_t* blk_offsets;      // scratch [B][nblk][2]
     unsigned sw;               // Switch bits of the handle
+    // one-pass form (fuse.hip fuse_onepass_kernel): post-processing folded in, decoupled look-back compaction
+    const float* disp_raw;     // nullable [B,2,H,W]: the net's raw pair; disp_pp is then COMPUTED here (post_processing) and written
+    float* pp_out;             // [B,H,W], written when disp_raw is given
+    unsigned long long* lb_state;   // scratch [B][nblk1024]: look-back words (epoch | flag | road count | fence count)
+    int32_t* lb_ticket;        // scratch [B]: arrival tickets (zero between launches)
+    unsigned epoch;            // 1..1023, different from the previous launch on this scratch (0 = freshly zeroed scratch)
 };
+size_t fuse_onepass_scratch_bytes(int B, int H, int W);
+bool fuse_onepass_eligible(const FuseParams& p);
 size_t fuse_scratch_bytes(int B, int H, int W);
 hipError_t launch_fuse(const FuseParams& p, hipStream_t s);
 

@@ -6,6 +6,7 @@ C ABI of include/semdepth.h.  One Engine per process / per GPU.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, asdict
 
 import numpy as np
@@ -104,6 +105,7 @@ class Engine:
         self._ws = torch.zeros(ws.value, dtype=torch.uint8, device=self.device)
         L.check(self.lib, h, self.lib.sd_bind_memory(h, _ptr(self._wf), _ptr(self._wm), _ptr(self._ws)), "sd_bind_memory")
         self.cap = H * W
+        self.pass_frames = min(max_batch, int(os.environ.get("SEMDEPTH_CHUNK", "32")))   # frames per network pass (sd_create)
 
     def close(self):
         if getattr(self, "h", None):
@@ -155,8 +157,13 @@ class Engine:
         L.check(self.lib, self.h, st, "sd_fcn8s_forward")
         return dict(logits=logits, road=road, fence=fence, argmax=amax)
 
-    def monodepth_forward(self, frames: torch.Tensor, want_raw: bool = False):
+    def monodepth_forward(self, frames: torch.Tensor, want_raw: bool = False, post_process: bool = True):
+        """post_process=False: leave the flip-pair post-processing to fuse_from_raw (one pass); returns None (B <= 32 frames)"""
         B = self._frames(frames)
+        if not post_process:
+            st = self.lib.sd_monodepth_forward(self.h, _ptr(frames), B, None, None, self._stream())
+            L.check(self.lib, self.h, st, "sd_monodepth_forward")
+            return None
         pp = torch.empty((B, self.H, self.W), dtype=torch.float32, device=self.device)
         raw = torch.empty((B, 2, self.H, self.W), dtype=torch.float32, device=self.device) if want_raw else None
         st = self.lib.sd_monodepth_forward(self.h, _ptr(frames), B, _ptr(pp), _ptr(raw), self._stream())
@@ -204,6 +211,24 @@ class Engine:
                                           _ptr(out["dense"]), _ptr(out["road_xyz"]), _ptr(out["road_rgb"]), _ptr(out["n_road"]),
                                           _ptr(out["fence_xyz"]), _ptr(out["fence_rgb"]), _ptr(out["n_fence"]), self._stream())
         L.check(self.lib, self.h, st, "sd_fuse_backproject")
+        return out
+
+    def fuse_from_raw(self, road, fence, frames, cams, disp_raw=None, cap: int | None = None, want_rgb: bool = True):
+        """post-processing + back-projection + gather in ONE launch (sd_postprocess_fuse_backproject).  ``disp_raw`` None = the raw
+        pair of the last monodepth_forward on this engine.  Returns the fuse dict plus 'disp_pp'."""
+        B = road.shape[0]
+        cap = cap or self.cap
+        dev = self.device
+        carr = (L.sd_camera * B)(*[L.sd_camera(c.cx, c.cy, c.f, c.b, c.disp_mult) for c in cams])
+        out = dict(dense=None, disp_pp=torch.empty((B, self.H, self.W), dtype=torch.float32, device=dev))
+        for k, m in (("road", road), ("fence", fence)):
+            out[f"{k}_xyz"] = torch.empty((B, cap, 3), dtype=torch.float32, device=dev) if m is not None else None
+            out[f"{k}_rgb"] = torch.empty((B, cap, 3), dtype=torch.uint8, device=dev) if (m is not None and want_rgb and frames is not None) else None
+            out[f"n_{k}"] = torch.empty((B,), dtype=torch.int32, device=dev) if m is not None else None
+        st = self.lib.sd_postprocess_fuse_backproject(self.h, _ptr(disp_raw), _ptr(out["disp_pp"]), _ptr(road), _ptr(fence), _ptr(frames), carr, B,
+                                                      cap, _ptr(out["road_xyz"]), _ptr(out["road_rgb"]), _ptr(out["n_road"]),
+                                                      _ptr(out["fence_xyz"]), _ptr(out["fence_rgb"]), _ptr(out["n_fence"]), self._stream())
+        L.check(self.lib, self.h, st, "sd_postprocess_fuse_backproject")
         return out
 
     def road_width(self, road_xyz, n_road, params: RoadWidthParams = RoadWidthParams(), want_final: bool = False, road_rgb=None):
@@ -261,8 +286,14 @@ class Engine:
         if approach not in ("rw", "both"):
             raise ValueError("approach must be 'rw' or 'both' (semantic_depth.py:743-745)")
         seg = self.fcn8s_forward(frames)
-        disp_pp = self.monodepth_forward(frames)
-        fz = self.fuse_backproject(disp_pp, seg["road"], seg["fence"], frames, cams, want_rgb=colours)
+        if frames.shape[0] <= self.pass_frames:
+            # the raw disparity pair stays in the activation arena: post-processing, back-projection and both gathers in ONE launch
+            self.monodepth_forward(frames, post_process=False)
+            fz = self.fuse_from_raw(seg["road"], seg["fence"], frames, cams, want_rgb=colours)
+            disp_pp = fz["disp_pp"]
+        else:
+            disp_pp = self.monodepth_forward(frames)
+            fz = self.fuse_backproject(disp_pp, seg["road"], seg["fence"], frames, cams, want_rgb=colours)
         out = dict(seg=seg, disp_pp=disp_pp, fuse=fz, f2f=None)
         rw = self.road_width(fz["road_xyz"], fz["n_road"], params, want_final=want_final, road_rgb=fz["road_rgb"] if colours else None)
         if want_final:
