@@ -27,8 +27,37 @@ for k in f:
     wb = w.get(k, [0, 0.0])[1]
     per[k] = {"launches": n, "fetch_bytes_per_launch": fb / n, "write_bytes_per_launch": wb / n}
     tl += n; tf += fb; tw += wb
+import re
+
+
+def label(k):
+    """the bench's profiling label (conv_*_kernel_name in csrc) of a demangled instantiation"""
+    m = re.search(r"sd::(conv_\w+)_kernel<([^>]*)>", k)
+    if not m:
+        return None
+    fam, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
+    if fam == "conv_direct":       # <NB, MT, F16, N16, UP>
+        f16 = args[2] == "true"
+        shape = "<1,n16>" if args[3] == "true" else ("<1,2>" if args[0] == "1" else "<2,2>")
+        return f"conv_direct{'_f16w' if f16 else ''}_kernel{shape}"
+    if fam == "conv_dma":          # <WM, WN, MT, NT, SIMPLE, STAGES, F16>
+        return f"conv_dma{'_f16w' if args[6] == 'true' else ''}_kernel<{args[0]},{args[1]},{args[2]},{args[3]}>"
+    if fam == "conv_stem":
+        return "conv_stem_f16w_kernel" if args[2] == "true" else "conv_stem_kernel"
+    return fam + "_kernel"
+
+
+by_label = collections.defaultdict(lambda: [0, 0.0, 0.0])
+for k, v in per.items():
+    lb = label(k)
+    if lb:
+        by_label[lb][0] += v["launches"]
+        by_label[lb][1] += v["fetch_bytes_per_launch"] * v["launches"]
+        by_label[lb][2] += v["write_bytes_per_launch"] * v["launches"]
 out = {
-    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline (bf16x2)",
+    "by_label": {lb: {"launches": n, "fetch_bytes_per_launch": fb / n, "write_bytes_per_launch": wb / n, "hbm_bytes_per_launch": (fb + wb) / n}
+                 for lb, (n, fb, wb) in by_label.items()},
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-f32-leg (default precision plan)",
     "units": "FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B: MI355X_MICROARCH.md HBM section); WRITE_SIZE uncorrected",
     "per_kernel": per,
     "all_conv": {"launches": tl, "hbm_bytes_per_launch": (tf + tw) / max(tl, 1), "fetch_bytes_per_launch": tf / max(tl, 1),
