@@ -47,10 +47,10 @@ PEAK_F32, PEAK_3P, PEAK_2P = 157.3, 2500.0 / 3.0, 2500.0 / 2.0
 DTYPE = {
     "f32": "f32 (exact: v_mfma_f32_16x16x4_f32)",
     "bf16x2": "bf16x2 split operands (hi+lo, 16 mantissa bits), 3 bf16 MFMA products per product, f32 accumulate",
-    "mixed": "FCN-8s: bf16x2 split operands, 3 bf16 MFMA products; monodepth: fp16x2 split activations (22 bits) x fp16 weights, "
+    "mixed": "FCN-8s: bf16x2 split operands, 3 bf16 MFMA products; monodepth: fp16 activations x fp16x2 split weights (22 bits), "
              "2 fp16 MFMA products; f32 accumulate",
-    "plan": "per-layer precision plan: bf16x2 split operands (3 bf16 MFMA products) / fp16x2 split activations x fp16 weights "
-            "(2 fp16 MFMA products) chosen per layer under an error budget; f32 accumulate",
+    "plan": "per-layer precision plan: bf16x2 split operands (3 bf16 MFMA products) or fp16 activations x fp16x2 split weights "
+            "(2 fp16 MFMA products), chosen per layer under an error budget against the exact-f32 engine; f32 accumulate",
 }
 
 

@@ -36,14 +36,15 @@ enum {
 
 typedef enum { SD_ENC_VGG = 0, SD_ENC_RESNET50 = 1 } sd_encoder;      /* semantic_depth.py:721-722 --encoder */
 typedef enum { SD_NET_FCN8S = 0, SD_NET_MONODEPTH = 1 } sd_net;
-/* arithmetic of the conv stacks: SD_PREC_F32 = exact f32 MFMA; SD_PREC_BF16X2 = every f32 operand split into two bf16
- * (hi + lo), three bf16 MFMA products per product, f32 accumulate (~1e-5 relative; gfx950 has no TF32);
- * SD_PREC_MIXED = FCN-8s as SD_PREC_BF16X2, monodepth with activations split into two fp16 (22 bits) and weights rounded
- * once to fp16, two fp16 MFMA products per product (~2e-4 relative on the disparity: the 2^-12 weight rounding; the
- * same scheme on FCN-8s gives 6e-4..1.6e-3 on the logits, over the 1e-3 budget, hence "mixed");
- * SD_PREC_PLAN = per-layer precision plan: each conv layer runs either the 3-product bf16 scheme or the 2-product fp16 one; the
- * built-in plan (sd_default_plan) was calibrated on the MI355X against the exact-f32 engine under an error budget
- * (DESIGN.md); sd_create_with_plan takes any other choice */
+/* arithmetic of the conv stacks (f32 accumulate everywhere; gfx950 has no TF32):
+ *   SD_PREC_F32    exact f32 MFMA;
+ *   SD_PREC_BF16X2 every f32 operand split into two bf16 (hi + lo), THREE bf16 MFMA products per product (~1e-5 relative);
+ *   2-product form: the activation rounded once to fp16 (one 16-bit plane: half the bytes of every tensor), the weight split into
+ *                  two fp16 (22 bits), TWO fp16 MFMA products x*w_hi + x*w_lo; the only error is the 2^-12 rounding of the
+ *                  activations (3e-5 .. 2e-4 on the outputs per layer, profiles/r02_precision_calibration.json);
+ *   SD_PREC_MIXED  FCN-8s as SD_PREC_BF16X2, every monodepth layer in the 2-product form;
+ *   SD_PREC_PLAN   per-layer choice between the two: the built-in plan (sd_default_plan) was calibrated on the MI355X against the
+ *                  exact-f32 engine under an error budget; sd_create_with_plan takes any other choice */
 typedef enum { SD_PREC_F32 = 0, SD_PREC_BF16X2 = 1, SD_PREC_MIXED = 2, SD_PREC_PLAN = 3 } sd_precision;
 
 typedef struct sd_handle sd_handle;

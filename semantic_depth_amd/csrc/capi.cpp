@@ -273,10 +273,10 @@ int32_t* cnt_slot(sd_handle* h, int i) { return reinterpret_cast<int32_t*>(h->ws
 extern "C" {
 
 #ifndef SD_DEFAULT_PLAN_FCN
-#define SD_DEFAULT_PLAN_FCN "conv3_3,conv4_1,conv4_2,conv4_3,conv5_1,conv5_2,conv5_3,fc6,fc7"
+#define SD_DEFAULT_PLAN_FCN "conv1_2,conv2_2,conv4_2,conv4_3,conv5_1,conv5_2,conv5_3,fc6,fc7"
 #endif
 #ifndef SD_DEFAULT_PLAN_MONO
-#define SD_DEFAULT_PLAN_MONO "enc/conv1,enc/res3*,enc/res4*,enc/res5*,dec/*"
+#define SD_DEFAULT_PLAN_MONO "enc/res2*,enc/res3*,enc/res4*,enc/res5*,dec/upconv6,dec/iconv6,dec/upconv5,dec/iconv5,dec/upconv4,dec/iconv4,dec/disp4,dec/upconv1,dec/iconv1"
 #endif
 #ifndef SD_SOURCE_HASH
 #define SD_SOURCE_HASH "unhashed"
@@ -296,10 +296,11 @@ const char* sd_status_string(sd_status s) {
     }
 }
 
-// the default precision plan (SD_PREC_PLAN): from scripts/calibrate_precision.py on the MI355X (per-group error against the exact-f32
-// engine, profiles/r02_precision_calibration.json; DESIGN.md §3 "Precision plan" has the table).  Taken: every group whose
-// 2-product form costs < 1.1e-4 on its own.  Left on three products: the full-resolution VGG layers conv1_1 .. conv3_2 (1.5e-4 ..
-// 2.1e-4 each) and monodepth's res2 stage (1.1e-4 for 0.4 ms: its 1x1 layers are HBM-bound in either form).
+// the default precision plan (SD_PREC_PLAN): the output of scripts/calibrate_precision.py on the MI355X (per-group error of the
+// 2-product form against the exact-f32 engine, greedy by error per saved product under 3e-4 per network on 4 frames of 512 x 1024;
+// profiles/r02_precision_calibration.json; DESIGN.md §3 "Precision plan" has the table).  FCN-8s: 69 % of its FLOPs on two products
+// at 2.9e-4 (left on three: conv1_1, conv2_1, conv3_x, conv4_1 -- the layers whose INPUT tensor also feeds a score head, or whose
+// own error is ~2e-4), monodepth-resnet50: 96 % at 2.7e-4 (left on three: the stem and decoder levels 3 and 2).
 static const char* const kDefaultPlanFcn = SD_DEFAULT_PLAN_FCN;
 static const char* const kDefaultPlanMono = SD_DEFAULT_PLAN_MONO;
 

@@ -64,7 +64,7 @@ __device__ __forceinline__ DirectChunk load_chunk(const DirectChunk* ptr) {
 
 // persistent: workgroup b walks tiles b, b + grid, ...; the (tile, chunk) sequence is one software pipeline, so the first
 // chunk of the next tile lands while the current tile's epilogue runs.
-// F16: fp16 planes, ONE fp16 weight plane, two MFMA products per product (split_fmt.hpp)
+// F16: ONE fp16 activation plane, two fp16 weight planes, two MFMA products per product (split_fmt.hpp)
 // N16 (Cout <= 16, NB = 1): the 32-row MFMA would spend half its rows on padding, so the products run on
 // v_mfma_f32_16x16x32 instead: K = 32 is one PAIR of taps x 16 channels, a wave's 2 x 32 pixels are four 16-pixel blocks.
 template <int NB, int MT, bool F16, bool N16 = false, bool UP = false>
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
 #pragma unroll
         for (int i = 0; i < XS; ++i) {
             const int j = wave + D_WAVES * i;
-            if (j >= 2 * D_XI) continue;
+            if (j >= (F16 ? 1 : 2) * D_XI) continue;          // fp16 activations: ONE plane
             const int ry = geo[i] & 0xff, rx = (geo[i] >> 8) & 0xff, oct = (geo[i] >> 16) & 1;
             // UP: source coordinates directly (an output-resolution pixel is outside the image exactly when its source pixel is)
             const int gy = (UP ? (tl.ty0 >> 1) : tl.ty0) - 1 + ry, gx = (UP ? (tl.tx0 >> 1) : tl.tx0) - 1 + rx;
@@ -137,9 +137,9 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
             ddma16(ok ? reinterpret_cast<const u32x4*>(src) : zero, sbyte + (unsigned)(j * 1024));
         }
 #pragma unroll
-        for (int i = 0; i < ((F16 ? 1 : 2) * D_WI + D_WAVES - 1) / D_WAVES; ++i) {
+        for (int i = 0; i < (2 * D_WI + D_WAVES - 1) / D_WAVES; ++i) {      // both weight planes in either format
             const int jw = wave + D_WAVES * i;
-            if (jw < (F16 ? 1 : 2) * D_WI) {
+            if (jw < 2 * D_WI) {
                 const int pl = jw >= D_WI ? 1 : 0;
                 const int u = (jw - pl * D_WI) * 64 + lane;
                 const u32x4* gw = p.wt + ((size_t)(2 * half + pl) * p.nchunks + c) * D_GW + (N16 ? (u >> 4) * 32 + (u & 15) : u);
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                     const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;         // tap / 3, tap % 3 for tap < 10
                     const int wi = (tap * 2 + oct) * 16 + c16;
                     const u32x4 wh = live ? Wh[wi] : z4;
-                    const u32x4 wl = F16 ? wh : (live ? Wl[wi] : z4);
+                    const u32x4 wl = live ? Wl[wi] : z4;
 #pragma unroll
                     for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -203,10 +203,12 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                             const int lp = hpix(MT * wave + a + dy, 16 * pb + c16 + dx);
                             const int idx = lp * 2 + (oct ^ ((lp >> 3) & 1));
                             const u32x4 xh = live ? Xh[idx] : z4;
-                            const u32x4 xl = live ? Xl[idx] : z4;
+                            const u32x4 xl = F16 ? xh : (live ? Xl[idx] : z4);
 #pragma unroll
-                            for (int pr = (F16 ? 1 : 0); pr < 3; ++pr)
+                            for (int pr = 0; pr < 3; ++pr) {      // x_hi*w_lo, x_lo*w_hi, x_hi*w_hi; fp16 activations have no lo plane
+                                if (F16 && pr == 1) continue;
                                 acc16[a][pb] = mfma_frag16<F16>(pr == 0 ? wl : wh, pr == 1 ? xl : xh, acc16[a][pb]);
+                            }
                         }
                 }
             } else {
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                     const int lp = hpix(MT * wave + r, frow + dx);
                     const int idx = lp * 2 + (fk ^ ((lp >> 3) & 1));
                     xh[r] = Xh[idx];
-                    xl[r] = Xl[idx];
+                    xl[r] = F16 ? xh[r] : Xl[idx];
                 }
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
@@ -226,12 +228,14 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                     for (int nb = 0; nb < NB; ++nb) {
                         const int wi = ((dy * 3 + dx) * 2 + fk) * (32 * NB) + nb * 32 + frow;
                         const u32x4 wh = Wh[wi];
-                        const u32x4 wl = F16 ? wh : Wl[wi];
+                        const u32x4 wl = Wl[wi];
 #pragma unroll
-                        for (int pr = (F16 ? 1 : 0); pr < 3; ++pr)
+                        for (int pr = 0; pr < 3; ++pr) {          // x_hi*w_lo, x_lo*w_hi, x_hi*w_hi; fp16 activations have no lo plane
+                            if (F16 && pr == 1) continue;
 #pragma unroll
                             for (int a = 0; a < MT; ++a)
                                 acc[a][nb] = mfma_frag<F16>(pr == 0 ? wl : wh, pr == 1 ? xl[a + dy] : xh[a + dy], acc[a][nb]);
+                        }
                     }
             }
             }
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                         split4_t<O16>(v, h, l);
                         if (4 * kg16 < p.Cout) {
                             *reinterpret_cast<uint2*>(s16 + (16 * pb + c16) * R16 + kg16 * 8) = h;
-                            *reinterpret_cast<uint2*>(s16 + 32 * R16 + (16 * pb + c16) * R16 + kg16 * 8) = l;
+                            if constexpr (!O16) *reinterpret_cast<uint2*>(s16 + 32 * R16 + (16 * pb + c16) * R16 + kg16 * 8) = l;
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -290,11 +294,10 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                     {   // 32 pixels x 2 segments of 8 channels = 64 lanes, one pass per plane
                         const int pix = lane >> 1, sg = lane & 1;
                         const u32x4 h = *reinterpret_cast<const u32x4*>(s16 + pix * R16 + sg * 16);
-                        const u32x4 l = *reinterpret_cast<const u32x4*>(s16 + 32 * R16 + pix * R16 + sg * 16);
                         if (y < p.H && sg * 8 < p.Cout) {
                             uint16_t* o = oaddr((size_t)(cur.img * p.H + y) * p.W + cur.tx0 + pix, (size_t)p.H * p.W, sg);
                             *reinterpret_cast<u32x4*>(o) = h;
-                            *reinterpret_cast<u32x4*>(o + p.out_plane) = l;
+                            if constexpr (!O16) *reinterpret_cast<u32x4*>(o + p.out_plane) = *reinterpret_cast<const u32x4*>(s16 + 32 * R16 + pix * R16 + sg * 16);
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                 const int pp = frow >> 1;                    // pooled pixel of this lane pair
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
-                    if (TWO && pl == 1) break;
+                    if ((TWO || O16) && pl == 1) break;          // fp16 outputs: the hi plane only
                     if (!(lane & 1)) {
 #pragma unroll
                         for (int r4 = 0; r4 < 4 * NB; ++r4) {
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                             const int nl = 8 * r4 + 4 * fk;
                             if (TWO) {
                                 *reinterpret_cast<uint2*>(sh + pp * ROW + nl * 2) = hh[r4];
-                                *reinterpret_cast<uint2*>(sl + pp * ROW + nl * 2) = ll[r4];
+                                if constexpr (!O16) *reinterpret_cast<uint2*>(sl + pp * ROW + nl * 2) = ll[r4];
                             } else {
                                 *reinterpret_cast<uint2*>(sh + pp * ROW + nl * 2) = pl ? ll[r4] : hh[r4];
                             }
@@ -348,9 +351,8 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                             const u32x4 h = *reinterpret_cast<const u32x4*>(sh + pix * ROW + seg * 16);
                             uint16_t* o = oaddr((size_t)(cur.img * Hp + yp) * Wp + (cur.tx0 >> 1) + pix, (size_t)Hp * Wp, seg);
                             if (TWO) {
-                                const u32x4 l = *reinterpret_cast<const u32x4*>(sl + pix * ROW + seg * 16);
                                 *reinterpret_cast<u32x4*>(o) = h;
-                                *reinterpret_cast<u32x4*>(o + p.out_plane) = l;
+                                if constexpr (!O16) *reinterpret_cast<u32x4*>(o + p.out_plane) = *reinterpret_cast<const u32x4*>(sl + pix * ROW + seg * 16);
                             } else {
                                 *reinterpret_cast<u32x4*>(pl ? o + p.out_plane : o) = h;
                             }
@@ -377,14 +379,14 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                 }
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
-                    if (TWO && pl == 1) break;
+                    if ((TWO || O16) && pl == 1) break;          // fp16 outputs: the hi plane only
 #pragma unroll
                     for (int r4 = 0; r4 < 4 * NB; ++r4) {
                         if (8 * r4 >= p.Cout) continue;
                         const int nl = 8 * r4 + 4 * fk;
                         if (TWO) {
                             *reinterpret_cast<uint2*>(sh + frow * ROW + nl * 2) = hh[r4];
-                            *reinterpret_cast<uint2*>(sl + frow * ROW + nl * 2) = ll[r4];
+                            if constexpr (!O16) *reinterpret_cast<uint2*>(sl + frow * ROW + nl * 2) = ll[r4];
                         } else {
                             *reinterpret_cast<uint2*>(sh + frow * ROW + nl * 2) = pl ? ll[r4] : hh[r4];
                         }
@@ -396,12 +398,12 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                         const int pix = ps * PPP + prow;
                         const u32x4 h = *reinterpret_cast<const u32x4*>(sh + pix * ROW + seg * 16);
                         u32x4 l = h;
-                        if (TWO) l = *reinterpret_cast<const u32x4*>(sl + pix * ROW + seg * 16);
+                        if (TWO && !O16) l = *reinterpret_cast<const u32x4*>(sl + pix * ROW + seg * 16);
                         if (y < p.H && seg * 8 < p.Cout) {
                             uint16_t* o = oaddr((size_t)(cur.img * p.H + y) * p.W + cur.tx0 + pix, (size_t)p.H * p.W, seg);
                             if (TWO) {
                                 *reinterpret_cast<u32x4*>(o) = h;
-                                *reinterpret_cast<u32x4*>(o + p.out_plane) = l;
+                                if constexpr (!O16) *reinterpret_cast<u32x4*>(o + p.out_plane) = l;
                             } else {
                                 *reinterpret_cast<u32x4*>(pl ? o + p.out_plane : o) = h;
                             }

@@ -60,8 +60,8 @@ __device__ __forceinline__ KEntry load_kentry(const KEntry* ptr) {
 // tile's first k-tiles in flight under the epilogue) measured the same fps within noise (348.4 vs 347.4) and was dropped;
 // issuing the DMAs of the two waves of a SIMD at different points of the k-tile (one before, one between the MFMA clusters)
 // measured -2 % (337.7 vs 344.9 fps); four waves (one per SIMD) with 64 x 128 wave tiles on the same 128 x 256 block -8 %.
-// F16: fp16 planes, ONE fp16 weight plane, two MFMA products per product (split_fmt.hpp): a k-tile then carries 4 weight
-// DMAs less per workgroup and 16 instead of 24 MFMAs per wave.
+// F16: ONE fp16 activation plane, two fp16 weight planes, two MFMA products per product (split_fmt.hpp): a k-tile then carries half
+// the activation DMAs and 16 instead of 24 MFMAs per wave.
 // SIMPLE = 2: the two-source 1x1 GEMM of a ResNet block tail (conv3 over its 3x3 output + projection over the block input,
 // each with its own stride): two base pointers per lane, the k-tile index selects the source.
 template <int WAVES_M, int WAVES_N, int MT, int NT, int SIMPLE, int STAGES, bool F16 = false>
@@ -71,9 +71,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
     constexpr int STAGE_UNITS = 8 * (BM + BN);                // 16-B units: Xh [4][BM] | Xl [4][BM] | Wh [4][BN] | Wl [4][BN]
     constexpr int XI = 8 * BM / 64 / NW;                      // activation DMA instructions per wave and tile (2 or 4), hi first then lo
     constexpr int WI_ALL = 8 * BN / 64;                       // weight instructions of a tile, both planes (32, 16 or 8)
-    constexpr int WI = (F16 ? WI_ALL / 2 : WI_ALL);           // F16: the hi plane only
+    constexpr int WI = WI_ALL;                                // both weight planes in either format (fp16: w_hi, w_lo)
     constexpr int WPW = (WI + NW - 1) / NW;                   // per wave (a short last round re-fetches earlier units: equal counts)
-    constexpr int NDMA = XI + WPW;                            // DMA instructions per wave per tile (6; F16: 4 or 5)
+    constexpr int NDMA = (F16 ? XI / 2 : XI) + WPW;           // DMA instructions per wave per tile (6; fp16 activations have ONE plane: 4 or 5)
     constexpr int EPI_ROW = NT * 64 + 16;
     static_assert(NW * 2 * 32 * EPI_ROW <= STAGES * STAGE_UNITS * 16, "epilogue slabs fit in the ring");
     static_assert((8 * BM / 64) % (2 * NW) == 0 && ((8 * BN / 64) % NW == 0 || NW % (8 * BN / 64 / 2) == 0), "whole DMA instructions per wave and plane (fewer weight instructions than waves: duplicate fetches)");
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
                 const u32x4* gh = ok ? reinterpret_cast<const u32x4*>(px) : zero;
                 const u32x4* gl = ok ? reinterpret_cast<const u32x4*>(px + pln) : zero;
                 dma16(gh, sbyte + (unsigned)((wave + NW * i) * 1024));
-                dma16(gl, sbyte + (unsigned)((4 * BM + (wave + NW * i) * 64) * 16));
+                if constexpr (!F16) dma16(gl, sbyte + (unsigned)((4 * BM + (wave + NW * i) * 64) * 16));
             }
         } else if constexpr (SIMPLE == 1) {
             const int tap = s_ty * p.kw + s_tx;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
                 const u32x4* gh = ok ? reinterpret_cast<const u32x4*>(px) : zero;
                 const u32x4* gl = ok ? reinterpret_cast<const u32x4*>(px + splane) : zero;
                 dma16(gh, sbyte + (unsigned)((wave + NW * i) * 1024));
-                dma16(gl, sbyte + (unsigned)((4 * BM + (wave + NW * i) * 64) * 16));
+                if constexpr (!F16) dma16(gl, sbyte + (unsigned)((4 * BM + (wave + NW * i) * 64) * 16));
             }
             if (++s_tx == p.kw) { s_tx = 0; if (++s_ty == p.kh) { s_ty = 0; ++s_cb; } }
         } else {
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
                 const u32x4* gh = ok ? reinterpret_cast<const u32x4*>(px) : zero;
                 const u32x4* gl = ok ? reinterpret_cast<const u32x4*>(px + plane) : zero;
                 dma16(gh, sbyte + (unsigned)((wave + NW * i) * 1024));
-                dma16(gl, sbyte + (unsigned)((4 * BM + (wave + NW * i) * 64) * 16));
+                if constexpr (!F16) dma16(gl, sbyte + (unsigned)((4 * BM + (wave + NW * i) * 64) * 16));
             }
         }
         // ---- weights: the stage image is the global image ----
@@ -247,14 +247,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
 #pragma unroll
             for (int b = 0; b < NT; ++b) {
                 wh[s][b] = Wh[kg * BN + wn0 + b * 32 + frow];
-                wl[s][b] = F16 ? wh[s][b] : Wl[kg * BN + wn0 + b * 32 + frow];
+                wl[s][b] = Wl[kg * BN + wn0 + b * 32 + frow];
             }
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
                 const int mrow = wm0 + a * 32 + frow;
                 const int slot = mrow * 4 + (kg ^ ((mrow >> 2) & 3));        // [pixel][octet ^ swizzle]
                 xh[s][a] = Xh[slot];
-                xl[s][a] = Xl[slot];
+                xl[s][a] = F16 ? xh[s][a] : Xl[slot];
             }
         };
         fragments(0);
@@ -266,12 +266,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
-            for (int pr = (F16 ? 1 : 0); pr < 3; ++pr)
+            for (int pr = 0; pr < 3; ++pr) {      // x_hi*w_lo, x_lo*w_hi, x_hi*w_hi; fp16 activations have no lo plane
+                if (F16 && pr == 1) continue;
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
 #pragma unroll
                     for (int a = 0; a < MT; ++a)
                         acc[a][b] = mfma_frag<F16>(pr == 0 ? wl[s][b] : wh[s][b], pr == 1 ? xl[s][a] : xh[s][a], acc[a][b]);
+            }
         }
     }
 
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
                         split4_t<O16>(v, h, l);
                         if ((lane & 3) == 0) {
                             *reinterpret_cast<uint2*>(sh + ((lane & 31) >> 2) * ROW + nl * 2) = h;
-                            *reinterpret_cast<uint2*>(sl + ((lane & 31) >> 2) * ROW + nl * 2) = l;
+                            if constexpr (!O16) *reinterpret_cast<uint2*>(sl + ((lane & 31) >> 2) * ROW + nl * 2) = l;
                         }
                     }
                 __builtin_amdgcn_wave_barrier();
@@ -328,10 +330,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
                     const int mo = m0 + a * 32 + pix * 4;
                     if (pix < 8 && mo < M) {
                         const u32x4 h = *reinterpret_cast<const u32x4*>(sh + pix * ROW + seg * 16);
-                        const u32x4 l = *reinterpret_cast<const u32x4*>(sl + pix * ROW + seg * 16);
                         uint16_t* o = oaddr((size_t)(mo >> 2), n0 + seg * 8);
                         *reinterpret_cast<u32x4*>(o) = h;
-                        *reinterpret_cast<u32x4*>(o + p.out_plane) = l;
+                        if constexpr (!O16) *reinterpret_cast<u32x4*>(o + p.out_plane) = *reinterpret_cast<const u32x4*>(sl + pix * ROW + seg * 16);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
                     uint2 h, l;
                     split4_t<O16>(v, h, l);
                     *reinterpret_cast<uint2*>(sh + (lane & 31) * ROW + nl * 2) = h;
-                    *reinterpret_cast<uint2*>(sl + (lane & 31) * ROW + nl * 2) = l;
+                    if constexpr (!O16) *reinterpret_cast<uint2*>(sl + (lane & 31) * ROW + nl * 2) = l;
                 }
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -362,11 +363,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
                 const int pix = ps * PPP + prow;
                 const int mo = m0 + a * 32 + pix;
                 const u32x4 h = *reinterpret_cast<const u32x4*>(sh + pix * ROW + seg * 16);
-                const u32x4 l = *reinterpret_cast<const u32x4*>(sl + pix * ROW + seg * 16);
                 if (mo < M) {
                     uint16_t* o = oaddr((size_t)mo, n0 + seg * 8);
                     *reinterpret_cast<u32x4*>(o) = h;
-                    *reinterpret_cast<u32x4*>(o + p.out_plane) = l;
+                    if constexpr (!O16) *reinterpret_cast<u32x4*>(o + p.out_plane) = *reinterpret_cast<const u32x4*>(sl + pix * ROW + seg * 16);
                 }
             }
             __builtin_amdgcn_wave_barrier();

@@ -69,7 +69,7 @@ __device__ __forceinline__ void split_epilogue_act(f32x16 (&acc)[MT][NT], unsign
             if (mo < M && n < p.Cout) {
                 uint16_t* o = out_hi + (size_t)mo * p.Cout + n;
                 *reinterpret_cast<u32x4*>(o) = h;
-                *reinterpret_cast<u32x4*>(o + p.out_plane) = l;
+                if constexpr (!F16) *reinterpret_cast<u32x4*>(o + p.out_plane) = l;      // (F16 here = the OUTPUT format)
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -103,7 +103,8 @@ struct STile {
     static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
 };
 
-// F16: fp16 planes, one fp16 weight plane, two MFMA products per product (split_fmt.hpp)
+// F16: ONE fp16 activation plane (the lo-plane reads below fetch unused bytes), two fp16 weight planes, two MFMA products per
+// product (split_fmt.hpp)
 template <int WAVES_M, int WAVES_N, int MT, int NT, bool VEC, bool F16 = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_split_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
     using T = STile<WAVES_M, WAVES_N, MT, NT>;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_split_kernel(cons
             if (BN * 4 >= NTHR || idx < BN * 4) {
                 const size_t o = (size_t)(kt * 4 + kg) * CoutPad + bn0 + n_l;
                 rwh[i] = wt_hi[o];
-                if (!F16) rwl[i] = wt_lo[o];
+                rwl[i] = wt_lo[o];
             }
         }
         if (VEC || kt < vtiles) {
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_split_kernel(cons
 #pragma unroll
         for (int i = 0; i < T::B_LD; ++i) {
             const int idx = t + NTHR * i;
-            if (BN * 4 >= NTHR || idx < BN * 4) { Wh[idx] = rwh[i]; if (!F16) Wl[idx] = rwl[i]; }
+            if (BN * 4 >= NTHR || idx < BN * 4) { Wh[idx] = rwh[i]; Wl[idx] = rwl[i]; }
         }
         __syncthreads();
         if (kt + 1 < ktiles) load_tile(kt + 1);
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_split_kernel(cons
 #pragma unroll
             for (int b = 0; b < NT; ++b) {
                 wh[b] = Wh[kg * BN + wn0 + b * 32 + frow];
-                wl[b] = F16 ? wh[b] : Wl[kg * BN + wn0 + b * 32 + frow];
+                wl[b] = Wl[kg * BN + wn0 + b * 32 + frow];
             }
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
@@ -264,12 +265,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_split_kernel(cons
             // the three products of one accumulator are issued MT*NT MFMAs apart (no back-to-back dependent MFMAs).
             // (s_setprio(1) around this cluster was measured: -25 %, the co-resident blocks' staging starves)
 #pragma unroll
-            for (int pr = (F16 ? 1 : 0); pr < 3; ++pr)
+            for (int pr = 0; pr < 3; ++pr) {
+                if (F16 && pr == 1) continue;                      // fp16 activations: no lo plane, products x*w_lo and x*w_hi
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
 #pragma unroll
                     for (int a = 0; a < MT; ++a)
                         acc[a][b] = mfma_frag<F16>(pr == 0 ? wl[b] : wh[b], pr == 1 ? xl[a] : xh[a], acc[a][b]);
+            }
         }
     }
 

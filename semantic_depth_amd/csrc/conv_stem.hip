@@ -33,7 +33,7 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
     uint2* const Xl = Xh + ST_MAXPIX;
     u32x4* const Wh = reinterpret_cast<u32x4*>(Xl + ST_MAXPIX);
     u32x4* const Wl = Wh + wunits;
-    unsigned char* const slab = reinterpret_cast<unsigned char*>(Wl + (F16 ? 0 : wunits));
+    unsigned char* const slab = reinterpret_cast<unsigned char*>(Wl + wunits);          // (both weight planes in either format)
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
         const size_t wplane = (size_t)(p.Kpad / 8) * p.CoutPad;
         for (int i = t; i < wunits; i += 512) {
             Wh[i] = g[i];
-            if (!F16) Wl[i] = g[wplane + i];
+            Wl[i] = g[wplane + i];
         }
     }
     f32x4 bias[4 * NB];
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
             const int ry = px / IW, rx = px - ry * IW;
             const int gy = tl.ty0 * s - p.pad + ry, gx = tl.tx0 * s - p.pad + rx;
             uint2 v = {0u, 0u};
-            if (u < 2 * npix && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win)
+            if (u < (F16 ? 1 : 2) * npix && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win)      // fp16 input: ONE plane
                 v = src[(pl ? splane : (size_t)0) + ((size_t)tl.img * p.Hin + gy) * p.Win + gx];
             pf[i] = v;
         }
@@ -123,12 +123,14 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
             for (int nb = 0; nb < NB; ++nb) {
                 const int wi = (2 * ks + fk) * CP + nb * 32 + frow;
                 const u32x4 wh = Wh[wi];
-                const u32x4 wl = F16 ? wh : Wl[wi];
+                const u32x4 wl = Wl[wi];
 #pragma unroll
-                for (int pr = (F16 ? 1 : 0); pr < 3; ++pr)
+                for (int pr = 0; pr < 3; ++pr) {              // x_hi*w_lo, x_lo*w_hi, x_hi*w_hi; an fp16 input has no lo plane
+                    if (F16 && pr == 1) continue;
 #pragma unroll
                     for (int a = 0; a < RW; ++a)
                         acc[a][nb] = mfma_frag<F16>(pr == 0 ? wl : wh, pr == 1 ? xl[a] : xh[a], acc[a][nb]);
+                }
             }
         }
 
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
                     split4_t<O16>(v, hh[r4], ll[r4]);
                 }
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
+                for (int pl = 0; pl < (O16 ? 1 : 2); ++pl) {      // fp16 outputs: the hi plane only
 #pragma unroll
                     for (int r4 = 0; r4 < 4 * NB; ++r4)
                         *reinterpret_cast<uint2*>(sh + frow * ROW + (8 * r4 + 4 * fk) * 2) = pl ? ll[r4] : hh[r4];
@@ -205,7 +207,7 @@ hipError_t launch_conv_stem(const ConvParams& p, hipStream_t s) {
     }
     const int nb = p.Cout / 32, rw = p.stride == 1 ? 2 : 1;
     const int tiles = (p.Wout / ST_TW) * ((p.Hout + 8 * rw - 1) / (8 * rw)) * p.N;
-    const size_t wbytes = (size_t)(p.Kpad / 8) * p.Cout * 16 * (p.f16 ? 1 : 2);
+    const size_t wbytes = (size_t)(p.Kpad / 8) * p.Cout * 16 * 2;
     const size_t lds = (size_t)2 * ST_MAXPIX * 8 + wbytes + (size_t)8 * 32 * (64 * nb + 16);
     const dim3 grid((unsigned)(tiles < cus ? tiles : cus));
 #define SD_STEM(NB_, RW_, F_)                                                                                          \

@@ -9,7 +9,7 @@ namespace sd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Every op below exists for the three activation formats: f32 NHWC (0), split-bf16 planes (1) and split-fp16 planes (2)
+// Every op below exists for the three activation formats: f32 NHWC (0), split-bf16 planes (1) and ONE fp16 plane (2)
 // of split_fmt.hpp (template parameter SPLIT; `plane` = element offset of the lo plane).
 // ---------------------------------------------------------------------------------------------
 // K1: VGG 'Processing' block [UPSTREAM Udacity vgg]: split (c0,c1,c2), subtract means, concat reversed.
@@ -22,7 +22,7 @@ __device__ __forceinline__ void store4(float* base, size_t plane, long quad_inde
         split4_t<SPLIT == 2>(v, h, l);
         uint2* hp = reinterpret_cast<uint2*>(base);             // bf16 plane: one uint2 per channel quad
         hp[quad_index] = h;
-        reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + plane)[quad_index] = l;
+        if (SPLIT != 2) reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + plane)[quad_index] = l;      // fp16: ONE plane
     } else {
         reinterpret_cast<f32x4*>(base)[quad_index] = v;
     }
@@ -31,7 +31,8 @@ template <int SPLIT>
 __device__ __forceinline__ f32x4 load4(const float* base, size_t plane, long quad_index) {
     if (SPLIT) {
         const uint2 h = reinterpret_cast<const uint2*>(base)[quad_index];
-        const uint2 l = reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + plane)[quad_index];
+        uint2 l = {0u, 0u};
+        if (SPLIT != 2) l = reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + plane)[quad_index];
         return recon4_t<SPLIT == 2>(h, l);
     }
     return reinterpret_cast<const f32x4*>(base)[quad_index];
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void maxpool3z_oct_kernel(const float* __restr
             f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;   // the padding is ZERO and takes part in the max (upstream quirk)
             if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
                 const long q = (((long)n * H + iy) * W + ix) * C8 + c;
-                const u32x4_t h = xh[q], l = xl[q];
+                const u32x4_t h = xh[q], l = F16 ? h : xl[q];
                 v0 = recon4_t<F16>(uint2{h[0], h[1]}, uint2{l[0], l[1]});
                 v1 = recon4_t<F16>(uint2{h[2], h[3]}, uint2{l[2], l[3]});
             }
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void maxpool3z_oct_kernel(const float* __restr
     split4_t<F16>(m0, h0, l0);
     split4_t<F16>(m1, h1, l1);
     reinterpret_cast<u32x4_t*>(y)[i] = (u32x4_t){h0.x, h0.y, h1.x, h1.y};
-    reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(y) + plane_out)[i] = (u32x4_t){l0.x, l0.y, l1.x, l1.y};
+    if (!F16) reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(y) + plane_out)[i] = (u32x4_t){l0.x, l0.y, l1.x, l1.y};
 }
 hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
@@ -244,10 +245,10 @@ __global__ __launch_bounds__(256) void conv_smalln_thread_kernel(const SmallNPar
         else split2_t<false>(f32x2_t{smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)}, h, l);
         if (p.out_c == 8) {       // one zero-padded channel octet per pixel (source of the direct 3x3 kernel)
             reinterpret_cast<u32x4_t*>(p.out)[pix] = (u32x4_t){h, 0u, 0u, 0u};
-            reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(p.out) + p.out_plane)[pix] = (u32x4_t){l, 0u, 0u, 0u};
+            if (!p.out_f16) reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(p.out) + p.out_plane)[pix] = (u32x4_t){l, 0u, 0u, 0u};
         } else {
             reinterpret_cast<unsigned*>(p.out)[pix] = h;
-            reinterpret_cast<unsigned*>(reinterpret_cast<uint16_t*>(p.out) + p.out_plane)[pix] = l;
+            if (!p.out_f16) reinterpret_cast<unsigned*>(reinterpret_cast<uint16_t*>(p.out) + p.out_plane)[pix] = l;
         }
     } else {
         float* o = p.out + pix * NOUT;
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(256) void conv_smalln_tile_kernel(const SmallNParam
     for (int c0 = 0; c0 < p.C; c0 += 16) {
         const int nvalid = (p.C - c0) >= 16 ? 2 : 1;
         __syncthreads();                                   // the previous chunk is consumed (and the weights are staged)
-        for (int j = wave; j < 2 * SN_XI; j += 4) {        // wave-uniform: instruction j of [hi plane | lo plane]
+        for (int j = wave; j < (F16 ? 1 : 2) * SN_XI; j += 4) {        // wave-uniform: instruction j of [hi plane | lo plane]; fp16: ONE plane
             const int pl = j >= SN_XI ? 1 : 0;
             const int u = (j - pl * SN_XI) * 64 + lane;
             const int pix = u >> 1;
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(256) void conv_smalln_tile_kernel(const SmallNParam
             const int lp = (row + tap / 3) * SN_HW + col + tap % 3;
             for (int oct = 0; oct < nvalid; ++oct) {
                 const int idx = lp * 2 + (oct ^ ((lp >> 3) & 1));
-                const u32x4_t h = X[idx], l = X[SN_XUNITS + idx];
+                const u32x4_t h = X[idx], l = F16 ? h : X[SN_XUNITS + idx];
                 const f32x4 v0 = recon4_t<F16>(uint2{h[0], h[1]}, uint2{l[0], l[1]});
                 const f32x4 v1 = recon4_t<F16>(uint2{h[2], h[3]}, uint2{l[2], l[3]});
 #pragma unroll
@@ -375,10 +376,10 @@ __global__ __launch_bounds__(256) void conv_smalln_tile_kernel(const SmallNParam
         else split2_t<false>(f32x2_t{smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)}, h, l);
         if (p.out_c == 8) {
             reinterpret_cast<u32x4_t*>(p.out)[pix] = (u32x4_t){h, 0u, 0u, 0u};
-            reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(p.out) + p.out_plane)[pix] = (u32x4_t){l, 0u, 0u, 0u};
+            if (!p.out_f16) reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(p.out) + p.out_plane)[pix] = (u32x4_t){l, 0u, 0u, 0u};
         } else {
             reinterpret_cast<unsigned*>(p.out)[pix] = h;
-            reinterpret_cast<unsigned*>(reinterpret_cast<uint16_t*>(p.out) + p.out_plane)[pix] = l;
+            if (!p.out_f16) reinterpret_cast<unsigned*>(reinterpret_cast<uint16_t*>(p.out) + p.out_plane)[pix] = l;
         }
     } else {
         float* o = p.out + pix * NOUT;
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(256) void unsplit_kernel(const float* __restrict__ 
     const long pix = i / Ctf;
     const int c = (int)(i - pix * Ctf);
     const uint16_t* h = reinterpret_cast<const uint16_t*>(x) + (sub ? (size_t)(c >> 4) * sub + (size_t)pix * 16 + (c & 15) : (size_t)pix * C + c);
-    if (f16) y[i] = (float)__builtin_bit_cast(_Float16, h[0]) + (float)__builtin_bit_cast(_Float16, h[plane]);
+    if (f16) y[i] = (float)__builtin_bit_cast(_Float16, h[0]);                        // fp16 tensors have ONE plane
     else y[i] = __uint_as_float((unsigned)h[0] << 16) + __uint_as_float((unsigned)h[plane] << 16);
 }
 hipError_t launch_unsplit(const float* x, float* y, long npix, int C, int Ctf, size_t plane, size_t sub, int f16, hipStream_t s) {

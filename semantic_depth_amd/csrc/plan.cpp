@@ -566,6 +566,28 @@ static uint16_t f32_to_f16_rne(float v) {
     return (uint16_t)(sign | r);
 }
 
+static float f16_bits_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    uint32_t u;
+    if (e == 0) {
+        if (m == 0) u = sign;
+        else {                                   // subnormal: m * 2^-24
+            float f = (float)m * 5.9604644775390625e-08f;
+            std::memcpy(&u, &f, 4);
+            u |= sign;
+        }
+    } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+    else u = sign | ((e + 112u) << 23) | (m << 13);
+    float f; std::memcpy(&f, &u, 4);
+    return f;
+}
+// the two fp16 weight planes of the 2-product scheme (split_fmt.hpp): w_hi = RNE(w), w_lo = RNE(w - w_hi) (22 bits together; w_lo of
+// an ordinary weight is an fp16 subnormal, which the MFMA honours)
+static inline void f16_split(float w, uint16_t& hi, uint16_t& lo) {
+    hi = f32_to_f16_rne(w);
+    lo = f32_to_f16_rne(w - f16_bits_to_f32(hi));
+}
+
 // ---------------------------------------------------------------------------------------------
 void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& out) {
     out.assign(s.bytes / sizeof(float), 0.f);
@@ -578,7 +600,7 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
             u += 0x7FFFu + ((u >> 16) & 1u);
             return (uint16_t)(u >> 16);
         };
-        const bool f16 = s.f16 != 0;                   // hi plane = fp16(w) (RNE, subnormals kept), lo plane stays zero
+        const bool f16 = s.f16 != 0;                   // two fp16 planes: hi = fp16(w) (RNE, subnormals kept), lo = fp16(w - hi)
         auto bf16_to_f = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; };
         const int64_t taps = s.shape[0] * s.shape[1], Ctf = s.shape[2], Cout = s.shape[3];
         int CtotPad = 0;
@@ -603,7 +625,7 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
                     } else {                          // two bf16 planes [k/8][n][8]
                         const size_t base = (size_t)(k / 8) * s.CoutPad * 8 + (k % 8);
                         for (int64_t n = 0; n < Cout; ++n) {
-                            if (f16) { hi[base + n * 8] = f32_to_f16_rne(src[n]); continue; }
+                            if (f16) { f16_split(src[n], hi[base + n * 8], lo[base + n * 8]); continue; }
                             const uint16_t h = bf16(src[n]);
                             hi[base + n * 8] = h;
                             lo[base + n * 8] = bf16(src[n] - bf16_to_f(h));
@@ -631,7 +653,7 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
                         const size_t base = (((size_t)chunk * 9 + tap) * 2 + oct) * s.CoutPad * 8 + e;
                         for (int64_t n = 0; n < Cout; ++n) {
                             uint16_t* hi = hi0 + (size_t)(n / s.CoutPad) * 2 * plane + base + (n % s.CoutPad) * 8;
-                            if (s.f16) { *hi = f32_to_f16_rne(src[n]); continue; }
+                            if (s.f16) { f16_split(src[n], *hi, hi[plane]); continue; }
                             const uint16_t h = bf16(src[n]);
                             *hi = h;
                             hi[plane] = bf16(src[n] - bf16_to_f(h));

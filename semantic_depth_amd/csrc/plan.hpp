@@ -16,8 +16,8 @@ struct TensorDesc {
     int N = 0, H = 0, W = 0, C = 0;   // C = stored channels
     int Ctf = 0;                      // channels the TensorFlow graph sees (input_pre stores 4, TF sees 3)
     int fmt = 0;                      // 0: f32 NHWC; 1: split-bf16 planes (split_fmt.hpp)
-    int f16 = 0;                      // split planes are fp16 (hi + lo, 22 bits) instead of bf16: every conv that reads it runs the
-                                      // 2-product scheme (precision plan, see NetPlan::f16_spec)
+    int f16 = 0;                      // ONE fp16 plane instead of two bf16 planes (split_fmt.hpp): every conv that reads it runs the
+                                      // 2-product scheme x * (w_hi + w_lo) (precision plan, see NetPlan::f16_spec)
     int planar16 = 0;                 // split planes stored as C/16 sub-planes of 16 channels ([C/16][N][H][W][16] per plane): the
                                       // producer is the stem kernel, the only consumer a direct conv, whose 16-channel halo DMA
                                       // then reads whole 128-byte lines
@@ -38,7 +38,7 @@ struct WeightSlot {
     int nsplit = 1;        // WL_DIRECT_SPLIT: output channels are stored as nsplit blocks of CoutPad (128-channel layers: 2 x 64)
     int nsrc = 1, srcCtf[3] = {0, 0, 0}, srcCpad[3] = {0, 0, 0};   // WL_IGEMM: channel structure of the K axis
     int vec = 0;           // 1: K axis is ordered (32-channel block, tap, channel) instead of (tap, channel)
-    int f16 = 0;           // split layouts: hi plane = fp16(w), lo plane unused (the 2-product scheme of split_fmt.hpp)
+    int f16 = 0;           // split layouts: two fp16 planes, hi = fp16(w), lo = fp16(w - hi) (the 2-product scheme of split_fmt.hpp)
     // a slot may be a VIEW of rows [k_off, k_off+Kpad) of a larger device matrix of Ktotal rows owned by slot `owner`
     // (ResNet block: conv3 and the projection shortcut are one GEMM over the concatenated K axis); a bias view is ADDED
     // to its owner's bias
@@ -62,7 +62,7 @@ struct OpDesc {
     // conv engine
     int Ctot = 0;          // padded channels per tap (every source rounded up to a multiple of 4)
     int K = 0, Kpad = 0, vec = 0, m_fastest = 0;
-    int f16 = 0;                 // conv ops: sources are fp16 planes, weights one fp16 plane, TWO MFMA products per product
+    int f16 = 0;                 // conv ops: sources are single fp16 planes, weights two fp16 planes, TWO MFMA products per product
     int fuse_pool = 0;           // OP_CONV_DIRECT / OP_CONV (LDS-DMA kernel): the 2x2 max pool that follows is applied in the epilogue
     int nchunks = 0;             // OP_CONV_DIRECT: 32-channel chunks over the concatenated sources
     int nsplit = 1;              // OP_CONV_DIRECT: passes of <= 64 output channels per tile

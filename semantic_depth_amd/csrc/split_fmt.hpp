@@ -1,11 +1,15 @@
-// "Split planes" activation format of the split precisions: a tensor [N,H,W,C] is stored as two 16-bit planes,
-// hi = RNE(v) and lo = RNE(v - hi), the lo plane following the hi plane at a fixed element offset (plane stride =
-// Nmax*H*W*C, Nmax = images of a full chunk).  Same bytes as f32; the MFMA operands of the conv engine are read straight
-// from the planes (16-byte runs of 8 channels), nothing is split at load time.
-//   bf16 planes (16 mantissa bits, f32 range): SD_PREC_BF16X2, weights split the same way, 3 MFMA products per product;
-//   fp16 planes (22 mantissa bits, |v| < 65504; the MFMA honours fp16 subnormals): the monodepth network of
-//   SD_PREC_MIXED, weights rounded ONCE to fp16, 2 MFMA products per product (x_hi*w + x_lo*w): the only error is the
-//   2^-12 relative rounding of the weights.  The F16 template argument of the helpers selects the element type.
+// Activation formats of the split precisions (a tensor [N,H,W,C] is stored as 16-bit planes; same bytes reserved as f32):
+//   bf16 x 2 planes (SD_PREC_BF16X2; 16 mantissa bits, f32 range): hi = RNE(v), lo = RNE(v - hi), the lo plane following the hi
+//     plane at a fixed element offset (plane stride = Nmax*H*W*C, Nmax = images of a full chunk).  Weights are split the same
+//     way; a product is THREE MFMA products  x_hi*w_hi + x_hi*w_lo + x_lo*w_hi  (dropped term ~2^-18).
+//   fp16 x 1 plane (the 2-product layers of a precision plan; |v| < 65504, the MFMA honours fp16 subnormals): the activation is
+//     rounded ONCE to fp16 (11 bits) by the epilogue that produces it and only the hi plane exists; the WEIGHTS are split into two
+//     fp16 planes (w_hi = RNE(w), w_lo = RNE(w - w_hi): 22 bits); a product is TWO MFMA products  x*w_hi + x*w_lo.  The only
+//     error is the 2^-12 relative rounding of the activation -- the same size as rounding the weights instead (round 1's form
+//     of the scheme: fp16 x 2 activation planes times ONE fp16 weight plane), but every activation tensor is half the bytes in
+//     HBM, L2 and the LDS-DMA, which is what the HBM-bound layers (ResNet 1x1 layers, the full-resolution decoder) run against.
+// The MFMA operands of the conv engine are read straight from the planes (16-byte runs of 8 channels), nothing is converted at
+// load time.  The F16 template argument of the helpers selects the format; their `l` argument is ignored / zero for fp16.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -53,7 +57,7 @@ typedef unsigned u32x4s_t __attribute__((ext_vector_type(4)));
 
 template <bool F16> __device__ __forceinline__ f32x2_t recon2_t(unsigned h, unsigned l) {
     if constexpr (F16) {
-        return __builtin_convertvector(__builtin_bit_cast(f16x2_t, h), f32x2_t) + __builtin_convertvector(__builtin_bit_cast(f16x2_t, l), f32x2_t);
+        return __builtin_convertvector(__builtin_bit_cast(f16x2_t, h), f32x2_t);      // one plane: the lo argument is not read
     } else {
         return recon2(h, l);
     }
@@ -64,11 +68,9 @@ template <bool F16> __device__ __forceinline__ f32x4_t recon4_t(uint2 h, uint2 l
 }
 template <bool F16> __device__ __forceinline__ void split2_t(f32x2_t v, unsigned& h, unsigned& l) {
     if constexpr (F16) {
-        const f16x2_t hb = __builtin_convertvector(v, f16x2_t);                   // round to nearest even
-        const f32x2_t r = v - __builtin_convertvector(hb, f32x2_t);               // exact
-        const f16x2_t lb = __builtin_convertvector(r, f16x2_t);
+        const f16x2_t hb = __builtin_convertvector(v, f16x2_t);                   // round to nearest even; there is no lo plane
         h = __builtin_bit_cast(unsigned, hb);
-        l = __builtin_bit_cast(unsigned, lb);
+        l = 0u;
     } else {
         split2(v, h, l);
     }
