@@ -43,7 +43,7 @@ H, W = 512, 1024
 # MI355X_MICROARCH.md peaks.  f32: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz.
 # split-bf16 (3 products): every algorithmic product costs three dense-bf16 MFMA products (hi*hi + hi*lo + lo*hi), so the
 # ceiling for ALGORITHMIC flops is the dense bf16 peak / 3; split-fp16 x fp16 weights (2 products): dense fp16 peak / 2.
-PEAK_F32, PEAK_3P, PEAK_2P = 157.3, 2500.0 / 3.0, 2500.0 / 2.0
+PEAK_F32, PEAK_3P, PEAK_2P, PEAK_1P = 157.3, 2500.0 / 3.0, 2500.0 / 2.0, 2500.0
 DTYPE = {
     "f32": "f32 (exact: v_mfma_f32_16x16x4_f32)",
     "bf16x2": "bf16x2 split operands (hi+lo, 16 mantissa bits), 3 bf16 MFMA products per product, f32 accumulate",
@@ -318,6 +318,8 @@ def main():
 def peak_of(kernel: str, precision: str) -> float:
     if "igemm" in kernel:
         return PEAK_F32
+    if "f16x1" in kernel:
+        return PEAK_1P
     return PEAK_2P if "f16w" in kernel else PEAK_3P
 
 

@@ -80,40 +80,65 @@ def main():
     top = 6 if a.encoder == "resnet50" else 7
     mono_groups += [f"dec/upconv{l},dec/iconv{l}" + (f",dec/disp{l}" if 2 <= l <= 4 else "") for l in range(top, 0, -1)]
 
+    def with_mode(g, mode):        # "a,b" -> "a:1,b:1" for the one-product form
+        return g if mode == 2 else ",".join(t + ":1" for t in g.split(","))
+
     rows = []
     for net, groups in (("fcn", fcn_groups), ("mono", mono_groups)):
         for g in groups:
-            r = run("plan", (g, "") if net == "fcn" else ("", g), nets=(net,))
-            layers, share = r["plan"]["fcn8s" if net == "fcn" else "monodepth"]
-            err = rel(r["logits"], ref["logits"]) if net == "fcn" else rel(r["disp"], ref["disp"])
-            rows.append(dict(net=net, group=g, layers=layers, flop_share=share, err_vs_f32=err,
-                             err_added=max(err * err - floor[net] ** 2, 0.0) ** 0.5))
-            print(f"{net:5s} {g:40s} share {share:6.3f}  err {err:.2e}  (+{rows[-1]['err_added']:.2e})  layers {len(layers)}", flush=True)
+            row = dict(net=net, group=g)
+            for mode in (2, 1):          # two MFMA products (x * (w_hi + w_lo)) / one (x * w_hi)
+                spec = with_mode(g, mode)
+                r = run("plan", (spec, "") if net == "fcn" else ("", spec), nets=(net,))
+                layers, share = r["plan"]["fcn8s" if net == "fcn" else "monodepth"]
+                err = rel(r["logits"], ref["logits"]) if net == "fcn" else rel(r["disp"], ref["disp"])
+                row.update({f"layers_{mode}p": layers, "flop_share": share, f"err_{mode}p": err,
+                            f"err_added_{mode}p": max(err * err - floor[net] ** 2, 0.0) ** 0.5})
+            rows.append(row)
+            print(f"{net:5s} {g:40s} share {row['flop_share']:6.3f}  2 products +{row['err_added_2p']:.2e}   1 product +{row['err_added_1p']:.2e}", flush=True)
 
-    groups_of = {}
+    # greedy: steps (3 -> 2 products) and (2 -> 1) of every group, cheapest added error^2 per saved product-FLOP first
+    mode_of = {}
     for net in ("fcn", "mono"):
-        cand = sorted((r for r in rows if r["net"] == net), key=lambda r: r["err_added"] / max(r["flop_share"], 1e-9))
-        chosen, acc2 = [], floor[net] ** 2
-        for r in cand:
-            if (acc2 + r["err_added"] ** 2) ** 0.5 <= a.budget:
-                chosen.append(r["group"])
-                acc2 += r["err_added"] ** 2
-        groups_of[net] = chosen
-    # measure the combined plan; drop the costliest group of a network while that network is over budget
+        steps = []
+        for r in (x for x in rows if x["net"] == net):
+            steps.append((r["err_added_2p"] ** 2 / max(r["flop_share"], 1e-9), r["group"], 2, r["err_added_2p"] ** 2))
+            steps.append((max(r["err_added_1p"] ** 2 - r["err_added_2p"] ** 2, 0.0) / max(r["flop_share"], 1e-9), r["group"], 1,
+                          max(r["err_added_1p"] ** 2 - r["err_added_2p"] ** 2, 0.0)))
+        acc2 = floor[net] ** 2
+        mode_of[net] = {}
+        for _, g, mode, d2 in sorted(steps):
+            if mode == 1 and mode_of[net].get(g) != 2:
+                continue                                   # one product only on top of two
+            if (acc2 + d2) ** 0.5 <= a.budget:
+                mode_of[net][g] = mode
+                acc2 += d2
+        # a second sweep for (2 -> 1) steps that came before their (3 -> 2) step in the order
+        for _, g, mode, d2 in sorted(steps):
+            if mode == 1 and mode_of[net].get(g) == 2 and (acc2 + d2) ** 0.5 <= a.budget:
+                mode_of[net][g] = 1
+                acc2 += d2
+    # measure the combined plan; take back the costliest step of a network while that network is over budget
     final = None
     while True:
-        plan = {n: ",".join(g) for n, g in groups_of.items()}
+        plan = {n: ",".join(with_mode(g, m) for g, m in mode_of[n].items()) for n in ("fcn", "mono")}
         r = run("plan", (plan["fcn"], plan["mono"]))
         e = dict(fcn=rel(r["logits"], ref["logits"]), mono=rel(r["disp"], ref["disp"]))
         flips = float((r["road"] != ref["road"]).float().mean())
         print(f"combined plan: fcn [{plan['fcn']}] err {e['fcn']:.2e}; mono [{plan['mono']}] err {e['mono']:.2e}; road mask flips {flips:.2e}", flush=True)
-        over = [n for n in ("fcn", "mono") if e[n] > a.budget and groups_of[n]]
+        over = [n for n in ("fcn", "mono") if e[n] > a.budget and mode_of[n]]
         if not over:
             final = dict(err=e, road_mask_flip_frac=flips, effective=r["plan"])
             break
         for n in over:
-            worst = max(groups_of[n], key=lambda g: next(x["err_added"] for x in rows if x["group"] == g))
-            groups_of[n].remove(worst)
+            def cost(g):
+                x = next(x for x in rows if x["group"] == g)
+                return x["err_added_1p"] if mode_of[n][g] == 1 else x["err_added_2p"]
+            worst = max(mode_of[n], key=cost)
+            if mode_of[n][worst] == 1:
+                mode_of[n][worst] = 2
+            else:
+                del mode_of[n][worst]
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     with open(a.out, "w") as f:
         json.dump(dict(budget=a.budget, frames=B, size=[H, W], encoder=a.encoder, floor_all_3_product=floor, groups=rows, plan=plan, final=final),

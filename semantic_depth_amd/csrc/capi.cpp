@@ -273,10 +273,10 @@ int32_t* cnt_slot(sd_handle* h, int i) { return reinterpret_cast<int32_t*>(h->ws
 extern "C" {
 
 #ifndef SD_DEFAULT_PLAN_FCN
-#define SD_DEFAULT_PLAN_FCN "conv1_2,conv2_2,conv4_2,conv4_3,conv5_1,conv5_2,conv5_3,fc6,fc7"
+#define SD_DEFAULT_PLAN_FCN "conv1_2,conv2_2,conv4_2:1,conv4_3:1,conv5_1:1,conv5_2:1,conv5_3:1,fc6:1,fc7:1"
 #endif
 #ifndef SD_DEFAULT_PLAN_MONO
-#define SD_DEFAULT_PLAN_MONO "enc/res2*,enc/res3*,enc/res4*,enc/res5*,dec/upconv6,dec/iconv6,dec/upconv5,dec/iconv5,dec/upconv4,dec/iconv4,dec/disp4,dec/upconv1,dec/iconv1"
+#define SD_DEFAULT_PLAN_MONO "enc/res2*,enc/res3*,enc/res4*:1,enc/res5*:1,dec/upconv6:1,dec/iconv6:1,dec/upconv5:1,dec/iconv5:1,dec/upconv4:1,dec/iconv4:1,dec/disp4,dec/upconv1:1,dec/iconv1:1"
 #endif
 #ifndef SD_SOURCE_HASH
 #define SD_SOURCE_HASH "unhashed"

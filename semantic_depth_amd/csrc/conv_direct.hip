@@ -67,7 +67,8 @@ __device__ __forceinline__ DirectChunk load_chunk(const DirectChunk* ptr) {
 // F16: ONE fp16 activation plane, two fp16 weight planes, two MFMA products per product (split_fmt.hpp)
 // N16 (Cout <= 16, NB = 1): the 32-row MFMA would spend half its rows on padding, so the products run on
 // v_mfma_f32_16x16x32 instead: K = 32 is one PAIR of taps x 16 channels, a wave's 2 x 32 pixels are four 16-pixel blocks.
-template <int NB, int MT, bool F16, bool N16 = false, bool UP = false>
+// W1 (with F16): ONE MFMA product per product -- the w_lo plane is neither fetched nor multiplied (plain fp16 x fp16, f32 accumulate)
+template <int NB, int MT, bool F16, bool N16 = false, bool UP = false, bool W1 = false>
 __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_kernel(const ConvDirectParams p) {
     static_assert(!N16 || NB == 1, "N16 is a variant of the 32-channel kernel");
     using Cfg = DirectCfg<NB, MT, UP>;
@@ -137,9 +138,9 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
             ddma16(ok ? reinterpret_cast<const u32x4*>(src) : zero, sbyte + (unsigned)(j * 1024));
         }
 #pragma unroll
-        for (int i = 0; i < (2 * D_WI + D_WAVES - 1) / D_WAVES; ++i) {      // both weight planes in either format
+        for (int i = 0; i < ((W1 ? 1 : 2) * D_WI + D_WAVES - 1) / D_WAVES; ++i) {      // both weight planes in either format (W1: w_hi only)
             const int jw = wave + D_WAVES * i;
-            if (jw < 2 * D_WI) {
+            if (jw < (W1 ? 1 : 2) * D_WI) {
                 const int pl = jw >= D_WI ? 1 : 0;
                 const int u = (jw - pl * D_WI) * 64 + lane;
                 const u32x4* gw = p.wt + ((size_t)(2 * half + pl) * p.nchunks + c) * D_GW + (N16 ? (u >> 4) * 32 + (u & 15) : u);
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                     const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;         // tap / 3, tap % 3 for tap < 10
                     const int wi = (tap * 2 + oct) * 16 + c16;
                     const u32x4 wh = live ? Wh[wi] : z4;
-                    const u32x4 wl = live ? Wl[wi] : z4;
+                    const u32x4 wl = W1 ? wh : (live ? Wl[wi] : z4);
 #pragma unroll
                     for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                             const u32x4 xl = F16 ? xh : (live ? Xl[idx] : z4);
 #pragma unroll
                             for (int pr = 0; pr < 3; ++pr) {      // x_hi*w_lo, x_lo*w_hi, x_hi*w_hi; fp16 activations have no lo plane
-                                if (F16 && pr == 1) continue;
+                                if ((F16 && pr == 1) || (W1 && pr == 0)) continue;
                                 acc16[a][pb] = mfma_frag16<F16>(pr == 0 ? wl : wh, pr == 1 ? xl : xh, acc16[a][pb]);
                             }
                         }
@@ -228,10 +229,10 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                     for (int nb = 0; nb < NB; ++nb) {
                         const int wi = ((dy * 3 + dx) * 2 + fk) * (32 * NB) + nb * 32 + frow;
                         const u32x4 wh = Wh[wi];
-                        const u32x4 wl = Wl[wi];
+                        const u32x4 wl = W1 ? wh : Wl[wi];
 #pragma unroll
                         for (int pr = 0; pr < 3; ++pr) {          // x_hi*w_lo, x_lo*w_hi, x_hi*w_hi; fp16 activations have no lo plane
-                            if (F16 && pr == 1) continue;
+                            if ((F16 && pr == 1) || (W1 && pr == 0)) continue;
 #pragma unroll
                             for (int a = 0; a < MT; ++a)
                                 acc[a][nb] = mfma_frag<F16>(pr == 0 ? wl : wh, pr == 1 ? xl[a + dy] : xh[a + dy], acc[a][nb]);
@@ -446,23 +447,28 @@ hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
     const int th = mt1 ? 8 : 16;
     const int tiles = (p.W / D_TW) * ((p.H + th - 1) / th) * p.N * p.nsplit;
     // persistent grid: as many workgroups as the instantiation keeps resident (1-3 per CU, by LDS and registers)
-#define SD_DIRECT_(NB_, MT_, F16_, N16_, UP_) \
+#define SD_DIRECT_(NB_, MT_, F16_, N16_, UP_, W1_) \
     do { static int per_cu = 0; \
-         if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_direct_kernel<NB_, MT_, F16_, N16_, UP_>, 512, 0) != hipSuccess || per_cu < 1)) per_cu = 1; \
+         if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_direct_kernel<NB_, MT_, F16_, N16_, UP_, W1_>, 512, 0) != hipSuccess || per_cu < 1)) per_cu = 1; \
          const int slots = cus * per_cu; \
          const dim3 grid((unsigned)(tiles < slots ? tiles : slots)); \
-         hipLaunchKernelGGL((conv_direct_kernel<NB_, MT_, F16_, N16_, UP_>), grid, dim3(512), 0, s, q); } while (0)
-#define SD_DIRECT(NB_, MT_, F16_, N16_) do { if (up) SD_DIRECT_(NB_, MT_, F16_, N16_, true); else SD_DIRECT_(NB_, MT_, F16_, N16_, false); } while (0)
-    if (p.f16) {
-        if (mt1) SD_DIRECT(1, 1, true, true);
-        else if (n16) SD_DIRECT(1, 2, true, true);
-        else if (nb == 1) SD_DIRECT(1, 2, true, false);
-        else SD_DIRECT(2, 2, true, false);
+         hipLaunchKernelGGL((conv_direct_kernel<NB_, MT_, F16_, N16_, UP_, W1_>), grid, dim3(512), 0, s, q); } while (0)
+#define SD_DIRECT(NB_, MT_, F16_, N16_, W1_) do { if (up) SD_DIRECT_(NB_, MT_, F16_, N16_, true, W1_); else SD_DIRECT_(NB_, MT_, F16_, N16_, false, W1_); } while (0)
+    if (p.f16 == 2) {           // fp16, ONE product
+        if (mt1) SD_DIRECT(1, 1, true, true, true);
+        else if (n16) SD_DIRECT(1, 2, true, true, true);
+        else if (nb == 1) SD_DIRECT(1, 2, true, false, true);
+        else SD_DIRECT(2, 2, true, false, true);
+    } else if (p.f16) {
+        if (mt1) SD_DIRECT(1, 1, true, true, false);
+        else if (n16) SD_DIRECT(1, 2, true, true, false);
+        else if (nb == 1) SD_DIRECT(1, 2, true, false, false);
+        else SD_DIRECT(2, 2, true, false, false);
     } else {
-        if (mt1) SD_DIRECT(1, 1, false, true);
-        else if (n16) SD_DIRECT(1, 2, false, true);
-        else if (nb == 1) SD_DIRECT(1, 2, false, false);
-        else SD_DIRECT(2, 2, false, false);
+        if (mt1) SD_DIRECT(1, 1, false, true, false);
+        else if (n16) SD_DIRECT(1, 2, false, true, false);
+        else if (nb == 1) SD_DIRECT(1, 2, false, false, false);
+        else SD_DIRECT(2, 2, false, false, false);
     }
 #undef SD_DIRECT_
 #undef SD_DIRECT
@@ -473,9 +479,10 @@ hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
 // 16-wide MFMA form
 const char* conv_direct_kernel_name(const ConvDirectParams& p) {
     const bool n16 = p.Cout <= 16 && p.nsplit == 1 && !p.pool && !(p.sw & SW_NO_N16);
-    if (n16) return p.f16 ? "conv_direct_f16w_kernel<1,n16>" : "conv_direct_kernel<1,n16>";
-    if (p.Cout <= 32) return p.f16 ? "conv_direct_f16w_kernel<1,2>" : "conv_direct_kernel<1,2>";
-    return p.f16 ? "conv_direct_f16w_kernel<2,2>" : "conv_direct_kernel<2,2>";
+    // f16w: fp16 activations x two fp16 weight planes (2 products); f16x1: fp16 x fp16 (1 product)
+    if (n16) return p.f16 == 2 ? "conv_direct_f16x1_kernel<1,n16>" : p.f16 ? "conv_direct_f16w_kernel<1,n16>" : "conv_direct_kernel<1,n16>";
+    if (p.Cout <= 32) return p.f16 == 2 ? "conv_direct_f16x1_kernel<1,2>" : p.f16 ? "conv_direct_f16w_kernel<1,2>" : "conv_direct_kernel<1,2>";
+    return p.f16 == 2 ? "conv_direct_f16x1_kernel<2,2>" : p.f16 ? "conv_direct_f16w_kernel<2,2>" : "conv_direct_kernel<2,2>";
 }
 
 }  // namespace sd

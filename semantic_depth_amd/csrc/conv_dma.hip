@@ -64,14 +64,15 @@ __device__ __forceinline__ KEntry load_kentry(const KEntry* ptr) {
 // the activation DMAs and 16 instead of 24 MFMAs per wave.
 // SIMPLE = 2: the two-source 1x1 GEMM of a ResNet block tail (conv3 over its 3x3 output + projection over the block input,
 // each with its own stride): two base pointers per lane, the k-tile index selects the source.
-template <int WAVES_M, int WAVES_N, int MT, int NT, int SIMPLE, int STAGES, bool F16 = false>
+// W1 (with F16): ONE MFMA product per product -- the w_lo plane is neither fetched nor multiplied (plain fp16 x fp16, f32 accumulate)
+template <int WAVES_M, int WAVES_N, int MT, int NT, int SIMPLE, int STAGES, bool F16 = false, bool W1 = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
     constexpr int STAGE_UNITS = 8 * (BM + BN);                // 16-B units: Xh [4][BM] | Xl [4][BM] | Wh [4][BN] | Wl [4][BN]
     constexpr int XI = 8 * BM / 64 / NW;                      // activation DMA instructions per wave and tile (2 or 4), hi first then lo
     constexpr int WI_ALL = 8 * BN / 64;                       // weight instructions of a tile, both planes (32, 16 or 8)
-    constexpr int WI = WI_ALL;                                // both weight planes in either format (fp16: w_hi, w_lo)
+    constexpr int WI = W1 ? WI_ALL / 2 : WI_ALL;              // both weight planes in either format (fp16: w_hi, w_lo); W1: w_hi only
     constexpr int WPW = (WI + NW - 1) / NW;                   // per wave (a short last round re-fetches earlier units: equal counts)
     constexpr int NDMA = (F16 ? XI / 2 : XI) + WPW;           // DMA instructions per wave per tile (6; fp16 activations have ONE plane: 4 or 5)
     constexpr int EPI_ROW = NT * 64 + 16;
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
 #pragma unroll
             for (int b = 0; b < NT; ++b) {
                 wh[s][b] = Wh[kg * BN + wn0 + b * 32 + frow];
-                wl[s][b] = Wl[kg * BN + wn0 + b * 32 + frow];
+                wl[s][b] = W1 ? wh[s][b] : Wl[kg * BN + wn0 + b * 32 + frow];
             }
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int pr = 0; pr < 3; ++pr) {      // x_hi*w_lo, x_lo*w_hi, x_hi*w_hi; fp16 activations have no lo plane
-                if (F16 && pr == 1) continue;
+                if ((F16 && pr == 1) || (W1 && pr == 0)) continue;
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
 #pragma unroll
@@ -399,7 +400,11 @@ static void launch_dma_variant(const ConvParams& p, long M, hipStream_t s) {
     const int tilesM = (int)((M + WM * MT * 32 - 1) / (WM * MT * 32)), tilesN = p.Cout / (WN * NT * 32);
     const dim3 grid((unsigned)(tilesM * tilesN)), block(64 * WM * WN);
     const int mode = (p.dbg & 16) ? 0 : p.simple;
-    if (p.f16) {
+    if (p.f16 == 2) {
+        if (mode == 2) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 2, STAGES, true, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+        else if (mode == 1) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 1, STAGES, true, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+        else hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 0, STAGES, true, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+    } else if (p.f16) {
         if (mode == 2) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 2, STAGES, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
         else if (mode == 1) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 1, STAGES, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
         else hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 0, STAGES, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
@@ -423,22 +428,15 @@ hipError_t launch_conv_dma(const ConvParams& p0, hipStream_t s) {
 }
 
 const char* conv_dma_kernel_name(const ConvParams& p) {
-    if (p.f16) {
-        switch (conv_dma_variant(p)) {
-            case 1: return "conv_dma_f16w_kernel<2,4,2,2>";
-            case 2: return "conv_dma_f16w_kernel<4,2,2,2>";
-            case 4: return "conv_dma_f16w_kernel<8,1,1,1>";
-            case 5: return "conv_dma_f16w_kernel<2,4,4,2>";
-            default: return "conv_dma_f16w_kernel<4,2,2,1>";
-        }
-    }
-    switch (conv_dma_variant(p)) {
-        case 1: return "conv_dma_kernel<2,4,2,2>";
-        case 2: return "conv_dma_kernel<4,2,2,2>";
-        case 4: return "conv_dma_kernel<8,1,1,1>";
-        case 5: return "conv_dma_kernel<2,4,4,2>";
-        default: return "conv_dma_kernel<4,2,2,1>";
-    }
+    // f16w: fp16 activations x two fp16 weight planes (2 products); f16x1: fp16 x fp16 (1 product)
+    static const char* const names[3][5] = {
+        {"conv_dma_kernel<2,4,2,2>", "conv_dma_kernel<4,2,2,2>", "conv_dma_kernel<4,2,2,1>", "conv_dma_kernel<8,1,1,1>", "conv_dma_kernel<2,4,4,2>"},
+        {"conv_dma_f16w_kernel<2,4,2,2>", "conv_dma_f16w_kernel<4,2,2,2>", "conv_dma_f16w_kernel<4,2,2,1>", "conv_dma_f16w_kernel<8,1,1,1>",
+         "conv_dma_f16w_kernel<2,4,4,2>"},
+        {"conv_dma_f16x1_kernel<2,4,2,2>", "conv_dma_f16x1_kernel<4,2,2,2>", "conv_dma_f16x1_kernel<4,2,2,1>", "conv_dma_f16x1_kernel<8,1,1,1>",
+         "conv_dma_f16x1_kernel<2,4,4,2>"}};
+    const int v = conv_dma_variant(p);
+    return names[p.f16 == 2 ? 2 : (p.f16 ? 1 : 0)][v >= 1 && v <= 5 ? v - 1 : 2];
 }
 
 }  // namespace sd

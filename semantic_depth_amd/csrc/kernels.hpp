@@ -54,7 +54,8 @@ struct ConvParams {
     int Nmax;          // split engine: images of a full chunk (plane stride of a source = Nmax*H*W*C elements)
     const void* src0;  // first source tensor (hi plane) and the element offset of its lo plane: conv_stem.hip reads it directly
     size_t src0_plane;
-    int f16;           // INPUT split planes are fp16 and the weights one fp16 plane (2 MFMA products): split_fmt.hpp
+    int f16;           // 1: the INPUT is ONE fp16 plane and the weights two fp16 planes (2 MFMA products, split_fmt.hpp); 2: the same
+                       // input and w_hi only (1 MFMA product: plain fp16 x fp16; conv_dma / conv_direct, the others run the 2-product form)
     int out_f16;       // OUTPUT split planes are fp16 (the format the consumers of the output tensor compute in)
     int out_planar16;  // conv_stem.hip: write the output as Cout/16 sub-planes of 16 channels (TensorDesc::planar16)
     int pool;          // conv_dma.hip: output pixels are walked in 2x2-window-major order and the epilogue max-pools each
@@ -136,7 +137,7 @@ struct ConvDirectParams {
     int act, Nmax;
     const void* zero16;
     int rows_per_wave;           // 1: 8 x 32 tiles, 2: 16 x 32 tiles (see conv_direct.hip)
-    int f16;                     // INPUT fp16 planes + single fp16 weight plane (2 MFMA products)
+    int f16;                     // 1: ONE fp16 input plane x two fp16 weight planes (2 MFMA products); 2: x w_hi only (1 product)
     int out_f16;                 // OUTPUT planes are fp16
     int pool;                    // 1: fused 2x2 stride-2 max pool, out is [N,H/2,W/2,Cout] (needs rows_per_wave == 2)
     unsigned sw;                 // Switch bits of the handle

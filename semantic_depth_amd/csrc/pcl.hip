@@ -855,14 +855,14 @@ struct O3dScratch {       // carved from one arena, per-frame strides
     int* seg_sum;         // [B][SCAN_NSEG]
     int* cell_of;         // [B][cap]
     int* sidx;            // [B][cap]  original index of the j-th sorted point
-    float* sxyz;          // [B][cap][3]
+    float* sxyz;          // [B][cap][4]: the cell-sorted copy, one 16-byte load per candidate (w unused)
     double* mean_d;       // [B][cap]  (by original index)
     uint8_t* keep;        // [B][cap]
     int* hard_n;          // [B]  statistical filter: queries deferred to the wave-cooperative search (list in cell_of)
     double* hard_best;    // [B][cap][KMAX]  their k best distances after the per-thread shells (ascending, inf padded)
 };
 size_t o3d_scratch_bytes(int B, int cap) {
-    size_t per = sizeof(GridMeta) + (size_t)GRID_CELLS * 4 + (size_t)(GRID_CELLS + 1) * 4 + SCAN_NSEG * 4 + (size_t)cap * (4 + 4 + 12 + 8 + 1) +
+    size_t per = sizeof(GridMeta) + (size_t)GRID_CELLS * 4 + (size_t)(GRID_CELLS + 1) * 4 + SCAN_NSEG * 4 + (size_t)cap * (4 + 4 + 16 + 8 + 1) +
                  (size_t)cap * KMAX * 8;
     return (size_t)B * (per + 4) + 8192 + 256;
 }
@@ -877,7 +877,7 @@ static O3dScratch carve(void* base, int B, int cap) {
     s.seg_sum = (int*)take((size_t)B * SCAN_NSEG * 4);
     s.cell_of = (int*)take((size_t)B * cap * 4);
     s.sidx = (int*)take((size_t)B * cap * 4);
-    s.sxyz = (float*)take((size_t)B * cap * 12);
+    s.sxyz = (float*)take((size_t)B * cap * 16);
     s.keep = (uint8_t*)take((size_t)B * cap);
     s.hard_n = (int*)take((size_t)B * 4);
     s.hard_best = (double*)take((size_t)B * cap * KMAX * 8);
@@ -1073,8 +1073,7 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(CloudView in, int cap
     const int pos = cell_start[(size_t)b * (GRID_CELLS + 1) + c] + base + (lane - first);
     sidx[(size_t)b * cap + pos] = i;
     const float* p = in.xyz + ((size_t)b * cap + i) * 3;
-    float* q = sxyz + ((size_t)b * cap + pos) * 3;
-    q[0] = p[0]; q[1] = p[1]; q[2] = p[2];
+    reinterpret_cast<float4*>(sxyz)[(size_t)b * cap + pos] = make_float4(p[0], p[1], p[2], 0.f);
 }
 
 __device__ __forceinline__ double dist2(double ax, double ay, double az, const float* p) {
@@ -1156,8 +1155,7 @@ __device__ __forceinline__ void visit_points(const float* __restrict__ pts, doub
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int tt = min(t + u, t1 - 1);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) c[u][j] = pts[(size_t)tt * 3 + j];
+            { const float4 v4 = reinterpret_cast<const float4*>(pts)[tt]; c[u][0] = v4.x; c[u][1] = v4.y; c[u][2] = v4.z; }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -1177,8 +1175,8 @@ __global__ __launch_bounds__(256) void sor_knn_kernel(CloudView in, int cap, con
     if (j >= n) return;
     const GridMeta g = meta[b];
     const int* st = cell_start + (size_t)b * (GRID_CELLS + 1);
-    const float* pts = sxyz + (size_t)b * cap * 3;
-    const float* q = pts + (size_t)j * 3;
+    const float* pts = sxyz + (size_t)b * cap * 4;      // float4 per point
+    const float* q = pts + (size_t)j * 4;
     const double qx = q[0], qy = q[1], qz = q[2];
     const int cx = cell_coord(qx, g.ox, g.inv, g.gx), cy = cell_coord(qy, g.oy, g.inv, g.gy), cz = cell_coord(qz, g.oz, g.inv, g.gz);
     const int kk = k < n ? k : n;
@@ -1280,12 +1278,12 @@ __global__ __launch_bounds__(256) void sor_knn_hard_kernel(CloudView in, int cap
     const int nh = hard_n[b];
     const GridMeta g = meta[b];
     const int* st = cell_start + (size_t)b * (GRID_CELLS + 1);
-    const float* pts = sxyz + (size_t)b * cap * 3;
+    const float* pts = sxyz + (size_t)b * cap * 4;      // float4 per point
     const int kk = k < n ? k : n;
     const int rall = max(g.gx, max(g.gy, g.gz));
     for (int h = blockIdx.x * 4 + (threadIdx.x >> 6); h < nh; h += gridDim.x * 4) {
         const int j = hard_idx[(size_t)b * cap + h];
-        const float* q = pts + (size_t)j * 3;
+        const float* q = pts + (size_t)j * 4;
         const double qx = q[0], qy = q[1], qz = q[2];
         const int cx = cell_coord(qx, g.ox, g.inv, g.gx), cy = cell_coord(qy, g.oy, g.inv, g.gy), cz = cell_coord(qz, g.oz, g.inv, g.gz);
         TopK<CAPK> top;          // this lane's candidates of the current shell
@@ -1349,7 +1347,7 @@ __global__ __launch_bounds__(256) void sor_knn_hard_kernel(CloudView in, int cap
             for (int t = 0; t < CAPK; ++t) best[t] = INFINITY;
             gk = INFINITY;
             top.init(kk);
-            for (int t = lane; t < n; t += 64) top.push(dist2(qx, qy, qz, pts + (size_t)t * 3));
+            for (int t = lane; t < n; t += 64) top.push(dist2(qx, qy, qz, pts + (size_t)t * 4));
             merge();
         }
         if (lane == 0) {
@@ -1394,8 +1392,8 @@ __global__ __launch_bounds__(256) void ror_count_kernel(CloudView in, int cap, c
     if (j >= n) return;
     const GridMeta g = meta[b];
     const int* st = cell_start + (size_t)b * (GRID_CELLS + 1);
-    const float* pts = sxyz + (size_t)b * cap * 3;
-    const float* q = pts + (size_t)j * 3;
+    const float* pts = sxyz + (size_t)b * cap * 4;      // float4 per point
+    const float* q = pts + (size_t)j * 4;
     const double qx = q[0], qy = q[1], qz = q[2];
     const int cx = cell_coord(qx, g.ox, g.inv, g.gx), cy = cell_coord(qy, g.oy, g.inv, g.gy), cz = cell_coord(qz, g.oz, g.inv, g.gz);
     int cnt = 0;
@@ -1431,8 +1429,7 @@ __global__ __launch_bounds__(256) void ror_count_kernel(CloudView in, int cap, c
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int tt = min(t + u, e - 1);
-#pragma unroll
-                            for (int jj = 0; jj < 3; ++jj) c4[u][jj] = pts[(size_t)tt * 3 + jj];
+                            { const float4 v4 = reinterpret_cast<const float4*>(pts)[tt]; c4[u][0] = v4.x; c4[u][1] = v4.y; c4[u][2] = v4.z; }
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) cnt += (t + u < e) && dist2(qx, qy, qz, c4[u]) < r2;

@@ -296,23 +296,17 @@ struct Builder {
             }
         }
         auto is_conv = [](const OpDesc& op) { return op.kind == OP_CONV || op.kind == OP_CONV_DIRECT; };
-        auto wanted = [&](const std::string& n) {
-            for (const std::string& t : toks) {
-                if (t == "*" || t == n) return true;
-                if (t.size() > 1 && t.back() == '*' && n.compare(0, t.size() - 1, t, 0, t.size() - 1) == 0) return true;
-            }
-            return false;
+        // token = layer name | prefix* | *, optionally followed by ":1" = ONE MFMA product (x * w_hi: plain fp16) instead of two
+        auto match = [](const std::string& t, const std::string& n) {
+            return t == "*" || t == n || (t.size() > 1 && t.back() == '*' && n.compare(0, t.size() - 1, t, 0, t.size() - 1) == 0);
         };
-        std::vector<char> matched(toks.size(), 0);
-        for (OpDesc& op : p.ops)
-            if (is_conv(op) && wanted(op.name)) op.f16 = 1;
-        for (size_t i = 0; i < toks.size(); ++i) {
-            bool any = toks[i] == "*";
-            for (const OpDesc& op : p.ops)
-                if (is_conv(op) && (toks[i] == op.name || (toks[i].size() > 1 && toks[i].back() == '*' &&
-                                                           op.name.compare(0, toks[i].size() - 1, toks[i], 0, toks[i].size() - 1) == 0)))
-                    any = true;
-            if (!any) throw std::runtime_error("precision plan of " + p.net + ": no conv layer matches '" + toks[i] + "'");
+        for (std::string t : toks) {
+            int mode = 1;
+            if (t.size() > 2 && t.compare(t.size() - 2, 2, ":1") == 0) { mode = 2; t.erase(t.size() - 2); }
+            bool any = false;
+            for (OpDesc& op : p.ops)
+                if (is_conv(op) && match(t, op.name)) { op.f16 = std::max(op.f16, mode); any = true; }
+            if (!any) throw std::runtime_error("precision plan of " + p.net + ": no conv layer matches '" + t + "'");
         }
         for (bool changed = true; changed;) {
             changed = false;
@@ -333,8 +327,9 @@ struct Builder {
         double fl = 0;
         for (OpDesc& op : p.ops) {
             if (!is_conv(op) || !op.f16) continue;
-            p.f16_ops += (p.f16_ops.empty() ? "" : ",") + op.name;
+            p.f16_ops += (p.f16_ops.empty() ? "" : ",") + op.name + (op.f16 == 2 ? ":1" : "");
             fl += op.flops;
+            if (op.f16 == 2) p.flops_f16x1 += op.flops / std::max(1, p.images);
             p.weights[op.w].f16 = 1;
             for (WeightSlot& s : p.weights)
                 if (s.owner == op.w && (s.layout == WL_IGEMM_SPLIT || s.layout == WL_DIRECT_SPLIT)) s.f16 = 1;

@@ -62,7 +62,8 @@ struct OpDesc {
     // conv engine
     int Ctot = 0;          // padded channels per tap (every source rounded up to a multiple of 4)
     int K = 0, Kpad = 0, vec = 0, m_fastest = 0;
-    int f16 = 0;                 // conv ops: sources are single fp16 planes, weights two fp16 planes, TWO MFMA products per product
+    int f16 = 0;                 // conv ops: 1 = sources are single fp16 planes, weights two fp16 planes, TWO MFMA products per product;
+                                 // 2 = the same sources, w_hi only, ONE product (plain fp16 x fp16)
     int fuse_pool = 0;           // OP_CONV_DIRECT / OP_CONV (LDS-DMA kernel): the 2x2 max pool that follows is applied in the epilogue
     int nchunks = 0;             // OP_CONV_DIRECT: 32-channel chunks over the concatenated sources
     int nsplit = 1;              // OP_CONV_DIRECT: passes of <= 64 output channels per tile
@@ -82,7 +83,8 @@ struct NetPlan {
     // prefix, "*" = every layer, empty = none); f16_ops = the layers that run it after the consistency closure (a tensor has ONE
     // plane format, so every conv reading an fp16 tensor is a 2-product layer and every source of a 2-product layer is fp16)
     std::string f16_spec, f16_ops;
-    double flops_f16 = 0;  // per image, of the 2-product layers
+    double flops_f16 = 0;  // per image, of the fp16 layers (2-product and 1-product)
+    double flops_f16x1 = 0;   // per image, of the 1-product layers among them
     std::vector<TensorDesc> tensors;
     std::vector<OpDesc> ops;
     std::vector<WeightSlot> weights;
