@@ -846,7 +846,14 @@ constexpr int SOR_RSOFT = 2;       // shells searched one-thread-per-query (99 %
 constexpr int SCAN_SEG = 2048;     // cells per scan segment
 constexpr int SCAN_NSEG = GRID_CELLS / SCAN_SEG;
 
-struct GridMeta { double ox, oy, oz, inv; double cell; int gx, gy, gz, occupied; double ext[3], mn[3], mxz; };
+struct GridMeta { double ox, oy, oz, inv; double cell; int gx, gy, gz, occupied; double ext[3], mn[3], mxz; int nonfinite, pad_; };
+// does the grid hold every finite point inside its NOMINAL cells along each axis (no clamping into the face layers)?  Then, with
+// no non-finite point in the cloud either, a face layer is an ordinary bounded cell.
+__device__ __forceinline__ bool grid_covers(const GridMeta& g) {
+    const double m = 1.0 - 1e-9;
+    return g.nonfinite == 0 && g.ext[0] < (double)g.gx * g.cell * m && g.ext[1] < (double)g.gy * g.cell * m && g.oz <= g.mn[2] &&
+           g.mxz < g.oz + (double)g.gz * g.cell * m && g.ox <= g.mn[0] && g.oy <= g.mn[1];
+}
 
 struct O3dScratch {       // carved from one arena, per-frame strides
     GridMeta* meta;       // [B]
@@ -927,14 +934,20 @@ __global__ __launch_bounds__(TB) void grid_meta_kernel(CloudView in, int cap, do
     const float* xyz = in.xyz + (size_t)b * cap * 3;
     const int n = min(in.n[b], cap);
     __shared__ float smin[3][NW], smax[3][NW];
+    __shared__ int s_nonfinite;
+    if (threadIdx.x == 0) s_nonfinite = 0;
+    __syncthreads();
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    int bad = 0;
 #pragma unroll 4
     for (int i = threadIdx.x; i < n; i += TB)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const float v = xyz[(size_t)i * 3 + j];
             if (v > -INFINITY && v < INFINITY) { mn[j] = fminf(mn[j], v); mx[j] = fmaxf(mx[j], v); }
+            else ++bad;
         }
+    if (bad) atomicAdd(&s_nonfinite, bad);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
 #pragma unroll
@@ -960,6 +973,7 @@ __global__ __launch_bounds__(TB) void grid_meta_kernel(CloudView in, int cap, do
         GridMeta g;
         for (int j = 0; j < 3; ++j) { g.ext[j] = ext[j]; g.mn[j] = mn[j]; }
         g.mxz = mx[2];
+        g.nonfinite = s_nonfinite; g.pad_ = 0;
         g.occupied = 0;
         grid_layout(g, cell);
         meta[b] = g;
@@ -1397,6 +1411,26 @@ __global__ __launch_bounds__(256) void ror_count_kernel(CloudView in, int cap, c
     const double qx = q[0], qy = q[1], qz = q[2];
     const int cx = cell_coord(qx, g.ox, g.inv, g.gx), cy = cell_coord(qy, g.oy, g.inv, g.gy), cz = cell_coord(qz, g.oz, g.inv, g.gz);
     int cnt = 0;
+    // fast accept: every point of the 3 x 3 x 3 cells around the query's cell is closer than 2 sqrt(3) cell = 0.866 (r / 4) (1 + 1e-6)
+    // ... = 0.433 r < r away (cells are r / 4 wide; the 1e-9 cell inflation of axis_bounds is far inside that margin), PROVIDED
+    // none of them is a face layer that holds clamped or non-finite points (grid_covers).  Nine row lookups in the cell-sorted prefix array; a
+    // dense cloud (every interior road point) is decided here, the exact ring walk below only sees the sparse remainder.
+    const bool covers = grid_covers(g);                     // else a face layer may hold clamped (far) or non-finite points
+    if (3.4641016151377545 * g.cell * (1.0 + 1e-6) < sqrt(r2) &&
+        (covers || (cx >= 2 && cx + 2 < g.gx && cy >= 2 && cy + 2 < g.gy && cz >= 2 && cz + 2 < g.gz))) {
+        int c27 = 0;
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.gx - 1);
+#pragma unroll
+        for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int z = cz + dz, y = cy + dy;
+                if (z < 0 || z >= g.gz || y < 0 || y >= g.gy) continue;
+                const int rb = (z * g.gy + y) * g.gx;
+                c27 += st[rb + x1 + 1] - st[rb + x0];
+            }
+        if (c27 > nb) { keep[(size_t)b * cap + sidx[(size_t)b * cap + j]] = 1; return; }
+    }
     for (int r = 0; r <= ROR_RINGS && cnt <= nb; ++r) {
         for (int dz = -r; dz <= r && cnt <= nb; ++dz) {
             const int z = cz + dz;

@@ -169,6 +169,34 @@ def test_o3d_sparse_cloud_deep_shells(pcl):
     _o3d_compare(pcl, pts, col, k=16, ratio=1.5, nb=3, radius=2.0)
 
 
+def test_radius_filter_fast_accept_stays_exact(pcl):
+    """the radius filter accepts a query from the counts of its 3 x 3 x 3 cells alone when those cells are bounded; clouds that
+    break that premise -- a grid clamped in y (extent / cell > 64 layers), strays far outside, points AT the grid faces, dense
+    clusters of just nb / nb + 1 points, and the radius filter called directly on a cloud with clamped layers -- must still
+    match the oracle point for point"""
+    rng = np.random.default_rng(5)
+    sheet = np.stack([rng.uniform(-6, 6, 20000), rng.normal(-1.5, 0.02, 20000), rng.uniform(-14, -8, 20000)], 1)
+    tall = np.stack([rng.uniform(-1, 1, 3000), rng.uniform(-12, 12, 3000), rng.uniform(-10, -9, 3000)], 1)      # 24 m of y: clamps
+    strays = np.float64([[300, 0, -10], [0, 250, -10], [0, 0, -4000], [-300, -250, 2000]])
+    # clusters of exactly nb and nb + 1 points inside one cell-sized blob (the count must EXCEED nb)
+    c80 = np.float64([20.0, 5.0, -30.0]) + rng.uniform(-0.04, 0.04, (80, 3))
+    c81 = np.float64([-20.0, 5.0, -30.0]) + rng.uniform(-0.04, 0.04, (81, 3))
+    pts = np.concatenate([sheet, tall, strays, c80, c81]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    col = rng.integers(0, 256, (len(pts), 3), dtype=np.uint8)
+    for nb, radius in ((80, 0.5), (79, 0.5), (10, 0.25), (300, 1.0)):
+        keep = oracle_o3d.radius_outlier_mask(pts, nb, radius)
+        p, c = pcl.radius_outlier_removal(pts, col, nb, radius)
+        assert len(p) == int(keep.sum()), (nb, radius, len(p), int(keep.sum()))
+        _eq(p, pts[keep]); _eq(c, col[keep])
+        assert 0 < len(p) < len(pts)
+    # the sheet alone: every face layer bounded -> the fast accept decides nearly every point; same answer
+    sh = sheet.astype(np.float32)
+    keep = oracle_o3d.radius_outlier_mask(sh, 80, 0.5)
+    p, _ = pcl.radius_outlier_removal(sh, col[:len(sh)], 80, 0.5)
+    _eq(p, sh[keep])
+
+
 def test_o3d_knn_mean_distance_exact(pcl, mini):
     """the per-point mean kNN distance itself is bit-exact vs the oracle's canonical float64 definition."""
     from semantic_depth_amd.engine import _ptr
