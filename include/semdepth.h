@@ -96,7 +96,7 @@ sd_status sd_create(sd_handle** out, int device, int H, int W, int max_batch, sd
  * (sd_precision_plan returns what actually runs).  An unknown layer name is SD_ERR_INVALID. */
 sd_status sd_create_with_plan(sd_handle** out, int device, int H, int W, int max_batch, sd_encoder enc, const char* fcn_f16_layers,
                               const char* mono_f16_layers);
-const char* sd_default_plan(sd_net net);
+const char* sd_default_plan(sd_net net);      /* (monodepth: the ResNet-50 plan; the vgg encoder's default plan is empty) */
 /* layers_out (nullable): the 2-product layers of the handle's plan, comma-separated; flop_share_out (nullable): their share of
  * the network's algorithmic FLOPs */
 sd_status sd_precision_plan(const sd_handle* h, sd_net net, char* layers_out, size_t cap, double* flop_share_out);

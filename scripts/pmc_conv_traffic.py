@@ -36,12 +36,13 @@ def label(k):
     if not m:
         return None
     fam, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
-    if fam == "conv_direct":       # <NB, MT, F16, N16, UP>
-        f16 = args[2] == "true"
+    if fam == "conv_direct":       # <NB, MT, F16, N16, UP, W1>
+        prec = "_f16x1" if (len(args) > 5 and args[5] == "true") else ("_f16w" if args[2] == "true" else "")
         shape = "<1,n16>" if args[3] == "true" else ("<1,2>" if args[0] == "1" else "<2,2>")
-        return f"conv_direct{'_f16w' if f16 else ''}_kernel{shape}"
-    if fam == "conv_dma":          # <WM, WN, MT, NT, SIMPLE, STAGES, F16>
-        return f"conv_dma{'_f16w' if args[6] == 'true' else ''}_kernel<{args[0]},{args[1]},{args[2]},{args[3]}>"
+        return f"conv_direct{prec}_kernel{shape}"
+    if fam == "conv_dma":          # <WM, WN, MT, NT, SIMPLE, STAGES, F16, W1>
+        prec = "_f16x1" if (len(args) > 7 and args[7] == "true") else ("_f16w" if args[6] == "true" else "")
+        return f"conv_dma{prec}_kernel<{args[0]},{args[1]},{args[2]},{args[3]}>"
     if fam == "conv_stem":
         return "conv_stem_f16w_kernel" if args[2] == "true" else "conv_stem_kernel"
     return fam + "_kernel"

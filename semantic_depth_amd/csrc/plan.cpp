@@ -304,9 +304,12 @@ struct Builder {
             int mode = 1;
             if (t.size() > 2 && t.compare(t.size() - 2, 2, ":1") == 0) { mode = 2; t.erase(t.size() - 2); }
             bool any = false;
-            for (OpDesc& op : p.ops)
-                if (is_conv(op) && match(t, op.name)) { op.f16 = std::max(op.f16, mode); any = true; }
-            if (!any) throw std::runtime_error("precision plan of " + p.net + ": no conv layer matches '" + t + "'");
+            for (OpDesc& op : p.ops) {
+                if (!match(t, op.name)) continue;
+                any = true;          // (a layer that is not an MFMA conv at this geometry, e.g. a small-N head, follows its input's format)
+                if (is_conv(op)) op.f16 = std::max(op.f16, mode);
+            }
+            if (!any) throw std::runtime_error("precision plan of " + p.net + ": no layer matches '" + t + "'");
         }
         for (bool changed = true; changed;) {
             changed = false;

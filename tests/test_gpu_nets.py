@@ -25,8 +25,9 @@ def _frames(B, H, W, seed=0):
     return np.random.default_rng(seed).integers(0, 256, (B, H, W, 3), dtype=np.uint8)
 
 
-PRECISIONS = ["f32", "bf16x2"]      # exact f32 MFMA / split-bf16 MFMA (3 bf16 products per product)
-# "mixed": FCN-8s as bf16x2, monodepth with split-fp16 activations x fp16 weights (2 products): only the monodepth tests
+# exact f32 MFMA / split-bf16 MFMA (3 bf16 products per product) / the built-in per-layer precision plan (3-, 2- and 1-product layers)
+PRECISIONS = ["f32", "bf16x2", "plan"]
+# "mixed": FCN-8s as bf16x2, every monodepth layer on fp16 activations x split fp16 weights (2 products): only the monodepth tests
 # gain a case, at the same 1e-3 budget
 MONO_PRECISIONS = PRECISIONS + ["mixed"]
 
