@@ -9,10 +9,14 @@ Pinning status:
   * oracle.pcl        — PINNED: checked function by function against the reference's own
                         ``semantic_depth_lib/pcl.py`` (imported in the build container by
                         tests/golden/make_golden.py; outputs committed under tests/golden/).
-  * oracle.fusion     — post_processing / mask gather restate reference code that cannot be
-                        imported (needs cv2/tf); pinned to closed-form vectors + the Appendix-F
-                        scene whose reference-pcl results are in tests/golden/.
-                        ``reproject`` restates cv2.reprojectImageTo3D [UPSTREAM OpenCV 4.0.0.21]:
+  * oracle.fusion     — ``post_processing``: PINNED — bit-exact (float64) against the reference's own
+                        DepthFrame.post_processing (semantic_depth.py:656-664), lifted from the
+                        reference's AST and executed by tests/golden/make_golden.py (the module
+                        itself needs tf/cv2 and cannot be imported); vectors in
+                        tests/golden/ref_pieces.npz, checked by tests/test_outputs.py.
+                        mask gather: numpy boolean indexing, as the reference.
+                        ``reproject`` restates cv2.reprojectImageTo3D [UPSTREAM OpenCV 4.0.0.21]
+                        (Vec3f /= double is a multiply by 1./W, core/matx.hpp):
                         PARITY UNPINNED against OpenCV itself.
   * oracle.nets       — FCN-8s decoder follows fcn8s/fcn.py:159-224; the VGG16 body (Udacity
                         SavedModel) and the monodepth body (mrharicot/monodepth, unpinned copy)

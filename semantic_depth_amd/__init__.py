@@ -5,7 +5,9 @@ FCN-8s forward + monodepth forward + per-pixel fusion/back-projection -> class-m
 (include/semdepth.h); this package is the Python host side mirroring the reference's operator interface:
 
     SegmentFrame, DepthFrame, FrameProcessor     (semantic_depth.py:82-96, :464-571, :575-697)
-    pcl                                           (semantic_depth_lib/pcl.py)
+    pcl, point_cloud_2_ply                        (semantic_depth_lib/pcl.py, point_cloud_2_ply.py)
+    outputs, frame_io, distributed, tf_import     (file outputs + focal sweep, PNG reader / feeder, the multi-GPU sequence driver,
+                                                   TensorFlow-free checkpoint import)
 
 There is no CPU fallback: without the built library or without a GPU the operators raise.
 """
@@ -14,13 +16,13 @@ from .weights import (NUM_CLASSES, fcn8s_weight_shapes, make_fcn8s_weights, make
 
 
 def __getattr__(name):  # lazy: importing the package must not need torch/GPU (weights tables are pure numpy)
-    if name in ("Engine", "RoadWidthParams", "Camera", "RW_DTYPE"):
+    if name in ("Engine", "RoadWidthParams", "FenceParams", "Camera", "RW_DTYPE", "F2F_DTYPE"):
         from . import engine
         return getattr(engine, name)
     if name in ("SegmentFrame", "DepthFrame", "FrameProcessor"):
         from . import api
         return getattr(api, name)
-    if name == "pcl":
+    if name in ("pcl", "outputs", "frame_io", "distributed", "tf_import", "point_cloud_2_ply", "api", "engine"):
         import importlib
-        return importlib.import_module(".pcl", __name__)
+        return importlib.import_module("." + name, __name__)
     raise AttributeError(name)
