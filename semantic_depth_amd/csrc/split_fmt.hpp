@@ -68,7 +68,10 @@ template <bool F16> __device__ __forceinline__ f32x4_t recon4_t(uint2 h, uint2 l
 }
 template <bool F16> __device__ __forceinline__ void split2_t(f32x2_t v, unsigned& h, unsigned& l) {
     if constexpr (F16) {
-        const f16x2_t hb = __builtin_convertvector(v, f16x2_t);                   // round to nearest even; there is no lo plane
+        // saturate at the largest finite fp16 (v_med3_f32): an activation beyond 65504 must not become inf and poison the layers
+        // behind it (NaN passes through); then round to nearest even.  There is no lo plane.
+        const f32x2_t c = {__builtin_amdgcn_fmed3f(v[0], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v[1], -65504.f, 65504.f)};
+        const f16x2_t hb = __builtin_convertvector(c, f16x2_t);
         h = __builtin_bit_cast(unsigned, hb);
         l = 0u;
     } else {

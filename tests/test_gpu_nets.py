@@ -204,3 +204,23 @@ def test_full_size_split_engine_matches_the_exact_f32_engine(H, W, B, enc):
         del eng
     assert relerr(res["bf16x2"][0], res["f32"][0]) < 1e-4
     assert relerr(res["bf16x2"][1], res["f32"][1]) < 1e-4
+
+
+def test_fp16_activation_planes_saturate_instead_of_overflowing():
+    """an activation beyond the fp16 range that lands in a single-plane fp16 tensor (the input of a 2- / 1-product layer of the plan) is
+    stored as 65504, not inf: the network's outputs stay finite.  conv4_1 (three products, f32-range bf16 planes in) gets a bias of
+    1e5; its output feeds conv4_2, a one-product layer of the built-in plan."""
+    from semantic_depth_amd.engine import Engine
+    from semantic_depth_amd import weights as Wt
+    H, W = 64, 128
+    wf = Wt.make_fcn8s_weights(1, decoder_std=0.05)
+    wf["vgg/conv4_1/biases"] = np.full_like(wf["vgg/conv4_1/biases"], 1.0e5)
+    fr = _frames(1, H, W, seed=2)
+    eng = Engine(H, W, 1, "resnet50", precision="plan")
+    assert "conv4_2:1" in eng.precision_plan()["fcn8s"][0] and "conv4_1" not in eng.precision_plan()["fcn8s"][0]
+    eng.load_weights(L.SD_NET_FCN8S, wf)
+    eng.load_weights(L.SD_NET_MONODEPTH, Wt.make_monodepth_weights("resnet50", 2))
+    lg = eng.fcn8s_forward(dev(fr), want_logits=True)["logits"].cpu().numpy()
+    assert np.isfinite(lg).all()
+    ref = nets.fcn8s_forward(fr, wf)                      # f32: the same activations are ~1e5, far outside fp16
+    assert np.isfinite(ref).all() and np.abs(ref).max() > 1e3
