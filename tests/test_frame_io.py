@@ -105,3 +105,23 @@ def test_frame_feeder_batches_in_order(tmp_path):
         got.append(dev.numpy().copy()); los.append(lo)
     assert los == [0, 3, 6] and [g.shape[0] for g in got] == [3, 3, 1]
     assert np.array_equal(np.concatenate(got), frames)
+
+
+@pytest.mark.gpu
+def test_frame_feeder_uploads_through_pinned_buffers(tmp_path):
+    """the same feeder onto the GPU (pinned staging, asynchronous upload, double buffering) followed by the GPU cubic resize"""
+    import torch
+    from semantic_depth_amd.engine import Engine
+    from oracle import resize as oresize
+    rng = np.random.default_rng(2)
+    frames = rng.integers(0, 256, (5, 128, 192, 3), dtype=np.uint8)
+    paths = [outputs.write_png(str(tmp_path / f"f{i:03d}.png"), f) for i, f in enumerate(frames)]
+    eng = Engine(64, 128, 2, "resnet50")
+    got = []
+    for dev_frames, lo in frame_io.FrameFeeder(paths, batch=2, device="cuda", workers=3):
+        assert dev_frames.is_cuda and dev_frames.dtype == torch.uint8
+        got.append(eng.resize_cubic(dev_frames).cpu().numpy())
+    got = np.concatenate(got)
+    assert got.shape == (5, 64, 128, 3)
+    for i in range(5):
+        assert np.array_equal(got[i], oresize.resize_cubic_u8(frames[i], 64, 128))
