@@ -116,8 +116,13 @@ def main():
     import torch
     import torch.distributed as dist
 
-    if torch.cuda.device_count() < world:
+    # SD_BENCH_SHARE_GPU=1 (plumbing test on a single-GPU box): the ranks share the visible GPUs and talk over gloo -- RCCL refuses two
+    # ranks on one device; the line is then labelled and is NOT a scaling measurement
+    share = os.environ.get("SD_BENCH_SHARE_GPU") == "1" and torch.cuda.device_count() >= 1
+    if torch.cuda.device_count() < world and not share:
         sys.exit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) visible")
+    if share:
+        local_rank = local_rank % torch.cuda.device_count()
     import __graft_entry__ as graft
     from semantic_depth_amd import build as sd_build
     if world == 1 or rank == 0:
@@ -136,8 +141,11 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    ones = torch.ones(1, device="cuda")
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    ones = torch.ones(1, device="cpu" if share else "cuda")
     if world > 1:
         dist.all_reduce(ones)         # RCCL over xGMI: every rank contributes 1
     ranks_seen = int(ones.item())
@@ -205,14 +213,16 @@ def main():
     # The two networks run on the main stream; with --overlap the per-frame tail of step i (back-projection, road chain, record
     # gather) runs on a side stream underneath the convolutions of step i+1; the default keeps everything on one stream.
     side = torch.cuda.Stream() if args.overlap else None
-    fused_once = False
-    for _ in range(args.steps):
+    state = {"fused_once": False}
+
+    def instrumented_step():
+        """one step, stage by stage with stream events (the same launches as Engine.process_batch / make_engine_step)"""
         ev[0].record()
         fr = eng.resize_cubic(src_frames) if args.config == 5 else frames
         ev[1].record()
         seg = eng.fcn8s_forward(fr)
         ev[2].record()
-        if side is not None and fused_once:
+        if side is not None and state["fused_once"]:
             torch.cuda.current_stream().wait_event(ev[4])      # the previous step's fusion stage has consumed the raw pair in the arena
         eng.monodepth_forward(fr, post_process=False)          # the raw pair stays in the arena for the one-pass fusion stage
         ev[3].record()
@@ -226,24 +236,32 @@ def main():
         with ctx:
             # flip-pair post-processing + back-projection + both ordered gathers: ONE launch (sd_postprocess_fuse_backproject)
             fz = eng.fuse_from_raw(seg["road"], seg["fence"], fr, cams, want_rgb=colours)
-            disp_pp = fz["disp_pp"]
             ev[4].record()
-            fused_once = True
+            state["fused_once"] = True
             rec = eng.road_width(fz["road_xyz"], fz["n_road"], prm, road_rgb=fz["road_rgb"] if colours else None)
-            allrec = gather_records(rec, world * B)
+            allr = gather_records(rec, world * B)
             ev[5].record()
-        out = dict(seg=seg, disp_pp=disp_pp, fuse=fz, records=rec)
+        return dict(seg=seg, disp_pp=fz["disp_pp"], fuse=fz, records=rec), allr
+
+    for _ in range(args.steps):
+        if args.config == 5:
+            allrec = step()                                    # distributed.run_sequence: shard -> resize -> process_batch -> all_gather
+        else:
+            out, allrec = instrumented_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    # stage split of the LAST step (events are only read after the timed region)
-    stage_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
     buckets = eng.profile_read()
     eng.profile(False)
+    if args.config == 5:                                       # stage split + report tensors from one more (untimed) instrumented step
+        out, _ = instrumented_step()
+        torch.cuda.synchronize()
+    # stage split of the LAST step (events are only read after the timed region)
+    stage_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -298,7 +316,7 @@ def main():
                 "RCCL all_gather of the records), ")
     line = {
         "metric": "fused frames/sec (FCN-8s+monodepth+pcl fusion) at 512x1024", "value": round(value, 3), "unit": "frames/s",
-        "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "n_gpus": world, "ranks_seen": ranks_seen, **({"shared_gpu_plumbing_test": True} if share else {}), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
         "config": {"workload": workload + f"batch {B} per GPU, 512x1024, monodepth-{args.encoder} on frame+flip, seeded synthetic weights",
                    "survey_config": args.config, "frames_per_step": world * B, "gflop_per_frame": round(flops_frame / 1e9, 2),

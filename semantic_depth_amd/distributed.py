@@ -32,12 +32,15 @@ def gather_records(local: torch.Tensor, n_frames: int | None = None, group=None)
         n_frames = local.shape[0] * world
     sizes = [shard_range(n_frames, r, world) for r in range(world)]
     bmax = max(hi - lo for lo, hi in sizes)
-    pad = torch.zeros((bmax, RECORD_BYTES), dtype=torch.uint8, device=local.device)
-    pad[: local.shape[0]] = local
-    out = torch.empty((world * bmax, RECORD_BYTES), dtype=torch.uint8, device=local.device)
+    # RCCL ("nccl") gathers device buffers in place; a gloo group (CPU tests, or ranks sharing one GPU) stages through the host
+    via_host = local.is_cuda and dist.get_backend(group) == "gloo"
+    dev = torch.device("cpu") if via_host else local.device
+    pad = torch.zeros((bmax, RECORD_BYTES), dtype=torch.uint8, device=dev)
+    pad[: local.shape[0]] = local.to(dev)
+    out = torch.empty((world * bmax, RECORD_BYTES), dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(out, pad, group=group)
     parts = [out[r * bmax: r * bmax + (hi - lo)] for r, (lo, hi) in enumerate(sizes)]
-    return torch.cat(parts, 0)
+    return torch.cat(parts, 0).to(local.device)
 
 
 def records_view(buf: torch.Tensor) -> np.ndarray:
