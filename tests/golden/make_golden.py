@@ -192,6 +192,43 @@ def main():
     with np.errstate(all="ignore"):
         p, c = ref.remove_noise_by_mad(flat, col, 1, 15.0)
     z["mad0_in"], z["mad0_pts"] = flat, p
+    # threshold edges: a cut that float32 cannot represent, points at the float32 neighbours of every cut, and points whose
+    # plane residual sits within rounding of the threshold.  Captured under this container's numpy (NEP 50: the python-float
+    # threshold is compared in the array's float32; the plane residual is evaluated in float64) -- the reference's pinned numpy
+    # 1.16 promotes differently in exactly these two places.
+    edge = []
+    for cut in (7.0, 7.1, 6.999999, 35.0, 0.1):
+        c32 = np.float32(-cut)
+        for k in range(-3, 4):
+            v = c32
+            for _ in range(abs(k)):
+                v = np.nextafter(v, np.float32(-np.inf if k < 0 else np.inf), dtype=np.float32)
+            edge.append([0.5 * k, -1.5, v])
+            edge.append([0.5 * k, -1.5, -v])
+    edge = np.asarray(edge, np.float32)
+    ecol = (np.arange(len(edge) * 3) % 251).astype(np.uint8).reshape(-1, 3)
+    z["edge_in"], z["edge_col"] = edge, ecol
+    for tag, cut in (("70", 7.0), ("71", 7.1), ("69", 6.999999)):
+        p, c = ref.remove_from_to(edge, ecol, 2, 0.0, cut)
+        z[f"edge_rft_{tag}_pts"], z[f"edge_rft_{tag}_col"] = p, c
+    p, c = ref.threshold_complete(edge, ecol, 2, 35.0)
+    z["edge_thr35_pts"] = p
+    p, c = ref.threshold_complete(edge, ecol, 2, 0.1)
+    z["edge_thr01_pts"] = p
+    # plane y = 0.25 x - 0.125 z - 1.5 exactly representable; outliers placed at threshold +- a few ulps of the residual
+    rngp = np.random.default_rng(3)
+    base = np.stack([rngp.integers(-64, 64, 400) / 8.0, np.zeros(400), -rngp.integers(40, 200, 400) / 4.0], 1)
+    base[:, 1] = 0.25 * base[:, 0] - 0.125 * base[:, 2] - 1.5
+    sym = base.copy(); sym[:, 1] = base[:, 1]                      # (the fit is exact up to rounding: residuals of the inliers ~1e-16)
+    offs = np.float64([0.75 - 2e-7, 0.75 - 6e-8, 0.75, 0.75 + 6e-8, 0.75 + 2e-7, -(0.75 - 6e-8), -0.75, -(0.75 + 6e-8)])
+    outl = base[:len(offs)].copy(); outl[:, 1] += offs
+    # mirror outliers so that the fitted plane stays the exact one (their residuals cancel in the normal equations)
+    mirror = outl.copy(); mirror[:, 1] = 2 * base[:len(offs), 1] - outl[:, 1]
+    pl = np.concatenate([base, outl, mirror]).astype(np.float32)
+    pcol = (np.arange(len(pl) * 3) % 253).astype(np.uint8).reshape(-1, 3)
+    p, c, _, _, coeff = ref.remove_noise_by_fitting_plane(pl, pcol, axis=1, threshold=0.75)
+    z["edge_plane_in"], z["edge_plane_col"], z["edge_plane_pts"] = pl, pcol, p
+    z["edge_plane_coeff"] = np.array([coeff[k] for k in ("Cx", "Cy", "Cz", "C")], np.float64)
     # fence-side helpers
     fp, fc = fz["fence3d"], fz["fence_rgb"]
     p, c = ref.threshold_complete(fp, fc, 2, 35.0)

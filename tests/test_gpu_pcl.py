@@ -169,6 +169,19 @@ def test_o3d_sparse_cloud_deep_shells(pcl):
     _o3d_compare(pcl, pts, col, k=16, ratio=1.5, nb=3, radius=2.0)
 
 
+def test_threshold_edges_golden(pcl, mini):
+    """the reference's answers (captured by make_golden.py) for cuts float32 cannot represent, points at the float32 neighbours of a
+    cut and plane residuals within rounding of the threshold: the HIP filters take the same side of every comparison"""
+    e, ec = mini["edge_in"], mini["edge_col"]
+    for tag, cut in (("70", 7.0), ("71", 7.1), ("69", 6.999999)):
+        p, c = pcl.remove_from_to(e, ec, 2, 0.0, cut)
+        _eq(p, mini[f"edge_rft_{tag}_pts"]); _eq(c, mini[f"edge_rft_{tag}_col"])
+    _eq(pcl.threshold_complete(e, ec, 2, 35.0)[0], mini["edge_thr35_pts"])
+    _eq(pcl.threshold_complete(e, ec, 2, 0.1)[0], mini["edge_thr01_pts"])
+    p, c, _, _, coeff = pcl.remove_noise_by_fitting_plane(mini["edge_plane_in"], mini["edge_plane_col"], axis=1, threshold=0.75)
+    _eq(p, mini["edge_plane_pts"])
+
+
 def test_radius_filter_fast_accept_stays_exact(pcl):
     """the radius filter accepts a query from the counts of its 3 x 3 x 3 cells alone when those cells are bounded; clouds that
     break that premise -- a grid clamped in y (extent / cell > 64 layers), strays far outside, points AT the grid faces, dense

@@ -171,3 +171,19 @@ def test_numpy_mean_is_chunked_pairwise():
             s = pw(col[i:i + 8192])
             tot = s if tot is None else np.float32(tot + s)
         assert np.float32(tot / np.float32(n)) == np.mean(col), n
+
+
+def test_threshold_edges_match_the_reference(mini):
+    """cuts that float32 cannot represent, points at the float32 neighbours of a cut, plane residuals within rounding of the
+    threshold: the oracle takes the reference's side of every comparison (goldens captured under numpy >= 2)"""
+    e, ec = mini["edge_in"], mini["edge_col"]
+    for tag, cut in (("70", 7.0), ("71", 7.1), ("69", 6.999999)):
+        p, c = pcl.remove_from_to(e, ec, 2, 0.0, cut)
+        _eq(p, mini[f"edge_rft_{tag}_pts"]); _eq(c, mini[f"edge_rft_{tag}_col"])
+        assert 0 < len(p) < len(e)
+    _eq(pcl.threshold_complete(e, ec, 2, 35.0)[0], mini["edge_thr35_pts"])
+    _eq(pcl.threshold_complete(e, ec, 2, 0.1)[0], mini["edge_thr01_pts"])
+    p, c, coeff = pcl.remove_noise_by_fitting_plane(mini["edge_plane_in"], mini["edge_plane_col"], axis=1, threshold=0.75)
+    _eq(p, mini["edge_plane_pts"])
+    assert len(mini["edge_plane_in"]) - 16 <= len(p) < len(mini["edge_plane_in"])      # some of the 16 edge points go, none of the inliers
+    np.testing.assert_allclose([coeff[k] for k in ("Cx", "Cy", "Cz", "C")], mini["edge_plane_coeff"], rtol=1e-12, atol=1e-14)
