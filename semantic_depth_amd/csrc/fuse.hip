@@ -314,6 +314,9 @@ bool fuse_onepass_eligible(const FuseParams& p) {
 }
 
 struct F1Quad { float4 L, R; unsigned fw[3]; };
+struct __attribute__((packed, aligned(4))) F1Vec3 { float x, y, z; };        // one point: a single 12-byte store
+struct __attribute__((packed, aligned(1))) F1Vec3u { unsigned x, y, z; };     // the 12 colour bytes of four points: ONE store at any
+                                                                              // byte alignment (gfx9+ global memory accesses may be unaligned)
 __device__ __forceinline__ F1Quad f1_load(const FuseParams& p, int b, int npix, int i4, bool in, unsigned masks) {
     F1Quad qd;
     qd.L = qd.R = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -486,31 +489,46 @@ __global__ __launch_bounds__(256, SD_F1_WAVES) void fuse_onepass_kernel(const Fu
         const int cnt_f = p.fence_xyz ? wf[u][0] + wf[u][1] + wf[u][2] + wf[u][3] : 0;
         if (cnt_r + cnt_f == 0) continue;                       // (uniform over the block)
         // write each masked pixel at (exclusive prefix of the block) + (sub-tiles before) + (rank inside the sub-tile): thread order ==
-        // pixel order, so the lanes of a wave write one contiguous run per class
+        // pixel order, so the lanes of a wave write one contiguous run per class.  A point is ONE 12-byte store; a quad whose four
+        // pixels are all masked (the interior of a mask blob) writes its 12 colour bytes as one (unaligned) 12-byte store too,
+        // B<->R swapped per pixel by four byte permutes.
 #pragma unroll
         for (int cls = 0; cls < 2; ++cls) {
             const int cnt = cls ? cnt_f : cnt_r;
             if (cnt == 0) continue;
-            float* oxyz = cls ? p.fence_xyz : p.road_xyz;
-            uint8_t* orgb = cls ? p.fence_rgb : p.road_rgb;
+            F1Vec3* const oxyz = reinterpret_cast<F1Vec3*>(cls ? p.fence_xyz : p.road_xyz) + (size_t)b * p.cap;        // (uniform base)
+            uint8_t* const orgb = (cls ? p.fence_rgb : p.road_rgb) ? (cls ? p.fence_rgb : p.road_rgb) + (size_t)b * p.cap * 3 : nullptr;
             const unsigned m4 = cls ? mf : mr;
-            int pos = (cls ? ex_f + pre_f : ex_r + pre_r);
-            for (int w = 0; w < wave; ++w) pos += cls ? wf[u][w] : wr[u][w];
+            unsigned pos = (unsigned)(cls ? ex_f + pre_f : ex_r + pre_r);
+            for (int w = 0; w < wave; ++w) pos += (unsigned)(cls ? wf[u][w] : wr[u][w]);
+            const bool full = (m4 & 0xffu) && (m4 & 0xff00u) && (m4 & 0xff0000u) && (m4 & 0xff000000u);
+            if (full && pos + 4u <= (unsigned)p.cap) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!((m4 >> (8 * k)) & 0xffu)) continue;
-                if (pos < p.cap) {
-                    float* o = oxyz + ((size_t)b * p.cap + pos) * 3;
-                    o[0] = X[k]; o[1] = Y[k]; o[2] = Z[k];
-                    if (orgb) {
-                        // bytes 3k .. 3k+2 of the 12 frame bytes: B, G, R -> colours = cv2.cvtColor(frame, BGR2RGB), semantic_depth.py:161
-                        const unsigned long long lo64 = ((unsigned long long)cur.fw[1] << 32) | cur.fw[0], hi64 = ((unsigned long long)cur.fw[2] << 32) | cur.fw[1];
-                        const unsigned bgr = k < 2 ? (unsigned)(lo64 >> (24 * k)) : (unsigned)(hi64 >> (24 * k - 32));
-                        uint8_t* c = orgb + ((size_t)b * p.cap + pos) * 3;
-                        c[0] = (uint8_t)(bgr >> 16); c[1] = (uint8_t)(bgr >> 8); c[2] = (uint8_t)bgr;
-                    }
+                for (int k = 0; k < 4; ++k) oxyz[pos + k] = F1Vec3{X[k], Y[k], Z[k]};
+                if (orgb) {
+                    // frame bytes B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3  ->  R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+                    F1Vec3u c;
+                    c.x = __builtin_amdgcn_perm(cur.fw[1], cur.fw[0], 0x05000102u);
+                    c.y = __builtin_amdgcn_perm(cur.fw[2], __builtin_amdgcn_perm(cur.fw[1], cur.fw[0], 0x07000304u), 0x03040100u);
+                    c.z = __builtin_amdgcn_perm(cur.fw[2], cur.fw[1], 0x05060702u);
+                    *reinterpret_cast<F1Vec3u*>(orgb + (size_t)pos * 3) = c;
                 }
-                ++pos;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (!((m4 >> (8 * k)) & 0xffu)) continue;
+                    if (pos < (unsigned)p.cap) {
+                        oxyz[pos] = F1Vec3{X[k], Y[k], Z[k]};
+                        if (orgb) {
+                            // bytes 3k .. 3k+2 of the 12 frame bytes: B, G, R -> colours = cv2.cvtColor(frame, BGR2RGB), semantic_depth.py:161
+                            const unsigned long long lo64 = ((unsigned long long)cur.fw[1] << 32) | cur.fw[0], hi64 = ((unsigned long long)cur.fw[2] << 32) | cur.fw[1];
+                            const unsigned bgr = k < 2 ? (unsigned)(lo64 >> (24 * k)) : (unsigned)(hi64 >> (24 * k - 32));
+                            uint8_t* c = orgb + (size_t)pos * 3;
+                            c[0] = (uint8_t)(bgr >> 16); c[1] = (uint8_t)(bgr >> 8); c[2] = (uint8_t)bgr;
+                        }
+                    }
+                    ++pos;
+                }
             }
             if (cls) ex_f += cnt; else ex_r += cnt;
         }
