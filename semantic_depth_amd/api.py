@@ -51,6 +51,14 @@ def register_engine(engine: Engine):
     _engines.setdefault(key, {})[engine.encoder] = engine
 
 
+def release_engines():
+    """drop the shared Engines (their arenas are freed once the operator objects that hold them are gone too)"""
+    for per in _engines.values():
+        for e in per.values():
+            e.close()
+    _engines.clear()
+
+
 def any_engine() -> Engine | None:
     for per in _engines.values():
         for e in per.values():

@@ -80,6 +80,15 @@ class FrameFeeder:
         self._torch = torch
         self._pinned = [None, None]
 
+    def close(self):
+        self.pool.shutdown(wait=False)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     def _decode_into(self, slot: int, lo: int, hi: int):
         torch = self._torch
         first = imread(self.paths[lo])

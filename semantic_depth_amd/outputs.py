@@ -136,6 +136,10 @@ def save_frame_outputs(output_name: str, res: dict, depth: float, approach: str 
     ``api.FrameProcessor.process_frame(..., want_clouds=True)`` returns.  Returns the list of files written."""
     files = []
     rec = res["record"]
+    if not rec["found"]:
+        # semantic_depth.py indexes left_pt_rw[0] unconditionally (:259) and dies on (None, None); the sequence tool guards it
+        # (seq:232-234).  Here: the same TypeError the reference raises, before anything is written.
+        raise TypeError("'NoneType' object is not subscriptable (no road point in the depth window: left_pt_rw is None)")
     left_rw, right_rw = rec["left_pt"].astype(np.float64)[None, :], rec["right_pt"].astype(np.float64)[None, :]
     dist_rw = res["dist_rw"]
     line_rw, colors_line_rw = pcl.create_3Dline_from_3Dpoints(left_rw.copy(), right_rw.copy(), [250, 0, 0])
