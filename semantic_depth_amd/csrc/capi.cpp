@@ -117,7 +117,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
     auto T = [&](int t) -> float* { return reinterpret_cast<float*>(abase + p.tensors[t].offset); };
     auto Wp = [&](int w) -> const float* { return reinterpret_cast<const float*>(wbase + p.weights[w].offset); };
     auto PL = [&](int t) -> size_t { const TensorDesc& d = p.tensors[t]; return (size_t)p.images * d.H * d.W * d.C; };   // lo-plane offset
-    auto FMT = [&](int t) -> int { return p.tensors[t].fmt ? (p.tensors[t].f16 ? 2 : 1) : 0; };     // 0 f32, 1 split bf16, 2 split fp16
+    auto FMT = [&](int t) -> int { return p.tensors[t].fmt ? (p.tensors[t].f16 ? 2 : 1) : 0; };     // (fp16 hi+lo tensors never reach the ops that take this)     // 0 f32, 1 split bf16, 2 split fp16
     for (const WeightSlot& wsl : p.weights)
         if (!wsl.loaded) return fail(h, SD_ERR_STATE, "weight not loaded: " + wsl.name);
     for (const OpDesc& op : p.ops) {
@@ -273,7 +273,7 @@ int32_t* cnt_slot(sd_handle* h, int i) { return reinterpret_cast<int32_t*>(h->ws
 extern "C" {
 
 #ifndef SD_DEFAULT_PLAN_FCN
-#define SD_DEFAULT_PLAN_FCN "conv1_2,conv2_2,conv4_2:1,conv4_3:1,conv5_1:1,conv5_2:1,conv5_3:1,fc6:1,fc7:1"
+#define SD_DEFAULT_PLAN_FCN "conv1_2,conv2_2,conv3_3:x,conv4_1:x,conv4_2:1,conv4_3:1,conv5_1:1,conv5_2:1,conv5_3:1,fc6:1,fc7:1"
 #endif
 #ifndef SD_DEFAULT_PLAN_MONO
 #define SD_DEFAULT_PLAN_MONO "enc/res2*,enc/res3*,enc/res4*:1,enc/res5*:1,dec/upconv6:1,dec/iconv6:1,dec/upconv5:1,dec/iconv5:1,dec/upconv4:1,dec/iconv4:1,dec/disp4,dec/upconv1:1,dec/iconv1:1"

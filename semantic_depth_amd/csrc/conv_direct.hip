@@ -68,7 +68,8 @@ __device__ __forceinline__ DirectChunk load_chunk(const DirectChunk* ptr) {
 // N16 (Cout <= 16, NB = 1): the 32-row MFMA would spend half its rows on padding, so the products run on
 // v_mfma_f32_16x16x32 instead: K = 32 is one PAIR of taps x 16 channels, a wave's 2 x 32 pixels are four 16-pixel blocks.
 // W1 (with F16): ONE MFMA product per product -- the w_lo plane is neither fetched nor multiplied (plain fp16 x fp16, f32 accumulate)
-template <int NB, int MT, bool F16, bool N16 = false, bool UP = false, bool W1 = false>
+// X2 (with F16): the input is fp16 hi + lo planes and only w_hi is used: TWO products x_hi*w_hi + x_lo*w_hi (split_fmt.hpp)
+template <int NB, int MT, bool F16, bool N16 = false, bool UP = false, bool W1 = false, bool X2 = false>
 __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_kernel(const ConvDirectParams p) {
     static_assert(!N16 || NB == 1, "N16 is a variant of the 32-channel kernel");
     using Cfg = DirectCfg<NB, MT, UP>;
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
 #pragma unroll
         for (int i = 0; i < XS; ++i) {
             const int j = wave + D_WAVES * i;
-            if (j >= (F16 ? 1 : 2) * D_XI) continue;          // fp16 activations: ONE plane
+            if (j >= ((F16 && !X2) ? 1 : 2) * D_XI) continue;          // fp16 activations: ONE plane (X2: hi + lo)
             const int ry = geo[i] & 0xff, rx = (geo[i] >> 8) & 0xff, oct = (geo[i] >> 16) & 1;
             // UP: source coordinates directly (an output-resolution pixel is outside the image exactly when its source pixel is)
             const int gy = (UP ? (tl.ty0 >> 1) : tl.ty0) - 1 + ry, gx = (UP ? (tl.tx0 >> 1) : tl.tx0) - 1 + rx;
@@ -138,9 +139,9 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
             ddma16(ok ? reinterpret_cast<const u32x4*>(src) : zero, sbyte + (unsigned)(j * 1024));
         }
 #pragma unroll
-        for (int i = 0; i < ((W1 ? 1 : 2) * D_WI + D_WAVES - 1) / D_WAVES; ++i) {      // both weight planes in either format (W1: w_hi only)
+        for (int i = 0; i < (((W1 || X2) ? 1 : 2) * D_WI + D_WAVES - 1) / D_WAVES; ++i) {      // both weight planes (W1, X2: w_hi only)
             const int jw = wave + D_WAVES * i;
-            if (jw < (W1 ? 1 : 2) * D_WI) {
+            if (jw < ((W1 || X2) ? 1 : 2) * D_WI) {
                 const int pl = jw >= D_WI ? 1 : 0;
                 const int u = (jw - pl * D_WI) * 64 + lane;
                 const u32x4* gw = p.wt + ((size_t)(2 * half + pl) * p.nchunks + c) * D_GW + (N16 ? (u >> 4) * 32 + (u & 15) : u);
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                     const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;         // tap / 3, tap % 3 for tap < 10
                     const int wi = (tap * 2 + oct) * 16 + c16;
                     const u32x4 wh = live ? Wh[wi] : z4;
-                    const u32x4 wl = W1 ? wh : (live ? Wl[wi] : z4);
+                    const u32x4 wl = (W1 || X2) ? wh : (live ? Wl[wi] : z4);
 #pragma unroll
                     for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -204,10 +205,10 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                             const int lp = hpix(MT * wave + a + dy, 16 * pb + c16 + dx);
                             const int idx = lp * 2 + (oct ^ ((lp >> 3) & 1));
                             const u32x4 xh = live ? Xh[idx] : z4;
-                            const u32x4 xl = F16 ? xh : (live ? Xl[idx] : z4);
+                            const u32x4 xl = (F16 && !X2) ? xh : (live ? Xl[idx] : z4);
 #pragma unroll
                             for (int pr = 0; pr < 3; ++pr) {      // x_hi*w_lo, x_lo*w_hi, x_hi*w_hi; fp16 activations have no lo plane
-                                if ((F16 && pr == 1) || (W1 && pr == 0)) continue;
+                                if ((F16 && !X2 && pr == 1) || ((W1 || X2) && pr == 0)) continue;
                                 acc16[a][pb] = mfma_frag16<F16>(pr == 0 ? wl : wh, pr == 1 ? xl : xh, acc16[a][pb]);
                             }
                         }
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                     const int lp = hpix(MT * wave + r, frow + dx);
                     const int idx = lp * 2 + (fk ^ ((lp >> 3) & 1));
                     xh[r] = Xh[idx];
-                    xl[r] = F16 ? xh[r] : Xl[idx];
+                    xl[r] = (F16 && !X2) ? xh[r] : Xl[idx];
                 }
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
@@ -229,10 +230,10 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                     for (int nb = 0; nb < NB; ++nb) {
                         const int wi = ((dy * 3 + dx) * 2 + fk) * (32 * NB) + nb * 32 + frow;
                         const u32x4 wh = Wh[wi];
-                        const u32x4 wl = W1 ? wh : Wl[wi];
+                        const u32x4 wl = (W1 || X2) ? wh : Wl[wi];
 #pragma unroll
                         for (int pr = 0; pr < 3; ++pr) {          // x_hi*w_lo, x_lo*w_hi, x_hi*w_hi; fp16 activations have no lo plane
-                            if ((F16 && pr == 1) || (W1 && pr == 0)) continue;
+                            if ((F16 && !X2 && pr == 1) || ((W1 || X2) && pr == 0)) continue;
 #pragma unroll
                             for (int a = 0; a < MT; ++a)
                                 acc[a][nb] = mfma_frag<F16>(pr == 0 ? wl : wh, pr == 1 ? xl[a + dy] : xh[a + dy], acc[a][nb]);
@@ -247,7 +248,8 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
         __builtin_amdgcn_s_barrier();
         auto epilogue = [&](auto tag, auto otag) {
             constexpr int ACT = decltype(tag)::value;
-            constexpr bool O16 = decltype(otag)::value;        // output planes: fp16 or bf16 (the consumers' format)
+            constexpr int OF = decltype(otag)::value;          // output planes (the consumers' format): 0 bf16 hi+lo, 1 ONE fp16, 2 fp16 hi+lo
+            constexpr bool O16 = OF == 1;
             constexpr int ROW = 64 * NB + 16;
             constexpr int SEGS = 4 * NB, PPP = 64 / SEGS;        // 16-byte segments per pixel, pixels per store pass
             // per wave: hi slab and lo slab of 32 pixels (a lo slab that does not fit the stage reuses the hi slab)
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                             for (int r = 0; r < 4; ++r) v[r] = 4 * kg16 + r < p.nreal ? v[r] : 0.f;
                         }
                         uint2 h, l;
-                        split4_t<O16>(v, h, l);
+                        split4_fmt<OF>(v, h, l);
                         if (4 * kg16 < p.Cout) {
                             *reinterpret_cast<uint2*>(s16 + (16 * pb + c16) * R16 + kg16 * 8) = h;
                             if constexpr (!O16) *reinterpret_cast<uint2*>(s16 + 32 * R16 + (16 * pb + c16) * R16 + kg16 * 8) = l;
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                     v += bias[r4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
-                    split4_t<O16>(v, hh[r4], ll[r4]);
+                    split4_fmt<OF>(v, hh[r4], ll[r4]);
                 }
                 const int pp = frow >> 1;                    // pooled pixel of this lane pair
 #pragma unroll
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                     v += bias[r4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
-                    split4_t<O16>(v, hh[r4], ll[r4]);
+                    split4_fmt<OF>(v, hh[r4], ll[r4]);
                 }
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
@@ -415,7 +417,10 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                 }
             }
         };
-        auto ep = [&](auto tag) { if (p.out_f16) epilogue(tag, BoolTag<true>{}); else epilogue(tag, BoolTag<false>{}); };
+        auto ep = [&](auto tag) {
+            if constexpr (!N16) { if (p.out_f16 == 2) { epilogue(tag, IntTag<2>{}); return; } }
+            if (p.out_f16) epilogue(tag, IntTag<1>{}); else epilogue(tag, IntTag<0>{});
+        };
         if (p.act == ACT_RELU) ep(ActTag<ACT_RELU>{});
         else if (p.act == ACT_ELU) ep(ActTag<ACT_ELU>{});
         else if (N16 && p.act == ACT_SIGMOID03) ep(ActTag<ACT_SIGMOID03>{});
@@ -426,6 +431,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
 
 hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
     if ((p.act == ACT_SIGMOID03 || p.nreal) && (p.Cout > 16 || p.nsplit != 1 || p.pool || (p.sw & SW_NO_N16))) return hipErrorInvalidValue;
+    if (p.out_f16 == 2 && p.Cout <= 16 && p.nsplit == 1 && !p.pool) return hipErrorInvalidValue;      // (the 16-wide form writes formats 0 and 1)
     if (p.W % D_TW || p.Cout > 64 || p.Cout % 8 || p.nsplit < 1 || p.nsplit > 8 || (p.nsplit > 1 && p.Cout != 64)) return hipErrorInvalidValue;
     static int cus = 0;
     if (!cus) {
@@ -447,14 +453,17 @@ hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
     const int th = mt1 ? 8 : 16;
     const int tiles = (p.W / D_TW) * ((p.H + th - 1) / th) * p.N * p.nsplit;
     // persistent grid: as many workgroups as the instantiation keeps resident (1-3 per CU, by LDS and registers)
-#define SD_DIRECT_(NB_, MT_, F16_, N16_, UP_, W1_) \
+#define SD_DIRECT_(NB_, MT_, F16_, N16_, UP_, W1_, X2_) \
     do { static int per_cu = 0; \
-         if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_direct_kernel<NB_, MT_, F16_, N16_, UP_, W1_>, 512, 0) != hipSuccess || per_cu < 1)) per_cu = 1; \
+         if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_direct_kernel<NB_, MT_, F16_, N16_, UP_, W1_, X2_>, 512, 0) != hipSuccess || per_cu < 1)) per_cu = 1; \
          const int slots = cus * per_cu; \
          const dim3 grid((unsigned)(tiles < slots ? tiles : slots)); \
-         hipLaunchKernelGGL((conv_direct_kernel<NB_, MT_, F16_, N16_, UP_, W1_>), grid, dim3(512), 0, s, q); } while (0)
-#define SD_DIRECT(NB_, MT_, F16_, N16_, W1_) do { if (up) SD_DIRECT_(NB_, MT_, F16_, N16_, true, W1_); else SD_DIRECT_(NB_, MT_, F16_, N16_, false, W1_); } while (0)
-    if (p.f16 == 2) {           // fp16, ONE product
+         hipLaunchKernelGGL((conv_direct_kernel<NB_, MT_, F16_, N16_, UP_, W1_, X2_>), grid, dim3(512), 0, s, q); } while (0)
+#define SD_DIRECT(NB_, MT_, F16_, N16_, W1_) do { if (up) SD_DIRECT_(NB_, MT_, F16_, N16_, true, W1_, false); else SD_DIRECT_(NB_, MT_, F16_, N16_, false, W1_, false); } while (0)
+    if (p.f16 == 3) {           // fp16 hi + lo input x w_hi: the 64-channel-pass form only (the planner asks for nothing else)
+        if (mt1 || n16 || nb == 1 || up) return hipErrorInvalidValue;
+        SD_DIRECT_(2, 2, true, false, false, false, true);
+    } else if (p.f16 == 2) {           // fp16, ONE product
         if (mt1) SD_DIRECT(1, 1, true, true, true);
         else if (n16) SD_DIRECT(1, 2, true, true, true);
         else if (nb == 1) SD_DIRECT(1, 2, true, false, true);
@@ -479,7 +488,8 @@ hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
 // 16-wide MFMA form
 const char* conv_direct_kernel_name(const ConvDirectParams& p) {
     const bool n16 = p.Cout <= 16 && p.nsplit == 1 && !p.pool && !(p.sw & SW_NO_N16);
-    // f16w: fp16 activations x two fp16 weight planes (2 products); f16x1: fp16 x fp16 (1 product)
+    // f16w: fp16 activations x two fp16 weight planes (2 products); f16x1: fp16 x fp16 (1 product); f16w_x2: fp16 hi+lo x w_hi (2 products)
+    if (p.f16 == 3) return "conv_direct_f16w_x2_kernel<2,2>";
     if (n16) return p.f16 == 2 ? "conv_direct_f16x1_kernel<1,n16>" : p.f16 ? "conv_direct_f16w_kernel<1,n16>" : "conv_direct_kernel<1,n16>";
     if (p.Cout <= 32) return p.f16 == 2 ? "conv_direct_f16x1_kernel<1,2>" : p.f16 ? "conv_direct_f16w_kernel<1,2>" : "conv_direct_kernel<1,2>";
     return p.f16 == 2 ? "conv_direct_f16x1_kernel<2,2>" : p.f16 ? "conv_direct_f16w_kernel<2,2>" : "conv_direct_kernel<2,2>";

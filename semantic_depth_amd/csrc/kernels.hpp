@@ -96,6 +96,7 @@ __device__ __forceinline__ float fast_elu_split(float v) {
 }
 template <int ACT> struct ActTag { static constexpr int value = ACT; };
 template <bool B> struct BoolTag { static constexpr bool value = B; };   // output plane format of an epilogue: true = fp16 planes
+template <int I> struct IntTag { static constexpr int value = I; };      // the same, three-way (split_fmt.hpp split2_fmt)
 // activation selected at compile time inside the epilogues (a run-time switch per value costs more than the arithmetic)
 template <int ACT> __device__ __forceinline__ float act_split(float v) {
     if (ACT == 1) return fmaxf(v, 0.f);
@@ -137,8 +138,9 @@ struct ConvDirectParams {
     int act, Nmax;
     const void* zero16;
     int rows_per_wave;           // 1: 8 x 32 tiles, 2: 16 x 32 tiles (see conv_direct.hip)
-    int f16;                     // 1: ONE fp16 input plane x two fp16 weight planes (2 MFMA products); 2: x w_hi only (1 product)
-    int out_f16;                 // OUTPUT planes are fp16
+    int f16;                     // 1: ONE fp16 input plane x two fp16 weight planes (2 MFMA products); 2: x w_hi only (1 product);
+                                 // 3: fp16 hi + lo input planes x w_hi (2 products: x_hi*w_hi + x_lo*w_hi)
+    int out_f16;                 // OUTPUT planes: 0 bf16 hi + lo, 1 ONE fp16 plane, 2 fp16 hi + lo
     int pool;                    // 1: fused 2x2 stride-2 max pool, out is [N,H/2,W/2,Cout] (needs rows_per_wave == 2)
     unsigned sw;                 // Switch bits of the handle
 };
@@ -161,7 +163,7 @@ struct SmallNParams {
     float* out;         // [N,H,W,nout]
     int act;
     const void* zero16; // 16 zero bytes (padding source of the LDS-DMA halo loads of the tiled kernel)
-    int f16;            // INPUT split planes are fp16 instead of bf16
+    int f16;            // INPUT planes: 0 bf16 hi + lo, 1 ONE fp16 plane, 2 fp16 hi + lo (per-thread / per-wave kernels)
     int out_f16;        // OUTPUT split planes (out_split) are fp16
     unsigned sw;        // Switch bits of the handle
 };

@@ -33,6 +33,10 @@ __device__ __forceinline__ f32x4 load4(const float* base, size_t plane, long qua
         const uint2 h = reinterpret_cast<const uint2*>(base)[quad_index];
         uint2 l = {0u, 0u};
         if (SPLIT != 2) l = reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + plane)[quad_index];
+        if (SPLIT == 3) {          // fp16 hi + lo planes (read side only: the score heads on pool3 / pool4)
+            const f32x2_t a = recon2_f16x2(h.x, l.x), b = recon2_f16x2(h.y, l.y);
+            return f32x4{a[0], a[1], b[0], b[1]};
+        }
         return recon4_t<SPLIT == 2>(h, l);
     }
     return reinterpret_cast<const f32x4*>(base)[quad_index];
@@ -425,7 +429,12 @@ bool conv_smalln_tiled(int in_split, int k, int W, int C, int nout, unsigned sw)
 hipError_t launch_conv_smalln(const SmallNParams& p, hipStream_t s) {
     if (p.in_sub && !(conv_smalln_tiled(p.in_split, p.k, p.W, p.C, p.nout, p.sw) && p.zero16)) return hipErrorInvalidValue;   // sub-planes: tiled kernel only
     if (p.out_split && (p.nout != 2 || p.k * p.k * p.C > 2048)) return hipErrorInvalidValue;
-    if (p.in_split && p.f16) launch_smalln_t<2>(p, s);
+    if (p.in_split && p.f16 == 2) {      // fp16 hi + lo input: the per-thread / per-wave kernels only
+        if (p.in_sub || p.out_split) return hipErrorInvalidValue;
+        SmallNParams q = p;
+        q.sw |= SW_NO_SMALLN_TILE;
+        launch_smalln_t<3>(q, s);
+    } else if (p.in_split && p.f16) launch_smalln_t<2>(p, s);
     else if (p.in_split) launch_smalln_t<1>(p, s);
     else launch_smalln_t<0>(p, s);
     return hipGetLastError();
@@ -439,7 +448,8 @@ __global__ __launch_bounds__(256) void unsplit_kernel(const float* __restrict__ 
     const long pix = i / Ctf;
     const int c = (int)(i - pix * Ctf);
     const uint16_t* h = reinterpret_cast<const uint16_t*>(x) + (sub ? (size_t)(c >> 4) * sub + (size_t)pix * 16 + (c & 15) : (size_t)pix * C + c);
-    if (f16) y[i] = (float)__builtin_bit_cast(_Float16, h[0]);                        // fp16 tensors have ONE plane
+    if (f16 == 2) y[i] = (float)__builtin_bit_cast(_Float16, h[0]) + (float)__builtin_bit_cast(_Float16, h[plane]);      // fp16 hi + lo
+    else if (f16) y[i] = (float)__builtin_bit_cast(_Float16, h[0]);                   // ONE fp16 plane
     else y[i] = __uint_as_float((unsigned)h[0] << 16) + __uint_as_float((unsigned)h[plane] << 16);
 }
 hipError_t launch_unsplit(const float* x, float* y, long npix, int C, int Ctf, size_t plane, size_t sub, int f16, hipStream_t s) {

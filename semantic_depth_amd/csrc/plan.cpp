@@ -296,21 +296,36 @@ struct Builder {
             }
         }
         auto is_conv = [](const OpDesc& op) { return op.kind == OP_CONV || op.kind == OP_CONV_DIRECT; };
-        // token = layer name | prefix* | *, optionally followed by ":1" = ONE MFMA product (x * w_hi: plain fp16) instead of two
+        // token = layer name | prefix* | *, optionally followed by ":1" = ONE MFMA product (x * w_hi: plain fp16) instead of two, or by
+        // ":x" = two products on fp16 hi + lo ACTIVATION planes and w_hi (the error is the weight's rounding, the input tensor keeps 22
+        // bits: for layers whose input also feeds a score head; direct 3x3 layers only)
         auto match = [](const std::string& t, const std::string& n) {
             return t == "*" || t == n || (t.size() > 1 && t.back() == '*' && n.compare(0, t.size() - 1, t, 0, t.size() - 1) == 0);
         };
         for (std::string t : toks) {
             int mode = 1;
             if (t.size() > 2 && t.compare(t.size() - 2, 2, ":1") == 0) { mode = 2; t.erase(t.size() - 2); }
+            else if (t.size() > 2 && t.compare(t.size() - 2, 2, ":x") == 0) { mode = 3; t.erase(t.size() - 2); }
             bool any = false;
             for (OpDesc& op : p.ops) {
                 if (!match(t, op.name)) continue;
                 any = true;          // (a layer that is not an MFMA conv at this geometry, e.g. a small-N head, follows its input's format)
-                if (is_conv(op)) op.f16 = std::max(op.f16, mode);
+                if (!is_conv(op)) continue;
+                if (mode == 3) {
+                    if (op.k != 3 || op.stride != 1 || p.tensors[op.dst].C % 64)
+                        throw std::runtime_error("precision plan of " + p.net + ": ':x' needs a 3x3 stride-1 layer with a multiple of 64 output channels (" + op.name + ")");
+                    // the form exists in the direct kernel only, on planes a direct kernel's epilogue wrote: where this geometry routes the
+                    // layer or its producer elsewhere (narrow images, a stand-alone pool, the stem kernel) the layer keeps three products
+                    bool ok = op.kind == OP_CONV_DIRECT && op.nsplit * 64 == p.tensors[op.dst].C && !op.up[0];
+                    for (int j = 0; j < op.nsrc && ok; ++j)
+                        for (const OpDesc& q : p.ops)
+                            if (q.dst == op.src[j] && q.kind != OP_CONV_DIRECT) ok = false;
+                    if (ok) op.f16 = 3;
+                } else if (op.f16 != 3) op.f16 = std::max(op.f16, mode);
             }
             if (!any) throw std::runtime_error("precision plan of " + p.net + ": no layer matches '" + t + "'");
         }
+        // closure.  tensor.f16: 0 bf16 hi+lo, 1 ONE fp16 plane, 2 fp16 hi+lo (its hi plane IS format 1: every fp16 layer can read it)
         for (bool changed = true; changed;) {
             changed = false;
             for (OpDesc& op : p.ops) {
@@ -319,18 +334,28 @@ struct Builder {
                     for (int j = 0; j < op.nsrc; ++j) reads16 = reads16 || p.tensors[op.src[j]].f16;
                     if (reads16 && !op.f16) { op.f16 = 1; changed = true; }
                     if (op.f16)
-                        for (int j = 0; j < op.nsrc; ++j)
-                            if (p.tensors[op.src[j]].fmt && !p.tensors[op.src[j]].f16) { p.tensors[op.src[j]].f16 = 1; changed = true; }
+                        for (int j = 0; j < op.nsrc; ++j) {
+                            TensorDesc& t = p.tensors[op.src[j]];
+                            const int want = op.f16 == 3 ? 2 : 1;
+                            if (t.fmt && t.f16 < want) { t.f16 = want; changed = true; }
+                        }
                 } else if (op.kind == OP_POOL2 || op.kind == OP_POOL3Z) {      // a stand-alone pool keeps the format of its source
                     TensorDesc &a = p.tensors[op.src[0]], &b = p.tensors[op.dst];
-                    if (a.fmt && b.fmt && a.f16 != b.f16) { a.f16 = b.f16 = 1; changed = true; }
+                    if (a.fmt && b.fmt && a.f16 != b.f16) { a.f16 = b.f16 = std::max(a.f16, b.f16); changed = true; }
                 }
             }
+        }
+        // an fp16 hi+lo tensor is written by a direct conv's epilogue and read by convs / per-thread heads only
+        for (const OpDesc& op : p.ops) {
+            if (op.dst >= 0 && p.tensors[op.dst].fmt && p.tensors[op.dst].f16 == 2 && op.kind != OP_CONV_DIRECT)
+                throw std::runtime_error("precision plan of " + p.net + ": the input of a ':x' layer must come from a direct 3x3 layer (" + op.name + ")");
+            if ((op.kind == OP_POOL2 || op.kind == OP_POOL3Z) && p.tensors[op.src[0]].f16 == 2)
+                throw std::runtime_error("precision plan of " + p.net + ": a stand-alone pool cannot read fp16 hi+lo planes (" + op.name + ")");
         }
         double fl = 0;
         for (OpDesc& op : p.ops) {
             if (!is_conv(op) || !op.f16) continue;
-            p.f16_ops += (p.f16_ops.empty() ? "" : ",") + op.name + (op.f16 == 2 ? ":1" : "");
+            p.f16_ops += (p.f16_ops.empty() ? "" : ",") + op.name + (op.f16 == 2 ? ":1" : op.f16 == 3 ? ":x" : "");
             fl += op.flops;
             if (op.f16 == 2) p.flops_f16x1 += op.flops / std::max(1, p.images);
             p.weights[op.w].f16 = 1;

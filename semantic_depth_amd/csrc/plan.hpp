@@ -16,7 +16,7 @@ struct TensorDesc {
     int N = 0, H = 0, W = 0, C = 0;   // C = stored channels
     int Ctf = 0;                      // channels the TensorFlow graph sees (input_pre stores 4, TF sees 3)
     int fmt = 0;                      // 0: f32 NHWC; 1: split-bf16 planes (split_fmt.hpp)
-    int f16 = 0;                      // ONE fp16 plane instead of two bf16 planes (split_fmt.hpp): every conv that reads it runs the
+    int f16 = 0;                      // 1: ONE fp16 plane, 2: fp16 hi + lo planes, instead of two bf16 planes (split_fmt.hpp): every conv that reads it runs the
                                       // 2-product scheme x * (w_hi + w_lo) (precision plan, see NetPlan::f16_spec)
     int planar16 = 0;                 // split planes stored as C/16 sub-planes of 16 channels ([C/16][N][H][W][16] per plane): the
                                       // producer is the stem kernel, the only consumer a direct conv, whose 16-channel halo DMA

@@ -8,6 +8,9 @@
 //     error is the 2^-12 relative rounding of the activation -- the same size as rounding the weights instead (round 1's form
 //     of the scheme: fp16 x 2 activation planes times ONE fp16 weight plane), but every activation tensor is half the bytes in
 //     HBM, L2 and the LDS-DMA, which is what the HBM-bound layers (ResNet 1x1 layers, the full-resolution decoder) run against.
+//   fp16 x 2 planes (hi as above + lo = RNE(v - hi)): for the few layers whose input tensor is precision-critical (it also feeds a
+//     score head) the plan keeps 22 bits of the activation and drops the weight's low part instead: TWO products x_hi*w_hi + x_lo*w_hi
+//     (conv_direct X2).  Any other fp16 layer reads the hi plane of such a tensor as if it were the one-plane format.
 // The MFMA operands of the conv engine are read straight from the planes (16-byte runs of 8 channels), nothing is converted at
 // load time.  The F16 template argument of the helpers selects the format; their `l` argument is ignored / zero for fp16.
 #pragma once
@@ -81,6 +84,28 @@ template <bool F16> __device__ __forceinline__ void split2_t(f32x2_t v, unsigned
 template <bool F16> __device__ __forceinline__ void split4_t(f32x4_t v, uint2& h, uint2& l) {
     split2_t<F16>(f32x2_t{v[0], v[1]}, h.x, l.x);
     split2_t<F16>(f32x2_t{v[2], v[3]}, h.y, l.y);
+}
+// output format of an epilogue: 0 = bf16 hi + lo, 1 = ONE fp16 plane, 2 = fp16 hi + lo (the hi plane is bit for bit the one of format
+// 1, so every fp16 layer can read such a tensor; the lo plane serves the layers that multiply x_hi and x_lo by ONE weight plane)
+template <int FMT> __device__ __forceinline__ void split2_fmt(f32x2_t v, unsigned& h, unsigned& l) {
+    if constexpr (FMT == 2) {
+        const f32x2_t c = {__builtin_amdgcn_fmed3f(v[0], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v[1], -65504.f, 65504.f)};
+        const f16x2_t hb = __builtin_convertvector(c, f16x2_t);
+        const f32x2_t r = c - __builtin_convertvector(hb, f32x2_t);               // exact
+        const f16x2_t lb = __builtin_convertvector(r, f16x2_t);
+        h = __builtin_bit_cast(unsigned, hb);
+        l = __builtin_bit_cast(unsigned, lb);
+    } else {
+        split2_t<FMT == 1>(v, h, l);
+    }
+}
+template <int FMT> __device__ __forceinline__ void split4_fmt(f32x4_t v, uint2& h, uint2& l) {
+    split2_fmt<FMT>(f32x2_t{v[0], v[1]}, h.x, l.x);
+    split2_fmt<FMT>(f32x2_t{v[2], v[3]}, h.y, l.y);
+}
+// fp16 hi + lo -> f32
+__device__ __forceinline__ f32x2_t recon2_f16x2(unsigned h, unsigned l) {
+    return __builtin_convertvector(__builtin_bit_cast(f16x2_t, h), f32x2_t) + __builtin_convertvector(__builtin_bit_cast(f16x2_t, l), f32x2_t);
 }
 // one 32x32x16 MFMA on raw 16-byte fragments of the selected element type
 template <bool F16> __device__ __forceinline__ f32x16_t mfma_frag(u32x4s_t a, u32x4s_t b, f32x16_t c) {

@@ -117,6 +117,12 @@ def test_precision_plan_closure(lib):
     assert {"enc/res5_1/conv1", "enc/res5_3/conv3", "dec/iconv6"} <= set(mono) and "enc/res4_1/conv1" not in mono and "enc/conv1" not in mono
     st, _ = _plan(lib, "no_such_layer", "")
     assert st == L.SD_OK - 1                                                # SD_ERR_INVALID
+    # ':1' = one product (x * w_hi); ':x' = fp16 hi + lo activations times w_hi, direct 3x3 layers fed by direct 3x3 layers only
+    st, p = _plan(lib, "conv3_3:x,conv4_1:x,conv4_2:1", "")
+    assert st == 0 and p[L.SD_NET_FCN8S][0] == ["conv3_3:x", "conv4_1:x", "conv4_2:1"]
+    st, p = _plan(lib, "conv1_2:x,conv2_2", "")
+    assert st == 0 and p[L.SD_NET_FCN8S][0] == ["conv2_2"]                  # its input comes from the stem kernel: three products
+    assert _plan(lib, "fc6:x", "")[0] == L.SD_OK - 1                        # not a 3x3 layer
     assert lib.sd_default_plan(L.SD_NET_FCN8S).decode() != "" or lib.sd_default_plan(L.SD_NET_MONODEPTH).decode() != ""
     # the built-in plan is a valid plan
     h = C.c_void_p()
