@@ -9,6 +9,8 @@
 // (stage (t+2)%3 was last read in iteration t-1, which every wave finished before this barrier).
 // 8 waves; block 256x256 in TWO 64-KiB stages (layers with >= 512 such blocks: 170 B of DMA per MFMA, half the barriers), else
 // 128x256 (Cout % 256 == 0), 256x128 (Cout % 128 == 0), 256x64 or 256x32 with 3 x 36-48 KiB stages; one workgroup per CU.
+// The fp16 forms keep only the planes they read in a stage (48 / 32 KB for 256x256), which buys a deeper ring (one-product
+// 256x256: 4 stages, three k-tiles in flight: fc7 +26 %, fc6 +5 %) or a second workgroup per CU (256x64; one-product 128x256, 256x128).
 // (3x3 stride-1 layers of widths that are multiples of 32 never come here: conv_direct.hip.)
 // Out-of-image taps and pixels beyond M read a 16-byte zero page, so zero padding costs no branch in the pipeline.
 // Gather granularity: four consecutive lanes fetch the four 16-byte octets of ONE pixel (64 contiguous bytes per plane),
@@ -66,10 +68,14 @@ __device__ __forceinline__ KEntry load_kentry(const KEntry* ptr) {
 // each with its own stride): two base pointers per lane, the k-tile index selects the source.
 // W1 (with F16): ONE MFMA product per product -- the w_lo plane is neither fetched nor multiplied (plain fp16 x fp16, f32 accumulate)
 template <int WAVES_M, int WAVES_N, int MT, int NT, int SIMPLE, int STAGES, bool F16 = false, bool W1 = false>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 : 1) void conv_dma_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
-    constexpr int STAGE_UNITS = 8 * (BM + BN);                // 16-B units: Xh [4][BM] | Xl [4][BM] | Wh [4][BN] | Wl [4][BN]
+    // 16-B units of a stage: Xh [4][BM] | Xl [4][BM] | Wh [4][BN] | Wl [4][BN]; the fp16 forms drop the planes they do not read
+    // (Xl; W1: Wl too), so the same LDS holds a deeper ring: more k-tiles in flight against the L2 -> LDS latency
+    constexpr int X_UNITS = (F16 ? 4 : 8) * BM, W_UNITS = (W1 ? 4 : 8) * BN;
+    constexpr int STAGE_UNITS = X_UNITS + W_UNITS;
+    static_assert(STAGES * STAGE_UNITS * 16 <= 160 * 1024, "ring fits in the LDS of a CU");
     constexpr int XI = 8 * BM / 64 / NW;                      // activation DMA instructions per wave and tile (2 or 4), hi first then lo
     constexpr int WI_ALL = 8 * BN / 64;                       // weight instructions of a tile, both planes (32, 16 or 8)
     constexpr int WI = W1 ? WI_ALL / 2 : WI_ALL;              // both weight planes in either format (fp16: w_hi, w_lo); W1: w_hi only
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
             const int wu = jw * 64 + lane;                    // unit inside the W region: [plane][kg][n]
             const int pl = wu / (4 * BN), r = wu % (4 * BN), kg = r / BN, n_l = r % BN;
             const u32x4* g = wt_hi + pl * wplane + (size_t)(kt * 4 + kg) * CoutPad + bn0 + n_l;
-            dma16(g, sbyte + (unsigned)((XI * NW + jw) * 1024));
+            dma16(g, sbyte + (unsigned)(X_UNITS * 16 + jw * 1024));
         }
     };
 
@@ -227,17 +233,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_dma_kernel(con
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     constexpr int AHEAD = STAGES - 1;                         // k-tiles in flight
-    issue(0, 0);
-    if (AHEAD > 1 && ktiles > 1) issue(1, 1);
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a)
+        if (a < ktiles) issue(a, a);
     const int frow = lane & 31, fk = lane >> 5;
     for (int kt = 0; kt < ktiles; ++kt) {
-        if (AHEAD > 1 && kt + 1 < ktiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        {   // tile kt has landed once at most the DMAs of the tiles issued after it are outstanding
+            const int later = min(AHEAD - 1, ktiles - 1 - kt);
+            static_assert((AHEAD - 1) * NDMA < 64 && AHEAD <= 6, "vmcnt is a 6-bit counter");
+            if (later == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+            else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+            else if (later == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NDMA) : "memory");
+            else if (later == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NDMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * NDMA) : "memory");
+        }
         __builtin_amdgcn_s_barrier();
         const u32x4* Xh = ring + (kt % STAGES) * STAGE_UNITS;
-        const u32x4* Xl = Xh + 4 * BM;
-        const u32x4* Wh = Xl + 4 * BM;
-        const u32x4* Wl = Wh + 4 * BN;
+        const u32x4* Xl = Xh + 4 * BM;                         // (not read by the fp16 forms)
+        const u32x4* Wh = Xh + X_UNITS;
+        const u32x4* Wl = Wh + 4 * BN;                         // (not read by W1)
         // schedule of one k-tile, pinned with sched_barriers (left alone, hipcc hoists the DMA issue to the top and sinks
         // every LDS read to just before its first use, which exposes the LDS latency four times per tile):
         //   fragments of k-step 0 -> DMA issue of tile kt+2 (its address arithmetic runs under the LDS latency) ->
@@ -387,7 +402,11 @@ int conv_dma_variant(const ConvParams& p) {
     const long thr = (p.pool || p.out_planar16) ? 0 : 96;     // tiles needed: the DMA pipeline at half occupancy still beats the register-staged
                                           // kernel (a fused pool exists only here: such layers always take this kernel)
     const bool big = !(p.sw & SW_NO_DMA_BIG);
-    if (big && !p.pool && p.Cout % 256 == 0 && ((M + 255) / 256) * (p.Cout / 256) >= 512) return 5;     // 256 x 256, two stages
+    // 256 x 256 (one workgroup per CU): 128 flop per byte of L2 -> LDS DMA, the resource the long-K GEMMs run against.  The one-product
+    // form of 128 x 256 / 256 x 128 fits TWO workgroups per CU (72 KB of ring, 124 VGPRs): one's epilogue and pipeline fill run under
+    // the other's k-loop, which wins below ~32 k-tiles (measured: K <= 640 +5..14 %, K = 768..1280 equal, K >= 1536 and fc6 -2..4 %)
+    const bool shortk = p.f16 == 2 && p.Kpad < 1024;
+    if (big && !shortk && !p.pool && p.Cout % 256 == 0 && ((M + 255) / 256) * (p.Cout / 256) >= 512) return 5;
     if (p.Cout % 256 == 0 && ((M + 127) / 128) * (p.Cout / 256) >= thr) return 1;     // 128 x 256
     if (p.Cout % 128 == 0 && ((M + 255) / 256) * (p.Cout / 128) >= thr) return 2;     // 256 x 128
     if (p.Cout % 64 == 0 && p.Cout % 128 != 0 && ((M + 255) / 256) * (p.Cout / 64) >= thr) return 3;      // 256 x 64
@@ -395,22 +414,23 @@ int conv_dma_variant(const ConvParams& p) {
     return 0;
 }
 
-template <int WM, int WN, int MT, int NT, int STAGES>
+// S3 / S2 / S1: ring depth of the three-product / two-product / one-product form (the stage shrinks with the planes it holds)
+template <int WM, int WN, int MT, int NT, int S3, int S2, int S1>
 static void launch_dma_variant(const ConvParams& p, long M, hipStream_t s) {
     const int tilesM = (int)((M + WM * MT * 32 - 1) / (WM * MT * 32)), tilesN = p.Cout / (WN * NT * 32);
     const dim3 grid((unsigned)(tilesM * tilesN)), block(64 * WM * WN);
     const int mode = (p.dbg & 16) ? 0 : p.simple;
     if (p.f16 == 2) {
-        if (mode == 2) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 2, STAGES, true, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
-        else if (mode == 1) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 1, STAGES, true, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
-        else hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 0, STAGES, true, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+        if (mode == 2) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 2, S1, true, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+        else if (mode == 1) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 1, S1, true, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+        else hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 0, S1, true, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
     } else if (p.f16) {
-        if (mode == 2) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 2, STAGES, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
-        else if (mode == 1) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 1, STAGES, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
-        else hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 0, STAGES, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
-    } else if (mode == 2) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 2, STAGES>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
-    else if (mode == 1) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 1, STAGES>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
-    else hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 0, STAGES>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+        if (mode == 2) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 2, S2, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+        else if (mode == 1) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 1, S2, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+        else hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 0, S2, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+    } else if (mode == 2) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 2, S3>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+    else if (mode == 1) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 1, S3>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+    else hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 0, S3>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
 }
 
 hipError_t launch_conv_dma(const ConvParams& p0, hipStream_t s) {
@@ -418,11 +438,11 @@ hipError_t launch_conv_dma(const ConvParams& p0, hipStream_t s) {
     p.dbg = (p.sw & SW_DMA_DBG16) ? 16 : 0;
     const long M = (long)p.N * p.Hout * p.Wout;
     const int v = conv_dma_variant(p);
-    if (v == 1) launch_dma_variant<2, 4, 2, 2, 3>(p, M, s);
-    else if (v == 2) launch_dma_variant<4, 2, 2, 2, 3>(p, M, s);
-    else if (v == 3) launch_dma_variant<4, 2, 2, 1, 3>(p, M, s);
-    else if (v == 4) launch_dma_variant<8, 1, 1, 1, 3>(p, M, s);
-    else if (v == 5) launch_dma_variant<2, 4, 4, 2, 2>(p, M, s);
+    if (v == 1) launch_dma_variant<2, 4, 2, 2, 3, 3, 3>(p, M, s);            // 48 / 40 / 24 KB per stage
+    else if (v == 2) launch_dma_variant<4, 2, 2, 2, 3, 3, 3>(p, M, s);       // 48 / 32 / 24
+    else if (v == 3) launch_dma_variant<4, 2, 2, 1, 3, 3, 4>(p, M, s);       // 40 / 24 / 20
+    else if (v == 4) launch_dma_variant<8, 1, 1, 1, 3, 3, 3>(p, M, s);
+    else if (v == 5) launch_dma_variant<2, 4, 4, 2, 2, 2, 4>(p, M, s);       // 64 / 48 / 32
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -267,6 +267,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_split_kernel(cons
 #pragma unroll
             for (int pr = 0; pr < 3; ++pr) {
                 if (F16 && pr == 1) continue;                      // fp16 activations: no lo plane, products x*w_lo and x*w_hi
+                if (F16 && pr == 0 && p.f16 == 2) continue;        // one-product layer (':1'): x*w_hi only, as conv_dma / conv_direct W1
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
 #pragma unroll
