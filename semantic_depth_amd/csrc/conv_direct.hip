@@ -62,6 +62,19 @@ __device__ __forceinline__ DirectChunk load_chunk(const DirectChunk* ptr) {
     return e;
 }
 
+// the same load in two halves: the fetch is issued right after the chunk's barrier, the wait sits in front of the first DMA slot
+// (both in one straight-line stretch of code: the SGPR tuple is not live across a loop edge while the load is in flight)
+__device__ __forceinline__ void fetch_chunk(i32x8d& v, const DirectChunk* ptr) {
+    asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(v) : "s"(ptr) : "memory");
+}
+__device__ __forceinline__ DirectChunk wait_chunk(i32x8d& v) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v) : : "memory");
+    DirectChunk e;
+    e.base = reinterpret_cast<const void*>(((unsigned long long)(unsigned)v[1] << 32) | (unsigned)v[0]);
+    e.H = v[2]; e.W = v[3]; e.C = v[4]; e.up = v[5]; e.nvalid = v[6]; e.pad = v[7];
+    return e;
+}
+
 // persistent: workgroup b walks tiles b, b + grid, ...; the (tile, chunk) sequence is one software pipeline, so the first
 // chunk of the next tile lands while the current tile's epilogue runs.
 // F16: ONE fp16 activation plane, two fp16 weight planes, two MFMA products per product (split_fmt.hpp)
@@ -105,50 +118,80 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
         return r;
     };
 
-    // halo geometry of this lane's five X-DMA slots (instruction j = wave + 8 i, i < 5; i = 5..7 are weight DMAs): constant
-    // over tiles and chunks.  packed: ry | rx << 8 | octet << 16 | inside-halo << 17
+    // halo geometry of this lane's X-DMA slots (instruction j = wave + 8 i): constant over tiles and chunks.
+    // packed: ry | rx << 8 | 8 * octet << 16 | inside-halo << 20
+    constexpr int XPL = (F16 && !X2) ? 1 : 2, WPL = (W1 || X2) ? 1 : 2;
+    constexpr int WS = (WPL * D_WI + D_WAVES - 1) / D_WAVES;       // weight-DMA slots per wave
     int geo[XS];
 #pragma unroll
     for (int i = 0; i < XS; ++i) {
         const int j = wave + D_WAVES * i;
-        const int u = (j - (j >= D_XI ? D_XI : 0)) * 64 + lane;      // (slots with j >= 2 XI are never issued)
+        const int u = (j - (j >= D_XI ? D_XI : 0)) * 64 + lane;      // (slots with j >= XPL * XI are never issued)
         const int pix = u >> 1;
         const int oct = (u & 1) ^ ((pix >> 3) & 1);
         const int ry = pix / S_HW, rx = pix - ry * S_HW;
-        geo[i] = ry | (rx << 8) | (oct << 16) | ((pix < S_HH * S_HW ? 1 : 0) << 17);
+        geo[i] = ry | (rx << 8) | (oct << 19) | ((pix < S_HH * S_HW ? 1 : 0) << 20);
+    }
+    // lane offsets (16-byte units) of the weight slots inside a (plane, chunk) block
+    int wu[WS];
+#pragma unroll
+    for (int i = 0; i < WS; ++i) {
+        const int jw = wave + D_WAVES * i;
+        const int u = (jw - (jw >= D_WI ? D_WI : 0)) * 64 + lane;
+        wu[i] = N16 ? (u >= 288 ? -1 : (u >> 4) * 32 + (u & 15)) : u;
     }
 
-    // stage image: Xh[1280] Xl[1280] Wh[576] Wl[576]; X unit = [halo pixel][octet ^ ((pixel >> 3) & 1)]
-    auto issue = [&](const Tile& tl, int half, int c, int stage) {
-        const DirectChunk ch = load_chunk(p.chunks + c);
-        const size_t plane = (size_t)p.Nmax * ch.H * ch.W * (ch.pad ? ch.pad : ch.C);      // elements (pad: channels of a sub-planar tensor)
-        const unsigned sbyte = lds0 + (unsigned)(stage * D_STAGE * 16);
-        const uint16_t* const img_hi = reinterpret_cast<const uint16_t*>(ch.base) + (size_t)tl.img * ch.H * ch.W * ch.C;
+    // The DMA issue of one (tile, chunk) item is cut into SLOTS (one DMA instruction each) that the product loop spreads between
+    // its first MFMA groups; what depends on the tile only -- source pixel coordinates and the in-image mask of every slot -- is
+    // computed once per tile, so a slot costs about a dozen VALU operations per chunk.
+    // Round-2 decomposition of conv4_2 (one product, 32 frames): whole kernel 0.975 ms; no DMA issued (MFMA + LDS reads) 0.761
+    // = 1.62 PF/s; no MFMA (DMA only) 0.577; neither 0.128.  Tried against the 0.21 ms the two cost each other, and measured
+    // equal or slower: a four-stage ring with counted vmcnt waits (-8..15 %), the weight blocks through VGPRs and ds_write_b128
+    // instead of the DMA path (-15 %), the slots at the top of the chunk vs spread through it (+-1 %).  Latency is therefore not
+    // what the DMA costs; the kernels run at the chip's power limit (profiles/r01_mfma_sustained_probe.txt), and bytes moved per
+    // MFMA -- 38 KB per 36 MFMAs and wave here -- are the remaining lever.
+    int sgy[XS], sgx[XS];
+    unsigned okA = 0, okB = 0;            // bit i: slot i reads an existing pixel (okB: ... and the first channel octet of a chunk)
+    auto set_tile = [&](const Tile& tl) {
+        okA = 0; okB = 0;
 #pragma unroll
         for (int i = 0; i < XS; ++i) {
-            const int j = wave + D_WAVES * i;
-            if (j >= ((F16 && !X2) ? 1 : 2) * D_XI) continue;          // fp16 activations: ONE plane (X2: hi + lo)
-            const int ry = geo[i] & 0xff, rx = (geo[i] >> 8) & 0xff, oct = (geo[i] >> 16) & 1;
+            const int ry = geo[i] & 0xff, rx = (geo[i] >> 8) & 0xff;
             // UP: source coordinates directly (an output-resolution pixel is outside the image exactly when its source pixel is)
             const int gy = (UP ? (tl.ty0 >> 1) : tl.ty0) - 1 + ry, gx = (UP ? (tl.tx0 >> 1) : tl.tx0) - 1 + rx;
-            const bool ok = (geo[i] >> 17) && (unsigned)gy < (unsigned)(UP ? ch.H : p.H) && (unsigned)gx < (unsigned)(UP ? ch.W : p.W) &&
-                            oct < ch.nvalid;
-            const unsigned off = UP ? (unsigned)((gy * ch.W + gx) * ch.C + oct * 8)
-                                    : (unsigned)(((gy >> ch.up) * ch.W + (gx >> ch.up)) * ch.C + oct * 8);
-            const uint16_t* src = (j >= D_XI ? img_hi + plane : img_hi) + off;
-            ddma16(ok ? reinterpret_cast<const u32x4*>(src) : zero, sbyte + (unsigned)(j * 1024));
-        }
-#pragma unroll
-        for (int i = 0; i < (((W1 || X2) ? 1 : 2) * D_WI + D_WAVES - 1) / D_WAVES; ++i) {      // both weight planes (W1, X2: w_hi only)
-            const int jw = wave + D_WAVES * i;
-            if (jw < ((W1 || X2) ? 1 : 2) * D_WI) {
-                const int pl = jw >= D_WI ? 1 : 0;
-                const int u = (jw - pl * D_WI) * 64 + lane;
-                const u32x4* gw = p.wt + ((size_t)(2 * half + pl) * p.nchunks + c) * D_GW + (N16 ? (u >> 4) * 32 + (u & 15) : u);
-                ddma16(N16 && u >= 288 ? zero : gw, sbyte + (unsigned)((2 * D_XUNITS + jw * 64) * 16));
-            }
+            const bool in = ((geo[i] >> 20) & 1) && (unsigned)gy < (unsigned)(UP ? p.H >> 1 : p.H) && (unsigned)gx < (unsigned)(UP ? p.W >> 1 : p.W);
+            sgy[i] = gy; sgx[i] = gx;
+            okA |= (in ? 1u : 0u) << i;
+            okB |= ((in && !((geo[i] >> 19) & 1)) ? 1u : 0u) << i;
         }
     };
+    // stage image: Xh[1280] Xl[1280] Wh[576] Wl[576]; X unit = [halo pixel][octet ^ ((pixel >> 3) & 1)]
+    struct ChunkCtx { const uint16_t* img; size_t plane; unsigned rowel, C, okm, sbyte; int up; const u32x4* w; };
+    auto begin_chunk = [&](const DirectChunk& ch, const Tile& tl, int c, int stage) {
+        ChunkCtx k;
+        k.plane = (size_t)p.Nmax * ch.H * ch.W * (ch.pad ? ch.pad : ch.C);      // elements (pad: channels of a sub-planar tensor)
+        k.img = reinterpret_cast<const uint16_t*>(ch.base) + (size_t)tl.img * ch.H * ch.W * ch.C;
+        k.rowel = (unsigned)(ch.W * ch.C); k.C = (unsigned)ch.C; k.up = UP ? 0 : ch.up;
+        k.okm = ch.nvalid >= 2 ? okA : okB;
+        k.sbyte = lds0 + (unsigned)(stage * D_STAGE * 16);
+        k.w = p.wt + ((size_t)(2 * tl.half) * p.nchunks + c) * D_GW;
+        return k;
+    };
+    auto xslot = [&](const ChunkCtx& k, int i) {
+        const int j = wave + D_WAVES * i;
+        if (j >= XPL * D_XI) return;                   // fp16 activations: ONE plane (X2: hi + lo)
+        const unsigned off = (unsigned)(sgy[i] >> k.up) * k.rowel + ((unsigned)(sgx[i] >> k.up) * k.C + ((unsigned)(geo[i] >> 16) & 8u));
+        const uint16_t* src = (j >= D_XI ? k.img + k.plane : k.img) + off;
+        ddma16(((k.okm >> i) & 1u) ? reinterpret_cast<const u32x4*>(src) : zero, k.sbyte + (unsigned)(j * 1024));
+    };
+    auto wslot = [&](const ChunkCtx& k, int i) {
+        const int jw = wave + D_WAVES * i;
+        if (jw >= WPL * D_WI) return;                  // both weight planes (W1, X2: w_hi only)
+        const u32x4* gw = (jw >= D_WI ? k.w + (size_t)p.nchunks * D_GW : k.w) + wu[i];
+        ddma16(N16 && wu[i] < 0 ? zero : gw, k.sbyte + (unsigned)((2 * D_XUNITS + jw * 64) * 16));
+    };
+    constexpr int NSLOT = XS + WS;
+    auto slot = [&](const ChunkCtx& k, int sidx) { if (sidx < XS) xslot(k, sidx); else if (sidx < NSLOT) wslot(k, sidx - XS); };
 
     // the bias vector lives in LDS (zero past the layer's channels) and is read by the epilogue: no registers held
     // through the product loop
@@ -162,7 +205,21 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
     int tid = blockIdx.x;
     if (tid >= items) return;
     Tile cur = tile_of(tid);
-    issue(cur, cur.half, 0, 0);
+    // the issue cursor: the (tile, chunk) item that goes into the ring next
+    int itid = tid, ic = 0;
+    Tile icur = cur;
+    set_tile(icur);
+    auto advance = [&]() {
+        if (++ic == p.nchunks) { ic = 0; itid += gridDim.x; if (itid < items) { icur = tile_of(itid); set_tile(icur); } }
+    };
+    {
+        i32x8d dv;
+        fetch_chunk(dv, p.chunks);
+        const ChunkCtx k = begin_chunk(wait_chunk(dv), icur, 0, 0);
+#pragma unroll
+        for (int sidx = 0; sidx < NSLOT; ++sidx) slot(k, sidx);
+        advance();
+    }
     int g = 0;                                     // stages consumed so far
     for (; tid < items; tid += gridDim.x) {
         const int half = cur.half;
@@ -178,12 +235,21 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
         for (int a = 0; a < MT; ++a)
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb) acc16[a][pb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        Tile nxt = cur;
         for (int c = 0; c < p.nchunks; ++c, ++g) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();          // stage g has landed for every wave; everyone is done with stage g-1
-            if (c + 1 < p.nchunks) issue(cur, half, c + 1, (g + 1) & 1);
-            else if (tid + (int)gridDim.x < items) { nxt = tile_of(tid + gridDim.x); issue(nxt, nxt.half, 0, (g + 1) & 1); }
+            const bool more = itid < items;        // item g + 1 exists: its DMAs go into stage (g + 1) & 1 during this chunk
+            i32x8d dv;
+            fetch_chunk(dv, p.chunks + ic);        // (ic < nchunks always: a spent cursor re-reads a descriptor nobody uses)
+            ChunkCtx k;
+            if constexpr (N16) {
+                const DirectChunk chd = wait_chunk(dv);     // (waited for even when unused: a load in flight owns its SGPRs)
+                if (more) {
+                    k = begin_chunk(chd, icur, ic, (g + 1) & 1);
+#pragma unroll
+                    for (int sidx = 0; sidx < NSLOT; ++sidx) slot(k, sidx);
+                }
+            }
             const u32x4* Xh = lds + (g & 1) * D_STAGE;
             const u32x4* Xl = Xh + D_XUNITS;
             const u32x4* Wh = Xl + D_XUNITS;
@@ -214,6 +280,8 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                         }
                 }
             } else {
+            constexpr int NGRP = 9 * NB;               // MFMA groups of a chunk; the DMA slots follow groups 1 .. NSLOT
+            static_assert(NSLOT <= NGRP, "one DMA slot per MFMA group");
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 u32x4 xh[MT + 2], xl[MT + 2];
@@ -238,9 +306,21 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                             for (int a = 0; a < MT; ++a)
                                 acc[a][nb] = mfma_frag<F16>(pr == 0 ? wl : wh, pr == 1 ? xl[a + dy] : xh[a + dy], acc[a][nb]);
                         }
+                        const int grp = (dx * 3 + dy) * NB + nb;
+                        if (grp == 0) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            const DirectChunk chd = wait_chunk(dv);     // (waited for even when unused: a load in flight owns its SGPRs)
+                            if (more) k = begin_chunk(chd, icur, ic, (g + 1) & 1);
+                        }
+                        if (grp < NSLOT && more) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            slot(k, grp);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
             }
             }
+            if (more) advance();
         }
 
         // ---- epilogue: bias + activation, split once, LDS transpose (in the stage just consumed; the other one is being
@@ -425,7 +505,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
         else if (p.act == ACT_ELU) ep(ActTag<ACT_ELU>{});
         else if (N16 && p.act == ACT_SIGMOID03) ep(ActTag<ACT_SIGMOID03>{});
         else ep(ActTag<ACT_NONE>{});
-        cur = nxt;
+        if (tid + (int)gridDim.x < items) cur = tile_of(tid + gridDim.x);
     }
 }
 
