@@ -49,8 +49,9 @@ DTYPE = {
     "bf16x2": "bf16x2 split operands (hi+lo, 16 mantissa bits), 3 bf16 MFMA products per product, f32 accumulate",
     "mixed": "FCN-8s: bf16x2 split operands, 3 bf16 MFMA products; monodepth: fp16 activations x fp16x2 split weights (22 bits), "
              "2 fp16 MFMA products; f32 accumulate",
-    "plan": "per-layer precision plan: bf16x2 split operands (3 bf16 MFMA products) or fp16 activations x fp16x2 split weights "
-            "(2 fp16 MFMA products), chosen per layer under an error budget against the exact-f32 engine; f32 accumulate",
+    "plan": "per-layer precision plan, f32 accumulate: bf16x2 split operands (3 bf16 MFMA products), fp16 activations x fp16x2 split "
+            "weights (2), fp16x2 activations x fp16 weights (2, ':x') or fp16 x fp16 (1, ':1'), chosen per layer under an error budget "
+            "against the exact-f32 engine (config.precision_plan lists what ran)",
 }
 
 
@@ -72,6 +73,8 @@ def parse_args():
     ap.add_argument("--encoder", default="resnet50")
     ap.add_argument("--precision", default=os.environ.get("SD_BENCH_PRECISION", "plan"), choices=["f32", "bf16x2", "mixed", "plan"],
                     help="conv arithmetic of the measured engine")
+    ap.add_argument("--plan", default=None, help="precision plan to measure instead of the built-in one: 'fcn layers|monodepth layers' "
+                    "(sd_create_with_plan syntax; the line's dtype/config then say so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the exact-f32 engine leg (f32_exact + parity vs f32)")
     ap.add_argument("--f32-steps", type=int, default=2)
@@ -154,7 +157,10 @@ def main():
 
     # ------------------------------------------------------------------ setup (untimed)
     t_setup = time.time()
-    eng = Engine(H, W, B, args.encoder, local_rank, precision=args.precision)
+    custom_plan = tuple(args.plan.split("|")) if args.plan is not None else None
+    if custom_plan is not None and (args.precision != "plan" or len(custom_plan) != 2):
+        raise SystemExit("--plan needs --precision plan and the form 'fcn layers|monodepth layers'")
+    eng = Engine(H, W, B, args.encoder, local_rank, precision=args.precision, plan=custom_plan)
     # seeded synthetic weights.  decoder_std is raised from the reference's 0.01 so that the
     # softmax > 0.5 masks of a random-weight net are non-trivial and the road chain has real work.
     wf = Wt.make_fcn8s_weights(1, decoder_std=float(os.environ.get("SD_BENCH_DECODER_STD", "0.05")))
@@ -324,6 +330,8 @@ def main():
                    "stage_ms_last_step": {"resize": round(stage_ms[0], 2), "seg": round(stage_ms[1], 2), "disp": round(stage_ms[2], 2),
                                           "to3D": round(stage_ms[3], 2), "road": round(stage_ms[4], 2)},
                    "colours_through_road_chain": colours, "overlap": bool(args.overlap),
+                   **({"precision_plan": {k: {"layers": ",".join(v[0]), "flop_share": round(v[1], 4)} for k, v in eng.precision_plan().items()},
+                       "built_in_plan": custom_plan is None} if args.precision == "plan" else {}),
                    "road_fraction": round(road_frac, 4), "n_road_mean": float(recs["n_road"].mean()), "n_after_chain_mean": float(recs["n_ror"].mean()),
                    "found": int(recs["found"].sum())},
         "roofline": roofline, "fusion_roofline": fusion_roofline, "f32_exact": f32_exact, "parity": parity or None, "cpu_baseline": cpu,
