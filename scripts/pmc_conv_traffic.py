@@ -36,8 +36,8 @@ def label(k):
     if not m:
         return None
     fam, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
-    if fam == "conv_direct":       # <NB, MT, F16, N16, UP, W1>
-        prec = "_f16x1" if (len(args) > 5 and args[5] == "true") else ("_f16w" if args[2] == "true" else "")
+    if fam == "conv_direct":       # <NB, MT, F16, N16, UP, W1, X2>
+        prec = "_f16w_x2" if (len(args) > 6 and args[6] == "true") else "_f16x1" if (len(args) > 5 and args[5] == "true") else ("_f16w" if args[2] == "true" else "")
         shape = "<1,n16>" if args[3] == "true" else ("<1,2>" if args[0] == "1" else "<2,2>")
         return f"conv_direct{prec}_kernel{shape}"
     if fam == "conv_dma":          # <WM, WN, MT, NT, SIMPLE, STAGES, F16, W1>

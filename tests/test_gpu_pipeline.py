@@ -96,6 +96,45 @@ def test_monodepth_full_size_matches_oracle(precision, oracle_full, keep_taps):
     assert np.array_equal(pp.cpu().numpy()[0], fusion.post_processing(raw).astype(np.float32))
 
 
+@pytest.fixture(scope="module")
+def oracle_b8():
+    """BASELINE.json configs[1] / configs[2] as written: B = 8 frames of 512 x 1024 through the CPU oracle (once per module)"""
+    wf = Wt.make_fcn8s_weights(3, decoder_std=0.05, bias_std=0.1)
+    wm = Wt.make_monodepth_weights("resnet50", 4, bias_std=0.05)
+    fr = _smooth_frames(8, seed=43)
+    logits = np.concatenate([nets.fcn8s_forward(fr[b:b + 1], wf) for b in range(8)], 0)
+    disp = []
+    for b in range(8):
+        f = fr[b].astype(np.float32) / 255
+        disp.append(nets.monodepth_forward(np.stack((f, np.fliplr(f)), 0), wm, "resnet50", all_scales=True)[1][..., 0])
+    return dict(wf=wf, wm=wm, frames=fr, logits=logits, disp=np.stack(disp))
+
+
+@pytest.mark.parametrize("precision", ["f32", "plan"])
+def test_nets_b8_full_size_match_oracle(precision, oracle_b8):
+    """configs[1] (FCN-8s forward, B = 8) and configs[2] (monodepth-resnet50 forward on frame + flip, B = 8) in one network pass
+    each, every frame against the oracle: logits, masks, raw disparity pair, post-processed disparity"""
+    o = oracle_b8
+    eng = Engine(H, W, 8, "resnet50", precision=precision)
+    eng.load_weights(L.SD_NET_FCN8S, o["wf"])
+    eng.load_weights(L.SD_NET_MONODEPTH, o["wm"])
+    fr = dev(o["frames"])
+    out = eng.fcn8s_forward(fr, want_logits=True)
+    pp, raw = eng.monodepth_forward(fr, want_raw=True)
+    lg, raw, pp = out["logits"].cpu().numpy(), raw.cpu().numpy(), pp.cpu().numpy()
+    worst_l = worst_d = 0.0
+    for b in range(8):
+        worst_l = max(worst_l, relerr(lg[b], o["logits"][b]))
+        worst_d = max(worst_d, relerr(raw[b], o["disp"][b]))
+        _, road_r, _, am_r = nets.softmax_masks(o["logits"][b:b + 1])
+        assert float((out["road"][b].cpu().numpy().astype(bool) != road_r[0]).mean()) < 2e-3, b
+        assert float((out["argmax"][b].cpu().numpy() != am_r[0]).mean()) < 2e-3, b
+        assert np.array_equal(pp[b], fusion.post_processing(raw[b]).astype(np.float32)), b
+        assert relerr(pp[b], fusion.post_processing(o["disp"][b].astype(np.float32)).astype(np.float32)) < TOL, b
+    print("B=8 512x1024", precision, "worst logits", worst_l, "worst disparity", worst_d)
+    assert worst_l < TOL and worst_d < TOL
+
+
 def _camera_at_10m(disp_pp, mult=float(W)):
     """a camera that puts the median disparity at 10 m, so that the z-cut / depth window / Open3D filters all see points"""
     d0 = float(disp_pp.median().item()) * mult
