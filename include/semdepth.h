@@ -42,8 +42,11 @@ typedef enum { SD_NET_FCN8S = 0, SD_NET_MONODEPTH = 1 } sd_net;
  *   2-product form: the activation rounded once to fp16 (one 16-bit plane: half the bytes of every tensor), the weight split into
  *                  two fp16 (22 bits), TWO fp16 MFMA products x*w_hi + x*w_lo; the only error is the 2^-12 rounding of the
  *                  activations (3e-5 .. 2e-4 on the outputs per layer, profiles/r02_precision_calibration.json);
+ *   1-product form (":1"): the same one-plane fp16 activation times w_hi only: plain fp16 x fp16, adds the 2^-12 rounding of the weights;
+ *   x2 form (":x"):  fp16 hi + lo ACTIVATION planes times w_hi: TWO products x_hi*w_hi + x_lo*w_hi, the error is the weight rounding
+ *                  alone (for layers whose input tensor is precision-critical; direct 3x3 layers fed by direct 3x3 layers);
  *   SD_PREC_MIXED  FCN-8s as SD_PREC_BF16X2, every monodepth layer in the 2-product form;
- *   SD_PREC_PLAN   per-layer choice between the two: the built-in plan (sd_default_plan) was calibrated on the MI355X against the
+ *   SD_PREC_PLAN   per-layer choice between these forms: the built-in plan (sd_default_plan) was calibrated on the MI355X against the
  *                  exact-f32 engine under an error budget; sd_create_with_plan takes any other choice */
 typedef enum { SD_PREC_F32 = 0, SD_PREC_BF16X2 = 1, SD_PREC_MIXED = 2, SD_PREC_PLAN = 3 } sd_precision;
 
@@ -92,8 +95,10 @@ const char* sd_status_string(sd_status s);
 sd_status sd_create(sd_handle** out, int device, int H, int W, int max_batch, sd_encoder enc, sd_precision prec);
 /* the same with an explicit precision plan for the split engine: per network a comma-separated list of conv layer names
  * (sd_net_tensor names, e.g. "fc6,fc7" / "enc/res4*,dec/upconv6"; a trailing '*' matches a prefix, "*" = all, "" = none) that run
- * the 2-product fp16 scheme; the rest run the 3-product bf16 one.  The choice is closed under "one plane format per tensor"
- * (sd_precision_plan returns what actually runs).  An unknown layer name is SD_ERR_INVALID. */
+ * the 2-product fp16 scheme -- or, with the suffix ":1" / ":x", the 1-product / x2 form; the rest run the 3-product bf16 one.  The
+ * choice is closed under "one plane format per tensor" (sd_precision_plan returns what actually runs, with the suffixes).  ":x" on a
+ * layer the geometry does not route to the direct 3x3 kernel (or whose producer is not one) keeps three products; on a layer that
+ * is no 3x3 stride-1 convolution with a multiple of 64 output channels it is SD_ERR_INVALID, as is an unknown layer name. */
 sd_status sd_create_with_plan(sd_handle** out, int device, int H, int W, int max_batch, sd_encoder enc, const char* fcn_f16_layers,
                               const char* mono_f16_layers);
 const char* sd_default_plan(sd_net net);      /* (monodepth: the ResNet-50 plan; the vgg encoder's default plan is empty) */
