@@ -8,6 +8,7 @@
 // frame with wave ballots / shuffles inside; the Open3D filters run one thread per point over a uniform grid.
 // All filters keep the input row order (ordered compaction), which the reference's "first min / first max"
 // end-point pick depends on (pcl.py:307-311, semantic_depth.py:259).
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -857,7 +858,7 @@ __device__ __forceinline__ bool grid_covers(const GridMeta& g) {
 
 struct O3dScratch {       // carved from one arena, per-frame strides
     GridMeta* meta;       // [B]
-    int* cell_cnt;        // [B][GRID_CELLS]      counts, then scatter cursors
+    int* cell_cnt;        // [B][GRID_CELLS]      counts, then scatter cursors; behind them [B][8] bounding-box accumulators
     int* cell_start;      // [B][GRID_CELLS + 1]
     int* seg_sum;         // [B][SCAN_NSEG]
     int* cell_of;         // [B][cap]
@@ -871,7 +872,7 @@ struct O3dScratch {       // carved from one arena, per-frame strides
 size_t o3d_scratch_bytes(int B, int cap) {
     size_t per = sizeof(GridMeta) + (size_t)GRID_CELLS * 4 + (size_t)(GRID_CELLS + 1) * 4 + SCAN_NSEG * 4 + (size_t)cap * (4 + 4 + 16 + 8 + 1) +
                  (size_t)cap * KMAX * 8;
-    return (size_t)B * (per + 4) + 8192 + 256;
+    return (size_t)B * (per + 4 + 32) + 8192 + 256;
 }
 static O3dScratch carve(void* base, int B, int cap) {
     O3dScratch s;
@@ -879,7 +880,7 @@ static O3dScratch carve(void* base, int B, int cap) {
     auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) / 256 * 256; return r; };
     s.meta = (GridMeta*)take(sizeof(GridMeta) * B);
     s.mean_d = (double*)take((size_t)B * cap * 8);
-    s.cell_cnt = (int*)take((size_t)B * GRID_CELLS * 4);
+    s.cell_cnt = (int*)take((size_t)B * GRID_CELLS * 4 + (size_t)B * 32);
     s.cell_start = (int*)take((size_t)B * (GRID_CELLS + 1) * 4);
     s.seg_sum = (int*)take((size_t)B * SCAN_NSEG * 4);
     s.cell_of = (int*)take((size_t)B * cap * 4);
@@ -928,56 +929,67 @@ __global__ void grid_refine_kernel(CloudView in, int cap, GridMeta* meta, int B,
     meta[b] = g;
 }
 
-// bounding box (finite coordinates only) -> cell size, grid dims, origin.  fixed_cell > 0: use it; else adapt to ~6 points/cell
-__global__ __launch_bounds__(TB) void grid_meta_kernel(CloudView in, int cap, double fixed_cell, GridMeta* meta) {
-    const int b = blockIdx.x;
+// order-preserving map float -> unsigned (0 is below every float, -inf included): one atomicMax per component accumulates a maximum,
+// and the complement of the code a minimum, from an all-zero start
+__device__ __forceinline__ unsigned ord_f32(float v) { const unsigned u = __float_as_uint(v); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float unord_f32(unsigned c) { return __uint_as_float((c & 0x80000000u) ? (c & 0x7fffffffu) : ~c); }
+
+// bounding box of the finite coordinates, every CU on it: acc[b] = {~ord(min x,y,z), ord(max x,y,z), non-finite count, -} (zeroed before)
+__global__ __launch_bounds__(256) void grid_bbox_kernel(CloudView in, int cap, unsigned* acc) {
+    const int b = blockIdx.y;
     const float* xyz = in.xyz + (size_t)b * cap * 3;
     const int n = min(in.n[b], cap);
-    __shared__ float smin[3][NW], smax[3][NW];
-    __shared__ int s_nonfinite;
-    if (threadIdx.x == 0) s_nonfinite = 0;
-    __syncthreads();
+    if ((int)(blockIdx.x * 256) >= n) return;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     int bad = 0;
-#pragma unroll 4
-    for (int i = threadIdx.x; i < n; i += TB)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const float v = xyz[(size_t)i * 3 + j];
             if (v > -INFINITY && v < INFINITY) { mn[j] = fminf(mn[j], v); mx[j] = fmaxf(mx[j], v); }
             else ++bad;
         }
-    if (bad) atomicAdd(&s_nonfinite, bad);
+    unsigned* a = acc + (size_t)b * 8;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { mn[j] = fminf(mn[j], __shfl_xor(mn[j], o)); mx[j] = fmaxf(mx[j], __shfl_xor(mx[j], o)); }
-        if ((threadIdx.x & 63) == 0) { smin[j][threadIdx.x >> 6] = mn[j]; smax[j][threadIdx.x >> 6] = mx[j]; }
+        if ((threadIdx.x & 63) == 0 && mn[j] < INFINITY) { atomicMax(a + j, ~ord_f32(mn[j])); atomicMax(a + 3 + j, ord_f32(mx[j])); }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double ext[3];
-        for (int j = 0; j < 3; ++j) {
-            float a = INFINITY, c = -INFINITY;
-            for (int w = 0; w < NW; ++w) { a = fminf(a, smin[j][w]); c = fmaxf(c, smax[j][w]); }
-            if (a == INFINITY) { a = 0.f; c = 0.f; }
-            mn[j] = a; mx[j] = c;
-            ext[j] = (double)c - (double)a;
-        }
-        double cell = fixed_cell;
-        if (!(cell > 0.0)) {
-            const double vol = fmax(ext[0], 0.05) * fmax(ext[1], 0.05) * fmax(ext[2], 0.05);
-            cell = cbrt(6.0 * vol / (double)max(n, 1));
-            cell = fmin(fmax(cell, 0.01), 4.0);
-        }
-        GridMeta g;
-        for (int j = 0; j < 3; ++j) { g.ext[j] = ext[j]; g.mn[j] = mn[j]; }
-        g.mxz = mx[2];
-        g.nonfinite = s_nonfinite; g.pad_ = 0;
-        g.occupied = 0;
-        grid_layout(g, cell);
-        meta[b] = g;
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(a + 6, (unsigned)bad);
+}
+
+// bounding box -> cell size, grid dims, origin (one thread per frame).  fixed_cell > 0: use it; else adapt to ~6 points/cell
+__global__ __launch_bounds__(64) void grid_meta_kernel(CloudView in, int cap, int B, double fixed_cell, const unsigned* acc, GridMeta* meta) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const int n = min(in.n[b], cap);
+    const unsigned* a = acc + (size_t)b * 8;
+    float mn[3], mx[3];
+    double ext[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const unsigned cmin = ~a[j], cmax = a[3 + j];
+        const bool any = a[j] != 0u;                               // (else: no finite coordinate)
+        mn[j] = any ? unord_f32(cmin) : 0.f;
+        mx[j] = any ? unord_f32(cmax) : 0.f;
+        ext[j] = (double)mx[j] - (double)mn[j];
     }
+    double cell = fixed_cell;
+    if (!(cell > 0.0)) {
+        const double vol = fmax(ext[0], 0.05) * fmax(ext[1], 0.05) * fmax(ext[2], 0.05);
+        cell = cbrt(6.0 * vol / (double)max(n, 1));
+        cell = fmin(fmax(cell, 0.01), 4.0);
+    }
+    GridMeta g;
+    for (int j = 0; j < 3; ++j) { g.ext[j] = ext[j]; g.mn[j] = mn[j]; }
+    g.mxz = mx[2];
+    g.nonfinite = (int)a[6]; g.pad_ = 0;
+    g.occupied = 0;
+    grid_layout(g, cell);
+    meta[b] = g;
 }
 
 // runs of equal cell ids among the lanes of a wave (a pixel-ordered cloud puts neighbouring points into the same cell): one
@@ -1488,8 +1500,12 @@ __global__ __launch_bounds__(256) void zero16_kernel(uint4* p, size_t n16) {
 
 static void build_grid(CloudView in, int B, int cap, double fixed_cell, const O3dScratch& sc, hipStream_t s, bool keep_meta = false,
                        bool occupancy_only = false) {
-    hipLaunchKernelGGL(zero16_kernel, dim3(2048), dim3(256), 0, s, reinterpret_cast<uint4*>(sc.cell_cnt), (size_t)B * GRID_CELLS / 4);
-    if (!keep_meta) hipLaunchKernelGGL(grid_meta_kernel, dim3(B), dim3(TB), 0, s, in, cap, fixed_cell, sc.meta);
+    hipLaunchKernelGGL(zero16_kernel, dim3(2048), dim3(256), 0, s, reinterpret_cast<uint4*>(sc.cell_cnt), (size_t)B * GRID_CELLS / 4 + (size_t)B * 2);
+    if (!keep_meta) {
+        unsigned* acc = reinterpret_cast<unsigned*>(sc.cell_cnt + (size_t)B * GRID_CELLS);
+        hipLaunchKernelGGL(grid_bbox_kernel, dim3((unsigned)std::min((cap + 255) / 256, 64), B), dim3(256), 0, s, in, cap, acc);
+        hipLaunchKernelGGL(grid_meta_kernel, dim3((B + 63) / 64), dim3(64), 0, s, in, cap, B, fixed_cell, acc, sc.meta);
+    }
     dim3 grid((cap + 255) / 256, B);
     hipLaunchKernelGGL(grid_count_kernel, grid, dim3(256), 0, s, in, cap, sc.meta, sc.cell_cnt, sc.cell_of);
     hipLaunchKernelGGL(grid_scan_a_kernel, dim3(SCAN_NSEG, B), dim3(256), 0, s, sc.cell_cnt, sc.seg_sum, sc.meta);
