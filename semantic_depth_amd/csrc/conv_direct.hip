@@ -93,8 +93,13 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
     // only the 16 output channels it multiplies ([tap][octet][16][8], 288 units in 5 DMA instructions)
     constexpr int D_GW = Cfg::WUNITS;
     constexpr int D_WI = N16 ? 5 : Cfg::WI, D_WUNITS = N16 ? 320 : Cfg::WUNITS;
-    constexpr int SLAB16 = D_WAVES * 2 * 32 * 48 / 16;       // the N16 epilogue's transposition slabs live in a consumed stage
-    constexpr int D_STAGE = (N16 && 2 * Cfg::XUNITS + 2 * D_WUNITS < SLAB16) ? SLAB16 : 2 * Cfg::XUNITS + 2 * D_WUNITS;
+    // a stage holds the planes the form reads -- X hi [+ lo] | W hi [+ lo] -- and is at least as large as the epilogue's transposition
+    // slabs, which live in a consumed stage.  (The fp16 forms of the 16-channel kernels thereby fit THREE workgroups per CU instead of
+    // two: these layers -- two chunks of little arithmetic per tile -- are bound by the latency of the two-stage ring.)
+    constexpr int XPL = (F16 && !X2) ? 1 : 2, WPL = (W1 || X2) ? 1 : 2;
+    constexpr int SLAB = N16 ? D_WAVES * 2 * 32 * 48 / 16 : D_WAVES * 32 * (64 * NB + 16) / 16;
+    constexpr int STAGE_MIN = XPL * Cfg::XUNITS + WPL * D_WUNITS;
+    constexpr int D_STAGE = STAGE_MIN < SLAB ? SLAB : STAGE_MIN;
     constexpr int D_TH = Cfg::TH, D_HH = Cfg::HH, D_XI = Cfg::XI, D_XUNITS = Cfg::XUNITS, XS = Cfg::XS;
     __shared__ __attribute__((aligned(16))) u32x4 lds[2 * D_STAGE];
     const int t = threadIdx.x, lane = t & 63;
@@ -120,7 +125,6 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
 
     // halo geometry of this lane's X-DMA slots (instruction j = wave + 8 i): constant over tiles and chunks.
     // packed: ry | rx << 8 | 8 * octet << 16 | inside-halo << 20
-    constexpr int XPL = (F16 && !X2) ? 1 : 2, WPL = (W1 || X2) ? 1 : 2;
     constexpr int WS = (WPL * D_WI + D_WAVES - 1) / D_WAVES;       // weight-DMA slots per wave
     int geo[XS];
 #pragma unroll
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
             okB |= ((in && !((geo[i] >> 19) & 1)) ? 1u : 0u) << i;
         }
     };
-    // stage image: Xh[1280] Xl[1280] Wh[576] Wl[576]; X unit = [halo pixel][octet ^ ((pixel >> 3) & 1)]
+    // stage image: Xh[1280] [Xl[1280]] Wh[576 NB] [Wl[576 NB]] (the planes the form reads); X unit = [halo pixel][octet ^ ((pixel >> 3) & 1)]
     struct ChunkCtx { const uint16_t* img; size_t plane; unsigned rowel, C, okm, sbyte; int up; const u32x4* w; };
     auto begin_chunk = [&](const DirectChunk& ch, const Tile& tl, int c, int stage) {
         ChunkCtx k;
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
         const int jw = wave + D_WAVES * i;
         if (jw >= WPL * D_WI) return;                  // both weight planes (W1, X2: w_hi only)
         const u32x4* gw = (jw >= D_WI ? k.w + (size_t)p.nchunks * D_GW : k.w) + wu[i];
-        ddma16(N16 && wu[i] < 0 ? zero : gw, k.sbyte + (unsigned)((2 * D_XUNITS + jw * 64) * 16));
+        ddma16(N16 && wu[i] < 0 ? zero : gw, k.sbyte + (unsigned)((XPL * D_XUNITS + jw * 64) * 16));
     };
     constexpr int NSLOT = XS + WS;
     auto slot = [&](const ChunkCtx& k, int sidx) { if (sidx < XS) xslot(k, sidx); else if (sidx < NSLOT) wslot(k, sidx - XS); };
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
             }
             const u32x4* Xh = lds + (g & 1) * D_STAGE;
             const u32x4* Xl = Xh + D_XUNITS;
-            const u32x4* Wh = Xl + D_XUNITS;
+            const u32x4* Wh = Xh + XPL * D_XUNITS;
             const u32x4* Wl = Wh + D_WUNITS;
             if constexpr (N16) {
                 const u32x4 z4 = {0u, 0u, 0u, 0u};
