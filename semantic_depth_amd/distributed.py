@@ -20,12 +20,13 @@ def shard_range(n_frames: int, rank: int, world: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_records(local: torch.Tensor, n_frames: int | None = None, group=None) -> torch.Tensor:
+def gather_records(local: torch.Tensor, n_frames: int | None = None, group=None, force_collective: bool = False) -> torch.Tensor:
     """all_gather of the per-frame record buffers.  ``local``: uint8 [B_local, 104] on the rank's device.
     Returns uint8 [n_frames, 104] in global frame order on every rank (shards may be ragged: padded to the
-    largest shard for the collective, then trimmed)."""
+    largest shard for the collective, then trimmed).  ``force_collective``: run the collective in a group of one rank too
+    (the single-GPU test of the RCCL call)."""
     assert local.dtype == torch.uint8 and local.dim() == 2 and local.shape[1] == RECORD_BYTES
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force_collective):
         return local
     world = dist.get_world_size(group)
     if n_frames is None:
