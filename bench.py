@@ -75,6 +75,9 @@ def parse_args():
                     help="conv arithmetic of the measured engine")
     ap.add_argument("--plan", default=None, help="precision plan to measure instead of the built-in one: 'fcn layers|monodepth layers' "
                     "(sd_create_with_plan syntax; the line's dtype/config then say so)")
+    ap.add_argument("--approach", default="rw", choices=["rw", "both"],
+                    help="'both' adds the fence chain + fence-to-fence distance (semantic_depth.py:273-334; SURVEY §8f-1) to every frame; "
+                         "the metric's configuration is 'rw'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the exact-f32 engine leg (f32_exact + parity vs f32)")
     ap.add_argument("--f32-steps", type=int, default=2)
@@ -139,7 +142,7 @@ def main():
     from semantic_depth_amd import _lib as L
     from semantic_depth_amd import weights as Wt
     from semantic_depth_amd.distributed import gather_records, make_engine_step, run_sequence
-    from semantic_depth_amd.engine import Camera, Engine, RoadWidthParams
+    from semantic_depth_amd.engine import Camera, Engine, FenceParams, RoadWidthParams
 
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -195,13 +198,13 @@ def main():
         log(f"setup {time.time() - t_setup:.1f}s; arenas: " + ", ".join(f"{k} {v / 2**30:.2f} GiB" for k, v in eng.bytes.items()) +
             f"; disp1 bias {bias:+.3f} (median disparity {d0:.4f} -> {target:.4f})")
 
-    seq_step = make_engine_step(eng, lambda i: cam, prm)
+    seq_step = make_engine_step(eng, lambda i: cam, prm, approach=args.approach)
 
     def step():
         if args.config == 5:
             # the sequence driver: this rank's shard of the world*B frame list -> resize -> whole path -> ONE all_gather
             return run_sequence(lambda lo, hi: src_frames[lo - rank * B: hi - rank * B], world * B, seq_step, batch=B, device="cuda")
-        out = eng.process_batch(frames, cams, prm, colours=colours)
+        out = eng.process_batch(frames, cams, prm, approach=args.approach, colours=colours)
         # the only collective on the path: per-frame road-width records (104 B x B per rank), RCCL all_gather over xGMI
         return gather_records(out["records"], world * B)
 
@@ -211,7 +214,7 @@ def main():
 
     # ------------------------------------------------------------------ timed region
     eng.profile(True)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -247,7 +250,12 @@ def main():
             rec = eng.road_width(fz["road_xyz"], fz["n_road"], prm, road_rgb=fz["road_rgb"] if colours else None)
             allr = gather_records(rec, world * B)
             ev[5].record()
-        return dict(seg=seg, disp_pp=fz["disp_pp"], fuse=fz, records=rec), allr
+            f2f = None
+            if args.approach == "both":
+                f2f = eng.fence_to_fence(fz["fence_xyz"], fz["n_fence"], rec, FenceParams(depth=prm.depth),
+                                         fence_rgb=fz["fence_rgb"] if colours else None)
+            ev[6].record()
+        return dict(seg=seg, disp_pp=fz["disp_pp"], fuse=fz, records=rec, f2f=f2f), allr
 
     for _ in range(args.steps):
         if args.config == 5:
@@ -265,7 +273,7 @@ def main():
         out, _ = instrumented_step()
         torch.cuda.synchronize()
     # stage split of the LAST step (events are only read after the timed region)
-    stage_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
+    stage_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(6)]
 
     tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
     if world > 1:
@@ -328,7 +336,9 @@ def main():
                    "survey_config": args.config, "frames_per_step": world * B, "gflop_per_frame": round(flops_frame / 1e9, 2),
                    "camera": {"cx": cam.cx, "cy": cam.cy, "f": cam.f, "b": cam.b, "disp_mult": cam.disp_mult},
                    "stage_ms_last_step": {"resize": round(stage_ms[0], 2), "seg": round(stage_ms[1], 2), "disp": round(stage_ms[2], 2),
-                                          "to3D": round(stage_ms[3], 2), "road": round(stage_ms[4], 2)},
+                                          "to3D": round(stage_ms[3], 2), "road": round(stage_ms[4], 2),
+                                          **({"fence": round(stage_ms[5], 2)} if args.approach == "both" else {})},
+                   "approach": args.approach,
                    "colours_through_road_chain": colours, "overlap": bool(args.overlap),
                    **({"precision_plan": {k: {"layers": ",".join(v[0]), "flop_share": round(v[1], 4)} for k, v in eng.precision_plan().items()},
                        "built_in_plan": custom_plan is None} if args.precision == "plan" else {}),
