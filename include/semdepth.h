@@ -144,6 +144,12 @@ sd_status sd_resize_cubic_u8(sd_handle* h, const uint8_t* src, int B, int src_h,
  * memory; no handle, no GPU (semantic_depth_amd/frame_io.py inflates with zlib and calls this from a thread pool). */
 sd_status sd_png_unfilter_bgr(const uint8_t* filtered_host, int height, int width, int channels, uint8_t* bgr_out_host);
 
+/* HOST helper of the PLY writer that replaces semantic_depth_lib/point_cloud_2_ply.py:70 (numpy.savetxt(fh, rows, "%f %f %f %d %d %d")):
+ * n vertex rows "x y z r g b\n" -- coordinates as "%f" % float(v) prints them (fixed, six decimals, correctly rounded; nan / inf /
+ * -inf), colours as integers -- into out[0 .. cap).  xyz f64 [n,3], rgb int64 [n,3], HOST memory; threads <= 0: one per core, at most
+ * 16.  Returns the number of bytes written, or SD_ERR_INVALID (bad argument, or cap too small: cap / n bytes must hold any row). */
+int64_t sd_ply_format_rows(const double* xyz_host, const int64_t* rgb_host, int64_t n, char* out_host, int64_t cap, int threads);
+
 /* DepthFrame.post_processing alone, semantic_depth.py:656-664: disp_raw f32 [B,2,H,W] -> disp_pp f32 [B,H,W] */
 sd_status sd_post_process(sd_handle* h, const float* disp_raw, int B, float* disp_pp, void* stream);
 
