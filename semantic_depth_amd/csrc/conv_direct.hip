@@ -62,19 +62,6 @@ __device__ __forceinline__ DirectChunk load_chunk(const DirectChunk* ptr) {
     return e;
 }
 
-// the same load in two halves: the fetch is issued right after the chunk's barrier, the wait sits in front of the first DMA slot
-// (both in one straight-line stretch of code: the SGPR tuple is not live across a loop edge while the load is in flight)
-__device__ __forceinline__ void fetch_chunk(i32x8d& v, const DirectChunk* ptr) {
-    asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(v) : "s"(ptr) : "memory");
-}
-__device__ __forceinline__ DirectChunk wait_chunk(i32x8d& v) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v) : : "memory");
-    DirectChunk e;
-    e.base = reinterpret_cast<const void*>(((unsigned long long)(unsigned)v[1] << 32) | (unsigned)v[0]);
-    e.H = v[2]; e.W = v[3]; e.C = v[4]; e.up = v[5]; e.nvalid = v[6]; e.pad = v[7];
-    return e;
-}
-
 // persistent: workgroup b walks tiles b, b + grid, ...; the (tile, chunk) sequence is one software pipeline, so the first
 // chunk of the next tile lands while the current tile's epilogue runs.
 // F16: ONE fp16 activation plane, two fp16 weight planes, two MFMA products per product (split_fmt.hpp)
@@ -217,9 +204,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
         if (++ic == p.nchunks) { ic = 0; itid += gridDim.x; if (itid < items) { icur = tile_of(itid); set_tile(icur); } }
     };
     {
-        i32x8d dv;
-        fetch_chunk(dv, p.chunks);
-        const ChunkCtx k = begin_chunk(wait_chunk(dv), icur, 0, 0);
+        const ChunkCtx k = begin_chunk(load_chunk(p.chunks), icur, 0, 0);
 #pragma unroll
         for (int sidx = 0; sidx < NSLOT; ++sidx) slot(k, sidx);
         advance();
@@ -243,13 +228,10 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();          // stage g has landed for every wave; everyone is done with stage g-1
             const bool more = itid < items;        // item g + 1 exists: its DMAs go into stage (g + 1) & 1 during this chunk
-            i32x8d dv;
-            fetch_chunk(dv, p.chunks + ic);        // (ic < nchunks always: a spent cursor re-reads a descriptor nobody uses)
             ChunkCtx k;
             if constexpr (N16) {
-                const DirectChunk chd = wait_chunk(dv);     // (waited for even when unused: a load in flight owns its SGPRs)
                 if (more) {
-                    k = begin_chunk(chd, icur, ic, (g + 1) & 1);
+                    k = begin_chunk(load_chunk(p.chunks + ic), icur, ic, (g + 1) & 1);
 #pragma unroll
                     for (int sidx = 0; sidx < NSLOT; ++sidx) slot(k, sidx);
                 }
@@ -311,10 +293,11 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                                 acc[a][nb] = mfma_frag<F16>(pr == 0 ? wl : wh, pr == 1 ? xl[a + dy] : xh[a + dy], acc[a][nb]);
                         }
                         const int grp = (dx * 3 + dy) * NB + nb;
-                        if (grp == 0) {
+                        if (grp == 0 && more) {
+                            // the descriptor's scalar load is issued AND waited for here, behind the first MFMA group (whose execution it
+                            // overlaps); kept in one piece: SGPRs of a load in flight must not be live across code the compiler may spill in
                             __builtin_amdgcn_sched_barrier(0);
-                            const DirectChunk chd = wait_chunk(dv);     // (waited for even when unused: a load in flight owns its SGPRs)
-                            if (more) k = begin_chunk(chd, icur, ic, (g + 1) & 1);
+                            k = begin_chunk(load_chunk(p.chunks + ic), icur, ic, (g + 1) & 1);
                         }
                         if (grp < NSLOT && more) {
                             __builtin_amdgcn_sched_barrier(0);
