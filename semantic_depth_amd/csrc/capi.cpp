@@ -43,8 +43,11 @@ struct sd_handle {
     bool prof = false;
     struct ProfRec { const char* kernel; double flops; hipEvent_t a, b; const char* op; int M, N, K; };
     std::vector<ProfRec> prof_recs;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
+    // one event per conv launch: the end event of a conv is the start event of the conv launched right behind it (two events per
+    // launch cost 1.8 % of a step: every record is a barrier packet on the stream)
+    std::vector<hipEvent_t> prof_pool;
     size_t prof_used = 0;
+    hipEvent_t prof_last = nullptr;      // end event of the previous conv launch, if nothing else was launched since
 };
 
 namespace {
@@ -108,6 +111,16 @@ sd_status upload_tables(sd_handle* h, sd_net net) {
 
 struct HeadOut { float* logits; uint8_t* road; uint8_t* fence; uint8_t* argmax; };
 
+// next event of the handle's profiling pool (created on demand), nullptr on failure
+static hipEvent_t prof_event(sd_handle* h) {
+    if (h->prof_used == h->prof_pool.size()) {
+        hipEvent_t a;
+        if (hipEventCreate(&a) != hipSuccess) return nullptr;
+        h->prof_pool.push_back(a);
+    }
+    return h->prof_pool[h->prof_used++];
+}
+
 // one chunk through a plan.  frames: u8 [nframes,H,W,3] (device)
 sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes, const HeadOut* head, hipStream_t s) {
     NetPlan& p = plan_of(h, net);
@@ -120,8 +133,10 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
     auto FMT = [&](int t) -> int { return p.tensors[t].fmt ? (p.tensors[t].f16 ? 2 : 1) : 0; };     // (fp16 hi+lo tensors never reach the ops that take this)     // 0 f32, 1 split bf16, 2 split fp16
     for (const WeightSlot& wsl : p.weights)
         if (!wsl.loaded) return fail(h, SD_ERR_STATE, "weight not loaded: " + wsl.name);
+    h->prof_last = nullptr;                 // (other work may have been put on the stream since the previous call)
     for (const OpDesc& op : p.ops) {
         hipError_t e = hipSuccess;
+        bool conv_op = false;
         switch (op.kind) {
             case OP_PRE_VGG:
                 e = launch_pre_vgg(frames, T(op.dst), (long)nframes * h->H * h->W, FMT(op.dst), PL(op.dst), s);
@@ -159,14 +174,9 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.sw = h->sw;
                 hipEvent_t ea = nullptr, eb = nullptr;
                 if (h->prof) {
-                    if (h->prof_used == h->prof_pool.size()) {
-                        hipEvent_t a, b;
-                        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return fail(h, SD_ERR_HIP, "hipEventCreate");
-                        h->prof_pool.push_back({a, b});
-                    }
-                    ea = h->prof_pool[h->prof_used].first; eb = h->prof_pool[h->prof_used].second;
-                    ++h->prof_used;
-                    hipEventRecord(ea, s);
+                    ea = h->prof_last;
+                    if (!ea) { if (!(ea = prof_event(h))) return fail(h, SD_ERR_HIP, "hipEventCreate"); hipEventRecord(ea, s); }
+                    if (!(eb = prof_event(h))) return fail(h, SD_ERR_HIP, "hipEventCreate");
                 }
                 const bool dma = split && conv_dma_variant(c) != 0 && !(h->sw & SW_NO_DMA);
                 const bool stem = split && !dma && conv_stem_eligible(c);
@@ -175,6 +185,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 e = dma ? launch_conv_dma(c, s) : stem ? launch_conv_stem(c, s) : split ? launch_conv_split(c, s) : launch_conv_igemm(c, s);
                 if (h->prof) {
                     hipEventRecord(eb, s);
+                    h->prof_last = eb; conv_op = true;
                     h->prof_recs.push_back({dma ? conv_dma_kernel_name(c) : stem ? (c.f16 ? "conv_stem_f16w_kernel" : "conv_stem_kernel") : split ? conv_split_kernel_name(c) : conv_igemm_kernel_name(c), op.flops * N / p.images, ea, eb,
                                             op.name.c_str(), N * c.Hout * c.Wout, d.C, op.K});
                 }
@@ -199,18 +210,14 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.sw = h->sw;
                 hipEvent_t ea = nullptr, eb = nullptr;
                 if (h->prof) {
-                    if (h->prof_used == h->prof_pool.size()) {
-                        hipEvent_t a, b;
-                        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return fail(h, SD_ERR_HIP, "hipEventCreate");
-                        h->prof_pool.push_back({a, b});
-                    }
-                    ea = h->prof_pool[h->prof_used].first; eb = h->prof_pool[h->prof_used].second;
-                    ++h->prof_used;
-                    hipEventRecord(ea, s);
+                    ea = h->prof_last;
+                    if (!ea) { if (!(ea = prof_event(h))) return fail(h, SD_ERR_HIP, "hipEventCreate"); hipEventRecord(ea, s); }
+                    if (!(eb = prof_event(h))) return fail(h, SD_ERR_HIP, "hipEventCreate");
                 }
                 e = launch_conv_direct(c, s);
                 if (h->prof) {
                     hipEventRecord(eb, s);
+                    h->prof_last = eb; conv_op = true;
                     h->prof_recs.push_back({conv_direct_kernel_name(c), op.flops * N / p.images, ea, eb, op.name.c_str(), N * c.H * c.W, d.C, op.K});
                 }
                 break;
@@ -251,6 +258,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 break;
             }
         }
+        if (!conv_op) h->prof_last = nullptr;       // something else went onto the stream: the next conv records its own start
         if (e != hipSuccess) return fail(h, SD_ERR_HIP, "launch " + op.name + ": " + hipGetErrorString(e));
     }
     (net == SD_NET_FCN8S ? h->last_fcn_images : h->last_mono_images) = N;
@@ -355,6 +363,8 @@ static sd_status create_impl(sd_handle** out, int device, int H, int W, int max_
 }
 
 sd_status sd_destroy(sd_handle* h) {
+    if (h)
+        for (hipEvent_t e : h->prof_pool) hipEventDestroy(e);      // (the library owns no device memory; the profiling events are its only HIP objects)
     delete h;
     return SD_OK;
 }
@@ -772,7 +782,7 @@ sd_status sd_net_tensor(sd_handle* h, sd_net net, const char* name, float* out, 
 sd_status sd_profile(sd_handle* h, int enable) {
     if (!h) return SD_ERR_INVALID;
     h->prof = enable != 0;
-    if (!h->prof) { h->prof_recs.clear(); h->prof_used = 0; }
+    if (!h->prof) { h->prof_recs.clear(); h->prof_used = 0; h->prof_last = nullptr; }
     return SD_OK;
 }
 
@@ -802,6 +812,7 @@ sd_status sd_profile_read(sd_handle* h, sd_profile_bucket* out, int cap_buckets,
     *n_out = n;
     h->prof_recs.clear();
     h->prof_used = 0;
+    h->prof_last = nullptr;
     return SD_OK;
 }
 
