@@ -330,3 +330,24 @@ def test_fence_chain_golden_and_oracle(pcl, mini, golden_dir):
     assert f2f[0]["ok"] == 1 and abs(f2f[0]["dist"] - ft["dist"]) <= 1e-9 * ft["dist"]
     assert np.allclose(f2f[0]["left_pt"], ft["left_pt"], rtol=1e-9, atol=1e-9)
     assert f2f[1]["ok"] == 0 and f2f[1]["counts"][0] == 0
+
+
+def test_o3d_filters_ties_and_degenerate_clouds(pcl):
+    """distance ties everywhere (a regular lattice: every point has 6 / 12 / 8 neighbours at exactly equal distances, so the k-th
+    neighbour is one of several equidistant candidates), heavy duplication (k-th distance 0 for most points), a cloud on a line
+    (one grid axis degenerate) and on a single point; both filters against the oracle, bit for bit"""
+    rng = np.random.default_rng(3)
+    g = np.arange(12, dtype=np.float32) * np.float32(0.125)               # exact in binary: the ties are exact ties
+    lattice = np.stack(np.meshgrid(g, g - 3, -g - 9, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    lattice = lattice[rng.permutation(len(lattice))]
+    col = rng.integers(0, 256, (len(lattice), 3), dtype=np.uint8)
+    n1, n2 = _o3d_compare(pcl, lattice, col, k=10, ratio=0.5, nb=6, radius=0.13)       # radius just above one spacing
+    assert n1 > 0
+    _o3d_compare(pcl, lattice, col, k=7, ratio=0.1, nb=18, radius=0.1768)              # sqrt(2) * 0.125 = 0.17678: face diagonals on the boundary
+    three = np.float32([[0, 0, -10], [0.5, 0, -10], [0, 0.25, -11]])
+    dup = three[rng.integers(0, 3, 600)]
+    _o3d_compare(pcl, dup, col[:600], k=10, ratio=0.5, nb=50, radius=0.3)
+    line = np.stack([np.linspace(-5, 5, 900), np.zeros(900), np.full(900, -12.0)], 1).astype(np.float32)
+    _o3d_compare(pcl, line, col[:900], k=10, ratio=1.0, nb=20, radius=0.2)
+    point = np.repeat(np.float32([[1.5, -2.0, -30.0]]), 40, axis=0)
+    _o3d_compare(pcl, point, col[:40], k=10, ratio=0.5, nb=5, radius=0.01)
