@@ -98,7 +98,9 @@ sd_status sd_create(sd_handle** out, int device, int H, int W, int max_batch, sd
  * the 2-product fp16 scheme -- or, with the suffix ":1" / ":x", the 1-product / x2 form; the rest run the 3-product bf16 one.  The
  * choice is closed under "one plane format per tensor" (sd_precision_plan returns what actually runs, with the suffixes).  ":x" on a
  * layer the geometry does not route to the direct 3x3 kernel (or whose producer is not one) keeps three products; on a layer that
- * is no 3x3 stride-1 convolution with a multiple of 64 output channels it is SD_ERR_INVALID, as is an unknown layer name. */
+ * is no 3x3 stride-1 convolution with a multiple of 64 output channels it is SD_ERR_INVALID, as is an unknown layer name.  A per-pixel
+ * head (FCN score layers, dec/disp1) named exactly makes its INPUT tensor one fp16 plane (the producer writes, the head reads half the
+ * bytes); heads otherwise follow the format the convolutions give their input. */
 sd_status sd_create_with_plan(sd_handle** out, int device, int H, int W, int max_batch, sd_encoder enc, const char* fcn_f16_layers,
                               const char* mono_f16_layers);
 const char* sd_default_plan(sd_net net);      /* (monodepth: the ResNet-50 plan; the vgg encoder's default plan is empty) */

@@ -318,7 +318,7 @@ constexpr int SN_XI = (SN_HH * SN_HW * 2 + 63) / 64;        // 11 DMA instructio
 constexpr int SN_XUNITS = SN_XI * 64;
 template <int NOUT, bool F16>
 __global__ __launch_bounds__(256) void conv_smalln_tile_kernel(const SmallNParams p) {
-    __shared__ __attribute__((aligned(16))) u32x4_t X[2 * SN_XUNITS];
+    __shared__ __attribute__((aligned(16))) u32x4_t X[(F16 ? 1 : 2) * SN_XUNITS];       // one plane for fp16 inputs
     extern __shared__ __attribute__((aligned(16))) float wl[];   // [NOUT][9 C]
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);

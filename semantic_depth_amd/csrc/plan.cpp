@@ -310,6 +310,10 @@ struct Builder {
             for (OpDesc& op : p.ops) {
                 if (!match(t, op.name)) continue;
                 any = true;          // (a layer that is not an MFMA conv at this geometry, e.g. a small-N head, follows its input's format)
+                // a per-thread head named EXACTLY (no wildcard): its input tensor becomes ONE fp16 plane -- the producer writes half the
+                // bytes and the head reads half (dec/disp1 reads the full-resolution iconv1 output: 2.1 -> 1.07 GB each way)
+                if (op.kind == OP_SMALLN && t == op.name && mode == 1 && p.tensors[op.src[0]].fmt && p.tensors[op.src[0]].f16 < 1)
+                    p.tensors[op.src[0]].f16 = 1;
                 if (!is_conv(op)) continue;
                 if (mode == 3) {
                     if (op.k != 3 || op.stride != 1 || p.tensors[op.dst].C % 64)
