@@ -284,7 +284,7 @@ extern "C" {
 #define SD_DEFAULT_PLAN_FCN "conv1_2,conv2_2,conv3_3:x,conv4_1:x,conv4_2:1,conv4_3:1,conv5_1:1,conv5_2:1,conv5_3:1,fc6:1,fc7:1"
 #endif
 #ifndef SD_DEFAULT_PLAN_MONO
-#define SD_DEFAULT_PLAN_MONO "enc/res2*:1,enc/res3*:1,enc/res4*:1,enc/res5*:1,dec/upconv6:1,dec/iconv6:1,dec/upconv5:1,dec/iconv5:1,dec/upconv4:1,dec/iconv4:1,dec/disp4,dec/upconv1:1,dec/iconv1:1,dec/disp1"
+#define SD_DEFAULT_PLAN_MONO "enc/res*:1,dec/upconv*:1,dec/iconv*:1,dec/disp4,dec/disp3,dec/disp1"
 #endif
 #ifndef SD_SOURCE_HASH
 #define SD_SOURCE_HASH "unhashed"
