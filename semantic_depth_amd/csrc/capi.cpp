@@ -142,7 +142,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 e = launch_pre_vgg(frames, T(op.dst), (long)nframes * h->H * h->W, FMT(op.dst), PL(op.dst), s);
                 break;
             case OP_PRE_MONO:
-                e = launch_pre_mono(frames, T(op.dst), nframes, h->H, h->W, FMT(op.dst), PL(op.dst), s);
+                e = launch_pre_mono(frames, T(op.dst), nframes, h->H, h->W, FMT(op.dst), PL(op.dst), p.input_scale == 1.f ? 1 : 0, s);
                 break;
             case OP_CONV: {
                 const TensorDesc& d = p.tensors[op.dst];
@@ -284,7 +284,7 @@ extern "C" {
 #define SD_DEFAULT_PLAN_FCN "conv1_2,conv2_2,conv3_3:x,conv4_1:x,conv4_2:1,conv4_3:1,conv5_1:1,conv5_2:1,conv5_3:1,fc6:1,fc7:1"
 #endif
 #ifndef SD_DEFAULT_PLAN_MONO
-#define SD_DEFAULT_PLAN_MONO "enc/res*:1,dec/upconv*:1,dec/iconv*:1,dec/disp4,dec/disp3,dec/disp1"
+#define SD_DEFAULT_PLAN_MONO "enc/conv1,enc/res*:1,dec/upconv*:1,dec/iconv*:1,dec/disp4,dec/disp3,dec/disp1"
 #endif
 #ifndef SD_SOURCE_HASH
 #define SD_SOURCE_HASH "unhashed"
@@ -412,7 +412,14 @@ sd_status sd_load_weight(sd_handle* h, sd_net net, const char* name, const float
     if (rank != s.rank) return fail(h, SD_ERR_INVALID, std::string("rank mismatch for ") + name);
     for (int i = 0; i < rank; ++i)
         if (shape[i] != s.shape[i]) return fail(h, SD_ERR_INVALID, std::string("shape mismatch for ") + name);
-    std::vector<float> buf;
+    std::vector<float> buf, scaled;
+    if (s.scale != 1.f) {               // (monodepth stem with integer input: the weights carry the 1/255)
+        size_t n = 1;
+        for (int i = 0; i < rank; ++i) n *= (size_t)shape[i];
+        scaled.resize(n);
+        for (size_t i = 0; i < n; ++i) scaled[i] = data[i] * s.scale;
+        data = scaled.data();
+    }
     relayout_weight(s, data, buf);
     char* base = warena(h, net) + s.offset;
     if (s.layout == WL_IGEMM) {                     // rows [k_off, k_off+Kpad) of a [Ktotal/4][CoutPad][4] matrix

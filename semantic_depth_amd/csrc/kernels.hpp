@@ -175,7 +175,7 @@ bool conv_smalln_tiled(int in_split, int k, int W, int C, int nout, unsigned sw)
 // ---------------------------------------------------------------------------------------------
 // `split`: activations are split-bf16 planes (split_fmt.hpp); `plane*` = element offset of the lo plane
 hipError_t launch_pre_vgg(const uint8_t* frames, float* out, long npix, int split, size_t plane, hipStream_t s);                 // K1
-hipError_t launch_pre_mono(const uint8_t* frames, float* out, int B, int H, int W, int split, size_t plane, hipStream_t s);      // /255 + fliplr pair
+hipError_t launch_pre_mono(const uint8_t* frames, float* out, int B, int H, int W, int split, size_t plane, int raw, hipStream_t s);      // /255 (raw: not) + fliplr pair
 hipError_t launch_maxpool2(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s);
 hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s);
 hipError_t launch_unsplit(const float* x, float* y, long npix, int C, int Ctf, size_t plane, size_t sub, int f16, hipStream_t s);  // split planes -> f32 [npix][Ctf]

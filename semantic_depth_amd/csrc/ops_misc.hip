@@ -59,7 +59,7 @@ hipError_t launch_pre_vgg(const uint8_t* frames, float* out, long npix, int spli
 
 // monodepth input: frame.astype(f32)/255 and its fliplr, stacked per frame (semantic_depth.py:671-672)
 template <int SPLIT>
-__global__ __launch_bounds__(256) void pre_mono_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int B, int H, int W, size_t plane) {
+__global__ __launch_bounds__(256) void pre_mono_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int B, int H, int W, size_t plane, int raw) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     long npix = (long)B * H * W;
     if (i >= npix) return;
@@ -68,16 +68,17 @@ __global__ __launch_bounds__(256) void pre_mono_kernel(const uint8_t* __restrict
     int b = (int)(row / H);
     int y = (int)(row - (long)b * H);
     const uint8_t* p = in + i * 3;
-    const f32x4 v = {(float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f, 0.f};
+    // raw: the pixel values themselves (exact in fp16; the stem's weights carry the 1/255: NetPlan::input_scale)
+    const f32x4 v = raw ? f32x4{(float)p[0], (float)p[1], (float)p[2], 0.f} : f32x4{(float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f, 0.f};
     store4<SPLIT>(out, plane, ((long)(2 * b) * H + y) * W + x, v);
     store4<SPLIT>(out, plane, ((long)(2 * b + 1) * H + y) * W + (W - 1 - x), v);
 }
-hipError_t launch_pre_mono(const uint8_t* frames, float* out, int B, int H, int W, int split, size_t plane, hipStream_t s) {
+hipError_t launch_pre_mono(const uint8_t* frames, float* out, int B, int H, int W, int split, size_t plane, int raw, hipStream_t s) {
     long npix = (long)B * H * W;
     const dim3 grid((unsigned)((npix + 255) / 256));
-    if (split == 2) hipLaunchKernelGGL(pre_mono_kernel<2>, grid, dim3(256), 0, s, frames, out, B, H, W, plane);
-    else if (split) hipLaunchKernelGGL(pre_mono_kernel<1>, grid, dim3(256), 0, s, frames, out, B, H, W, plane);
-    else hipLaunchKernelGGL(pre_mono_kernel<0>, grid, dim3(256), 0, s, frames, out, B, H, W, plane);
+    if (split == 2) hipLaunchKernelGGL(pre_mono_kernel<2>, grid, dim3(256), 0, s, frames, out, B, H, W, plane, raw);
+    else if (split) hipLaunchKernelGGL(pre_mono_kernel<1>, grid, dim3(256), 0, s, frames, out, B, H, W, plane, raw);
+    else hipLaunchKernelGGL(pre_mono_kernel<0>, grid, dim3(256), 0, s, frames, out, B, H, W, plane, raw);
     return hipGetLastError();
 }
 

@@ -356,6 +356,12 @@ struct Builder {
             if ((op.kind == OP_POOL2 || op.kind == OP_POOL3Z) && p.tensors[op.src[0]].f16 == 2)
                 throw std::runtime_error("precision plan of " + p.net + ": a stand-alone pool cannot read fp16 hi+lo planes (" + op.name + ")");
         }
+        if (p.net.compare(0, 9, "monodepth") == 0)
+            for (OpDesc& op : p.ops)
+                if (is_conv(op) && op.f16 && op.nsrc == 1 && op.src[0] == p.t_input) {
+                    p.input_scale = 1.f;
+                    p.weights[op.w].scale = 1.f / 255.f;
+                }
         double fl = 0;
         for (OpDesc& op : p.ops) {
             if (!is_conv(op) || !op.f16) continue;

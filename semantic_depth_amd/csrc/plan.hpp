@@ -39,6 +39,7 @@ struct WeightSlot {
     int nsrc = 1, srcCtf[3] = {0, 0, 0}, srcCpad[3] = {0, 0, 0};   // WL_IGEMM: channel structure of the K axis
     int vec = 0;           // 1: K axis is ordered (32-channel block, tap, channel) instead of (tap, channel)
     int f16 = 0;           // split layouts: two fp16 planes, hi = fp16(w), lo = fp16(w - hi) (the 2-product scheme of split_fmt.hpp)
+    float scale = 1.f;     // the tensor is multiplied by this while it is loaded (monodepth stem with integer input: 1/255, see NetPlan::input_scale)
     // a slot may be a VIEW of rows [k_off, k_off+Kpad) of a larger device matrix of Ktotal rows owned by slot `owner`
     // (ResNet block: conv3 and the projection shortcut are one GEMM over the concatenated K axis); a bias view is ADDED
     // to its owner's bias
@@ -93,6 +94,9 @@ struct NetPlan {
     size_t act_bytes = 0;
     double flops_per_image = 0;
     int t_input = -1, t_output = -1;
+    // monodepth, fp16 stem: the input tensor holds the pixel VALUES 0..255 (exact in fp16) instead of value / 255 and the stem's weights
+    // carry the 1/255 -- the two-product stem then has no activation rounding at all.  1/255 otherwise.
+    float input_scale = 1.f / 255.f;
 };
 
 NetPlan build_fcn8s(int frames, int H, int W, int prec, const char* f16_layers = nullptr);
