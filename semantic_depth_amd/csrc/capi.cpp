@@ -281,7 +281,7 @@ int32_t* cnt_slot(sd_handle* h, int i) { return reinterpret_cast<int32_t*>(h->ws
 extern "C" {
 
 #ifndef SD_DEFAULT_PLAN_FCN
-#define SD_DEFAULT_PLAN_FCN "conv1_2,conv2_2,conv3_3:x,conv4_1:x,conv4_2:1,conv4_3:1,conv5_1:1,conv5_2:1,conv5_3:1,fc6:1,fc7:1"
+#define SD_DEFAULT_PLAN_FCN "conv1_2,conv3_3:x,conv4_1:x,conv4_2:1,conv4_3:1,conv5_1:1,conv5_2:1,conv5_3:1,fc6:1,fc7:1"
 #endif
 #ifndef SD_DEFAULT_PLAN_MONO
 #define SD_DEFAULT_PLAN_MONO "enc/conv1,enc/res*:1,dec/upconv*:1,dec/iconv*:1,dec/disp4,dec/disp3,dec/disp1"
