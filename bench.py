@@ -19,11 +19,18 @@ One step = one pass of the whole hot path over one batch of synthetic frames alr
      under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it is one of the ranks.  Either way the
      world size must equal --gpus, and the JSON carries `ranks_seen` (an all_reduce of ones over RCCL).
 
+The HEADLINE engine (`value`, `dtype`, `roofline`) computes at the reference's precision (fp32: semantic_depth.py:550-552,675 run the
+TF graphs in float32); the reduced-precision engines are LEGS of the same line, timed for the same --steps in the same process.
+
 Prints ONE JSON line on rank 0 (contract in the round prompt) with
+  `value`        frames/s of the headline engine: EXACTLY --steps steps between barrier + synchronize, max over ranks; the region is
+                 repeated --repeats times back to back and `value` is steps * frames / mean(region time) (`repeat_ms_per_step` lists them)
   `roofline`     dominant conv kernel: algorithmic FLOPs per launch / its average HIP-event duration in THIS run vs the MFMA peak of
-                 its arithmetic; `roofline.engine` = all conv launches together
-  `f32_exact`    the same step on the exact-f32 engine (v_mfma_f32_16x16x4_f32), timed in the same process
-  `parity`       this run's outputs (the frames of the timed batch) against the f32 engine and against the CPU oracle
+                 its arithmetic; `roofline.engine` = all conv launches together; `by_kernel` = every instantiation
+  `legs`         the other engines (default: the per-layer precision plan) timed the same way, each with its own `roofline` and its
+                 `parity` against the exact-f32 engine over the whole batch
+  `f32_exact`    the exact-f32 engine's numbers (= the headline when --precision f32)
+  `parity`       the outputs of the timed batch against the CPU oracle (and, for a reduced-precision headline, the f32 engine)
   `cpu_baseline` the CPU oracle timed on this box's host cores (bounded sample), all cores and 1 thread
 """
 import argparse
@@ -43,7 +50,10 @@ H, W = 512, 1024
 # MI355X_MICROARCH.md peaks.  f32: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz.
 # split-bf16 (3 products): every algorithmic product costs three dense-bf16 MFMA products (hi*hi + hi*lo + lo*hi), so the
 # ceiling for ALGORITHMIC flops is the dense bf16 peak / 3; split-fp16 x fp16 weights (2 products): dense fp16 peak / 2.
-PEAK_F32, PEAK_3P, PEAK_2P, PEAK_1P = 157.3, 2500.0 / 3.0, 2500.0 / 2.0, 2500.0
+PEAK_F32, PEAK_3P, PEAK_2P, PEAK_1P, PEAK_6P = 157.3, 2500.0 / 3.0, 2500.0 / 2.0, 2500.0, 2500.0 / 6.0
+# the HEADLINE engine computes at the reference's precision (the reference runs its TF graphs in float32, semantic_depth.py:550-552,675);
+# the reduced-precision engines (within north_star's 1e-3, see `legs[*].parity_vs_f32_engine`) are reported beside it
+DEFAULT_PRECISION = "f32"
 DTYPE = {
     "f32": "f32 (exact: v_mfma_f32_16x16x4_f32)",
     "bf16x2": "bf16x2 split operands (hi+lo, 16 mantissa bits), 3 bf16 MFMA products per product, f32 accumulate",
@@ -64,30 +74,34 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--config", type=int, default=4, choices=[4, 5], help="SURVEY §8d config: 4 = fused B=32 (default), 5 = sequence driver")
     ap.add_argument("--overlap", action="store_true",
-                    help="run the per-frame tail of step i on a side stream under the convolutions of step i+1 (measured +2.7 %% frames/s, "
-                         "480 -> 493; off by default: the tail's workgroups then share CUs with the conv launches, whose HIP-event "
-                         "durations -- the roofline evidence of this line -- stop being the kernels' own)")
+                    help="run the per-frame tail of step i on a side stream under the convolutions of step i+1 (off by default: the tail's "
+                         "workgroups then share CUs with the conv launches, whose HIP-event durations -- the roofline evidence of this "
+                         "line -- stop being the kernels' own)")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--repeats", type=int, default=3, help="back-to-back timed regions of --steps steps each; value = mean over them")
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step (configs[3]: 32)")
     ap.add_argument("--encoder", default="resnet50")
-    ap.add_argument("--precision", default=os.environ.get("SD_BENCH_PRECISION", "plan"), choices=["f32", "bf16x2", "mixed", "plan"],
-                    help="conv arithmetic of the measured engine")
-    ap.add_argument("--plan", default=None, help="precision plan to measure instead of the built-in one: 'fcn layers|monodepth layers' "
-                    "(sd_create_with_plan syntax; the line's dtype/config then say so)")
+    ap.add_argument("--precision", default=os.environ.get("SD_BENCH_PRECISION", DEFAULT_PRECISION), choices=sorted(DTYPE),
+                    help="conv arithmetic of the HEADLINE engine (default: the reference's precision)")
+    ap.add_argument("--legs", default=None, help="comma-separated engines timed beside the headline (N = 1 only); default 'plan' "
+                    "(plus 'f32' when the headline is not f32); 'none' = no legs")
+    ap.add_argument("--plan", default=None, help="precision plan of the 'plan' engine instead of the built-in one: 'fcn layers|monodepth layers' "
+                    "(sd_create_with_plan syntax; the line then says so)")
     ap.add_argument("--approach", default="rw", choices=["rw", "both"],
                     help="'both' adds the fence chain + fence-to-fence distance (semantic_depth.py:273-334; SURVEY §8f-1) to every frame; "
                          "the metric's configuration is 'rw'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-f32-leg", action="store_true", help="skip the exact-f32 engine leg (f32_exact + parity vs f32)")
-    ap.add_argument("--f32-steps", type=int, default=2)
+    ap.add_argument("--no-f32-leg", action="store_true", help="(kept for old command lines) same as --legs none")
     ap.add_argument("--no-colours", action="store_true", help="do not carry the RGB of the points through the road chain")
     return ap.parse_args()
 
 
 def spawn_ranks(args) -> int:
     """--gpus N without a launcher: start N fresh rank processes of this script (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in
-    their environment).  Nothing in THIS process has touched a GPU: the library is built by hipcc subprocesses only."""
+    their environment).  Nothing in THIS process has touched a GPU: the library is built by hipcc subprocesses only.  The children
+    are polled together: the first one that fails takes its siblings down (terminate, then kill) instead of leaving them blocked in
+    init_process_group / a collective until the store timeout, and the launcher exits with THAT rank's code."""
     from semantic_depth_amd import build as b
     b.build()                                     # once, before the ranks start: no rank ever links or maps a half-written library
     with socket.socket() as s:
@@ -98,10 +112,39 @@ def spawn_ranks(args) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), SD_BENCH_SPAWNED="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
-    return rc
+    return wait_ranks(procs)
+
+
+def wait_ranks(procs, poll_s: float = 0.2, grace_s: float = 10.0) -> int:
+    """wait for every rank process; on the first non-zero exit terminate (then kill) the others and return that exit code
+    (a rank killed by signal n reports 128 + n)."""
+    live = dict(enumerate(procs))
+    failed = None
+    while live and failed is None:
+        for r, p in list(live.items()):
+            rc = p.poll()
+            if rc is None:
+                continue
+            del live[r]
+            if rc != 0:
+                failed = (r, rc)
+                break
+        if live and failed is None:
+            time.sleep(poll_s)
+    if failed is None:
+        return 0
+    r, rc = failed
+    log(f"bench.py: rank {r} exited with {rc}; stopping the other ranks")
+    for p in live.values():
+        p.terminate()
+    t_end = time.time() + grace_s
+    for p in live.values():
+        try:
+            p.wait(timeout=max(0.1, t_end - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+    return rc if rc > 0 else 128 - rc
 
 
 def main():
@@ -118,6 +161,7 @@ def main():
         sys.exit(f"bench.py: world size {world} (WORLD_SIZE) != --gpus {args.gpus}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+    import datetime
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -131,9 +175,10 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     import __graft_entry__ as graft
     from semantic_depth_amd import build as sd_build
-    if world == 1 or rank == 0:
-        graft.build()                 # returns at once when the library matches the tree (hash stamp); links aside + renames
-    else:                             # N > 1: local rank 0 (or the launcher) builds; the others wait for a library of THIS tree
+    if world == 1 or local_rank == 0 or os.environ.get("SD_BENCH_SPAWNED") == "1":
+        graft.build()                 # returns at once when the library matches the tree (hash stamp); links aside + renames.
+                                      # One builder per NODE (local rank 0); ranks spawned by this script find the launcher's build
+    else:                             # the other ranks of a node wait for a library of THIS tree
         t_wait = time.time()
         while not (os.path.exists(sd_build.LIB + ".hash") and open(sd_build.LIB + ".hash").read().strip() == sd_build.source_hash()):
             if time.time() - t_wait > 900:
@@ -147,29 +192,37 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # an explicit rendezvous / collective timeout: a rank that never arrives fails the job in minutes, not after the default 10-30
+        tmo = datetime.timedelta(seconds=float(os.environ.get("SD_BENCH_DIST_TIMEOUT_S", "300")))
         if share:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=tmo)
     ones = torch.ones(1, device="cpu" if share else "cuda")
     if world > 1:
         dist.all_reduce(ones)         # RCCL over xGMI: every rank contributes 1
     ranks_seen = int(ones.item())
     B = args.batch
     colours = not args.no_colours
+    custom_plan = tuple(args.plan.split("|")) if args.plan is not None else None
+    if custom_plan is not None and len(custom_plan) != 2:
+        raise SystemExit("--plan needs the form 'fcn layers|monodepth layers'")
+    if args.legs is None:
+        legs = [] if args.no_f32_leg else [p_ for p_ in ("f32", "plan") if p_ != args.precision]
+    else:
+        legs = [] if args.legs in ("", "none") else [p_ for p_ in args.legs.split(",") if p_ != args.precision]
+    for p_ in legs:
+        if p_ not in DTYPE:
+            raise SystemExit(f"--legs: unknown engine '{p_}'")
+    if world > 1:
+        legs = []
 
     # ------------------------------------------------------------------ setup (untimed)
     t_setup = time.time()
-    custom_plan = tuple(args.plan.split("|")) if args.plan is not None else None
-    if custom_plan is not None and (args.precision != "plan" or len(custom_plan) != 2):
-        raise SystemExit("--plan needs --precision plan and the form 'fcn layers|monodepth layers'")
-    eng = Engine(H, W, B, args.encoder, local_rank, precision=args.precision, plan=custom_plan)
     # seeded synthetic weights.  decoder_std is raised from the reference's 0.01 so that the
     # softmax > 0.5 masks of a random-weight net are non-trivial and the road chain has real work.
     wf = Wt.make_fcn8s_weights(1, decoder_std=float(os.environ.get("SD_BENCH_DECODER_STD", "0.05")))
     wm = Wt.make_monodepth_weights(args.encoder, 2)
-    eng.load_weights(L.SD_NET_FCN8S, wf)
-    eng.load_weights(L.SD_NET_MONODEPTH, wm)
     rng = np.random.default_rng(1000 + rank)
     # smooth random frames: low-pass of uniform noise (SURVEY §8d config 2 variant) so that masks form regions
     if args.config == 4:
@@ -182,178 +235,266 @@ def main():
     frames_np = np.repeat(np.repeat(base, 8, axis=1), 8, axis=2)
     frames_np = (frames_np.astype(np.int16) + rng.integers(-16, 17, frames_np.shape, dtype=np.int16)).clip(0, 255).astype(np.uint8)
     src_frames = torch.from_numpy(frames_np).cuda()
-    frames = src_frames if args.config == 4 else eng.resize_cubic(src_frames)
     cams = [cam] * B
     prm = RoadWidthParams()
-    # a random-weight monodepth puts its median disparity wherever its last bias puts it; calibrate that ONE bias (dec/disp1,
-    # untimed, part of the synthetic weights) so that the median depth is the measuring depth (10 m) for this config's camera:
-    # the z-cut, the depth window and the Open3D filters of the road chain then all see real work
-    d0 = float(eng.monodepth_forward(frames).median().item())
-    target = cam.f * cam.b / prm.depth / cam.disp_mult                            # disparity (fraction of width) of a point at 10 m
-    logit = lambda p: float(np.log(p / (1.0 - p)))
-    bias = logit(target / 0.3) - logit(min(max(d0, 1e-4), 0.2999) / 0.3)
-    wm["dec/disp1/biases"] = (wm["dec/disp1/biases"] + np.float32(bias)).astype(np.float32)
-    eng.load_weights(L.SD_NET_MONODEPTH, {"dec/disp1/biases": wm["dec/disp1/biases"]})
-    if rank == 0:
-        log(f"setup {time.time() - t_setup:.1f}s; arenas: " + ", ".join(f"{k} {v / 2**30:.2f} GiB" for k, v in eng.bytes.items()) +
-            f"; disp1 bias {bias:+.3f} (median disparity {d0:.4f} -> {target:.4f})")
+    state = {"bias": None, "frames": None}
 
-    seq_step = make_engine_step(eng, lambda i: cam, prm, approach=args.approach)
+    def make_engine(precision):
+        eng = Engine(H, W, B, args.encoder, local_rank, precision=precision, plan=custom_plan if precision == "plan" else None)
+        eng.load_weights(L.SD_NET_FCN8S, wf)
+        eng.load_weights(L.SD_NET_MONODEPTH, wm)
+        if state["frames"] is None:
+            state["frames"] = src_frames if args.config == 4 else eng.resize_cubic(src_frames)
+        if state["bias"] is None:
+            # a random-weight monodepth puts its median disparity wherever its last bias puts it; calibrate that ONE bias (dec/disp1,
+            # untimed, part of the synthetic weights, the same for every engine of this run) so that the median depth is the measuring
+            # depth (10 m) for this config's camera: the z-cut, the depth window and the Open3D filters of the road chain then all see real work
+            d0 = float(eng.monodepth_forward(state["frames"]).median().item())
+            target = cam.f * cam.b / prm.depth / cam.disp_mult                    # disparity (fraction of width) of a point at 10 m
+            logit = lambda p: float(np.log(p / (1.0 - p)))
+            state["bias"] = logit(target / 0.3) - logit(min(max(d0, 1e-4), 0.2999) / 0.3)
+            wm["dec/disp1/biases"] = (wm["dec/disp1/biases"] + np.float32(state["bias"])).astype(np.float32)
+            if rank == 0:
+                log(f"disp1 bias {state['bias']:+.3f} (median disparity {d0:.4f} -> {target:.4f})")
+        eng.load_weights(L.SD_NET_MONODEPTH, {"dec/disp1/biases": wm["dec/disp1/biases"]})
+        return eng
 
-    def step():
-        if args.config == 5:
-            # the sequence driver: this rank's shard of the world*B frame list -> resize -> whole path -> ONE all_gather
-            return run_sequence(lambda lo, hi: src_frames[lo - rank * B: hi - rank * B], world * B, seq_step, batch=B, device="cuda")
-        out = eng.process_batch(frames, cams, prm, approach=args.approach, colours=colours)
-        # the only collective on the path: per-frame road-width records (104 B x B per rank), RCCL all_gather over xGMI
-        return gather_records(out["records"], world * B)
+    def measure(eng, label):
+        """warm-up, then --repeats timed regions of EXACTLY --steps steps, each bracketed by barrier + synchronize (max over ranks)"""
+        frames = state["frames"]
+        seq_step = make_engine_step(eng, lambda i: cam, prm, approach=args.approach)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
+        def step():
+            if args.config == 5:
+                # the sequence driver: this rank's shard of the world*B frame list -> resize -> whole path -> ONE all_gather
+                return run_sequence(lambda lo, hi: src_frames[lo - rank * B: hi - rank * B], world * B, seq_step, batch=B, device="cuda")
+            out = eng.process_batch(frames, cams, prm, approach=args.approach, colours=colours)
+            # the only collective on the path: per-frame road-width records (104 B x B per rank), RCCL all_gather over xGMI
+            return gather_records(out["records"], world * B)
 
-    # ------------------------------------------------------------------ timed region
-    eng.profile(True)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    # The two networks run on the main stream; with --overlap the per-frame tail of step i (back-projection, road chain, record
-    # gather) runs on a side stream underneath the convolutions of step i+1; the default keeps everything on one stream.
-    side = torch.cuda.Stream() if args.overlap else None
-    state = {"fused_once": False}
-
-    def instrumented_step():
-        """one step, stage by stage with stream events (the same launches as Engine.process_batch / make_engine_step)"""
-        ev[0].record()
-        fr = eng.resize_cubic(src_frames) if args.config == 5 else frames
-        ev[1].record()
-        seg = eng.fcn8s_forward(fr)
-        ev[2].record()
-        if side is not None and state["fused_once"]:
-            torch.cuda.current_stream().wait_event(ev[4])      # the previous step's fusion stage has consumed the raw pair in the arena
-        eng.monodepth_forward(fr, post_process=False)          # the raw pair stays in the arena for the one-pass fusion stage
-        ev[3].record()
-        if side is not None:
-            side.wait_event(ev[3])
-            for t_ in (seg["road"], seg["fence"], fr):
-                t_.record_stream(side)
-            ctx = torch.cuda.stream(side)
-        else:
-            ctx = contextlib.nullcontext()
-        with ctx:
-            # flip-pair post-processing + back-projection + both ordered gathers: ONE launch (sd_postprocess_fuse_backproject)
-            fz = eng.fuse_from_raw(seg["road"], seg["fence"], fr, cams, want_rgb=colours)
-            ev[4].record()
-            state["fused_once"] = True
-            rec = eng.road_width(fz["road_xyz"], fz["n_road"], prm, road_rgb=fz["road_rgb"] if colours else None)
-            allr = gather_records(rec, world * B)
-            ev[5].record()
-            f2f = None
-            if args.approach == "both":
-                f2f = eng.fence_to_fence(fz["fence_xyz"], fz["n_fence"], rec, FenceParams(depth=prm.depth),
-                                         fence_rgb=fz["fence_rgb"] if colours else None)
-            ev[6].record()
-        return dict(seg=seg, disp_pp=fz["disp_pp"], fuse=fz, records=rec, f2f=f2f), allr
-
-    for _ in range(args.steps):
-        if args.config == 5:
-            allrec = step()                                    # distributed.run_sequence: shard -> resize -> process_batch -> all_gather
-        else:
-            out, allrec = instrumented_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    buckets = eng.profile_read()
-    eng.profile(False)
-    if args.config == 5:                                       # stage split + report tensors from one more (untimed) instrumented step
-        out, _ = instrumented_step()
+        for _ in range(args.warmup):
+            step()
         torch.cuda.synchronize()
-    # stage split of the LAST step (events are only read after the timed region)
-    stage_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(6)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+        # The two networks run on the main stream; with --overlap the per-frame tail of step i (back-projection, road chain, record
+        # gather) runs on a side stream underneath the convolutions of step i+1; the default keeps everything on one stream.
+        side = torch.cuda.Stream() if args.overlap else None
+        st = {"fused_once": False}
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    frames_total = world * B * args.steps
-    value = frames_total / dt
-    assert allrec.shape[0] == world * B
+        def instrumented_step():
+            """one step, stage by stage with stream events (the same launches as Engine.process_batch / make_engine_step)"""
+            ev[0].record()
+            fr = eng.resize_cubic(src_frames) if args.config == 5 else frames
+            ev[1].record()
+            seg = eng.fcn8s_forward(fr)
+            ev[2].record()
+            if side is not None and st["fused_once"]:
+                torch.cuda.current_stream().wait_event(ev[4])      # the previous step's fusion stage has consumed the raw pair in the arena
+            eng.monodepth_forward(fr, post_process=False)          # the raw pair stays in the arena for the one-pass fusion stage
+            ev[3].record()
+            if side is not None:
+                side.wait_event(ev[3])
+                for t_ in (seg["road"], seg["fence"], fr):
+                    t_.record_stream(side)
+                ctx = torch.cuda.stream(side)
+            else:
+                ctx = contextlib.nullcontext()
+            with ctx:
+                # flip-pair post-processing + back-projection + both ordered gathers: ONE launch (sd_postprocess_fuse_backproject)
+                fz = eng.fuse_from_raw(seg["road"], seg["fence"], fr, cams, want_rgb=colours)
+                ev[4].record()
+                st["fused_once"] = True
+                rec = eng.road_width(fz["road_xyz"], fz["n_road"], prm, road_rgb=fz["road_rgb"] if colours else None)
+                allr = gather_records(rec, world * B)
+                ev[5].record()
+                f2f = None
+                if args.approach == "both":
+                    f2f = eng.fence_to_fence(fz["fence_xyz"], fz["n_fence"], rec, FenceParams(depth=prm.depth),
+                                             fence_rgb=fz["fence_rgb"] if colours else None)
+                ev[6].record()
+            return dict(seg=seg, disp_pp=fz["disp_pp"], fuse=fz, records=rec, f2f=f2f), allr
 
+        eng.profile(True)
+        dts, buckets = [], {}
+        for _rep in range(max(1, args.repeats)):
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                if args.config == 5:
+                    allrec = step()                                # distributed.run_sequence: shard -> resize -> process_batch -> all_gather
+                else:
+                    out, allrec = instrumented_step()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
+            if world > 1:
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dts.append(float(tmax.item()))
+            for b_ in eng.profile_read():                          # HIP-event buckets of this region (read outside the timed region)
+                a_ = buckets.setdefault(b_["kernel"], dict(kernel=b_["kernel"], launches=0, ms=0.0, flops=0.0))
+                a_["launches"] += b_["launches"]; a_["ms"] += b_["ms"]; a_["flops"] += b_["flops"]
+        eng.profile(False)
+        if args.config == 5:                                       # stage split + report tensors from one more (untimed) instrumented step
+            out, _ = instrumented_step()
+            torch.cuda.synchronize()
+        stage_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(6)]   # of the LAST step (events are only read after the timed regions)
+        assert allrec.shape[0] == world * B
+        dt_mean = sum(dts) / len(dts)
+        res = {"label": label, "dts": dts, "dt_mean": dt_mean, "value": world * B * args.steps / dt_mean, "buckets": list(buckets.values()),
+               "stage_ms": stage_ms, "out": out}
+        if rank == 0:
+            log(f"[{label}] {res['value']:.1f} frames/s ({dt_mean / args.steps * 1e3:.2f} ms/step; regions " +
+                ", ".join(f"{d / args.steps * 1e3:.2f}" for d in dts) + f" ms/step); stage ms of the last step: resize {stage_ms[0]:.2f}  "
+                f"seg {stage_ms[1]:.2f}  disp {stage_ms[2]:.2f}  to3D {stage_ms[3]:.2f}  road {stage_ms[4]:.2f}")
+        return res
+
+    def outputs_of(eng):
+        """this engine's outputs for the frames of the timed batch (untimed): what the parity sections compare"""
+        frames = state["frames"]
+        segp = eng.fcn8s_forward(frames, want_logits=True)
+        o = eng.process_batch(frames, cams, prm, colours=colours)
+        return dict(logits=segp["logits"], road=segp["road"], fence=segp["fence"], argmax=segp["argmax"],
+                    disp=eng.monodepth_forward(frames), records=Engine.records(o["records"]))
+
+    def leg_record(eng, precision, res):
+        rl = conv_roofline(res["buckets"], precision, res["dt_mean"] * max(1, args.repeats))
+        pl = {}
+        if precision == "plan":
+            pl = {"precision_plan": {k: {"layers": ",".join(v[0]), "flop_share": round(v[1], 4)} for k, v in eng.precision_plan().items()},
+                  "built_in_plan": custom_plan is None}
+        sat = eng.saturation_count() if hasattr(eng, "saturation_count") else None
+        return {"value": round(res["value"], 3), "unit": "frames/s", "ms_per_step": round(res["dt_mean"] / args.steps * 1e3, 3),
+                "steps": args.steps, "warmup": args.warmup, "repeats": len(res["dts"]),
+                "repeat_ms_per_step": [round(d / args.steps * 1e3, 3) for d in res["dts"]], "dtype": DTYPE[precision],
+                "stage_ms_last_step": {"resize": round(res["stage_ms"][0], 2), "seg": round(res["stage_ms"][1], 2), "disp": round(res["stage_ms"][2], 2),
+                                       "to3D": round(res["stage_ms"][3], 2), "road": round(res["stage_ms"][4], 2),
+                                       **({"fence": round(res["stage_ms"][5], 2)} if args.approach == "both" else {})},
+                **({"fp16_saturated_values": sat} if sat is not None else {}), **pl, "roofline": rl}
+
+    eng = make_engine(args.precision)
+    if rank == 0:
+        log(f"setup {time.time() - t_setup:.1f}s; arenas: " + ", ".join(f"{k} {v / 2**30:.2f} GiB" for k, v in eng.bytes.items()))
+    head = measure(eng, args.precision)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
+    out, stage_ms, dt = head["out"], head["stage_ms"], head["dt_mean"]
     recs = Engine.records(out["records"])
     road_frac = float(out["seg"]["road"].float().mean().item())
     log(f"masks: road fraction {road_frac:.3f}; n_road mean {recs['n_road'].mean():.0f}; after chain {recs['n_ror'].mean():.0f}; "
         f"found {int(recs['found'].sum())}/{B}; width mean {np.nanmean(recs['width']) if recs['found'].any() else float('nan'):.3f}")
-    log(f"stage ms (last step, {B} frames): resize {stage_ms[0]:.2f}  seg {stage_ms[1]:.2f}  disp {stage_ms[2]:.2f}  to3D {stage_ms[3]:.2f}  "
-        f"road {stage_ms[4]:.2f}")
-
-    roofline = conv_roofline(buckets, args.precision, dt)
+    head_rec = leg_record(eng, args.precision, head)
+    roofline = head_rec.pop("roofline")
     # second roofline: the fusion / back-projection stage is HBM-bound (SURVEY §8d).  Algorithmic bytes of the stage as it runs
     # here (one launch): read the raw disparity pair (8 B) + two masks (2 B) + the frame (3 B) per pixel, write disp_pp (4 B) per
     # pixel and 15 B (xyz f32 + rgb u8) per gathered point.
     n_pts = float(out["fuse"]["n_road"].sum().item()) + float(out["fuse"]["n_fence"].sum().item())
     fuse_bytes = B * H * W * 17.0 + (15.0 if colours else 12.0) * n_pts
     fuse_gbs = fuse_bytes / (stage_ms[3] * 1e-3) / 1e9 if stage_ms[3] > 0 else 0.0
+    fuse_traffic, fuse_traffic_src = pmc_traffic("fuse_onepass_kernel", "*pmc_fuse_traffic.json")
     fusion_roofline = {"bound": "hbm", "achieved": round(fuse_gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(fuse_gbs / 8000.0, 4),
-                       "traffic": None, "kernel": "fuse_onepass_kernel (post-processing + back-projection + look-back gather; to3D stage of the last step, stream events)",
-                       "algorithmic_bytes_per_frame": round(fuse_bytes / B), "stage_us_per_frame": round(stage_ms[3] * 1e3 / B, 2)}
+                       "traffic": fuse_traffic, "traffic_source": fuse_traffic_src,
+                       "kernel": "fuse_onepass_kernel (post-processing + back-projection + look-back gather; to3D stage of the last step, stream events)",
+                       "algorithmic_bytes": round(fuse_bytes), "algorithmic_bytes_per_frame": round(fuse_bytes / B),
+                       "stage_us_per_frame": round(stage_ms[3] * 1e3 / B, 2)}
 
-    # ------------------------------------------------------------------ exact-f32 leg + parity of THIS run's outputs
-    f32_exact, parity, oracle_in = None, {}, None
+    # ------------------------------------------------------------------ legs (N = 1): the other engines, timed the same way, and parity
     want_parity = world == 1
+    parity, leg_out, f32_exact, oracle_in = {}, {}, None, None
+    outs = {}
     if want_parity:
-        segp = eng.fcn8s_forward(frames, want_logits=True)
-        planned = dict(logits=segp["logits"], road=segp["road"], fence=segp["fence"], argmax=segp["argmax"],
-                       disp=eng.monodepth_forward(frames), records=recs)
-        oracle_in = planned
-    if want_parity and not args.no_f32_leg and args.precision != "f32":
-        f32_exact, parity["vs_f32_engine"] = f32_leg(args, eng, wf, wm, frames, cams, prm, planned, colours, log)
+        outs[args.precision] = outputs_of(eng)
+        oracle_in = outs[args.precision]
+    engines = {args.precision: eng}
+    for p_ in legs:
+        e_ = engines[p_] = make_engine(p_)
+        r_ = measure(e_, p_)
+        leg_out[p_] = leg_record(e_, p_, r_)
+        outs[p_] = outputs_of(e_)
+    if args.precision == "f32":
+        f32_exact = {k: head_rec[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "repeats", "repeat_ms_per_step", "dtype")}
+        f32_exact["is_headline"] = True
+        f32_exact["roofline"] = roofline
+    elif "f32" in leg_out:
+        f32_exact = leg_out.pop("f32")
+    if "f32" in outs:
+        for p_ in outs:
+            if p_ == "f32":
+                continue
+            par = parity_vs_f32(outs[p_], outs["f32"], engines[p_], state["frames"], cams, prm, log, p_)
+            if p_ == args.precision:
+                parity["vs_f32_engine"] = par
+            else:
+                leg_out[p_]["parity_vs_f32_engine"] = par
 
     # ------------------------------------------------------------------ CPU baseline: the oracle on this box's host cores
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu, parity["vs_cpu_oracle"] = cpu_baseline(frames.cpu().numpy(), wf, wm, args.encoder, cam, oracle_in, eng, prm, log)
+        cpu, parity["vs_cpu_oracle"] = cpu_baseline(state["frames"].cpu().numpy(), wf, wm, args.encoder, cam, oracle_in, eng, prm, log)
+        for p_ in leg_out:      # the legs against the same oracle outputs
+            if p_ in outs and cpu_baseline.last_ref is not None:
+                leg_out[p_]["parity_vs_cpu_oracle"] = nets_vs_oracle(outs[p_], cpu_baseline.last_ref)
     if parity:
-        parity["tolerance"] = "north_star: outputs within 1e-3 relative (max |delta| / max |ref| per tensor); masks/argmax as mismatch fraction"
+        parity["tolerance"] = ("north_star: outputs within 1e-3 relative (max |delta| / max |ref| per tensor); strict_* = per element, "
+                               "|delta| / (|ref| + 1e-2 max|ref|); masks/argmax as mismatch fraction")
 
     flops_frame = eng.flops_per_image(L.SD_NET_FCN8S) + 2 * eng.flops_per_image(L.SD_NET_MONODEPTH)
     workload = ("BASELINE.json configs[3]: full fused pipeline (seg + depth + pcl back-projection + road width), " if args.config == 4 else
                 "BASELINE.json configs[4]: batch-sharded sequence driver (1024x2048 frames -> GPU cubic resize -> full fused pipeline -> "
                 "RCCL all_gather of the records), ")
     line = {
-        "metric": "fused frames/sec (FCN-8s+monodepth+pcl fusion) at 512x1024", "value": round(value, 3), "unit": "frames/s",
-        "n_gpus": world, "ranks_seen": ranks_seen, **({"shared_gpu_plumbing_test": True} if share else {}), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "metric": "fused frames/sec (FCN-8s+monodepth+pcl fusion) at 512x1024", "value": head_rec["value"], "unit": "frames/s",
+        "n_gpus": world, "ranks_seen": ranks_seen, **({"shared_gpu_plumbing_test": True} if share else {}), "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head_rec["ms_per_step"], "repeats": head_rec["repeats"], "repeat_ms_per_step": head_rec["repeat_ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
         "config": {"workload": workload + f"batch {B} per GPU, 512x1024, monodepth-{args.encoder} on frame+flip, seeded synthetic weights",
                    "survey_config": args.config, "frames_per_step": world * B, "gflop_per_frame": round(flops_frame / 1e9, 2),
                    "camera": {"cx": cam.cx, "cy": cam.cy, "f": cam.f, "b": cam.b, "disp_mult": cam.disp_mult},
-                   "stage_ms_last_step": {"resize": round(stage_ms[0], 2), "seg": round(stage_ms[1], 2), "disp": round(stage_ms[2], 2),
-                                          "to3D": round(stage_ms[3], 2), "road": round(stage_ms[4], 2),
-                                          **({"fence": round(stage_ms[5], 2)} if args.approach == "both" else {})},
-                   "approach": args.approach,
+                   "stage_ms_last_step": head_rec["stage_ms_last_step"],
+                   "approach": args.approach, "engine": args.precision,
                    "colours_through_road_chain": colours, "overlap": bool(args.overlap),
-                   **({"precision_plan": {k: {"layers": ",".join(v[0]), "flop_share": round(v[1], 4)} for k, v in eng.precision_plan().items()},
-                       "built_in_plan": custom_plan is None} if args.precision == "plan" else {}),
+                   **({k: head_rec[k] for k in ("precision_plan", "built_in_plan") if k in head_rec}),
+                   **({"fp16_saturated_values": head_rec["fp16_saturated_values"]} if "fp16_saturated_values" in head_rec else {}),
                    "road_fraction": round(road_frac, 4), "n_road_mean": float(recs["n_road"].mean()), "n_after_chain_mean": float(recs["n_ror"].mean()),
                    "found": int(recs["found"].sum())},
-        "roofline": roofline, "fusion_roofline": fusion_roofline, "f32_exact": f32_exact, "parity": parity or None, "cpu_baseline": cpu,
+        "roofline": roofline, "fusion_roofline": fusion_roofline, "f32_exact": f32_exact, "legs": leg_out or None, "parity": parity or None,
+        "cpu_baseline": cpu,
     }
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
+def pmc_traffic(label: str, pattern: str):
+    """HBM bytes per launch of a kernel label from the committed PMC profile (rocprofv3 FETCH_SIZE / WRITE_SIZE passes are separate runs
+    by construction: a constant read from profiles/, NOT a measurement of this run)"""
+    try:
+        import glob
+        pf = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+        if not pf:
+            return None, None
+        prof = json.load(open(pf[-1]))
+        per = prof.get("by_label", {})
+        src = "profiles/" + os.path.basename(pf[-1]) + " (separate rocprofv3 --pmc passes of this command; not measured in this run)"
+        if label in per:
+            return round(per[label]["hbm_bytes_per_launch"]), src
+        return None, src
+    except Exception:
+        return None, None
+
+
 def peak_of(kernel: str, precision: str) -> float:
     if "igemm" in kernel:
         return PEAK_F32
+    if "_x3" in kernel:
+        return PEAK_6P
     if "f16x1" in kernel:
         return PEAK_1P
     return PEAK_2P if "f16w" in kernel else PEAK_3P
@@ -361,7 +502,8 @@ def peak_of(kernel: str, precision: str) -> float:
 
 def conv_roofline(buckets, precision, dt):
     """`roofline` of the contract for the DOMINANT conv kernel (most time in this run) + the whole conv engine under `engine`.
-    Durations are HIP events recorded by the library around every conv launch on the launch stream (sd_profile)."""
+    Durations are HIP events recorded by the library around every conv launch on the launch stream (sd_profile).  ``dt``: seconds of
+    all timed regions the buckets cover."""
     buckets = [b for b in buckets if b["launches"]]
     if not buckets:
         return None
@@ -373,32 +515,19 @@ def conv_roofline(buckets, precision, dt):
     # effective peak of the launch mix: total flops / time at peak (harmonic mean over the kernels' own peaks)
     t_at_peak = sum(b["flops"] / (peak_of(b["kernel"], precision) * 1e12) for b in buckets)
     eff_peak = tot_fl / t_at_peak / 1e12
-    # HBM bytes per launch from the committed PMC profile of this same command (rocprofv3 FETCH_SIZE / WRITE_SIZE passes are
-    # separate runs by construction: a constant read from profiles/, NOT a measurement of this run)
-    traffic, traffic_src = None, None
-    try:
-        import glob
-        pf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_conv_traffic.json")))
-        if pf:
-            prof = json.load(open(pf[-1]))
-            per = prof.get("by_label", {})
-            if dom["kernel"] in per:
-                traffic = round(per[dom["kernel"]]["hbm_bytes_per_launch"])
-            elif "all_conv" in prof:
-                traffic = round(prof["all_conv"]["hbm_bytes_per_launch"])
-            traffic_src = "profiles/" + os.path.basename(pf[-1]) + " (separate rocprofv3 --pmc passes of this command; not measured in this run)"
-    except Exception:
-        traffic = None
+    traffic, traffic_src = pmc_traffic(dom["kernel"], f"*pmc_conv_traffic_{precision}.json")
+    if traffic_src is None:
+        traffic, traffic_src = pmc_traffic(dom["kernel"], "*pmc_conv_traffic.json")
     dpk = peak_of(dom["kernel"], precision)
     return {
         "bound": "mfma", "kernel": dom["kernel"], "achieved": round(ach(dom), 2), "peak": round(dpk, 1), "unit": "TFLOP/s",
         "frac": round(ach(dom) / dpk, 4), "traffic": traffic, "traffic_source": traffic_src,
         "launches": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
         "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
-        "peak_note": "f32 MFMA dense peak 157.3; split-bf16: dense bf16 MFMA peak 2500 / 3 MFMA products per algorithmic product; kernels "
-                     "named f16w: 2500 / 2 products.  `achieved` counts ALGORITHMIC flops (2*M*N*K of the layer, padding not counted). "
-                     "Measured on this pool: with random operands the chip sustains 1812 TF/s of v_mfma_f32_32x32x16_bf16 (power limit; "
-                     "profiles/r01_mfma_sustained_probe.txt)",
+        "peak_note": "f32 MFMA dense peak 157.3 (v_mfma_f32_16x16x4_f32: 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz); split engines: dense bf16/fp16 "
+                     "MFMA peak 2500 / MFMA products per algorithmic product (kernels named _x3: 6, plain: 3, f16w: 2, f16x1: 1).  `achieved` "
+                     "counts ALGORITHMIC flops (2*M*N*K of the layer, padding not counted).  Measured on this pool: with random operands the "
+                     "chip sustains 1812 TF/s of v_mfma_f32_32x32x16_bf16 (power limit; profiles/r01_mfma_sustained_probe.txt)",
         "engine": {"kernels": "all conv launches", "achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), "peak": round(eff_peak, 1),
                    "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / eff_peak, 4), "launches": tot_n,
                    "conv_time_share_of_step": round(tot_ms * 1e-3 / dt, 4)},
@@ -408,68 +537,59 @@ def conv_roofline(buckets, precision, dt):
 
 
 def err_stats(got, ref):
-    """max-normalised error (north_star's figure), plus per-element statistics: |delta| / (|ref| + 1e-3 * max|ref|)"""
+    """max-normalised error (north_star's figure) + per-element statistics.  p99_elem_rel / max_elem_rel: |delta| / (|ref| + 1e-3 max|ref|)
+    (round 2's figure, dominated by the near-zero elements); strict_p99 / strict_max: |delta| / (|ref| + 1e-2 max|ref|), the figure
+    the tests assert beside the max-normalised one."""
     import numpy as np
     got = np.asarray(got, np.float64).ravel()
     ref = np.asarray(ref, np.float64).ravel()
     d = np.abs(got - ref)
     scale = float(np.abs(ref).max()) + 1e-30
     per = d / (np.abs(ref) + 1e-3 * scale)
-    return {"max_rel": float(d.max() / scale), "p99_elem_rel": float(np.quantile(per, 0.99)), "max_elem_rel": float(per.max()),
+    strict = d / (np.abs(ref) + 1e-2 * scale)
+    return {"max_rel": float(d.max() / scale), "strict_p99": float(np.quantile(strict, 0.99)), "strict_max": float(strict.max()),
+            "p99_elem_rel": float(np.quantile(per, 0.99)), "max_elem_rel": float(per.max()),
             "rms_rel": float(np.sqrt((d * d).mean()) / scale)}
 
 
-def f32_leg(args, eng, wf, wm, frames, cams, prm, planned, colours, log):
-    """the same batch through the exact-f32 engine: its speed (f32_exact) and the planned-precision outputs against it"""
+def parity_vs_f32(o, o32, eng, frames, cams, prm, log, label):
+    """outputs of a reduced-precision engine over the whole timed batch against the exact-f32 engine's"""
     import numpy as np
-    import torch
-    from semantic_depth_amd import _lib as L
     from semantic_depth_amd.engine import Engine
-    B = frames.shape[0]
-    e32 = Engine(H, W, B, args.encoder, eng.device.index or 0, precision="f32")
-    e32.load_weights(L.SD_NET_FCN8S, wf)
-    e32.load_weights(L.SD_NET_MONODEPTH, wm)
-    e32.process_batch(frames, cams, prm, colours=colours)            # warm-up
-    e32.profile(True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.f32_steps):
-        o32 = e32.process_batch(frames, cams, prm, colours=colours)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    rl = conv_roofline(e32.profile_read(), "f32", dt)
-    e32.profile(False)
-    f32_exact = {"value": round(B * args.f32_steps / dt, 3), "unit": "frames/s", "ms_per_step": round(dt / args.f32_steps * 1e3, 3),
-                 "steps": args.f32_steps, "dtype": DTYPE["f32"],
-                 "roofline": {k: rl[k] for k in ("kernel", "achieved", "peak", "frac", "launches", "avg_launch_us")} | {"engine": rl["engine"]}}
-    s32 = e32.fcn8s_forward(frames, want_logits=True)
-    d32 = e32.monodepth_forward(frames)
-    r32 = Engine.records(o32["records"])
-    rp = planned["records"]
+    rp, r32 = o["records"], o32["records"]
     mism = lambda a, b: float((a != b).float().mean().item())
     both = (rp["found"] != 0) & (r32["found"] != 0)
     par = {
-        "frames": B,
-        "logits": err_stats(planned["logits"].cpu().numpy(), s32["logits"].cpu().numpy()),
-        "disp_pp": err_stats(planned["disp"].cpu().numpy(), d32.cpu().numpy()),
-        "road_mask_mismatch_frac": mism(planned["road"], s32["road"]), "fence_mask_mismatch_frac": mism(planned["fence"], s32["fence"]),
-        "argmax_mismatch_frac": mism(planned["argmax"], s32["argmax"]),
+        "frames": int(frames.shape[0]),
+        "logits": err_stats(o["logits"].cpu().numpy(), o32["logits"].cpu().numpy()),
+        "disp_pp": err_stats(o["disp"].cpu().numpy(), o32["disp"].cpu().numpy()),
+        "road_mask_mismatch_frac": mism(o["road"], o32["road"]), "fence_mask_mismatch_frac": mism(o["fence"], o32["fence"]),
+        "argmax_mismatch_frac": mism(o["argmax"], o32["argmax"]),
         "records": {"found_equal": bool((rp["found"] == r32["found"]).all()),
                     "n_road_max_rel_diff": float((np.abs(rp["n_road"] - r32["n_road"]) / np.maximum(r32["n_road"], 1)).max()),
                     "n_after_chain_max_rel_diff": float((np.abs(rp["n_ror"] - r32["n_ror"]) / np.maximum(r32["n_ror"], 1)).max()),
                     "width_max_abs_diff_m": float(np.abs(rp["width"][both] - r32["width"][both]).max()) if both.any() else None,
                     "width_mean_abs_diff_m": float(np.abs(rp["width"][both] - r32["width"][both]).mean()) if both.any() else None},
     }
-    # the tail is exact arithmetic: fed the f32 engine's masks and disparities, the measured engine's tail must reproduce the f32
+    # the tail is exact arithmetic: fed the f32 engine's masks and disparities, this engine's tail must reproduce the f32
     # engine's records bit for bit
-    fz = eng.fuse_backproject(d32, s32["road"], s32["fence"], frames, cams, want_rgb=False)
+    fz = eng.fuse_backproject(o32["disp"], o32["road"], o32["fence"], frames, cams, want_rgb=False)
     rs = Engine.records(eng.road_width(fz["road_xyz"], fz["n_road"], prm))
     par["records_given_same_masks_and_disparity_bit_equal"] = bool(rs.tobytes() == r32.tobytes())
-    log(f"f32 engine: {f32_exact['value']:.1f} frames/s; vs f32: logits {par['logits']['max_rel']:.2e}, disp {par['disp_pp']['max_rel']:.2e}, "
-        f"road mask mismatch {par['road_mask_mismatch_frac']:.2e}, width diff {par['records']['width_max_abs_diff_m']}")
-    del e32
-    torch.cuda.empty_cache()
-    return f32_exact, par
+    log(f"[{label}] vs f32 engine: logits {par['logits']['max_rel']:.2e} (strict p99 {par['logits']['strict_p99']:.2e}), "
+        f"disp {par['disp_pp']['max_rel']:.2e} (strict p99 {par['disp_pp']['strict_p99']:.2e}), road mask mismatch "
+        f"{par['road_mask_mismatch_frac']:.2e}, width diff {par['records']['width_max_abs_diff_m']}")
+    return par
+
+
+def nets_vs_oracle(o, ref):
+    """an engine's logits / disparities / masks of the first frames of the batch against the CPU oracle's (cpu_baseline.last_ref)"""
+    import numpy as np
+    n = ref["n"]
+    road = o["road"][:n].cpu().numpy().astype(bool)
+    return {"frames": n, "logits": err_stats(o["logits"][:n].cpu().numpy(), ref["logits"]), "disp_pp": err_stats(o["disp"][:n].cpu().numpy(), ref["disp"]),
+            "road_mask_mismatch_frac": float((road != ref["road"]).mean()),
+            "argmax_mismatch_frac": float((o["argmax"][:n].cpu().numpy() != ref["argmax"]).mean())}
 
 
 def cpu_baseline(frames_np, wf, wm, encoder, cam, planned, eng, prm, log):
@@ -510,17 +630,11 @@ def cpu_baseline(frames_np, wf, wm, encoder, cam, planned, eng, prm, log):
            "value_1_thread": round(1.0 / t1, 5),
            "sample": f"{n_done} of the bench's 512x1024 frames through the CPU oracle (torch-CPU f32 convs with TF semantics + numpy "
                      f"fusion/pcl + cKDTree Open3D filters), whole path, {cores} threads of {ncpu} host CPUs; 1 frame on 1 thread"}
+    cpu_baseline.last_ref = dict(n=n_done, logits=np.stack([o[0] for o in outs]), disp=np.stack([o[4]["disp_pp"] for o in outs]),
+                                 road=np.stack([o[1] for o in outs]), argmax=np.stack([o[3] for o in outs]))
     par = None
     if planned is not None:
-        lg = planned["logits"][:n_done].cpu().numpy()
-        dp = planned["disp"][:n_done].cpu().numpy()
-        ref_l = np.stack([o[0] for o in outs])
-        ref_d = np.stack([o[4]["disp_pp"] for o in outs])
-        road = planned["road"][:n_done].cpu().numpy().astype(bool)
-        am = planned["argmax"][:n_done].cpu().numpy()
-        par = {"frames": n_done, "logits": err_stats(lg, ref_l), "disp_pp": err_stats(dp, ref_d),
-               "road_mask_mismatch_frac": float((road != np.stack([o[1] for o in outs])).mean()),
-               "argmax_mismatch_frac": float((am != np.stack([o[3] for o in outs])).mean())}
+        par = nets_vs_oracle(planned, cpu_baseline.last_ref)
         # the exact tail: the oracle's frame_tail fed the GPU's OWN masks and raw disparity pair must give the GPU's records
         from semantic_depth_amd.engine import Engine
         pp, raw = eng.monodepth_forward(torch.from_numpy(frames_np[:n_done]).cuda(), want_raw=True)
@@ -538,6 +652,9 @@ def cpu_baseline(frames_np, wf, wm, encoder, cam, planned, eng, prm, log):
         par["tail_records_bit_equal_given_gpu_masks_and_disparity"] = bool(eq)
         log(f"vs cpu oracle ({n_done} frames): logits {par['logits']['max_rel']:.2e}, disp {par['disp_pp']['max_rel']:.2e}, tail bit-equal {eq}")
     return cpu, par
+
+
+cpu_baseline.last_ref = None
 
 
 if __name__ == "__main__":

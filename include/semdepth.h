@@ -136,7 +136,8 @@ sd_status sd_monodepth_forward(sd_handle* h, const uint8_t* frames, int B, float
 
 /* Input stage, semantic_depth.py:111 / seq:128: cv2.resize(frame, (dst_w, dst_h), interpolation=cv2.INTER_CUBIC) for B
  * uint8 HWC frames already in device memory (OpenCV's scalar fixed-point path: A = -0.75, weights cvRound(w*2048), borders
- * replicated, (sum + 2^21) >> 22).  dst_h x dst_w at most the handle's H x W; equal sizes copy. */
+ * replicated, (sum + 2^21) >> 22).  dst_h, dst_w at most 16384 (down- or up-scaling: semantic_depth.py:341 resizes the overlay back to
+ * the original frame size the same way); equal sizes copy. */
 sd_status sd_resize_cubic_u8(sd_handle* h, const uint8_t* src, int B, int src_h, int src_w, int channels, uint8_t* dst, int dst_h,
                              int dst_w, void* stream);
 
@@ -262,6 +263,16 @@ sd_status sd_profile_read(sd_handle* h, sd_profile_bucket* out_host, int cap_buc
 
 /* number of conv-engine FLOPs (2*M*N*K over all layers, per image) of a plan — for roofline accounting */
 double sd_net_flops_per_image(const sd_handle* h, sd_net net);
+
+/* frames of one network pass (the chunk size latched at sd_create: min(max_batch, SEMDEPTH_CHUNK or 32)); a batch of at most this many
+ * frames leaves its raw disparity pair in the arena for sd_postprocess_fuse_backproject(disp_raw = NULL) */
+int sd_pass_frames(const sd_handle* h);
+
+/* fp16 range guard of the reduced-precision plans: the conv epilogues that write fp16 planes clamp at +-65504 and COUNT the values
+ * they clamped (and NaNs) in a device counter.  *count_out = values clamped since the handle was bound or the counter last reset
+ * (synchronises the device); reset != 0 clears it.  A non-zero count means the plan does not fit these weights / inputs: run the
+ * layer's producer with more products, or the exact engine (the reference has no such failure mode: it computes in f32). */
+sd_status sd_saturation_count(sd_handle* h, uint64_t* count_out, int reset);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """HBM traffic per conv launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the same bench command.
-usage: pmc_conv_traffic.py fetch_counter_collection.csv write_counter_collection.csv out.json
+usage: pmc_conv_traffic.py fetch_counter_collection.csv write_counter_collection.csv out.json [kernel-substring [source note]]
+(kernel-substring, default "conv_": which kernels to aggregate -- e.g. "fuse_onepass" for the fusion stage)
 FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM
 section); WRITE_SIZE is left as reported."""
 import collections, csv, json, sys
@@ -11,12 +12,13 @@ def load(path, counter):
         if r["Counter_Name"] != counter:
             continue
         k = r["Kernel_Name"]
-        if "conv_" not in k or "smalln" in k:
+        if FILTER not in k or "smalln" in k:
             continue
         agg[k][0] += 1
         agg[k][1] += float(r["Counter_Value"]) * 1024.0
     return agg
 
+FILTER = sys.argv[4] if len(sys.argv) > 4 else "conv_"
 f = load(sys.argv[1], "FETCH_SIZE")
 w = load(sys.argv[2], "WRITE_SIZE")
 per = {}
@@ -34,7 +36,8 @@ def label(k):
     """the bench's profiling label (conv_*_kernel_name in csrc) of a demangled instantiation"""
     m = re.search(r"sd::(conv_\w+)_kernel<([^>]*)>", k)
     if not m:
-        return None
+        m2 = re.search(r"sd::(\w+_kernel)", k)
+        return m2.group(1) if m2 else None
     fam, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
     if fam == "conv_direct":       # <NB, MT, F16, N16, UP, W1, X2>
         prec = "_f16w_x2" if (len(args) > 6 and args[6] == "true") else "_f16x1" if (len(args) > 5 and args[5] == "true") else ("_f16w" if args[2] == "true" else "")
@@ -45,6 +48,8 @@ def label(k):
         return f"conv_dma{prec}_kernel<{args[0]},{args[1]},{args[2]},{args[3]}>"
     if fam == "conv_stem":
         return "conv_stem_f16w_kernel" if args[2] == "true" else "conv_stem_kernel"
+    if fam == "conv_igemm":        # <WM, WN, MT, NT, VEC>
+        return "conv_igemm_kernel<" + ",".join(args) + ">"
     return fam + "_kernel"
 
 
@@ -58,7 +63,7 @@ for k, v in per.items():
 out = {
     "by_label": {lb: {"launches": n, "fetch_bytes_per_launch": fb / n, "write_bytes_per_launch": wb / n, "hbm_bytes_per_launch": (fb + wb) / n}
                  for lb, (n, fb, wb) in by_label.items()},
-    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-f32-leg (default precision plan)",
+    "source": sys.argv[5] if len(sys.argv) > 5 else "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --repeats 1 --no-cpu-baseline --legs none",
     "units": "FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B: MI355X_MICROARCH.md HBM section); WRITE_SIZE uncorrected",
     "per_kernel": per,
     "all_conv": {"launches": tl, "hbm_bytes_per_launch": (tf + tw) / max(tl, 1), "fetch_bytes_per_launch": tf / max(tl, 1),

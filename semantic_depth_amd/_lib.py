@@ -87,6 +87,8 @@ SIGNATURES = {
     "sd_profile": (C.c_int, [_H, C.c_int]),
     "sd_profile_read": (C.c_int, [_H, C.POINTER(sd_profile_bucket), C.c_int, C.POINTER(C.c_int)]),
     "sd_net_flops_per_image": (C.c_double, [_H, C.c_int]),
+    "sd_pass_frames": (C.c_int, [_H]),
+    "sd_saturation_count": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int]),
 }
 
 _lib = None

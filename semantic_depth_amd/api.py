@@ -146,11 +146,19 @@ class DepthFrame:
             self.cx, self.cy, self.b = 314.05519001, 124.09658151, 1
             if self.f is None:
                 self.f = 380
-        self.engine = engine or shared_engine(input_height, input_width, device, precision, encoder)
-        if self.engine.encoder != encoder or (self.engine.H, self.engine.W) != (input_height, input_width):
-            raise ValueError(f"engine is {self.engine.encoder} {self.engine.H}x{self.engine.W}, DepthFrame wants {encoder} "
+        self._engine = engine or shared_engine(input_height, input_width, device, precision, encoder)
+        if self._engine.encoder != encoder or (self._engine.H, self._engine.W) != (input_height, input_width):
+            raise ValueError(f"engine is {self._engine.encoder} {self._engine.H}x{self._engine.W}, DepthFrame wants {encoder} "
                              f"{input_height}x{input_width}")
-        _ensure_loaded(self.engine, L.SD_NET_MONODEPTH, _load_weight_arg(checkpoint_path, "monodepth", encoder))
+        self._weights = _load_weight_arg(checkpoint_path, "monodepth", encoder)
+        _ensure_loaded(self._engine, L.SD_NET_MONODEPTH, self._weights)
+
+    @property
+    def engine(self) -> Engine:
+        """the shared Engine with THIS object's checkpoint in its monodepth arena: two DepthFrames of one geometry (city / kitti
+        checkpoints) share the handle, so every access re-checks which weights are loaded -- as SegmentFrame.engine does"""
+        _ensure_loaded(self._engine, L.SD_NET_MONODEPTH, self._weights)
+        return self._engine
 
     def camera(self, disp_mult: float) -> Camera:
         return Camera(self.cx, self.cy, self.f, self.b, float(disp_mult))
@@ -160,6 +168,31 @@ class DepthFrame:
         e = self.engine
         fr = torch.from_numpy(np.ascontiguousarray(frame, dtype=np.uint8))[None].to(e.device)
         return e.monodepth_forward(fr)[0].cpu().numpy()
+
+    def disp_to_image(self, disp_pp: np.ndarray, output_name: str, original_height: int, original_width: int) -> str:
+        """semantic_depth.py:681-683: ``scipy.misc.imresize(disp_pp.squeeze(), [h, w])`` + ``plt.imsave(name_disp.png, cmap='gray')``
+        (a PNG side effect only; not on the compute path).  imresize = min-max scaling to uint8 (bytescale: ``(v - min) * 255 / (max -
+        min)`` truncated after + 0.5) followed by PIL's bilinear resize; imsave maps the uint8 image linearly onto the gray colormap,
+        i.e. min -> 0, max -> 255 again.  Written as an 8-bit gray PNG ``<output_name>_disp.png``; returns its path.  PIL's resampling
+        arithmetic (bilinear with antialiasing support when shrinking) is restated as plain bilinear interpolation at pixel centres --
+        the reference only ever enlarges the map here (network size -> original frame size)."""
+        from .outputs import write_png
+        d = np.asarray(disp_pp, dtype=np.float64).squeeze()
+        lo, hi = float(d.min()), float(d.max())
+        scale = 255.0 / (hi - lo) if hi > lo else 1.0
+        u8 = np.clip((d - lo) * scale + 0.5, 0, 255).astype(np.uint8).astype(np.float64)
+        h, w = u8.shape
+        ys = np.clip((np.arange(original_height) + 0.5) * h / original_height - 0.5, 0, h - 1)
+        xs = np.clip((np.arange(original_width) + 0.5) * w / original_width - 0.5, 0, w - 1)
+        y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
+        y1, x1 = np.minimum(y0 + 1, h - 1), np.minimum(x0 + 1, w - 1)
+        fy, fx = (ys - y0)[:, None], (xs - x0)[None, :]
+        img = (u8[y0][:, x0] * (1 - fy) * (1 - fx) + u8[y0][:, x1] * (1 - fy) * fx + u8[y1][:, x0] * fy * (1 - fx) + u8[y1][:, x1] * fy * fx)
+        img = np.clip(img + 0.5, 0, 255).astype(np.uint8)
+        lo8, hi8 = int(img.min()), int(img.max())                  # plt.imsave normalises the array onto the colormap
+        if hi8 > lo8:
+            img = np.clip((img.astype(np.float64) - lo8) * (255.0 / (hi8 - lo8)) + 0.5, 0, 255).astype(np.uint8)
+        return write_png("{}_disp.png".format(output_name), img)
 
     def compute_3D_points(self, disp: np.ndarray) -> np.ndarray:
         """semantic_depth.py:686-697: cv2.reprojectImageTo3D(disp, Q) -> float32 (H,W,3).  ``disp`` in pixels."""
@@ -227,6 +260,10 @@ class FrameProcessor:
             res["f2f_record"] = f2
             res["dist_f2f"] = float(f2["dist"]) if f2["ok"] else None      # semantic_depth.py:327
         if want_clouds:
+            n_f = int(out["fuse"]["n_fence"][0].item()) if out["fuse"].get("n_fence") is not None else 0
+            if n_f and out["fuse"].get("fence_xyz") is not None:   # the gathered fence cloud (semantic_depth.py:186-187): the save path
+                res["fence3D"] = out["fuse"]["fence_xyz"][0, :n_f].cpu().numpy()      # rebuilds the visualisation planes from it
+                res["fence_colors"] = out["fuse"]["fence_rgb"][0, :n_f].cpu().numpy()
             nf = int(out["road_final"]["n"][0].item())
             res["road3D_final"] = out["road_final"]["xyz"][0, :nf].cpu().numpy()
             res["road_colors_final"] = out["road_final"]["rgb"][0, :nf].cpu().numpy()

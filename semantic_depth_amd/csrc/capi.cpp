@@ -53,6 +53,8 @@ struct sd_handle {
 namespace {
 
 size_t al(size_t v) { return (v + 255) / 256 * 256; }
+constexpr int RSZ_MAX = 16384;     // largest destination extent of sd_resize_cubic_u8
+constexpr size_t SAT_OFF = 512;     // the fp16 saturation counter inside the o_misc scratch (zero16 lives at +256)
 
 sd_status fail(sd_handle* h, sd_status code, const std::string& msg) {
     if (h) h->err = msg;
@@ -86,7 +88,7 @@ void carve_workspace(sd_handle* h) {
     h->o_o3d = take(o3d_scratch_bytes(h->max_batch, h->cap));
     h->o_misc = take(4096 + al(B * 7 * sizeof(int32_t)) + al(B * 12 * sizeof(double)));   // scalars | f2f counts | f2f planes
     h->o_cmp = take(cmp_scratch_bytes(h->max_batch));
-    h->o_rsz = take((size_t)(h->H + h->W) * 8 * sizeof(int));     // resize tap tables: [W][4] idx | [W][4] weight | [H][4] idx | [H][4] weight
+    h->o_rsz = take((size_t)RSZ_MAX * 16 * sizeof(int));          // resize tap tables: [RSZ_MAX][4] x idx | x weight | y idx | y weight
     h->ws_bytes = off;
 }
 
@@ -172,6 +174,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.src0 = T(op.src[0]); c.src0_plane = PL(op.src[0]);
                 c.out_planar16 = d.planar16;
                 c.sw = h->sw;
+                c.sat = reinterpret_cast<unsigned long long*>(h->ws + h->o_misc + SAT_OFF);
                 hipEvent_t ea = nullptr, eb = nullptr;
                 if (h->prof) {
                     ea = h->prof_last;
@@ -208,6 +211,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.rows_per_wave = 2;
                 c.f16 = op.f16; c.out_f16 = d.f16;
                 c.sw = h->sw;
+                c.sat = reinterpret_cast<unsigned long long*>(h->ws + h->o_misc + SAT_OFF);
                 hipEvent_t ea = nullptr, eb = nullptr;
                 if (h->prof) {
                     ea = h->prof_last;
@@ -384,6 +388,7 @@ sd_status sd_bind_memory(sd_handle* h, void* wf, void* wm, void* ws) {
     HIPCHK(h, hipSetDevice(h->device));
     h->wf = (char*)wf; h->wm = (char*)wm; h->ws = (char*)ws;
     h->bound = true;
+    HIPCHK(h, hipMemset(h->ws + h->o_misc, 0, 4096));      // zero page (+256), saturation counter (+512), the scalar slot (+0)
     sd_status st = upload_tables(h, SD_NET_FCN8S);
     if (st != SD_OK) return st;
     return upload_tables(h, SD_NET_MONODEPTH);
@@ -492,8 +497,8 @@ static void resize_tables(int dst, int src, int* idx, int* wgt) {
 sd_status sd_resize_cubic_u8(sd_handle* h, const uint8_t* src, int B, int src_h, int src_w, int channels, uint8_t* dst, int dst_h,
                              int dst_w, void* stream) {
     if (!h || !src || !dst || B <= 0 || src_h <= 0 || src_w <= 0 || channels <= 0 || channels > 4 || dst_h <= 0 || dst_w <= 0 ||
-        dst_h > h->H || dst_w > h->W)
-        return fail(h, SD_ERR_INVALID, "sd_resize_cubic_u8: bad arguments (destination at most the handle's H x W)");
+        dst_h > RSZ_MAX || dst_w > RSZ_MAX)
+        return fail(h, SD_ERR_INVALID, "sd_resize_cubic_u8: bad arguments (destination extent at most 16384)");
     if (!h->bound) return fail(h, SD_ERR_STATE, "sd_bind_memory first");
     hipStream_t s = (hipStream_t)stream;
     if (src_h == dst_h && src_w == dst_w) {                        // cv2.resize returns a copy
@@ -501,14 +506,14 @@ sd_status sd_resize_cubic_u8(sd_handle* h, const uint8_t* src, int B, int src_h,
         return SD_OK;
     }
     int* dev = reinterpret_cast<int*>(h->ws + h->o_rsz);
-    int *xi = dev, *xa = dev + 4 * (size_t)h->W, *yi = dev + 8 * (size_t)h->W, *ya = yi + 4 * (size_t)h->H;
+    int *xi = dev, *xa = dev + 4 * (size_t)RSZ_MAX, *yi = dev + 8 * (size_t)RSZ_MAX, *ya = dev + 12 * (size_t)RSZ_MAX;
     const int key[4] = {src_h, src_w, dst_h, dst_w};
     if (std::memcmp(key, h->rsz_key, sizeof(key)) != 0) {
         HIPCHK(h, hipStreamSynchronize(s));                        // the previous tables may still be in use
-        h->rsz_host.assign((size_t)(h->H + h->W) * 8, 0);
+        h->rsz_host.assign((size_t)RSZ_MAX * 16, 0);
         int* hx = h->rsz_host.data();
-        resize_tables(dst_w, src_w, hx, hx + 4 * (size_t)h->W);
-        resize_tables(dst_h, src_h, hx + 8 * (size_t)h->W, hx + 8 * (size_t)h->W + 4 * (size_t)h->H);
+        resize_tables(dst_w, src_w, hx, hx + 4 * (size_t)RSZ_MAX);
+        resize_tables(dst_h, src_h, hx + 8 * (size_t)RSZ_MAX, hx + 12 * (size_t)RSZ_MAX);
         HIPCHK(h, hipMemcpy(dev, hx, h->rsz_host.size() * sizeof(int), hipMemcpyHostToDevice));
         std::memcpy(h->rsz_key, key, sizeof(key));
     }
@@ -824,5 +829,20 @@ sd_status sd_profile_read(sd_handle* h, sd_profile_bucket* out, int cap_buckets,
 }
 
 double sd_net_flops_per_image(const sd_handle* h, sd_net net) { return h ? plan_of(h, net).flops_per_image : 0.0; }
+
+int sd_pass_frames(const sd_handle* h) { return h ? h->chunk : 0; }
+
+sd_status sd_saturation_count(sd_handle* h, uint64_t* count_out, int reset) {
+    if (!h) return SD_ERR_INVALID;
+    if (!h->bound) return fail(h, SD_ERR_STATE, "sd_bind_memory first");
+    HIPCHK(h, hipDeviceSynchronize());
+    unsigned long long v = 0;
+    if (count_out) {
+        HIPCHK(h, hipMemcpy(&v, h->ws + h->o_misc + SAT_OFF, sizeof(v), hipMemcpyDeviceToHost));
+        *count_out = (uint64_t)v;
+    }
+    if (reset) HIPCHK(h, hipMemset(h->ws + h->o_misc + SAT_OFF, 0, sizeof(v)));
+    return SD_OK;
+}
 
 }  // extern "C"

@@ -295,6 +295,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
 
     // ---- epilogue (as conv_split.hip): bias + activation, split once, LDS transpose, 16-byte runs per pixel ----
     __syncthreads();
+    unsigned sat = 0;                                          // values the fp16 output format clamped (split_fmt.hpp)
     auto epilogue = [&](auto tag, auto otag) {
         constexpr int ACT = decltype(tag)::value;
         constexpr bool O16 = decltype(otag)::value;            // output planes: fp16 or bf16 (the consumers' format)
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
                         uint2 h, l;
-                        split4_t<O16>(v, h, l);
+                        split4_t<O16>(v, h, l, sat);
                         if ((lane & 3) == 0) {
                             *reinterpret_cast<uint2*>(sh + ((lane & 31) >> 2) * ROW + nl * 2) = h;
                             if constexpr (!O16) *reinterpret_cast<uint2*>(sl + ((lane & 31) >> 2) * ROW + nl * 2) = l;
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
                     uint2 h, l;
-                    split4_t<O16>(v, h, l);
+                    split4_t<O16>(v, h, l, sat);
                     *reinterpret_cast<uint2*>(sh + (lane & 31) * ROW + nl * 2) = h;
                     if constexpr (!O16) *reinterpret_cast<uint2*>(sl + (lane & 31) * ROW + nl * 2) = l;
                 }
@@ -393,6 +394,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
     if (p.act == ACT_RELU) ep(ActTag<ACT_RELU>{});
     else if (p.act == ACT_ELU) ep(ActTag<ACT_ELU>{});
     else ep(ActTag<ACT_NONE>{});
+    sat_report(p.sat, sat);
 }
 
 // which layers take the DMA pipeline: vec layers with Cout a multiple of 64 and enough tiles to occupy the chip

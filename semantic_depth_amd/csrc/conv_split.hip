@@ -40,6 +40,7 @@ __device__ __forceinline__ void split_epilogue_act(f32x16 (&acc)[MT][NT], unsign
     constexpr int PPP = 64 / SEGS;                // pixels per read pass
     const int seg = lane % SEGS, prow = lane / SEGS;
     uint16_t* const out_hi = reinterpret_cast<uint16_t*>(p.out);
+    unsigned sat = 0;                             // values the fp16 output format clamped (split_fmt.hpp)
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
 #pragma unroll
@@ -53,7 +54,7 @@ __device__ __forceinline__ void split_epilogue_act(f32x16 (&acc)[MT][NT], unsign
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
                 uint2 h, l;
-                split4_t<F16>(v, h, l);
+                split4_t<F16>(v, h, l, sat);
                 *reinterpret_cast<uint2*>(sh + (lane & 31) * ROW + nl * 2) = h;
                 *reinterpret_cast<uint2*>(sl + (lane & 31) * ROW + nl * 2) = l;
             }
@@ -75,6 +76,7 @@ __device__ __forceinline__ void split_epilogue_act(f32x16 (&acc)[MT][NT], unsign
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    sat_report(p.sat, sat);
 }
 template <int MT, int NT, bool F16>
 __device__ __forceinline__ void split_epilogue(f32x16 (&acc)[MT][NT], unsigned char* slab, const ConvParams& p, int m0, int n0, int M, int lane) {

@@ -135,6 +135,7 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
         }
 
         // ---- epilogue: bias + activation, split once, LDS transpose one plane at a time, 16-byte runs per pixel ----
+        unsigned sat = 0;                                    // values the fp16 output format clamped (split_fmt.hpp)
         auto epilogue = [&](auto tag, auto otag) {
             constexpr int ACT = decltype(tag)::value;
             constexpr bool O16 = decltype(otag)::value;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
                     v += bias[r4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
-                    split4_t<O16>(v, hh[r4], ll[r4]);
+                    split4_t<O16>(v, hh[r4], ll[r4], sat);
                 }
 #pragma unroll
                 for (int pl = 0; pl < (O16 ? 1 : 2); ++pl) {      // fp16 outputs: the hi plane only
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
         if (p.act == ACT_RELU) ep(ActTag<ACT_RELU>{});
         else if (p.act == ACT_ELU) ep(ActTag<ACT_ELU>{});
         else ep(ActTag<ACT_NONE>{});
+        sat_report(p.sat, sat);
         cur = nxt;
     }
 }

@@ -65,6 +65,7 @@ struct ConvParams {
     int dbg;           // SEMDEPTH_DMA_DBG=16: general gather path on SIMPLE layers too (A/B switch; 0 in production)
     int m_fastest;     // block order: 1 = consecutive blocks walk M (share a weight panel), 0 = walk N
     unsigned sw;       // Switch bits of the handle
+    unsigned long long* sat;   // DEVICE counter of fp16-saturated output values (split_fmt.hpp sat_report; sd_saturation_count)
 };
 hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t s);
 const char* conv_igemm_kernel_name(const ConvParams& p);
@@ -143,6 +144,7 @@ struct ConvDirectParams {
     int out_f16;                 // OUTPUT planes: 0 bf16 hi + lo, 1 ONE fp16 plane, 2 fp16 hi + lo
     int pool;                    // 1: fused 2x2 stride-2 max pool, out is [N,H/2,W/2,Cout] (needs rows_per_wave == 2)
     unsigned sw;                 // Switch bits of the handle
+    unsigned long long* sat;     // DEVICE counter of fp16-saturated output values (split_fmt.hpp sat_report; sd_saturation_count)
 };
 hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s);
 const char* conv_direct_kernel_name(const ConvDirectParams& p);

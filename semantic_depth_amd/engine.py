@@ -105,7 +105,7 @@ class Engine:
         self._ws = torch.zeros(ws.value, dtype=torch.uint8, device=self.device)
         L.check(self.lib, h, self.lib.sd_bind_memory(h, _ptr(self._wf), _ptr(self._wm), _ptr(self._ws)), "sd_bind_memory")
         self.cap = H * W
-        self.pass_frames = min(max_batch, int(os.environ.get("SEMDEPTH_CHUNK", "32")))   # frames per network pass (sd_create)
+        self.pass_frames = int(self.lib.sd_pass_frames(h))        # frames per network pass, as the handle latched it at sd_create
 
     def close(self):
         if getattr(self, "h", None):
@@ -236,7 +236,7 @@ class Engine:
         through every filter.  want_final: also return the denoised cloud -> (records, xyz, n) or, with colours,
         (records, xyz, rgb, n)."""
         B, cap = road_xyz.shape[0], road_xyz.shape[1]
-        res = torch.zeros((B, RW_DTYPE.itemsize), dtype=torch.uint8, device=self.device)
+        res = torch.empty((B, RW_DTYPE.itemsize), dtype=torch.uint8, device=self.device)    # (every byte of a record is written by the tail kernels)
         fin = torch.empty_like(road_xyz) if want_final else None
         frgb = torch.empty_like(road_rgb) if (want_final and road_rgb is not None) else None
         nfin = torch.empty((B,), dtype=torch.int32, device=self.device) if want_final else None
@@ -339,6 +339,13 @@ class Engine:
             L.check(self.lib, self.h, self.lib.sd_precision_plan(self.h, net, buf, 8192, C.byref(share)), "sd_precision_plan")
             out[name] = ([s for s in buf.value.decode().split(",") if s], share.value)
         return out
+
+    def saturation_count(self, reset: bool = False) -> int:
+        """values the fp16 output formats of the reduced-precision plans had to clamp at +-65504 (or that were NaN) since the arenas were
+        bound / the last reset (synchronises).  Non-zero = the plan does not fit these weights: use more products or precision='f32'."""
+        n = C.c_uint64()
+        L.check(self.lib, self.h, self.lib.sd_saturation_count(self.h, C.byref(n), int(reset)), "sd_saturation_count")
+        return int(n.value)
 
     def flops_per_image(self, net: int) -> float:
         return float(self.lib.sd_net_flops_per_image(self.h, net))

@@ -2,7 +2,9 @@
 
     write_times / write_distances   <- semantic_depth.py:445-458  (``<name>_times.txt`` / ``<name>_distances.txt``)
     overlay_items / draw_overlay    <- semantic_depth.py:339-406  (banner + the text the reference draws; seq:301-327)
-    save_frame_outputs              <- semantic_depth.py:404-441  (``_ROAD`` / ``_FENCE`` / combined / ``_ALL`` PLY files)
+    save_frame_outputs              <- semantic_depth.py:339-441  (``_only_segmentation.png``, the annotated ``.png``, ``_ROAD`` / ``_FENCE`` /
+                                       combined / ``_ALL`` PLY files, incl. the three visualisation planes of the combined cloud)
+    road_plane_grid / fence_plane_grids <- the ``plane3D`` arrays of :215-219, :294-309 rebuilt through the reference's own pcl call sequence
     focal_sweep                     <- semantic_depth.py:854-944  (``results/<f>/data.txt``, ``best_focal_lengths.txt``)
     write_png                       <- cv2.imwrite(...png) at :406 (zlib-deflated 8-bit RGB; pixel-identical, not byte-identical)
 
@@ -129,11 +131,66 @@ def write_png(path: str, img_bgr: np.ndarray, level: int = 3) -> str:
 
 
 # ------------------------------------------------------------------------------------------------ per-frame outputs
+def road_plane_grid(road3D, road_colors, z_cut: float = 7.0, mad_y: float = 15.0, mad_x: float = 2.0, plane_thr: float = 5.0):
+    """``road_plane3D, road_colors_plane`` of semantic_depth.py:215-219: the 5 cm visualisation lattice over the bounding box of the
+    cloud that ENTERS the plane fit (after the z-cut and the two MAD filters, :206-212), lifted onto the fitted plane.  The batched
+    road chain keeps only the filtered cloud, so the save path replays the reference's own call sequence through the pcl module
+    (the same kernels, one cloud at a time) on the gathered road cloud.  (None, None) when a filter empties the cloud."""
+    p3, c = np.asarray(road3D), np.asarray(road_colors)
+    if not len(p3):
+        return None, None
+    p3, c = pcl.remove_from_to(p3, c, 2, 0.0, z_cut)
+    for axis, thr in ((1, mad_y), (0, mad_x)):
+        if not len(p3):
+            return None, None
+        p3, c = pcl.remove_noise_by_mad(p3, c, axis, thr)
+    if not len(p3):
+        return None, None
+    _, _, plane3D, colors_plane, _ = pcl.remove_noise_by_fitting_plane(p3, c, axis=1, threshold=plane_thr, plane_color=[200, 200, 200])
+    return plane3D, colors_plane
+
+
+def fence_plane_grids(fence3D, fence_colors, mad_y: float = 5.0, z_max: float = 35.0, mad_left: float = 5.0, mad_right: float = 1.0,
+                      plane_thr: float = 1.0):
+    """``fence_left_plane3D, fence_left_colors_plane, fence_right_plane3D, fence_right_colors_plane`` of semantic_depth.py:279-309,
+    replayed through the pcl module like road_plane_grid.  A side that runs empty gives (None, None) for that side."""
+    out = [None, None, None, None]
+    p3, c = np.asarray(fence3D), np.asarray(fence_colors)
+    if not len(p3):
+        return tuple(out)
+    p3, c = pcl.remove_noise_by_mad(p3, c, 1, mad_y)
+    if not len(p3):
+        return tuple(out)
+    p3, c = pcl.threshold_complete(p3, c, 2, z_max)
+    if not len(p3):
+        return tuple(out)
+    l3, lc, r3, rc = pcl.extract_pcls(p3, c)
+    for i, (q3, qc, thr) in enumerate(((l3, lc, mad_left), (r3, rc, mad_right))):
+        if not len(q3):
+            continue
+        q3, qc = pcl.remove_noise_by_mad(q3, qc, 0, thr)
+        if not len(q3):
+            continue
+        _, _, out[2 * i], out[2 * i + 1], _ = pcl.remove_noise_by_fitting_plane(q3, qc, axis=0, threshold=plane_thr, plane_color=[40, 70, 40])
+    return tuple(out)
+
+
+def resize_to_original(segmented_frame: np.ndarray, original_width: int, original_height: int) -> np.ndarray:
+    """``cv2.resize(segmented_frame, (original_width, original_height), interpolation=cv2.INTER_CUBIC)`` of semantic_depth.py:341-342,
+    on the GPU (sd_resize_cubic_u8, the kernel of the input stage)."""
+    import torch
+    e = pcl._eng()
+    fr = torch.from_numpy(np.ascontiguousarray(segmented_frame, dtype=np.uint8))[None].to(e.device)
+    return e.resize_cubic(fr, original_height, original_width)[0].cpu().numpy()
+
+
 def save_frame_outputs(output_name: str, res: dict, depth: float, approach: str = "rw", segmented_frame: np.ndarray | None = None,
                        is_city: bool = False, times: dict | None = None, road_plane3D=None, road_colors_plane=None,
-                       points3D_all=None, colors_all=None):
+                       points3D_all=None, colors_all=None, original_size: tuple | None = None, params=None, fence_params=None):
     """what FrameProcessor.process_frame writes when --save_data is set (semantic_depth.py:339-458), from the dict
-    ``api.FrameProcessor.process_frame(..., want_clouds=True)`` returns.  Returns the list of files written."""
+    ``api.FrameProcessor.process_frame(..., want_clouds=True)`` returns.  Returns the list of files written.
+    ``original_size`` = (original_height, original_width): the overlay is cubic-resized back to it before anything is drawn (:341);
+    ``params`` / ``fence_params`` (engine.RoadWidthParams / FenceParams): the chain literals the visualisation planes are rebuilt with."""
     files = []
     rec = res["record"]
     if not rec["found"]:
@@ -150,6 +207,9 @@ def save_frame_outputs(output_name: str, res: dict, depth: float, approach: str 
         left_f2f, right_f2f = f2["left_pt"][None, :].copy(), f2["right_pt"][None, :].copy()
         line_f2f, colors_line_f2f = pcl.create_3Dline_from_3Dpoints(left_f2f.copy(), right_f2f.copy(), [0, 255, 0])
     if segmented_frame is not None:
+        if original_size is not None and tuple(segmented_frame.shape[:2]) != tuple(original_size):
+            segmented_frame = resize_to_original(segmented_frame, int(original_size[1]), int(original_size[0]))     # :341-342
+        files.append(write_png("{}_only_segmentation.png".format(output_name), segmented_frame))                  # :345
         h, w = segmented_frame.shape[:2]
         banner, items = overlay_items(w, h, depth, is_city, left_rw, right_rw, dist_rw, "both" if both else "rw",
                                       left_f2f if both else None, right_f2f if both else None, res.get("dist_f2f"))
@@ -168,12 +228,22 @@ def save_frame_outputs(output_name: str, res: dict, depth: float, approach: str 
         pc.prepare_and_save_point_cloud()
         files.append("{}_FENCE.ply".format(output_name))
     pc = PointCloud2Ply(road3D, road_colors, output_name)                                   # :421-434
+    if road_plane3D is None and "road3D" in res:                                            # the visualisation plane of :215-219
+        kw = {k: getattr(params, k) for k in ("z_cut", "mad_y", "mad_x", "plane_thr")} if params is not None else {}
+        road_plane3D, road_colors_plane = road_plane_grid(res["road3D"], res["road_colors"], **kw)
     if road_plane3D is not None:
         pc.add_extra_point_cloud(road_plane3D, road_colors_plane)
     pc.add_extra_point_cloud(line_rw, colors_line_rw)
     if both and "fence3D_left" in res:
         pc.add_extra_point_cloud(res["fence3D_left"], res["fence_left_colors"])
         pc.add_extra_point_cloud(res["fence3D_right"], res["fence_right_colors"])
+        if "fence3D" in res:                                                                # :428-431
+            kw = ({k: getattr(fence_params, k) for k in ("mad_y", "z_max", "mad_left", "mad_right", "plane_thr")} if fence_params is not None else {})
+            lp, lcp, rp, rcp = fence_plane_grids(res["fence3D"], res["fence_colors"], **kw)
+            if lp is not None:
+                pc.add_extra_point_cloud(lp, lcp)
+            if rp is not None:
+                pc.add_extra_point_cloud(rp, rcp)
         pc.add_extra_point_cloud(line_f2f, colors_line_f2f)
     pc.prepare_and_save_point_cloud()
     files.append("{}.ply".format(output_name))

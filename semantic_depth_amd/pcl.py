@@ -29,12 +29,17 @@ def set_engine(engine: Engine):
 
 
 def _eng() -> Engine:
-    """the Engine the filters run on: one set with set_engine(), else whatever the api classes already share, else a
-    512 x 1024 one created (and registered for sharing) on first use — never a private second handle"""
+    """the Engine the filters run on: one set with set_engine(), else the LARGEST (most points per call) of the engines the api
+    classes already share, else a 512 x 1024 engine of its own.  (Not pinned when it comes from the api registry: a larger engine
+    registered later takes over.)"""
     global _engine
-    if _engine is None:
-        from . import api
-        _engine = api.any_engine() or api.shared_engine(512, 1024)
+    if _engine is not None:
+        return _engine
+    from . import api
+    shared = [e for per in api._engines.values() for e in per.values() if getattr(e, "h", None)]
+    if shared:
+        return max(shared, key=lambda e: e.max_batch * e.cap)
+    _engine = api.shared_engine(512, 1024)
     return _engine
 
 

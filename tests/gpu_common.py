@@ -37,12 +37,31 @@ def relerr(a, b):
 
 
 def err_report(a, b):
-    """max-normalised error (the north-star figure, = relerr) plus per-element statistics, |delta| / (|ref| + 1e-3 max|ref|):
-    a max-normalised bound alone is lenient for tensors with a wide range (logits)."""
+    """max-normalised error (the north-star figure, = relerr) plus per-element statistics: a max-normalised bound alone is lenient for
+    tensors with a wide range (logits).  strict_p99 / strict_max: |delta| / (|ref| + 1e-2 max|ref|), the strict figure the parity tests
+    ASSERT beside the max-normalised one (STRICT_P99 / STRICT_MAX below); p99_elem_rel / max_elem_rel: the same with 1e-3 max|ref| in the
+    denominator (round 2's figure: dominated by the elements nearest zero, reported only)."""
     a = np.asarray(a, np.float64).ravel()
     b = np.asarray(b, np.float64).ravel()
     d = np.abs(a - b)
     scale = float(np.abs(b).max()) + 1e-30
     per = d / (np.abs(b) + 1e-3 * scale)
-    return {"max_rel": float(d.max() / scale), "p99_elem_rel": float(np.quantile(per, 0.99)), "max_elem_rel": float(per.max()),
+    strict = d / (np.abs(b) + 1e-2 * scale)
+    return {"max_rel": float(d.max() / scale), "strict_p99": float(np.quantile(strict, 0.99)), "strict_max": float(strict.max()),
+            "p99_elem_rel": float(np.quantile(per, 0.99)), "max_elem_rel": float(per.max()),
             "rms_rel": float(np.sqrt((d * d).mean()) / scale)}
+
+
+# Bounds on the strict per-element figure, by engine, = 2 x the worst value measured at 512 x 1024 (profiles/r03_strict_error.txt):
+# an element of magnitude >= 1 % of the tensor's maximum is then within this RELATIVE error of the oracle's, 99 % of them within
+# the p99 bound.
+STRICT_P99 = {"f32": 2e-5, "bf16x3": 2e-5, "bf16x2": 2e-4, "mixed": 6e-3, "plan": 6e-3}
+STRICT_MAX = {"f32": 2e-4, "bf16x3": 2e-4, "bf16x2": 2e-3, "mixed": 5e-2, "plan": 5e-2}
+
+
+def assert_close(got, ref, precision, tol=1e-3, what=""):
+    """the parity bar: max-normalised error within north_star's 1e-3 AND the strict per-element figure within the engine's bound"""
+    rep = err_report(got, ref)
+    assert rep["max_rel"] < tol, (what, precision, rep)
+    assert rep["strict_p99"] < STRICT_P99[precision] and rep["strict_max"] < STRICT_MAX[precision], (what, precision, rep)
+    return rep

@@ -26,3 +26,25 @@ def test_world_size_must_equal_gpus():
     assert r.returncode != 0 and "world size 2 (WORLD_SIZE) != --gpus 4" in r.stderr
     r = _run(["--gpus", "1"], {"WORLD_SIZE": "8", "RANK": "3", "LOCAL_RANK": "3"})
     assert r.returncode != 0 and "world size 8 (WORLD_SIZE) != --gpus 1" in r.stderr
+
+
+def test_a_rank_that_dies_takes_its_siblings_down():
+    """VERDICT r2 / ADVICE r2: one rank exiting early (OOM, HIP error, failed GPU check) must not leave the launcher waiting for the
+    others' rendezvous timeout: wait_ranks polls every child, stops the siblings on the first failure and returns THAT exit code."""
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, "-c", "import time; time.sleep(120)"]),
+             subprocess.Popen([sys.executable, "-c", "import sys, time; time.sleep(0.5); sys.exit(7)"]),
+             subprocess.Popen([sys.executable, "-c", "import signal, time; signal.signal(signal.SIGTERM, signal.SIG_IGN); time.sleep(120)"])]
+    rc = bench.wait_ranks(procs, poll_s=0.05, grace_s=1.0)
+    assert rc == 7
+    assert time.time() - t0 < 30                               # not the sleepers' 120 s
+    assert all(p.poll() is not None for p in procs)            # the sibling that ignored SIGTERM was killed
+    # every rank fine -> 0; a rank killed by a signal -> 128 + n
+    assert bench.wait_ranks([subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(3)]) == 0
+    p = subprocess.Popen([sys.executable, "-c", "import os, signal; os.kill(os.getpid(), signal.SIGKILL)"])
+    assert bench.wait_ranks([p]) == 128 + 9
