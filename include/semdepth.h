@@ -47,8 +47,13 @@ typedef enum { SD_NET_FCN8S = 0, SD_NET_MONODEPTH = 1 } sd_net;
  *                  alone (for layers whose input tensor is precision-critical; direct 3x3 layers fed by direct 3x3 layers);
  *   SD_PREC_MIXED  FCN-8s as SD_PREC_BF16X2, every monodepth layer in the 2-product form;
  *   SD_PREC_PLAN   per-layer choice between these forms: the built-in plan (sd_default_plan) was calibrated on the MI355X against the
- *                  exact-f32 engine under an error budget; sd_create_with_plan takes any other choice */
-typedef enum { SD_PREC_F32 = 0, SD_PREC_BF16X2 = 1, SD_PREC_MIXED = 2, SD_PREC_PLAN = 3 } sd_precision;
+ *                  exact-f32 engine under an error budget; sd_create_with_plan takes any other choice
+ *   SD_PREC_BF16X3 fp32-grade on the bf16 MFMA: every f32 operand (activations and weights) is carried as THREE bf16 planes whose sum is
+ *                  the f32 value EXACTLY (8 + 8 + 8 significand bits, f32's exponent range); a product is SIX bf16 MFMA products
+ *                  (hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi, each exact in the f32 accumulator); the dropped terms are below
+ *                  2^-23 of the product, the size of the rounding an f32 FMA chain commits per accumulation.  Ceiling 2500 / 6 = 417
+ *                  TFLOP/s of algorithmic work against 157.3 for the f32 MFMA. */
+typedef enum { SD_PREC_F32 = 0, SD_PREC_BF16X2 = 1, SD_PREC_MIXED = 2, SD_PREC_PLAN = 3, SD_PREC_BF16X3 = 4 } sd_precision;
 
 typedef struct sd_handle sd_handle;
 

@@ -132,7 +132,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
     auto T = [&](int t) -> float* { return reinterpret_cast<float*>(abase + p.tensors[t].offset); };
     auto Wp = [&](int w) -> const float* { return reinterpret_cast<const float*>(wbase + p.weights[w].offset); };
     auto PL = [&](int t) -> size_t { const TensorDesc& d = p.tensors[t]; return (size_t)p.images * d.H * d.W * d.C; };   // lo-plane offset
-    auto FMT = [&](int t) -> int { return p.tensors[t].fmt ? (p.tensors[t].f16 ? 2 : 1) : 0; };     // (fp16 hi+lo tensors never reach the ops that take this)     // 0 f32, 1 split bf16, 2 split fp16
+    auto FMT = [&](int t) -> int { return p.tensors[t].fmt ? (p.tensors[t].x3 ? 4 : p.tensors[t].f16 ? 2 : 1) : 0; };     // (fp16 hi+lo tensors never reach the ops that take this)     // 0 f32, 1 split bf16, 2 split fp16
     for (const WeightSlot& wsl : p.weights)
         if (!wsl.loaded) return fail(h, SD_ERR_STATE, "weight not loaded: " + wsl.name);
     h->prof_last = nullptr;                 // (other work may have been put on the stream since the previous call)
@@ -175,6 +175,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.out_planar16 = d.planar16;
                 c.sw = h->sw;
                 c.sat = reinterpret_cast<unsigned long long*>(h->ws + h->o_misc + SAT_OFF);
+                c.x3 = p.x3;
                 hipEvent_t ea = nullptr, eb = nullptr;
                 if (h->prof) {
                     ea = h->prof_last;
@@ -189,7 +190,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 if (h->prof) {
                     hipEventRecord(eb, s);
                     h->prof_last = eb; conv_op = true;
-                    h->prof_recs.push_back({dma ? conv_dma_kernel_name(c) : stem ? (c.f16 ? "conv_stem_f16w_kernel" : "conv_stem_kernel") : split ? conv_split_kernel_name(c) : conv_igemm_kernel_name(c), op.flops * N / p.images, ea, eb,
+                    h->prof_recs.push_back({dma ? conv_dma_kernel_name(c) : stem ? (c.x3 ? "conv_stem_x3_kernel" : c.f16 ? "conv_stem_f16w_kernel" : "conv_stem_kernel") : split ? conv_split_kernel_name(c) : conv_igemm_kernel_name(c), op.flops * N / p.images, ea, eb,
                                             op.name.c_str(), N * c.Hout * c.Wout, d.C, op.K});
                 }
                 break;
@@ -218,11 +219,11 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                     if (!ea) { if (!(ea = prof_event(h))) return fail(h, SD_ERR_HIP, "hipEventCreate"); hipEventRecord(ea, s); }
                     if (!(eb = prof_event(h))) return fail(h, SD_ERR_HIP, "hipEventCreate");
                 }
-                e = launch_conv_direct(c, s);
+                e = p.x3 ? launch_conv_direct3(c, s) : launch_conv_direct(c, s);
                 if (h->prof) {
                     hipEventRecord(eb, s);
                     h->prof_last = eb; conv_op = true;
-                    h->prof_recs.push_back({conv_direct_kernel_name(c), op.flops * N / p.images, ea, eb, op.name.c_str(), N * c.H * c.W, d.C, op.K});
+                    h->prof_recs.push_back({p.x3 ? conv_direct3_kernel_name(c) : conv_direct_kernel_name(c), op.flops * N / p.images, ea, eb, op.name.c_str(), N * c.H * c.W, d.C, op.K});
                 }
                 break;
             }
@@ -232,7 +233,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.x = T(op.src[0]); c.N = N; c.H = s0.H; c.W = s0.W; c.C = s0.C; c.k = op.k; c.nout = op.nout;
                 c.wt = Wp(op.w); c.bias = Wp(op.b); c.out = T(op.dst); c.act = op.act;
                 c.in_split = FMT(op.src[0]) != 0; c.out_split = FMT(op.dst) != 0; c.in_plane = PL(op.src[0]); c.out_plane = PL(op.dst);
-                c.f16 = s0.f16; c.out_f16 = p.tensors[op.dst].f16;
+                c.f16 = s0.f16; c.out_f16 = p.tensors[op.dst].f16; c.x3 = p.x3;
                 c.in_sub = s0.planar16 ? (size_t)p.images * s0.H * s0.W * 16 : 0;
                 c.out_c = p.tensors[op.dst].C;
                 c.zero16 = h->ws + h->o_misc + 256;
@@ -295,7 +296,7 @@ extern "C" {
 #endif
 // "... src=<hash>": sha256 prefix of the sources this binary was built from (semantic_depth_amd/build.py source_hash);
 // the Python loader refuses a library whose hash differs from the tree's
-const char* sd_version(void) { return "semdepth 0.3 (gfx950; f32 MFMA, split-bf16/fp16 MFMA) src=" SD_SOURCE_HASH; }
+const char* sd_version(void) { return "semdepth 0.4 (gfx950; f32 MFMA, split-bf16 x2 / x3 and fp16 MFMA) src=" SD_SOURCE_HASH; }
 
 const char* sd_status_string(sd_status s) {
     switch (s) {
@@ -320,7 +321,7 @@ static sd_status create_impl(sd_handle** out, int device, int H, int W, int max_
                              const char* fcn_f16, const char* mono_f16);
 
 sd_status sd_create(sd_handle** out, int device, int H, int W, int max_batch, sd_encoder enc, sd_precision prec) {
-    if (prec != SD_PREC_F32 && prec != SD_PREC_BF16X2 && prec != SD_PREC_MIXED && prec != SD_PREC_PLAN) return SD_ERR_INVALID;
+    if (prec != SD_PREC_F32 && prec != SD_PREC_BF16X2 && prec != SD_PREC_MIXED && prec != SD_PREC_PLAN && prec != SD_PREC_BF16X3) return SD_ERR_INVALID;
     const char* fcn = prec == SD_PREC_PLAN ? kDefaultPlanFcn : "";
     // (the calibrated monodepth plan names ResNet-50 layers; the vgg encoder -- the ill-conditioned one of the two in the tests --
     //  stays on three products under SD_PREC_PLAN)
@@ -354,8 +355,9 @@ static sd_status create_impl(sd_handle** out, int device, int H, int W, int max_
     if (const char* e = std::getenv("SEMDEPTH_CHUNK")) chunk = std::max(1, atoi(e));
     h->chunk = std::min(max_batch, chunk);
     try {
-        h->fcn = build_fcn8s(h->chunk, H, W, h->prec != SD_PREC_F32 ? 1 : 0, fcn_f16);
-        h->mono = build_monodepth(enc == SD_ENC_VGG ? 0 : 1, h->chunk, H, W, h->prec != SD_PREC_F32 ? 1 : 0, mono_f16);
+        const int eng = h->prec == SD_PREC_F32 ? 0 : h->prec == SD_PREC_BF16X3 ? 2 : 1;      // exact f32 MFMA | split, three bf16 planes | split
+        h->fcn = build_fcn8s(h->chunk, H, W, eng, fcn_f16);
+        h->mono = build_monodepth(enc == SD_ENC_VGG ? 0 : 1, h->chunk, H, W, eng, mono_f16);
     } catch (const std::exception& ex) {
         std::fprintf(stderr, "sd_create: %s\n", ex.what());
         delete h;
@@ -433,6 +435,7 @@ sd_status sd_load_weight(sd_handle* h, sd_net net, const char* name, const float
         const size_t plane = (size_t)s.Ktotal * s.CoutPad * 2, rows = (size_t)s.Kpad * s.CoutPad * 2, ro = (size_t)s.k_off * s.CoutPad * 2;
         HIPCHK(h, hipMemcpy(base + ro, buf.data(), rows, hipMemcpyHostToDevice));
         HIPCHK(h, hipMemcpy(base + plane + ro, reinterpret_cast<char*>(buf.data()) + rows, rows, hipMemcpyHostToDevice));
+        if (s.x3) HIPCHK(h, hipMemcpy(base + 2 * plane + ro, reinterpret_cast<char*>(buf.data()) + 2 * rows, rows, hipMemcpyHostToDevice));
     } else {
         const int root = s.owner >= 0 ? s.owner : it->second;
         bool grouped = s.owner >= 0;
@@ -785,7 +788,7 @@ sd_status sd_net_tensor(sd_handle* h, sd_net net, const char* name, float* out, 
     const char* abase = h->ws + (net == SD_NET_FCN8S ? h->o_fcn : h->o_mono);
     if (t.fmt)      // split-bf16 planes -> f32
         HIPCHK(h, launch_unsplit(reinterpret_cast<const float*>(abase + t.offset), out, (long)N * t.H * t.W, t.C, t.Ctf, (size_t)p.images * t.H * t.W * t.C,
-                                 t.planar16 ? (size_t)p.images * t.H * t.W * 16 : 0, t.f16, (hipStream_t)stream));
+                                 t.planar16 ? (size_t)p.images * t.H * t.W * 16 : 0, t.x3 ? -1 : t.f16, (hipStream_t)stream));
     else
         HIPCHK(h, hipMemcpyAsync(out, abase + t.offset, numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return SD_OK;

@@ -78,6 +78,49 @@ __device__ __forceinline__ void split_epilogue_act(f32x16 (&acc)[MT][NT], unsign
     }
     sat_report(p.sat, sat);
 }
+// bf16 x 3 output (SD_PREC_BF16X3): the exact three-way split, one slab per plane
+template <int ACT, int MT, int NT>
+__device__ __forceinline__ void split_epilogue_x3(f32x16 (&acc)[MT][NT], unsigned char* slab, const ConvParams& p, int m0, int n0, int M, int lane) {
+    constexpr int ROW = NT * 64 + 16;
+    constexpr int SEGS = NT * 4, PPP = 64 / SEGS;
+    const int seg = lane % SEGS, prow = lane / SEGS;
+    uint16_t* const out_hi = reinterpret_cast<uint16_t*>(p.out);
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int nl = b * 32 + 8 * r4 + 4 * (lane >> 5);
+                const int n = n0 + nl;
+                f32x4 v = {acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
+                if (n < p.Cout) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = act_f32<ACT>(v[r]);
+                uint2 h, m, l;
+                split4_x3(v, h, m, l);
+                *reinterpret_cast<uint2*>(slab + (lane & 31) * ROW + nl * 2) = h;
+                *reinterpret_cast<uint2*>(slab + 32 * ROW + (lane & 31) * ROW + nl * 2) = m;
+                *reinterpret_cast<uint2*>(slab + 64 * ROW + (lane & 31) * ROW + nl * 2) = l;
+            }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ps = 0; ps < 32 / PPP; ++ps) {
+            const int pix = ps * PPP + prow;
+            const int mo = m0 + a * 32 + pix;
+            const int n = n0 + seg * 8;
+            if (mo < M && n < p.Cout) {
+                uint16_t* o = out_hi + (size_t)mo * p.Cout + n;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    *reinterpret_cast<u32x4*>(o + pl * p.out_plane) = *reinterpret_cast<const u32x4*>(slab + pl * 32 * ROW + pix * ROW + seg * 16);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
 template <int MT, int NT, bool F16>
 __device__ __forceinline__ void split_epilogue(f32x16 (&acc)[MT][NT], unsigned char* slab, const ConvParams& p, int m0, int n0, int M, int lane) {
     // the template's F16 is the INPUT format of the kernel; the output planes follow p.out_f16 (the consumers' format)
@@ -92,30 +135,29 @@ __device__ __forceinline__ void split_epilogue(f32x16 (&acc)[MT][NT], unsigned c
     else split_epilogue_act<ACT_NONE, MT, NT, false>(acc, slab, p, m0, n0, M, lane);
 }
 
-template <int WAVES_M, int WAVES_N, int MT, int NT>
+template <int WAVES_M, int WAVES_N, int MT, int NT, int NPL = 2>
 struct STile {
     static constexpr int BM = WAVES_M * MT * 32;
     static constexpr int BN = WAVES_N * NT * 32;
     static constexpr int NTHR = WAVES_M * WAVES_N * 64;
     static constexpr int A_IT = BM * 4 / NTHR;                // (pixel, k-octet) items per thread per k-tile
     static constexpr int B_LD = (BN * 4 + NTHR - 1) / NTHR;   // 16-B loads per thread per k-tile and plane
-    static constexpr int STAGE_BYTES = (BM + BN) * 32 * 2 * 2;                  // hi + lo, bf16
+    static constexpr int STAGE_BYTES = (BM + BN) * 32 * 2 * NPL;                // NPL planes (hi + lo, or hi + mid + lo), bf16
     static constexpr int EPI_ROW = NT * 64 + 16;                                // bytes per pixel row of a wave's output slab (+16 pad)
-    static constexpr int EPI_BYTES = WAVES_M * WAVES_N * 2 * 32 * EPI_ROW;      // per wave: hi + lo planes of 32 pixels
+    static constexpr int EPI_BYTES = WAVES_M * WAVES_N * NPL * 32 * EPI_ROW;    // per wave: one slab of 32 pixels per plane
     static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
 };
 
 // F16: ONE fp16 activation plane (the lo-plane reads below fetch unused bytes), two fp16 weight planes, two MFMA products per
-// product (split_fmt.hpp)
-template <int WAVES_M, int WAVES_N, int MT, int NT, bool VEC, bool F16 = false>
+// product (split_fmt.hpp).  X3: three bf16 planes per operand, six MFMA products per product (SD_PREC_BF16X3).
+template <int WAVES_M, int WAVES_N, int MT, int NT, bool VEC, bool F16 = false, bool X3 = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_split_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
-    using T = STile<WAVES_M, WAVES_N, MT, NT>;
+    constexpr int NPL = X3 ? 3 : 2;
+    using T = STile<WAVES_M, WAVES_N, MT, NT, NPL>;
     constexpr int BM = T::BM, BN = T::BN, NTHR = T::NTHR;
     __shared__ __attribute__((aligned(16))) unsigned char lds[T::LDS_BYTES];
-    u32x4* Xh = reinterpret_cast<u32x4*>(lds);             // [4][BM] 16-B units
-    u32x4* Xl = Xh + 4 * BM;
-    u32x4* Wh = Xl + 4 * BM;                               // [4][BN]
-    u32x4* Wl = Wh + 4 * BN;
+    u32x4* const Xp = reinterpret_cast<u32x4*>(lds);       // [NPL][4][BM] 16-B units
+    u32x4* const Wp = Xp + NPL * 4 * BM;                   // [NPL][4][BN]
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -152,11 +194,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_split_kernel(cons
     const KEntry* __restrict__ const ktab = p.ktab;
     const int CoutPad = p.CoutPad;
     const u32x4* __restrict__ const wt_hi = reinterpret_cast<const u32x4*>(p.wt);
-    const u32x4* __restrict__ const wt_lo = wt_hi + (size_t)(p.Kpad / 8) * CoutPad;
+    const size_t wplane = (size_t)(p.Kpad / 8) * CoutPad;
 
-    u32x4 rxh[T::A_IT], rxl[T::A_IT];      // one k-octet of one pixel: 8 bf16 hi, 8 bf16 lo
+    u32x4 rx[NPL][T::A_IT];                // one k-octet of one pixel per plane
     const int Nmax = p.Nmax;
-    u32x4 rwh[T::B_LD], rwl[T::B_LD];
+    u32x4 rw[NPL][T::B_LD];
     const int ktiles = p.Kpad / 32, vtiles = p.vtiles;
 
     auto load_tile = [&](int kt) {
@@ -166,8 +208,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_split_kernel(cons
             const int n_l = idx % BN, kg = idx / BN;
             if (BN * 4 >= NTHR || idx < BN * 4) {
                 const size_t o = (size_t)(kt * 4 + kg) * CoutPad + bn0 + n_l;
-                rwh[i] = wt_hi[o];
-                rwl[i] = wt_lo[o];
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) rw[pl][i] = wt_hi[pl * wplane + o];
             }
         }
         if (VEC || kt < vtiles) {
@@ -181,19 +223,21 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_split_kernel(cons
 #pragma unroll
             for (int i = 0; i < T::A_IT; ++i) {
                 const int kg = kg0 + KG_STEP * i;
-                u32x4 h = {0u, 0u, 0u, 0u}, l = h;
-                if (ok) {
-                    h = *reinterpret_cast<const u32x4*>(base + kg * 8);
-                    l = *reinterpret_cast<const u32x4*>(base + plane + kg * 8);
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (ok) v = *reinterpret_cast<const u32x4*>(base + pl * plane + kg * 8);
+                    rx[pl][i] = v;
                 }
-                rxh[i] = h; rxl[i] = l;
             }
         } else {
             const KEntry* __restrict__ const qtab = ktab + ktiles + (kt - vtiles) * 8;   // this tile's 8 quad descriptors
 #pragma unroll
             for (int i = 0; i < T::A_IT; ++i) {
                 const int kg = __builtin_amdgcn_readfirstlane(kg0 + KG_STEP * i);
-                u32x4 h = {0u, 0u, 0u, 0u}, l = h;
+                u32x4 v[NPL];
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) v[pl] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
                 for (int hq = 0; hq < 2; ++hq) {
                     const KEntry q4 = qtab[kg * 2 + hq];
@@ -204,23 +248,28 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_split_kernel(cons
                     const int nv = (q4.flags >> 8) & 7;
                     const uint16_t* q = reinterpret_cast<const uint16_t*>(q4.base) + ((size_t)(img * q4.H + iy) * q4.W + ix) * q4.C;
                     const size_t plane = (size_t)Nmax * q4.H * q4.W * q4.C;
-                    unsigned h0 = 0, h1 = 0, l0 = 0, l1 = 0;
-                    if (ok) {
-                        if (nv == 4) {
-                            const uint2 a = *reinterpret_cast<const uint2*>(q), b = *reinterpret_cast<const uint2*>(q + plane);
-                            h0 = a.x; h1 = a.y; l0 = b.x; l1 = b.y;
-                        } else if (nv == 2) {
-                            h0 = *reinterpret_cast<const unsigned*>(q); l0 = *reinterpret_cast<const unsigned*>(q + plane);
-                        } else {
-                            for (int j = 0; j < nv; ++j) {
-                                const unsigned a = q[j], b = q[plane + j];
-                                if (j == 0) { h0 |= a; l0 |= b; } else if (j == 1) { h0 |= a << 16; l0 |= b << 16; } else { h1 |= a; l1 |= b; }
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) {
+                        unsigned w0 = 0, w1 = 0;
+                        const uint16_t* qp = q + pl * plane;
+                        if (ok) {
+                            if (nv == 4) {
+                                const uint2 a = *reinterpret_cast<const uint2*>(qp);
+                                w0 = a.x; w1 = a.y;
+                            } else if (nv == 2) {
+                                w0 = *reinterpret_cast<const unsigned*>(qp);
+                            } else {
+                                for (int j = 0; j < nv; ++j) {
+                                    const unsigned a = qp[j];
+                                    if (j == 0) w0 |= a; else if (j == 1) w0 |= a << 16; else w1 |= a;
+                                }
                             }
                         }
+                        v[pl][2 * hq] = w0; v[pl][2 * hq + 1] = w1;
                     }
-                    h[2 * hq] = h0; h[2 * hq + 1] = h1; l[2 * hq] = l0; l[2 * hq + 1] = l1;
                 }
-                rxh[i] = h; rxl[i] = l;
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) rx[pl][i] = v[pl];
             }
         }
     };
@@ -240,48 +289,60 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_split_kernel(cons
 #pragma unroll
         for (int i = 0; i < T::A_IT; ++i) {
             const int kg = kg0 + KG_STEP * i;
-            Xh[kg * BM + m_l] = rxh[i];
-            Xl[kg * BM + m_l] = rxl[i];
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) Xp[pl * 4 * BM + kg * BM + m_l] = rx[pl][i];
         }
 #pragma unroll
         for (int i = 0; i < T::B_LD; ++i) {
             const int idx = t + NTHR * i;
-            if (BN * 4 >= NTHR || idx < BN * 4) { Wh[idx] = rwh[i]; Wl[idx] = rwl[i]; }
+            if (BN * 4 >= NTHR || idx < BN * 4) {
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) Wp[pl * 4 * BN + idx] = rw[pl][i];
+            }
         }
         __syncthreads();
         if (kt + 1 < ktiles) load_tile(kt + 1);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int kg = 2 * s + fk;
-            u32x4 wh[NT], wl[NT], xh[MT], xl[MT];
+            u32x4 w[NPL][NT], x[NPL][MT];
 #pragma unroll
-            for (int b = 0; b < NT; ++b) {
-                wh[b] = Wh[kg * BN + wn0 + b * 32 + frow];
-                wl[b] = Wl[kg * BN + wn0 + b * 32 + frow];
-            }
+            for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-            for (int a = 0; a < MT; ++a) {
-                xh[a] = Xh[kg * BM + wm0 + a * 32 + frow];
-                xl[a] = Xl[kg * BM + wm0 + a * 32 + frow];
+                for (int b = 0; b < NT; ++b) w[pl][b] = Wp[pl * 4 * BN + kg * BN + wn0 + b * 32 + frow];
+#pragma unroll
+                for (int a = 0; a < MT; ++a) x[pl][a] = Xp[pl * 4 * BM + kg * BM + wm0 + a * 32 + frow];
             }
-            // the three products of one accumulator are issued MT*NT MFMAs apart (no back-to-back dependent MFMAs).
+            // the products of one accumulator are issued MT*NT MFMAs apart (no back-to-back dependent MFMAs), small terms first.
             // (s_setprio(1) around this cluster was measured: -25 %, the co-resident blocks' staging starves)
+            // (x plane, w plane): bf16 x 3: hi*lo, lo*hi, mid*mid, hi*mid, mid*hi, hi*hi; bf16 x 2: hi*lo, lo*hi, hi*hi
+            constexpr int NPR = X3 ? 6 : 3;
+            constexpr int xp3[6] = {0, 2, 1, 0, 1, 0}, wp3[6] = {2, 0, 1, 1, 0, 0};
+            constexpr int xp2[3] = {0, 1, 0}, wp2[3] = {1, 0, 0};
 #pragma unroll
-            for (int pr = 0; pr < 3; ++pr) {
-                if (F16 && pr == 1) continue;                      // fp16 activations: no lo plane, products x*w_lo and x*w_hi
-                if (F16 && pr == 0 && p.f16 == 2) continue;        // one-product layer (':1'): x*w_hi only, as conv_dma / conv_direct W1
+            for (int pr = 0; pr < NPR; ++pr) {
+                if (!X3 && F16 && pr == 1) continue;                      // fp16 activations: no lo plane, products x*w_lo and x*w_hi
+                if (!X3 && F16 && pr == 0 && p.f16 == 2) continue;        // one-product layer (':1'): x*w_hi only, as conv_dma / conv_direct W1
+                const int xi = X3 ? xp3[pr] : xp2[pr], wi = X3 ? wp3[pr] : wp2[pr];
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
 #pragma unroll
                     for (int a = 0; a < MT; ++a)
-                        acc[a][b] = mfma_frag<F16>(pr == 0 ? wl[b] : wh[b], pr == 1 ? xl[a] : xh[a], acc[a][b]);
+                        acc[a][b] = mfma_frag<F16>(w[wi][b], x[xi][a], acc[a][b]);
             }
         }
     }
 
     // ---- epilogue: D[row = channel (r&3) + 8*(r>>2) + 4*(lane>>5)][col = pixel lane&31] ----
     __syncthreads();                      // every wave is done with the stage memory: reuse it as output staging
-    split_epilogue<MT, NT, F16>(acc, lds + wave * (2 * 32 * T::EPI_ROW), p, bm0 + wm0, bn0 + wn0, M, lane);
+    if constexpr (X3) {
+        unsigned char* slab = lds + wave * (3 * 32 * T::EPI_ROW);
+        if (p.act == ACT_RELU) split_epilogue_x3<ACT_RELU, MT, NT>(acc, slab, p, bm0 + wm0, bn0 + wn0, M, lane);
+        else if (p.act == ACT_ELU) split_epilogue_x3<ACT_ELU, MT, NT>(acc, slab, p, bm0 + wm0, bn0 + wn0, M, lane);
+        else split_epilogue_x3<ACT_NONE, MT, NT>(acc, slab, p, bm0 + wm0, bn0 + wn0, M, lane);
+    } else {
+        split_epilogue<MT, NT, F16>(acc, lds + wave * (2 * 32 * T::EPI_ROW), p, bm0 + wm0, bn0 + wn0, M, lane);
+    }
 }
 
 template <int WAVES_M, int WAVES_N, int MT, int NT>
@@ -291,7 +352,12 @@ static hipError_t launch_scfg(const ConvParams& p, hipStream_t s) {
     const int tilesM = (int)((M + T::BM - 1) / T::BM);
     const int tilesN = (p.Cout + T::BN - 1) / T::BN;
     dim3 grid((unsigned)(tilesM * tilesN));
-    if (p.f16) {
+    if (p.x3) {
+        if (p.vec)
+            hipLaunchKernelGGL((conv_split_kernel<WAVES_M, WAVES_N, MT, NT, true, false, true>), grid, dim3(T::NTHR), 0, s, p, (int)M, tilesM, tilesN);
+        else
+            hipLaunchKernelGGL((conv_split_kernel<WAVES_M, WAVES_N, MT, NT, false, false, true>), grid, dim3(T::NTHR), 0, s, p, (int)M, tilesM, tilesN);
+    } else if (p.f16) {
         if (p.vec)
             hipLaunchKernelGGL((conv_split_kernel<WAVES_M, WAVES_N, MT, NT, true, true>), grid, dim3(T::NTHR), 0, s, p, (int)M, tilesM, tilesN);
         else
@@ -332,6 +398,15 @@ hipError_t launch_conv_split(const ConvParams& p, hipStream_t s) {
 }
 
 const char* conv_split_kernel_name(const ConvParams& p) {
+    if (p.x3) {
+        switch (split_variant(p)) {
+            case 0:  return "conv_split_x3_kernel<2,4,2,2>";
+            case 1:  return "conv_split_x3_kernel<4,2,2,2>";
+            case 2:  return "conv_split_x3_kernel<2,2,2,2>";
+            case 3:  return "conv_split_x3_kernel<4,1,2,2>";
+            default: return "conv_split_x3_kernel<4,1,2,1>";
+        }
+    }
     if (p.f16) {
         switch (split_variant(p)) {
             case 0:  return "conv_split_f16w_kernel<2,4,2,2>";

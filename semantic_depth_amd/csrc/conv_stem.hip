@@ -19,21 +19,21 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ST_TW = 32;              // output tile width
 constexpr int ST_MAXPIX = 1536;        // halo pixels: 21 x 69 (7x7 stride 2, 8 rows) = 1449, 22 x 38 (7x7 stride 1, 16 rows) = 836
-constexpr int ST_PF = 2 * ST_MAXPIX / 512;   // halo units (pixel, plane) prefetched per thread
-
-template <int NB, int RW, bool F16>
+template <int NB, int RW, bool F16, bool X3 = false>
 __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
+    constexpr int NPL = X3 ? 3 : 2;              // planes per operand (X3: bf16 hi, mid, lo -- SD_PREC_BF16X3, six products per product)
+    constexpr int ST_PF = NPL * ST_MAXPIX / 512; // halo units (pixel, plane) prefetched per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TH = 8 * RW, CP = 32 * NB;                 // tile rows, padded output channels (= Cout)
     constexpr int ROW = 64 * NB + 16;                        // epilogue slab row (one plane of 32 pixels per wave)
     const int k = p.kh, s = p.stride, taps = k * k;
     const int IH = (TH - 1) * s + k, IW = (ST_TW - 1) * s + k, npix = IH * IW;
     const int wunits = (p.Kpad / 8) * CP;                    // 16-B units per weight plane
-    uint2* const Xh = reinterpret_cast<uint2*>(smem);        // [IH][IW] 4 channels
-    uint2* const Xl = Xh + ST_MAXPIX;
-    u32x4* const Wh = reinterpret_cast<u32x4*>(Xl + ST_MAXPIX);
+    uint2* const Xh = reinterpret_cast<uint2*>(smem);        // [plane][IH][IW] 4 channels
+    uint2* const Xl = Xh + ST_MAXPIX;                        // (X3: the mid plane; the lo plane follows)
+    u32x4* const Wh = reinterpret_cast<u32x4*>(Xh + NPL * ST_MAXPIX);
     u32x4* const Wl = Wh + wunits;
-    unsigned char* const slab = reinterpret_cast<unsigned char*>(Wl + wunits);          // (both weight planes in either format)
+    unsigned char* const slab = reinterpret_cast<unsigned char*>(Wh + NPL * wunits);    // (every weight plane in either format)
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -42,8 +42,8 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
         const u32x4* g = reinterpret_cast<const u32x4*>(p.wt);
         const size_t wplane = (size_t)(p.Kpad / 8) * p.CoutPad;
         for (int i = t; i < wunits; i += 512) {
-            Wh[i] = g[i];
-            Wl[i] = g[wplane + i];
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) Wh[pl * wunits + i] = g[pl * wplane + i];
         }
     }
     f32x4 bias[4 * NB];
@@ -67,13 +67,13 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
 #pragma unroll
         for (int i = 0; i < ST_PF; ++i) {
             const int u = t + 512 * i;
-            const int pl = u >= npix ? 1 : 0;
+            const int pl = u >= 2 * npix ? 2 : u >= npix ? 1 : 0;
             const int px = u - pl * npix;
             const int ry = px / IW, rx = px - ry * IW;
             const int gy = tl.ty0 * s - p.pad + ry, gx = tl.tx0 * s - p.pad + rx;
             uint2 v = {0u, 0u};
-            if (u < (F16 ? 1 : 2) * npix && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win)      // fp16 input: ONE plane
-                v = src[(pl ? splane : (size_t)0) + ((size_t)tl.img * p.Hin + gy) * p.Win + gx];
+            if (u < (F16 ? 1 : NPL) * npix && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win)      // fp16 input: ONE plane
+                v = src[(size_t)pl * splane + ((size_t)tl.img * p.Hin + gy) * p.Win + gx];
             pf[i] = v;
         }
     };
@@ -83,6 +83,7 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
             const int u = t + 512 * i;
             if (u < npix) Xh[u] = pf[i];
             else if (u < 2 * npix) Xl[u - npix] = pf[i];
+            else if (X3 && u < 3 * npix) Xh[2 * ST_MAXPIX + u - 2 * npix] = pf[i];
         }
     };
 
@@ -110,26 +111,43 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
             // this lane's two taps (k = 16 ks + 8 fk .. + 7 = taps 4 ks + 2 fk, + 1); taps past the kernel meet zero weights
             const int t0 = 4 * ks + 2 * fk, t1 = t0 + 1;
             const int o0 = t0 < taps ? (t0 / k) * IW + (t0 % k) : 0, o1 = t1 < taps ? (t1 / k) * IW + (t1 % k) : 0;
-            u32x4 xh[RW], xl[RW];
+            u32x4 xh[RW], xl[RW], xm[RW];        // (X3: xl = the mid plane, xm = the lo plane -- named by their position in memory)
 #pragma unroll
             for (int a = 0; a < RW; ++a) {
                 const int base = ((RW * wave + a) * s) * IW + frow * s;
                 const uint2 h0 = Xh[base + o0], h1 = Xh[base + o1], l0 = Xl[base + o0], l1 = Xl[base + o1];
                 xh[a] = u32x4{h0.x, h0.y, t1 < taps ? h1.x : 0u, t1 < taps ? h1.y : 0u};
                 xl[a] = u32x4{l0.x, l0.y, t1 < taps ? l1.x : 0u, t1 < taps ? l1.y : 0u};
-                if (t0 >= taps) { xh[a] = u32x4{0u, 0u, 0u, 0u}; xl[a] = xh[a]; }
+                if constexpr (X3) {
+                    const uint2 m0 = Xh[2 * ST_MAXPIX + base + o0], m1 = Xh[2 * ST_MAXPIX + base + o1];
+                    xm[a] = u32x4{m0.x, m0.y, t1 < taps ? m1.x : 0u, t1 < taps ? m1.y : 0u};
+                } else xm[a] = xl[a];
+                if (t0 >= taps) { xh[a] = u32x4{0u, 0u, 0u, 0u}; xl[a] = xh[a]; xm[a] = xh[a]; }
             }
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const int wi = (2 * ks + fk) * CP + nb * 32 + frow;
                 const u32x4 wh = Wh[wi];
                 const u32x4 wl = Wl[wi];
+                if constexpr (X3) {
+                    const u32x4 w3 = Wh[2 * wunits + wi];     // planes in memory order: wh = hi, wl = mid, w3 = lo; xh, xl (mid), xm (lo)
+#pragma unroll
+                    for (int pr = 0; pr < 6; ++pr) {          // hi*lo, lo*hi, mid*mid, hi*mid, mid*hi, hi*hi
+#pragma unroll
+                        for (int a = 0; a < RW; ++a) {
+                            const u32x4 wv = pr == 0 ? w3 : (pr == 2 || pr == 3) ? wl : wh;
+                            const u32x4 xv = pr == 1 ? xm[a] : (pr == 2 || pr == 4) ? xl[a] : xh[a];
+                            acc[a][nb] = mfma_frag<false>(wv, xv, acc[a][nb]);
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int pr = 0; pr < 3; ++pr) {              // x_hi*w_lo, x_lo*w_hi, x_hi*w_hi; an fp16 input has no lo plane
                     if (F16 && pr == 1) continue;
 #pragma unroll
                     for (int a = 0; a < RW; ++a)
                         acc[a][nb] = mfma_frag<F16>(pr == 0 ? wl : wh, pr == 1 ? xl[a] : xh[a], acc[a][nb]);
+                }
                 }
             }
         }
@@ -146,21 +164,28 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
 #pragma unroll
             for (int a = 0; a < RW; ++a) {
                 const int y = cur.ty0 + RW * wave + a;
-                uint2 hh[4 * NB], ll[4 * NB];
+                uint2 hh[4 * NB], ll[4 * NB], mm[4 * NB];
 #pragma unroll
                 for (int r4 = 0; r4 < 4 * NB; ++r4) {
                     const int nb = r4 >> 2, q = r4 & 3;
                     f32x4 v = {acc[a][nb][4 * q], acc[a][nb][4 * q + 1], acc[a][nb][4 * q + 2], acc[a][nb][4 * q + 3]};
                     v += bias[r4];
+                    if constexpr (X3) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
-                    split4_t<O16>(v, hh[r4], ll[r4], sat);
+                        for (int r = 0; r < 4; ++r) v[r] = act_f32<ACT>(v[r]);
+                        split4_x3(v, hh[r4], ll[r4], mm[r4]);          // hh = hi, ll = mid, mm = lo (memory order)
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
+                        split4_t<O16>(v, hh[r4], ll[r4], sat);
+                        mm[r4] = ll[r4];
+                    }
                 }
 #pragma unroll
-                for (int pl = 0; pl < (O16 ? 1 : 2); ++pl) {      // fp16 outputs: the hi plane only
+                for (int pl = 0; pl < (X3 ? 3 : O16 ? 1 : 2); ++pl) {      // fp16 outputs: the hi plane only
 #pragma unroll
                     for (int r4 = 0; r4 < 4 * NB; ++r4)
-                        *reinterpret_cast<uint2*>(sh + frow * ROW + (8 * r4 + 4 * fk) * 2) = pl ? ll[r4] : hh[r4];
+                        *reinterpret_cast<uint2*>(sh + frow * ROW + (8 * r4 + 4 * fk) * 2) = pl == 2 ? mm[r4] : pl ? ll[r4] : hh[r4];
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -171,7 +196,7 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
                             const size_t px = (size_t)(cur.img * p.Hout + y) * p.Wout + cur.tx0 + pix;
                             uint16_t* o = p.out_planar16 ? out_hi + ((size_t)(seg >> 1) * p.Nmax * p.Hout * p.Wout + px) * 16 + (seg & 1) * 8
                                                          : out_hi + px * p.Cout + seg * 8;
-                            *reinterpret_cast<u32x4*>(pl ? o + p.out_plane : o) = v;
+                            *reinterpret_cast<u32x4*>(o + pl * p.out_plane) = v;
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -209,16 +234,21 @@ hipError_t launch_conv_stem(const ConvParams& p, hipStream_t s) {
     }
     const int nb = p.Cout / 32, rw = p.stride == 1 ? 2 : 1;
     const int tiles = (p.Wout / ST_TW) * ((p.Hout + 8 * rw - 1) / (8 * rw)) * p.N;
-    const size_t wbytes = (size_t)(p.Kpad / 8) * p.Cout * 16 * 2;
-    const size_t lds = (size_t)2 * ST_MAXPIX * 8 + wbytes + (size_t)8 * 32 * (64 * nb + 16);
+    const int npl = p.x3 ? 3 : 2;
+    const size_t wbytes = (size_t)(p.Kpad / 8) * p.Cout * 16 * npl;
+    const size_t lds = (size_t)npl * ST_MAXPIX * 8 + wbytes + (size_t)8 * 32 * (64 * nb + 16);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     const dim3 grid((unsigned)(tiles < cus ? tiles : cus));
-#define SD_STEM(NB_, RW_, F_)                                                                                          \
+#define SD_STEM(NB_, RW_, F_, ...)                                                                                     \
     do {                                                                                                               \
         static bool attr = false;                                                                                      \
-        if (!attr) { hipFuncSetAttribute((const void*)conv_stem_kernel<NB_, RW_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
-        hipLaunchKernelGGL((conv_stem_kernel<NB_, RW_, F_>), grid, dim3(512), lds, s, p);                               \
+        if (!attr) { hipFuncSetAttribute((const void*)conv_stem_kernel<NB_, RW_, F_, ##__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        hipLaunchKernelGGL((conv_stem_kernel<NB_, RW_, F_, ##__VA_ARGS__>), grid, dim3(512), lds, s, p);                \
     } while (0)
-    if (p.f16) {
+    if (p.x3) {
+        if (nb == 1 && rw == 1) SD_STEM(1, 1, false, true); else if (nb == 1) SD_STEM(1, 2, false, true);
+        else if (rw == 1) SD_STEM(2, 1, false, true); else SD_STEM(2, 2, false, true);
+    } else if (p.f16) {
         if (nb == 1 && rw == 1) SD_STEM(1, 1, true); else if (nb == 1) SD_STEM(1, 2, true);
         else if (rw == 1) SD_STEM(2, 1, true); else SD_STEM(2, 2, true);
     } else {

@@ -66,6 +66,7 @@ struct ConvParams {
     int m_fastest;     // block order: 1 = consecutive blocks walk M (share a weight panel), 0 = walk N
     unsigned sw;       // Switch bits of the handle
     unsigned long long* sat;   // DEVICE counter of fp16-saturated output values (split_fmt.hpp sat_report; sd_saturation_count)
+    int x3;            // 1: bf16 x 3 planes in, out and in the weights (SD_PREC_BF16X3: six MFMA products per product, split_fmt.hpp)
 };
 hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t s);
 const char* conv_igemm_kernel_name(const ConvParams& p);
@@ -146,6 +147,8 @@ struct ConvDirectParams {
     unsigned sw;                 // Switch bits of the handle
     unsigned long long* sat;     // DEVICE counter of fp16-saturated output values (split_fmt.hpp sat_report; sd_saturation_count)
 };
+hipError_t launch_conv_direct3(const ConvDirectParams& p, hipStream_t s);       // conv_direct3.hip: the bf16 x 3 form (SD_PREC_BF16X3)
+const char* conv_direct3_kernel_name(const ConvDirectParams& p);
 hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s);
 const char* conv_direct_kernel_name(const ConvDirectParams& p);
 
@@ -166,6 +169,7 @@ struct SmallNParams {
     int act;
     const void* zero16; // 16 zero bytes (padding source of the LDS-DMA halo loads of the tiled kernel)
     int f16;            // INPUT planes: 0 bf16 hi + lo, 1 ONE fp16 plane, 2 fp16 hi + lo (per-thread / per-wave kernels)
+    int x3;             // split planes (in and out) are bf16 x 3 (per-thread / per-wave kernels)
     int out_f16;        // OUTPUT split planes (out_split) are fp16
     unsigned sw;        // Switch bits of the handle
 };
@@ -175,12 +179,12 @@ bool conv_smalln_tiled(int in_split, int k, int W, int C, int nout, unsigned sw)
 // ---------------------------------------------------------------------------------------------
 // misc network ops (ops_misc.hip)
 // ---------------------------------------------------------------------------------------------
-// `split`: activations are split-bf16 planes (split_fmt.hpp); `plane*` = element offset of the lo plane
+// `split`: 0 f32, 1 split-bf16 planes (split_fmt.hpp), 2 ONE fp16 plane, 4 bf16 x 3 planes; `plane*` = element offset of the lo plane
 hipError_t launch_pre_vgg(const uint8_t* frames, float* out, long npix, int split, size_t plane, hipStream_t s);                 // K1
 hipError_t launch_pre_mono(const uint8_t* frames, float* out, int B, int H, int W, int split, size_t plane, int raw, hipStream_t s);      // /255 (raw: not) + fliplr pair
 hipError_t launch_maxpool2(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s);
 hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s);
-hipError_t launch_unsplit(const float* x, float* y, long npix, int C, int Ctf, size_t plane, size_t sub, int f16, hipStream_t s);  // split planes -> f32 [npix][Ctf]
+hipError_t launch_unsplit(const float* x, float* y, long npix, int C, int Ctf, size_t plane, size_t sub, int f16, hipStream_t s);  // split planes -> f32 [npix][Ctf]; f16 = -1: bf16 x 3
 // y[n,2i+ky-1,2j+kx-1,o] += x[n,i,j,c]*w[ky,kx,o,c]; y += bias + skip   (3->3 channels; fcn8s/fcn.py:186-204)
 hipError_t launch_deconv4s2_add(const float* x, const float* w, const float* bias, const float* skip, float* y,
                                 int N, int H, int W, hipStream_t s);

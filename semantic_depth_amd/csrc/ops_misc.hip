@@ -9,15 +9,22 @@ namespace sd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Every op below exists for the three activation formats: f32 NHWC (0), split-bf16 planes (1) and ONE fp16 plane (2)
-// of split_fmt.hpp (template parameter SPLIT; `plane` = element offset of the lo plane).
+// Every op below exists for the activation formats f32 NHWC (0), split-bf16 planes (1), ONE fp16 plane (2), [read side: fp16 hi + lo (3)]
+// and bf16 x 3 planes (4) of split_fmt.hpp (template parameter SPLIT; `plane` = element offset between planes).
 // ---------------------------------------------------------------------------------------------
 // K1: VGG 'Processing' block [UPSTREAM Udacity vgg]: split (c0,c1,c2), subtract means, concat reversed.
 // 4 stored channels (the 4th is zero and meets zero weight rows): conv1_1 gathers whole channel quads.
 // ---------------------------------------------------------------------------------------------
 template <int SPLIT>
 __device__ __forceinline__ void store4(float* base, size_t plane, long quad_index, f32x4 v) {
-    if (SPLIT) {
+    if (SPLIT == 4) {              // bf16 x 3: exact
+        uint2 h, m, l;
+        split4_x3(v, h, m, l);
+        uint16_t* b16 = reinterpret_cast<uint16_t*>(base);
+        reinterpret_cast<uint2*>(b16)[quad_index] = h;
+        reinterpret_cast<uint2*>(b16 + plane)[quad_index] = m;
+        reinterpret_cast<uint2*>(b16 + 2 * plane)[quad_index] = l;
+    } else if (SPLIT) {
         uint2 h, l;
         split4_t<SPLIT == 2>(v, h, l);
         uint2* hp = reinterpret_cast<uint2*>(base);             // bf16 plane: one uint2 per channel quad
@@ -29,6 +36,11 @@ __device__ __forceinline__ void store4(float* base, size_t plane, long quad_inde
 }
 template <int SPLIT>
 __device__ __forceinline__ f32x4 load4(const float* base, size_t plane, long quad_index) {
+    if (SPLIT == 4) {
+        const uint16_t* b16 = reinterpret_cast<const uint16_t*>(base);
+        return recon4_x3(reinterpret_cast<const uint2*>(b16)[quad_index], reinterpret_cast<const uint2*>(b16 + plane)[quad_index],
+                         reinterpret_cast<const uint2*>(b16 + 2 * plane)[quad_index]);
+    }
     if (SPLIT) {
         const uint2 h = reinterpret_cast<const uint2*>(base)[quad_index];
         uint2 l = {0u, 0u};
@@ -51,7 +63,8 @@ __global__ __launch_bounds__(256) void pre_vgg_kernel(const uint8_t* __restrict_
 }
 hipError_t launch_pre_vgg(const uint8_t* frames, float* out, long npix, int split, size_t plane, hipStream_t s) {
     const dim3 grid((unsigned)((npix + 255) / 256));
-    if (split == 2) hipLaunchKernelGGL(pre_vgg_kernel<2>, grid, dim3(256), 0, s, frames, out, npix, plane);
+    if (split == 4) hipLaunchKernelGGL(pre_vgg_kernel<4>, grid, dim3(256), 0, s, frames, out, npix, plane);
+    else if (split == 2) hipLaunchKernelGGL(pre_vgg_kernel<2>, grid, dim3(256), 0, s, frames, out, npix, plane);
     else if (split) hipLaunchKernelGGL(pre_vgg_kernel<1>, grid, dim3(256), 0, s, frames, out, npix, plane);
     else hipLaunchKernelGGL(pre_vgg_kernel<0>, grid, dim3(256), 0, s, frames, out, npix, plane);
     return hipGetLastError();
@@ -76,7 +89,8 @@ __global__ __launch_bounds__(256) void pre_mono_kernel(const uint8_t* __restrict
 hipError_t launch_pre_mono(const uint8_t* frames, float* out, int B, int H, int W, int split, size_t plane, int raw, hipStream_t s) {
     long npix = (long)B * H * W;
     const dim3 grid((unsigned)((npix + 255) / 256));
-    if (split == 2) hipLaunchKernelGGL(pre_mono_kernel<2>, grid, dim3(256), 0, s, frames, out, B, H, W, plane, raw);
+    if (split == 4) hipLaunchKernelGGL(pre_mono_kernel<4>, grid, dim3(256), 0, s, frames, out, B, H, W, plane, raw);
+    else if (split == 2) hipLaunchKernelGGL(pre_mono_kernel<2>, grid, dim3(256), 0, s, frames, out, B, H, W, plane, raw);
     else if (split) hipLaunchKernelGGL(pre_mono_kernel<1>, grid, dim3(256), 0, s, frames, out, B, H, W, plane, raw);
     else hipLaunchKernelGGL(pre_mono_kernel<0>, grid, dim3(256), 0, s, frames, out, B, H, W, plane, raw);
     return hipGetLastError();
@@ -108,7 +122,8 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__
 hipError_t launch_maxpool2(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s) {
     long total = (long)N * (H / 2) * (W / 2) * (C / 4);
     const dim3 grid((unsigned)((total + 255) / 256));
-    if (split == 2) hipLaunchKernelGGL(maxpool2_kernel<2>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
+    if (split == 4) hipLaunchKernelGGL(maxpool2_kernel<4>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
+    else if (split == 2) hipLaunchKernelGGL(maxpool2_kernel<2>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
     else if (split) hipLaunchKernelGGL(maxpool2_kernel<1>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
     else hipLaunchKernelGGL(maxpool2_kernel<0>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
     return hipGetLastError();
@@ -178,7 +193,7 @@ __global__ __launch_bounds__(256) void maxpool3z_oct_kernel(const float* __restr
 }
 hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    if (split && C % 8 == 0) {
+    if (split && split != 4 && C % 8 == 0) {
         const long tot8 = (long)N * Ho * Wo * (C / 8);
         const dim3 g8((unsigned)((tot8 + 255) / 256));
         if (split == 2) hipLaunchKernelGGL(maxpool3z_oct_kernel<true>, g8, dim3(256), 0, s, x, y, N, H, W, C / 8, plane_in, plane_out);
@@ -187,7 +202,8 @@ hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C
     }
     long total = (long)N * Ho * Wo * (C / 4);
     const dim3 grid((unsigned)((total + 255) / 256));
-    if (split == 2) hipLaunchKernelGGL(maxpool3z_kernel<2>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
+    if (split == 4) hipLaunchKernelGGL(maxpool3z_kernel<4>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
+    else if (split == 2) hipLaunchKernelGGL(maxpool3z_kernel<2>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
     else if (split) hipLaunchKernelGGL(maxpool3z_kernel<1>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
     else hipLaunchKernelGGL(maxpool3z_kernel<0>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
     return hipGetLastError();
@@ -245,15 +261,24 @@ __global__ __launch_bounds__(256) void conv_smalln_thread_kernel(const SmallNPar
         }
     }
     if (p.out_split) {            // NOUT == 2: one bf16 pair per plane
-        unsigned h, l;
-        if (p.out_f16) split2_t<true>(f32x2_t{smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)}, h, l);
-        else split2_t<false>(f32x2_t{smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)}, h, l);
+        unsigned h, l, m = 0u;
+        const f32x2_t v2 = {smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)};
+        if (p.x3) split2_x3(v2, h, m, l);
+        else if (p.out_f16) split2_t<true>(v2, h, l);
+        else split2_t<false>(v2, h, l);
+        uint16_t* const o16 = reinterpret_cast<uint16_t*>(p.out);
         if (p.out_c == 8) {       // one zero-padded channel octet per pixel (source of the direct 3x3 kernel)
-            reinterpret_cast<u32x4_t*>(p.out)[pix] = (u32x4_t){h, 0u, 0u, 0u};
-            if (!p.out_f16) reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(p.out) + p.out_plane)[pix] = (u32x4_t){l, 0u, 0u, 0u};
+            reinterpret_cast<u32x4_t*>(o16)[pix] = (u32x4_t){h, 0u, 0u, 0u};
+            if (p.x3) {
+                reinterpret_cast<u32x4_t*>(o16 + p.out_plane)[pix] = (u32x4_t){m, 0u, 0u, 0u};
+                reinterpret_cast<u32x4_t*>(o16 + 2 * p.out_plane)[pix] = (u32x4_t){l, 0u, 0u, 0u};
+            } else if (!p.out_f16) reinterpret_cast<u32x4_t*>(o16 + p.out_plane)[pix] = (u32x4_t){l, 0u, 0u, 0u};
         } else {
-            reinterpret_cast<unsigned*>(p.out)[pix] = h;
-            if (!p.out_f16) reinterpret_cast<unsigned*>(reinterpret_cast<uint16_t*>(p.out) + p.out_plane)[pix] = l;
+            reinterpret_cast<unsigned*>(o16)[pix] = h;
+            if (p.x3) {
+                reinterpret_cast<unsigned*>(o16 + p.out_plane)[pix] = m;
+                reinterpret_cast<unsigned*>(o16 + 2 * p.out_plane)[pix] = l;
+            } else if (!p.out_f16) reinterpret_cast<unsigned*>(o16 + p.out_plane)[pix] = l;
         }
     } else {
         float* o = p.out + pix * NOUT;
@@ -430,7 +455,12 @@ bool conv_smalln_tiled(int in_split, int k, int W, int C, int nout, unsigned sw)
 hipError_t launch_conv_smalln(const SmallNParams& p, hipStream_t s) {
     if (p.in_sub && !(conv_smalln_tiled(p.in_split, p.k, p.W, p.C, p.nout, p.sw) && p.zero16)) return hipErrorInvalidValue;   // sub-planes: tiled kernel only
     if (p.out_split && (p.nout != 2 || p.k * p.k * p.C > 2048)) return hipErrorInvalidValue;
-    if (p.in_split && p.f16 == 2) {      // fp16 hi + lo input: the per-thread / per-wave kernels only
+    if (p.in_split && p.x3) {            // bf16 x 3 input: the per-thread / per-wave kernels (exact f32 arithmetic on the reconstructed values)
+        if (p.in_sub) return hipErrorInvalidValue;
+        SmallNParams q = p;
+        q.sw |= SW_NO_SMALLN_TILE;
+        launch_smalln_t<4>(q, s);
+    } else if (p.in_split && p.f16 == 2) {      // fp16 hi + lo input: the per-thread / per-wave kernels only
         if (p.in_sub || p.out_split) return hipErrorInvalidValue;
         SmallNParams q = p;
         q.sw |= SW_NO_SMALLN_TILE;
@@ -449,7 +479,8 @@ __global__ __launch_bounds__(256) void unsplit_kernel(const float* __restrict__ 
     const long pix = i / Ctf;
     const int c = (int)(i - pix * Ctf);
     const uint16_t* h = reinterpret_cast<const uint16_t*>(x) + (sub ? (size_t)(c >> 4) * sub + (size_t)pix * 16 + (c & 15) : (size_t)pix * C + c);
-    if (f16 == 2) y[i] = (float)__builtin_bit_cast(_Float16, h[0]) + (float)__builtin_bit_cast(_Float16, h[plane]);      // fp16 hi + lo
+    if (f16 < 0) y[i] = (__uint_as_float((unsigned)h[0] << 16) + __uint_as_float((unsigned)h[plane] << 16)) + __uint_as_float((unsigned)h[2 * plane] << 16);   // bf16 x 3
+    else if (f16 == 2) y[i] = (float)__builtin_bit_cast(_Float16, h[0]) + (float)__builtin_bit_cast(_Float16, h[plane]);      // fp16 hi + lo
     else if (f16) y[i] = (float)__builtin_bit_cast(_Float16, h[0]);                   // ONE fp16 plane
     else y[i] = __uint_as_float((unsigned)h[0] << 16) + __uint_as_float((unsigned)h[plane] << 16);
 }

@@ -37,7 +37,8 @@ struct Builder {
         TensorDesc t;
         t.name = name; t.N = N; t.H = H; t.W = W; t.C = C; t.Ctf = C;
         t.fmt = p.prec ? 1 : 0;          // the split engine keeps its activations as split-bf16 planes
-        t.bytes = (size_t)N * H * W * C * sizeof(float);
+        t.x3 = p.x3;
+        t.bytes = (size_t)N * H * W * C * (p.x3 ? 6 : sizeof(float));        // bf16 x 3: three 16-bit planes
         p.tensors.push_back(t);
         p.tensor_by_name[name] = (int)p.tensors.size() - 1;
         return (int)p.tensors.size() - 1;
@@ -58,6 +59,7 @@ struct Builder {
             default: n = 1; for (int j = 0; j < s.rank; ++j) n *= (size_t)s.shape[j];
         }
         s.bytes = n * sizeof(float);
+        if (p.x3 && (layout == WL_IGEMM_SPLIT || layout == WL_DIRECT_SPLIT)) { s.x3 = 1; s.bytes = n * 6; }      // three bf16 planes
         p.weights.push_back(s);
         p.weight_by_name[name] = (int)p.weights.size() - 1;
         return (int)p.weights.size() - 1;
@@ -188,7 +190,7 @@ struct Builder {
         const TensorDesc& t = p.tensors[src];
         // a 3x3 head whose output feeds the next iconv (disp4..disp2, written as one zero-padded octet per pixel) is a direct
         // conv on the 16-wide MFMA: its two real output channels ride in a 16-column weight image
-        if (feeds_conv && p.prec && k == 3 && t.W % 32 == 0 && t.C % 8 == 0 && nout <= 8 && nout == cout_tf &&
+        if (feeds_conv && p.prec && !p.x3 && k == 3 && t.W % 32 == 0 && t.C % 8 == 0 && nout <= 8 && nout == cout_tf &&
             !std::getenv("SEMDEPTH_NO_DIRECT") && !std::getenv("SEMDEPTH_NO_N16") && !std::getenv("SEMDEPTH_NO_MFMA_HEADS")) {
             op.kind = OP_CONV_DIRECT; op.stride = 1;
             op.nchunks = (t.C + 15) / 16;
@@ -225,7 +227,7 @@ struct Builder {
         const int Ho = zero3 ? (t.H - 1) / 2 + 1 : t.H / 2, Wo = zero3 ? (t.W - 1) / 2 + 1 : t.W / 2;
         // a direct conv whose only consumer is this pool applies it in its epilogue (max commutes with bias + ReLU/ELU);
         // the full-resolution tensor is then never written
-        if (!zero3 && !p.ops.empty() && p.ops.back().kind == OP_CONV_DIRECT && p.ops.back().dst == src && t.H % 2 == 0 && t.W % 2 == 0 &&
+        if (!zero3 && !(p.x3 && std::getenv("SEMDEPTH_X3_NO_POOL_FUSE")) && !p.ops.empty() && p.ops.back().kind == OP_CONV_DIRECT && p.ops.back().dst == src && t.H % 2 == 0 && t.W % 2 == 0 &&
             (p.ops.back().act == ACT_RELU || p.ops.back().act == ACT_ELU || p.ops.back().act == ACT_NONE) && !std::getenv("SEMDEPTH_NO_POOL_FUSE")) {
             OpDesc& prod = p.ops.back();
             prod.fuse_pool = 1;
@@ -235,7 +237,7 @@ struct Builder {
             return prod.dst;
         }
         // the LDS-DMA conv kernel does the same by walking its output pixels in 2x2-window-major order
-        if (!zero3 && p.prec && !p.ops.empty() && p.ops.back().kind == OP_CONV && p.ops.back().dst == src && p.ops.back().vec &&
+        if (!zero3 && p.prec && !p.x3 && !p.ops.empty() && p.ops.back().kind == OP_CONV && p.ops.back().dst == src && p.ops.back().vec &&
             p.ops.back().nsrc == 1 && p.ops.back().Kvec == p.ops.back().Kpad && p.ops.back().Kpad >= 64 && t.C % 64 == 0 &&
             p.ops.back().residual < 0 && t.H % 2 == 0 && t.W % 2 == 0 &&
             (p.ops.back().act == ACT_RELU || p.ops.back().act == ACT_ELU || p.ops.back().act == ACT_NONE) && !std::getenv("SEMDEPTH_NO_POOL_FUSE") &&
@@ -256,7 +258,7 @@ struct Builder {
     // LDS-tiled few-channel heads is handed over as 16-channel sub-planes (TensorDesc::planar16): the reader's 16-channel
     // chunk of a pixel row is then one contiguous run instead of 32 bytes out of every pixel's line
     void mark_planar() {
-        if (!p.prec || std::getenv("SEMDEPTH_NO_PLANAR")) return;
+        if (!p.prec || p.x3 || std::getenv("SEMDEPTH_NO_PLANAR")) return;     // (bf16 x 3: plain NHWC planes everywhere)
         const bool wide = !std::getenv("SEMDEPTH_NO_PLANAR_WIDE");
         for (size_t ti = 0; ti < p.tensors.size(); ++ti) {
             TensorDesc& t = p.tensors[ti];
@@ -281,7 +283,7 @@ struct Builder {
 
     // precision plan: mark the conv layers named in p.f16_spec, then close the choice under the one-format-per-tensor rule
     void apply_precision_plan() {
-        if (!p.prec || p.f16_spec.empty()) return;
+        if (!p.prec || p.x3 || p.f16_spec.empty()) return;
         std::vector<std::string> toks;
         {
             size_t a = 0;
@@ -396,7 +398,7 @@ struct Builder {
             if (s.owner >= 0) continue;
             s.offset = off;
             const bool ig = s.layout == WL_IGEMM || s.layout == WL_IGEMM_SPLIT;
-            off += align_up(ig ? (size_t)s.Ktotal * s.CoutPad * sizeof(float) : s.bytes);
+            off += align_up(ig ? (size_t)s.Ktotal * s.CoutPad * (s.x3 ? 6 : sizeof(float)) : s.bytes);
         }
         for (auto& s : p.weights) if (s.owner >= 0) s.offset = p.weights[s.owner].offset;
         for (auto& op : p.ops)
@@ -443,7 +445,7 @@ struct Builder {
 NetPlan build_fcn8s(int frames, int H, int W, int prec, const char* f16_layers) {
     if (H % 32 || W % 32) throw std::runtime_error("FCN-8s needs H, W multiples of 32");
     Builder b;
-    b.p.prec = prec; b.p.f16_spec = (prec && f16_layers) ? f16_layers : "";
+    b.p.prec = prec ? 1 : 0; b.p.x3 = prec == 2; b.p.f16_spec = (prec == 1 && f16_layers) ? f16_layers : "";
     b.p.net = "fcn8s"; b.p.frames = frames; b.p.images = frames; b.p.H = H; b.p.W = W;
     int x = b.tensor("input_pre", frames, H, W, 4);      // 4th channel is zero: float4 gathers in conv1_1
     b.p.tensors[x].Ctf = 3;
@@ -459,7 +461,7 @@ NetPlan build_fcn8s(int frames, int H, int W, int prec, const char* f16_layers) 
             const int xin = x;
             x = b.conv(n, {{x, 0}}, ch[s], 3, 1, ACT_RELU, "vgg/" + n + "/filter", "vgg/" + n + "/biases");
             // conv1_1 (stem kernel) -> conv1_2 (direct kernel): hand the 64 channels over as four 16-channel sub-planes
-            if (s == 0 && j == 1 && prec && b.p.ops.back().kind == OP_CONV_DIRECT && b.p.tensors[xin].C == 64 && W % 32 == 0 &&
+            if (s == 0 && j == 1 && prec == 1 && b.p.ops.back().kind == OP_CONV_DIRECT && b.p.tensors[xin].C == 64 && W % 32 == 0 &&
                 !std::getenv("SEMDEPTH_NO_PLANAR") && !std::getenv("SEMDEPTH_NO_STEM")) {
                 b.p.tensors[xin].planar16 = 1;
             }
@@ -505,7 +507,7 @@ NetPlan build_monodepth(int encoder, int frames, int H, int W, int prec, const c
     const int mult = encoder == 0 ? 128 : 64;
     if (H % mult || W % mult) throw std::runtime_error("monodepth needs H, W multiples of 128 (vgg) / 64 (resnet50)");
     Builder b;
-    b.p.prec = prec; b.p.f16_spec = (prec && f16_layers) ? f16_layers : "";
+    b.p.prec = prec ? 1 : 0; b.p.x3 = prec == 2; b.p.f16_spec = (prec == 1 && f16_layers) ? f16_layers : "";
     b.p.net = encoder == 0 ? "monodepth-vgg" : "monodepth-resnet50";
     b.p.frames = frames; b.p.images = 2 * frames; b.p.H = H; b.p.W = W;
     const int N = 2 * frames;
@@ -623,11 +625,12 @@ static inline void f16_split(float w, uint16_t& hi, uint16_t& lo) {
 
 // ---------------------------------------------------------------------------------------------
 void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& out) {
-    out.assign(s.bytes / sizeof(float), 0.f);
+    out.assign((s.bytes + sizeof(float) - 1) / sizeof(float), 0.f);
     if (s.layout == WL_IGEMM || s.layout == WL_IGEMM_SPLIT) {
         const bool split = s.layout == WL_IGEMM_SPLIT;
         uint16_t* hi = reinterpret_cast<uint16_t*>(out.data());
-        uint16_t* lo = hi + (size_t)s.Kpad * s.CoutPad;
+        uint16_t* lo = hi + (size_t)s.Kpad * s.CoutPad;             // (bf16 x 3: the mid plane; the lo plane follows it)
+        uint16_t* lo3 = lo + (size_t)s.Kpad * s.CoutPad;
         auto bf16 = [](float v) -> uint16_t {          // round to nearest even, like v_cvt_pk_bf16_f32
             uint32_t u; std::memcpy(&u, &v, 4);
             u += 0x7FFFu + ((u >> 16) & 1u);
@@ -661,7 +664,9 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
                             if (f16) { f16_split(src[n], hi[base + n * 8], lo[base + n * 8]); continue; }
                             const uint16_t h = bf16(src[n]);
                             hi[base + n * 8] = h;
-                            lo[base + n * 8] = bf16(src[n] - bf16_to_f(h));
+                            const float r1 = src[n] - bf16_to_f(h);
+                            lo[base + n * 8] = bf16(r1);
+                            if (s.x3) lo3[base + n * 8] = bf16(r1 - bf16_to_f(lo[base + n * 8]));        // exact: w = hi + mid + lo
                         }
                     }
                 }
@@ -685,11 +690,13 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
                         const float* src = w + ((int64_t)tap * Ctf + cb_tf + c) * Cout;
                         const size_t base = (((size_t)chunk * 9 + tap) * 2 + oct) * s.CoutPad * 8 + e;
                         for (int64_t n = 0; n < Cout; ++n) {
-                            uint16_t* hi = hi0 + (size_t)(n / s.CoutPad) * 2 * plane + base + (n % s.CoutPad) * 8;
+                            uint16_t* hi = hi0 + (size_t)(n / s.CoutPad) * (s.x3 ? 3 : 2) * plane + base + (n % s.CoutPad) * 8;
                             if (s.f16) { f16_split(src[n], *hi, hi[plane]); continue; }
                             const uint16_t h = bf16(src[n]);
                             *hi = h;
-                            hi[plane] = bf16(src[n] - bf16_to_f(h));
+                            const float r1 = src[n] - bf16_to_f(h);
+                            hi[plane] = bf16(r1);
+                            if (s.x3) hi[2 * plane] = bf16(r1 - bf16_to_f(hi[plane]));                    // exact: w = hi + mid + lo
                         }
                     }
             cb_tf += s.srcCtf[i];

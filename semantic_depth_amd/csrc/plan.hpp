@@ -18,6 +18,7 @@ struct TensorDesc {
     int fmt = 0;                      // 0: f32 NHWC; 1: split-bf16 planes (split_fmt.hpp)
     int f16 = 0;                      // 1: ONE fp16 plane, 2: fp16 hi + lo planes, instead of two bf16 planes (split_fmt.hpp): every conv that reads it runs the
                                       // 2-product scheme x * (w_hi + w_lo) (precision plan, see NetPlan::f16_spec)
+    int x3 = 0;                       // 1: bf16 x 3 planes (SD_PREC_BF16X3; 6 bytes per element, planes at 0, plane, 2 * plane)
     int planar16 = 0;                 // split planes stored as C/16 sub-planes of 16 channels ([C/16][N][H][W][16] per plane): the
                                       // producer is the stem kernel, the only consumer a direct conv, whose 16-channel halo DMA
                                       // then reads whole 128-byte lines
@@ -39,6 +40,7 @@ struct WeightSlot {
     int nsrc = 1, srcCtf[3] = {0, 0, 0}, srcCpad[3] = {0, 0, 0};   // WL_IGEMM: channel structure of the K axis
     int vec = 0;           // 1: K axis is ordered (32-channel block, tap, channel) instead of (tap, channel)
     int f16 = 0;           // split layouts: two fp16 planes, hi = fp16(w), lo = fp16(w - hi) (the 2-product scheme of split_fmt.hpp)
+    int x3 = 0;            // split layouts: THREE bf16 planes hi, mid, lo (exact: w = hi + mid + lo), SD_PREC_BF16X3
     float scale = 1.f;     // the tensor is multiplied by this while it is loaded (monodepth stem with integer input: 1/255, see NetPlan::input_scale)
     // a slot may be a VIEW of rows [k_off, k_off+Kpad) of a larger device matrix of Ktotal rows owned by slot `owner`
     // (ResNet block: conv3 and the projection shortcut are one GEMM over the concatenated K axis); a bias view is ADDED
@@ -79,6 +81,7 @@ struct NetPlan {
     int images = 0;        // images per chunk (monodepth: 2 per frame)
     int H = 0, W = 0;
     int prec = 0;          // 0: exact f32 MFMA, 1: split engine (planes of split_fmt.hpp)
+    int x3 = 0;            // split engine with bf16 x 3 planes everywhere (SD_PREC_BF16X3): fp32-grade, six MFMA products per product
     // precision plan of the split engine: which conv layers run the 2-product fp16 scheme (fp16x2 activations x fp16 weights)
     // instead of the 3-product bf16 one.  f16_spec = what was asked for (comma-separated op names, a trailing '*' matches a
     // prefix, "*" = every layer, empty = none); f16_ops = the layers that run it after the consistency closure (a tensor has ONE
@@ -99,6 +102,7 @@ struct NetPlan {
     float input_scale = 1.f / 255.f;
 };
 
+// prec: 0 exact f32 MFMA, 1 split engine (bf16 x 2 + the fp16 forms of f16_layers), 2 split engine with bf16 x 3 planes (f16_layers ignored)
 NetPlan build_fcn8s(int frames, int H, int W, int prec, const char* f16_layers = nullptr);
 NetPlan build_monodepth(int encoder /*0 vgg, 1 resnet50*/, int frames, int H, int W, int prec, const char* f16_layers = nullptr);
 

@@ -11,6 +11,12 @@
 //   fp16 x 2 planes (hi as above + lo = RNE(v - hi)): for the few layers whose input tensor is precision-critical (it also feeds a
 //     score head) the plan keeps 22 bits of the activation and drops the weight's low part instead: TWO products x_hi*w_hi + x_lo*w_hi
 //     (conv_direct X2).  Any other fp16 layer reads the hi plane of such a tensor as if it were the one-plane format.
+//   bf16 x 3 planes (SD_PREC_BF16X3; the fp32-grade split engine): hi = RNE(v), mid = RNE(v - hi), lo = v - hi - mid -- an f32 value is
+//     the EXACT sum of three bf16 values (8 + 8 + 8 significand bits, the same exponent range), so nothing is rounded when a tensor or a
+//     weight is stored; planes at element offsets 0, plane, 2 * plane.  A product is SIX MFMA products
+//        x_hi*w_hi + x_hi*w_mid + x_mid*w_hi + x_mid*w_mid + x_hi*w_lo + x_lo*w_hi
+//     (every bf16 x bf16 product is exact in the f32 accumulator); the three dropped terms x_mid*w_lo, x_lo*w_mid, x_lo*w_lo are below
+//     2^-23 |x w| together, the size of ONE f32 rounding of the product, which an f32 FMA chain commits on every accumulation anyway.
 // The MFMA operands of the conv engine are read straight from the planes (16-byte runs of 8 channels), nothing is converted at
 // load time.  The F16 template argument of the helpers selects the format; their `l` argument is ignored / zero for fp16.
 #pragma once
@@ -50,6 +56,32 @@ __device__ __forceinline__ void split2(f32x2_t v, unsigned& h, unsigned& l) {
 __device__ __forceinline__ void split4(f32x4_t v, uint2& h, uint2& l) {
     split2(f32x2_t{v[0], v[1]}, h.x, l.x);
     split2(f32x2_t{v[2], v[3]}, h.y, l.y);
+}
+
+// bf16 x 3: exact three-way split and its inverse (both exact for finite v above the bf16 subnormal range)
+__device__ __forceinline__ void split2_x3(f32x2_t v, unsigned& h, unsigned& m, unsigned& l) {
+    const bf16x2_t hb = __builtin_convertvector(v, bf16x2_t);
+    const f32x2_t r1 = v - __builtin_convertvector(hb, f32x2_t);              // exact (<= 16 significant bits)
+    const bf16x2_t mb = __builtin_convertvector(r1, bf16x2_t);
+    const f32x2_t r2 = r1 - __builtin_convertvector(mb, f32x2_t);             // exact (<= 8 significant bits)
+    const bf16x2_t lb = __builtin_convertvector(r2, bf16x2_t);                // exact
+    h = __builtin_bit_cast(unsigned, hb);
+    m = __builtin_bit_cast(unsigned, mb);
+    l = __builtin_bit_cast(unsigned, lb);
+}
+__device__ __forceinline__ void split4_x3(f32x4_t v, uint2& h, uint2& m, uint2& l) {
+    split2_x3(f32x2_t{v[0], v[1]}, h.x, m.x, l.x);
+    split2_x3(f32x2_t{v[2], v[3]}, h.y, m.y, l.y);
+}
+__device__ __forceinline__ f32x2_t recon2_x3(unsigned h, unsigned m, unsigned l) {
+    f32x2_t v;
+    v[0] = (bf16lo_to_f(h) + bf16lo_to_f(m)) + bf16lo_to_f(l);
+    v[1] = (bf16hi_to_f(h) + bf16hi_to_f(m)) + bf16hi_to_f(l);
+    return v;
+}
+__device__ __forceinline__ f32x4_t recon4_x3(uint2 h, uint2 m, uint2 l) {
+    const f32x2_t a = recon2_x3(h.x, m.x, l.x), b = recon2_x3(h.y, m.y, l.y);
+    return f32x4_t{a[0], a[1], b[0], b[1]};
 }
 
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));

@@ -52,16 +52,22 @@ def err_report(a, b):
             "rms_rel": float(np.sqrt((d * d).mean()) / scale)}
 
 
-# Bounds on the strict per-element figure, by engine, = 2 x the worst value measured at 512 x 1024 (profiles/r03_strict_error.txt):
-# an element of magnitude >= 1 % of the tensor's maximum is then within this RELATIVE error of the oracle's, 99 % of them within
-# the p99 bound.
-STRICT_P99 = {"f32": 2e-5, "bf16x3": 2e-5, "bf16x2": 2e-4, "mixed": 6e-3, "plan": 6e-3}
-STRICT_MAX = {"f32": 2e-4, "bf16x3": 2e-4, "bf16x2": 2e-3, "mixed": 5e-2, "plan": 5e-2}
+# Bounds on the strict per-element figure |delta| / (|ref| + 1e-2 max|ref|), by engine and tensor kind, = 2 x the worst value measured at
+# 512 x 1024 (profiles/r03_strict_error_*.txt: the plan and bf16x2 over 10 / 4 weight + frame seeds against the f32 engine; the f32 engine
+# against the CPU oracle in the bench run and in test_gpu_pipeline): an element of magnitude >= 1 % of the tensor's maximum is then within
+# STRICT_MAX relative error of the oracle's, 99 % of the elements within STRICT_P99.  The logits' figures are an order of magnitude above the
+# disparities': the three logits planes cross zero everywhere, the disparities are 0.3 * sigmoid.  Two f32 implementations with
+# different summation orders (the f32 engine vs the torch-CPU oracle) already differ by 3e-5 / 1.7e-4 on the logits.
+STRICT_P99 = {("f32", "logits"): 7e-5, ("bf16x3", "logits"): 7e-5, ("bf16x2", "logits"): 6e-4, ("mixed", "logits"): 6e-4, ("plan", "logits"): 1.4e-2,
+              ("f32", "disp"): 4e-6, ("bf16x3", "disp"): 4e-6, ("bf16x2", "disp"): 1.3e-5, ("mixed", "disp"): 9e-4, ("plan", "disp"): 9e-4}
+STRICT_MAX = {("f32", "logits"): 4e-4, ("bf16x3", "logits"): 4e-4, ("bf16x2", "logits"): 4e-3, ("mixed", "logits"): 4e-3, ("plan", "logits"): 9e-2,
+              ("f32", "disp"): 1e-5, ("bf16x3", "disp"): 1e-5, ("bf16x2", "disp"): 3e-5, ("mixed", "disp"): 2e-3, ("plan", "disp"): 2e-3}
 
 
-def assert_close(got, ref, precision, tol=1e-3, what=""):
-    """the parity bar: max-normalised error within north_star's 1e-3 AND the strict per-element figure within the engine's bound"""
+def assert_close(got, ref, precision, tol=1e-3, what="", kind="logits"):
+    """the parity bar: max-normalised error within north_star's 1e-3 AND the strict per-element figure within the engine's bound
+    (``kind``: 'logits' or 'disp')"""
     rep = err_report(got, ref)
     assert rep["max_rel"] < tol, (what, precision, rep)
-    assert rep["strict_p99"] < STRICT_P99[precision] and rep["strict_max"] < STRICT_MAX[precision], (what, precision, rep)
+    assert rep["strict_p99"] < STRICT_P99[(precision, kind)] and rep["strict_max"] < STRICT_MAX[(precision, kind)], (what, precision, rep)
     return rep

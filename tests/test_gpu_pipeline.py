@@ -83,7 +83,7 @@ def test_monodepth_full_size_matches_oracle(precision, oracle_full, keep_taps):
     pp, raw = eng.monodepth_forward(dev(o["frames"]), want_raw=True)
     raw = raw.cpu().numpy()[0]
     ref_raw = o["scales"][1][..., 0]
-    rep = assert_close(raw, ref_raw, precision, TOL, "raw disparity pair")
+    rep = assert_close(raw, ref_raw, precision, TOL, "raw disparity pair", kind="disp")
     print("monodepth-resnet50 512x1024 disparity", precision, rep)
     for lvl in (4, 3, 2):
         got = eng.net_tensor(L.SD_NET_MONODEPTH, f"dec/disp{lvl}").cpu().numpy()
@@ -129,7 +129,7 @@ def test_nets_b8_full_size_match_oracle(precision, oracle_b8):
         assert np.array_equal(pp[b], fusion.post_processing(raw[b]).astype(np.float32)), b
         assert relerr(pp[b], fusion.post_processing(o["disp"][b].astype(np.float32)).astype(np.float32)) < TOL, b
         assert_close(lg[b], o["logits"][b], precision, TOL, f"logits of frame {b}")
-        assert_close(raw[b], o["disp"][b], precision, TOL, f"raw disparity of frame {b}")
+        assert_close(raw[b], o["disp"][b], precision, TOL, f"raw disparity of frame {b}", kind="disp")
     print("B=8 512x1024", precision, "worst logits", worst_l, "worst disparity", worst_d)
     assert worst_l < TOL and worst_d < TOL
 
@@ -153,7 +153,7 @@ def test_nets_b32_as_benchmarked_match_oracle(precision, oracle_b8):
         pp, raw = eng.monodepth_forward(fr, want_raw=True)
         for i, b in enumerate(slots):
             rl = assert_close(out["logits"][b].cpu().numpy(), o["logits"][i], precision, TOL, f"logits of frame {b}")
-            rd = assert_close(raw[b].cpu().numpy(), o["disp"][i], precision, TOL, f"raw disparity of frame {b}")
+            rd = assert_close(raw[b].cpu().numpy(), o["disp"][i], precision, TOL, f"raw disparity of frame {b}", kind="disp")
             _, road_r, _, am_r = nets.softmax_masks(o["logits"][i:i + 1])
             assert float((out["road"][b].cpu().numpy().astype(bool) != road_r[0]).mean()) < 2e-3, b
             assert float((out["argmax"][b].cpu().numpy() != am_r[0]).mean()) < 2e-3, b
