@@ -56,6 +56,8 @@ PEAK_F32, PEAK_3P, PEAK_2P, PEAK_1P, PEAK_6P = 157.3, 2500.0 / 3.0, 2500.0 / 2.0
 DEFAULT_PRECISION = "f32"
 DTYPE = {
     "f32": "f32 (exact: v_mfma_f32_16x16x4_f32)",
+    "bf16x3": "f32 operands carried EXACTLY as three bf16 planes each (v = hi + mid + lo, 8+8+8 significand bits), 6 bf16 MFMA products per "
+              "product (the three dropped cross terms are below 2^-23 of the product), f32 accumulate",
     "bf16x2": "bf16x2 split operands (hi+lo, 16 mantissa bits), 3 bf16 MFMA products per product, f32 accumulate",
     "mixed": "FCN-8s: bf16x2 split operands, 3 bf16 MFMA products; monodepth: fp16 activations x fp16x2 split weights (22 bits), "
              "2 fp16 MFMA products; f32 accumulate",

@@ -14,13 +14,13 @@ for line in r.stderr.splitlines():
     if m:
         cur = m.group(1); rows[cur] = {}
         continue
-    m = re.search(r"remark: \S+\s+(\w[\w \[\]/]*): (\d+)", line)
+    m = re.search(r"remark:\s+([\w \[\]/]+?): (\d+)", line)
     if m and cur:
         rows[cur][m.group(1).strip()] = int(m.group(2))
 for k, v in rows.items():
     spill = v.get("VGPRs Spill", 0) + v.get("SGPRs Spill", 0) + v.get("ScratchSize [bytes/lane]", 0)
     if "--all" in sys.argv or spill:
-        name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", k], capture_output=True, text=True).stdout.strip()
+        name = subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.strip()
         print(f"{name[:110]:110s} VGPR {v.get('VGPRs', 0):3d} AGPR {v.get('AGPRs', 0):3d} vspill {v.get('VGPRs Spill', 0):3d} sspill {v.get('SGPRs Spill', 0):3d} "
               f"scratch {v.get('ScratchSize [bytes/lane]', 0):4d} occ {v.get('Occupancy [waves/SIMD]', 0)} LDS {v.get('LDS Size [bytes/block]', 0)}")
 if r.returncode:

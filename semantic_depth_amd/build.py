@@ -21,6 +21,7 @@ SOURCES = [
     ("conv_split.hip", []),
     ("conv_dma.hip", []),
     ("conv_direct.hip", []),
+    ("conv_direct3.hip", []),
     ("conv_stem.hip", []),
     ("ops_misc.hip", []),
     ("resize.hip", []),
@@ -84,6 +85,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs.append(op)
         if force or _stale(op, [sp] + hdrs) or (src == "capi.cpp" and hash_changed):
             cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", sp, "-o", op] + extra
+            if src.endswith(".hip"):
+                cmd.append("-Rpass-analysis=kernel-resource-usage")      # registers / spills / LDS per kernel -> <obj>.remarks
             if src == "capi.cpp":
                 cmd.append(f'-DSD_SOURCE_HASH="{digest}"')
             if src.endswith(".cpp"):
@@ -97,6 +100,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("build failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        if "-Rpass-analysis=kernel-resource-usage" in cmd:
+            with open(cmd[cmd.index("-o") + 1] + ".remarks", "w") as f:
+                f.write("\n".join(ln for ln in r.stderr.splitlines() if "remark:" in ln))
         return r
 
     if jobs:
@@ -111,6 +117,30 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with open(stamp, "w") as f:
         f.write(digest)
     return LIB
+
+
+def kernel_resources() -> dict:
+    """{mangled kernel name: {"VGPRs": n, "VGPRs Spill": n, "SGPRs Spill": n, "ScratchSize [bytes/lane]": n, "LDS Size [bytes/block]": n, ...}}
+    from the resource-usage remarks hipcc wrote while the objects of THIS tree were compiled (csrc/build/*.remarks; empty when the
+    object directory did not travel, e.g. on the GPU box).  tests/test_abi.py holds the conv kernels to zero spilled VGPRs: a spill
+    in a register-capped instantiation halves a layer's speed without failing any numerics test (round 3)."""
+    import re
+    out = {}
+    if not os.path.isdir(OBJ):
+        return out
+    for f in sorted(os.listdir(OBJ)):
+        if not f.endswith(".remarks"):
+            continue
+        cur = None
+        for line in open(os.path.join(OBJ, f)):
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                cur = out.setdefault(m.group(1), {"file": f[:-len(".o.remarks")]})
+                continue
+            m = re.search(r"remark:\s+([\w \[\]/]+?): (\d+)", line)
+            if m and cur is not None:
+                cur[m.group(1)] = int(m.group(2))
+    return out
 
 
 if __name__ == "__main__":

@@ -313,7 +313,6 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
         // ---- epilogue: bias + activation, split once, LDS transpose (in the stage just consumed; the other one is being
         //      filled for the next tile), 16-byte runs of 8 channels per pixel and plane ----
         __builtin_amdgcn_s_barrier();
-        unsigned sat = 0;                                      // values the fp16 output formats clamped (split_fmt.hpp)
         auto epilogue = [&](auto tag, auto otag) {
             constexpr int ACT = decltype(tag)::value;
             constexpr int OF = decltype(otag)::value;          // output planes (the consumers' format): 0 bf16 hi+lo, 1 ONE fp16, 2 fp16 hi+lo
@@ -354,7 +353,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                             for (int r = 0; r < 4; ++r) v[r] = 4 * kg16 + r < p.nreal ? v[r] : 0.f;
                         }
                         uint2 h, l;
-                        split4_fmt<OF>(v, h, l, sat);
+                        split4_fmt<OF>(v, h, l, p.sat);
                         if (4 * kg16 < p.Cout) {
                             *reinterpret_cast<uint2*>(s16 + (16 * pb + c16) * R16 + kg16 * 8) = h;
                             if constexpr (!O16) *reinterpret_cast<uint2*>(s16 + 32 * R16 + (16 * pb + c16) * R16 + kg16 * 8) = l;
@@ -393,7 +392,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                     v += bias[r4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
-                    split4_fmt<OF>(v, hh[r4], ll[r4], sat);
+                    split4_fmt<OF>(v, hh[r4], ll[r4], p.sat);
                 }
                 const int pp = frow >> 1;                    // pooled pixel of this lane pair
 #pragma unroll
@@ -446,7 +445,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                     v += bias[r4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
-                    split4_fmt<OF>(v, hh[r4], ll[r4], sat);
+                    split4_fmt<OF>(v, hh[r4], ll[r4], p.sat);
                 }
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
@@ -493,7 +492,6 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
         else if (p.act == ACT_ELU) ep(ActTag<ACT_ELU>{});
         else if (N16 && p.act == ACT_SIGMOID03) ep(ActTag<ACT_SIGMOID03>{});
         else ep(ActTag<ACT_NONE>{});
-        sat_report(p.sat, sat);
         if (tid + (int)gridDim.x < items) cur = tile_of(tid + gridDim.x);
     }
 }

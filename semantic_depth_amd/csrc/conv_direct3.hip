@@ -1,0 +1,366 @@
+// Direct 3x3 stride-1 convolution of the fp32-grade split engine (SD_PREC_BF16X3): every layer conv_direct.hip takes under the other
+// split precisions (VGG conv1_2..conv5_3 with their pools, the ResNet 3x3 layers, the monodepth decoder), on THREE bf16 planes per
+// operand -- v = hi + mid + lo exactly (split_fmt.hpp) -- and SIX MFMA products per product:
+//        x*w  =  x_hi*w_hi + x_mid*w_hi + x_lo*w_hi  +  x_hi*w_mid + x_mid*w_mid  +  x_hi*w_lo     (+ three terms below 2^-23 |x w|)
+// Same tiling as conv_direct.hip (a workgroup of 8 waves owns a 16 x 32 pixel tile, passes of 64 output channels, per 16-channel chunk
+// the 18 x 34 halo tile is DMAed into LDS once and serves all nine taps), but three planes of X (60 KB) plus three of W (54 KB) per chunk
+// do not fit twice into 160 KB.  The products are therefore grouped BY WEIGHT PLANE into three phases per chunk,
+//        phase hi : W_hi  x (X_hi, X_mid, X_lo)      108 MFMAs per wave (NB = 2)
+//        phase mid: W_mid x (X_hi, X_mid)              72
+//        phase lo : W_lo  x (X_hi)                     36
+// X is double-buffered per chunk (2 x 60 KB) and the weight planes stream through a two-slot ring (2 x 18 KB): 156 KB + 2 KB of bias.
+// While a phase multiplies, the LDS-DMA brings the next weight plane and, spread over the hi / mid phases, the next chunk's X planes:
+//        phase hi issues  W_mid(c) + X_hi(c+1) + X_mid(c+1)      58 KB under 108 MFMAs
+//        phase mid issues W_lo(c)  + X_lo(c+1)                   38 KB under  72
+//        phase lo issues  W_hi(c+1)                              18 KB under  36
+// so every phase moves at most ~0.55 of the bytes the 16 B/clk L2 -> LDS path could move in its MFMA time.  One barrier per phase.
+// The (tile, pass, chunk, phase) sequence is one software pipeline across tiles (persistent workgroups, XCD-aware tile order).
+// Epilogue: bias + activation in f32 (the f32 engine's own ELU), the exact three-way split, LDS transpose in the consumed X buffer,
+// 16-byte runs of 8 channels per pixel and plane; optional fused 2x2 max pool.
+#include <cstdlib>
+#include "kernels.hpp"
+#include "split_fmt.hpp"
+
+namespace sd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// one LDS-DMA (64 lanes x 16 B, lane-linear destination); inline asm so hipcc neither counts nor serialises them (conv_dma.hip)
+__device__ __forceinline__ void d3dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+typedef int i32x8t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ DirectChunk d3load_chunk(const DirectChunk* ptr) {
+    i32x8t v;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ptr) : "memory");
+    DirectChunk e;
+    e.base = reinterpret_cast<const void*>(((unsigned long long)(unsigned)v[1] << 32) | (unsigned)v[0]);
+    e.H = v[2]; e.W = v[3]; e.C = v[4]; e.up = v[5]; e.nvalid = v[6]; e.pad = v[7];
+    return e;
+}
+
+constexpr int T3_TW = 32, T3_HW = T3_TW + 2, T3_WAVES = 8, T3_TH = 16, T3_HH = T3_TH + 2, T3_MT = 2;
+
+// NB = 32-channel blocks of output channels per pass (Cout <= 32 NB).  UP: every source is read through a x2 nearest-neighbour
+// upsample (the upconv layers): the LDS tile holds the 10 x 18 SOURCE pixels under the halo (conv_direct.hip).
+template <int NB, bool UP>
+__global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectParams p) {
+    constexpr int S_HH = UP ? T3_HH / 2 + 1 : T3_HH, S_HW = UP ? T3_HW / 2 + 1 : T3_HW;      // stored tile
+    constexpr int XI = (S_HH * S_HW * 2 + 63) / 64;            // DMA instructions per halo plane (2 octet slots per pixel)
+    constexpr int XUNITS = XI * 64;
+    constexpr int XS = (XI + T3_WAVES - 1) / T3_WAVES;         // X-DMA slots per wave and plane
+    constexpr int WI = 9 * NB;                                 // DMA instructions per weight plane
+    constexpr int WUNITS = 9 * 2 * 32 * NB;                    // taps x octets x output channels
+    constexpr int WS = (WI + T3_WAVES - 1) / T3_WAVES;         // weight-DMA slots per wave and plane
+    constexpr int ROW = 64 * NB + 16;                          // epilogue slab row (bytes per pixel and plane, + pad)
+    constexpr int SLAB = T3_WAVES * 32 * ROW / 16;             // units: one plane of 32 pixels per wave
+    constexpr int XBUF = 3 * XUNITS < SLAB ? SLAB : 3 * XUNITS;
+    static_assert((2 * XBUF + 2 * WUNITS) * 16 + 2048 <= 160 * 1024, "two X buffers + two weight slots + bias fit the LDS of a CU");
+    static_assert(WS + 2 * XS <= 9 * NB, "one DMA slot per MFMA group of a phase");
+    __shared__ __attribute__((aligned(16))) u32x4 lds[2 * XBUF + 2 * WUNITS];
+    __shared__ __attribute__((aligned(16))) float sbias[512];
+    auto hpix = [](int hy, int hx) { return UP ? ((hy + 1) >> 1) * S_HW + ((hx + 1) >> 1) : hy * S_HW + hx; };
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int tiles_x = p.W / T3_TW, tiles_y = (p.H + T3_TH - 1) / T3_TH;
+    const int total = tiles_x * tiles_y * p.N;
+    const u32x4* const zero = reinterpret_cast<const u32x4*>(p.zero16);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds;      // LDS byte address
+    const int frow = lane & 31, fk = lane >> 5;
+
+    // work item = (tile, pass of <= 64 output channels); the passes of a tile are neighbouring items
+    const int items = total * p.nsplit;
+    struct Tile { int img, ty0, tx0, half; };
+    auto tile_of = [&](int it) {
+        if ((items & 7) == 0) it = (it & 7) * (items >> 3) + (it >> 3);     // neighbouring items (shared halos) on one XCD
+        Tile r;
+        int tid = it / p.nsplit;
+        r.half = it - tid * p.nsplit;
+        const int bx = tid % tiles_x; tid /= tiles_x;
+        r.tx0 = bx * T3_TW; r.ty0 = (tid % tiles_y) * T3_TH; r.img = tid / tiles_y;
+        return r;
+    };
+
+    // halo geometry of this lane's X-DMA slots (instruction j = wave + 8 i of a plane): constant over tiles and chunks.
+    // packed: ry | rx << 8 | octet << 19 | inside-halo << 20
+    int geo[XS];
+#pragma unroll
+    for (int i = 0; i < XS; ++i) {
+        const int j = wave + T3_WAVES * i;
+        const int u = j * 64 + lane;
+        const int pix = u >> 1;
+        const int oct = (u & 1) ^ ((pix >> 3) & 1);
+        const int ry = pix / S_HW, rx = pix - ry * S_HW;
+        geo[i] = ry | (rx << 8) | (oct << 19) | ((pix < S_HH * S_HW ? 1 : 0) << 20);
+    }
+    int sgy[XS], sgx[XS];
+    unsigned okA = 0, okB = 0;            // bit i: slot i reads an existing pixel (okB: ... and the first channel octet of a chunk)
+    auto set_tile = [&](const Tile& tl) {
+        okA = 0; okB = 0;
+#pragma unroll
+        for (int i = 0; i < XS; ++i) {
+            const int ry = geo[i] & 0xff, rx = (geo[i] >> 8) & 0xff;
+            const int gy = (UP ? (tl.ty0 >> 1) : tl.ty0) - 1 + ry, gx = (UP ? (tl.tx0 >> 1) : tl.tx0) - 1 + rx;
+            const bool in = ((geo[i] >> 20) & 1) && (unsigned)gy < (unsigned)(UP ? p.H >> 1 : p.H) && (unsigned)gx < (unsigned)(UP ? p.W >> 1 : p.W);
+            sgy[i] = gy; sgx[i] = gx;
+            okA |= (in ? 1u : 0u) << i;
+            okB |= ((in && !((geo[i] >> 19) & 1)) ? 1u : 0u) << i;
+        }
+    };
+    // a chunk in flight: source image + plane stride, its X buffer, its weight block (hi plane; plane stride = nchunks * WUNITS)
+    struct ChunkCtx { const uint16_t* img; size_t plane; unsigned rowel, C, okm, xbyte; int up; const u32x4* w; };
+    auto begin_chunk = [&](const DirectChunk& ch, const Tile& tl, int c, int buf) {
+        ChunkCtx k;
+        k.plane = (size_t)p.Nmax * ch.H * ch.W * ch.C;      // elements
+        k.img = reinterpret_cast<const uint16_t*>(ch.base) + (size_t)tl.img * ch.H * ch.W * ch.C;
+        k.rowel = (unsigned)(ch.W * ch.C); k.C = (unsigned)ch.C; k.up = UP ? 0 : ch.up;
+        k.okm = ch.nvalid >= 2 ? okA : okB;
+        k.xbyte = lds0 + (unsigned)(buf * XBUF * 16);
+        k.w = p.wt + ((size_t)(3 * tl.half) * p.nchunks + c) * WUNITS;
+        return k;
+    };
+    auto xslot = [&](const ChunkCtx& k, int pl, int i) {       // X-DMA instruction wave + 8 i of plane pl
+        const int j = wave + T3_WAVES * i;
+        if (j >= XI) return;
+        const unsigned off = (unsigned)(sgy[i] >> k.up) * k.rowel + ((unsigned)(sgx[i] >> k.up) * k.C + ((unsigned)(geo[i] >> 16) & 8u));
+        const uint16_t* src = k.img + (size_t)pl * k.plane + off;
+        d3dma16(((k.okm >> i) & 1u) ? reinterpret_cast<const u32x4*>(src) : zero, k.xbyte + (unsigned)((pl * XUNITS + j * 64) * 16));
+    };
+    auto wslot = [&](const u32x4* wbase, int pl, int i, int slot) {     // weight-DMA instruction wave + 8 i of plane pl into ring slot
+        const int jw = wave + T3_WAVES * i;
+        if (jw >= WI) return;
+        d3dma16(wbase + (size_t)pl * p.nchunks * WUNITS + jw * 64 + lane, lds0 + (unsigned)((2 * XBUF + slot * WUNITS + jw * 64) * 16));
+    };
+
+    sbias[threadIdx.x] = (int)threadIdx.x < p.nsplit * p.Cout ? p.bias[threadIdx.x] : 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    int tid = blockIdx.x;
+    if (tid >= items) return;
+    Tile cur = tile_of(tid);
+    // the issue cursor: the (tile, chunk) item whose X planes and W_hi go into the ring next
+    int itid = tid, ic = 0;
+    Tile icur = cur;
+    set_tile(icur);
+    auto advance = [&]() {
+        if (++ic == p.nchunks) { ic = 0; itid += gridDim.x; if (itid < items) { icur = tile_of(itid); set_tile(icur); } }
+    };
+    const u32x4* wcur;                   // weight block of the chunk being multiplied
+    {
+        const ChunkCtx k = begin_chunk(d3load_chunk(p.chunks), icur, 0, 0);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < XS; ++i) xslot(k, pl, i);
+#pragma unroll
+        for (int i = 0; i < WS; ++i) wslot(k.w, 0, i, 0);
+        wcur = k.w;
+        advance();
+    }
+    int g = 0, q = 0;                    // chunks / phases consumed so far
+    for (; tid < items; tid += gridDim.x) {
+        const int half = cur.half;
+        f32x16 acc[T3_MT][NB];
+#pragma unroll
+        for (int a = 0; a < T3_MT; ++a)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][nb][r] = 0.f;
+        for (int c = 0; c < p.nchunks; ++c, ++g) {
+            const bool more = itid < items;        // the cursor item exists: its X goes into buffer (g + 1) & 1 during this chunk
+            ChunkCtx kn;
+            const u32x4* const Xb = lds + (g & 1) * XBUF;
+            // one phase: NPX products of the weight plane in ring slot q & 1 with the first NPX planes of X; `issue(grp)` is called
+            // behind MFMA group grp (one DMA instruction per call)
+            auto phase = [&](auto npx_tag, auto&& issue) {
+                constexpr int NPX = decltype(npx_tag)::value;
+                const u32x4* const Wq = lds + 2 * XBUF + (q & 1) * WUNITS;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    u32x4 x[NPX][T3_MT + 2];
+#pragma unroll
+                    for (int r = 0; r < T3_MT + 2; ++r) {
+                        const int lp = hpix(T3_MT * wave + r, frow + dx);
+                        const int idx = lp * 2 + (fk ^ ((lp >> 3) & 1));
+#pragma unroll
+                        for (int pl = 0; pl < NPX; ++pl) x[pl][r] = Xb[pl * XUNITS + idx];
+                    }
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const u32x4 wv = Wq[((dy * 3 + dx) * 2 + fk) * (32 * NB) + nb * 32 + frow];
+#pragma unroll
+                            for (int pl = NPX - 1; pl >= 0; --pl)          // the smaller planes first
+#pragma unroll
+                                for (int a = 0; a < T3_MT; ++a)
+                                    acc[a][nb] = mfma_frag<false>(wv, x[pl][a + dy], acc[a][nb]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue((dx * 3 + dy) * NB + nb);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                }
+            };
+            // ---- phase hi: W_hi x (X_hi, X_mid, X_lo); brings W_mid of this chunk and X_hi, X_mid of the cursor chunk
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (more) kn = begin_chunk(d3load_chunk(p.chunks + ic), icur, ic, (g + 1) & 1);
+            phase(IntTag<3>{}, [&](int grp) {
+                if (grp < WS) wslot(wcur, 1, grp, (q + 1) & 1);
+                else if (more && grp < WS + 2 * XS) { const int s_ = grp - WS; xslot(kn, s_ / XS, s_ % XS); }
+            });
+            ++q;
+            // ---- phase mid: W_mid x (X_hi, X_mid); brings W_lo of this chunk and X_lo of the cursor chunk
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            phase(IntTag<2>{}, [&](int grp) {
+                if (grp < WS) wslot(wcur, 2, grp, (q + 1) & 1);
+                else if (more && grp < WS + XS) xslot(kn, 2, grp - WS);
+            });
+            ++q;
+            // ---- phase lo: W_lo x X_hi; brings W_hi of the cursor chunk
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            phase(IntTag<1>{}, [&](int grp) {
+                if (more && grp < WS) wslot(kn.w, 0, grp, (q + 1) & 1);
+            });
+            ++q;
+            if (more) { wcur = kn.w; advance(); }
+        }
+
+        // ---- epilogue: bias + activation, the exact three-way split, LDS transpose one plane at a time in the X buffer just consumed
+        //      (the other one is being filled for the next item), 16-byte runs of 8 channels per pixel and plane ----
+        __builtin_amdgcn_s_barrier();
+        auto epilogue = [&](auto tag) {
+            constexpr int ACT = decltype(tag)::value;
+            constexpr int SEGS = 4 * NB, PPP = 64 / SEGS;        // 16-byte segments per pixel, pixels per store pass
+            unsigned char* sh = reinterpret_cast<unsigned char*>(lds + ((g - 1) & 1) * XBUF) + wave * (32 * ROW);
+            const int seg = lane % SEGS, prow = lane / SEGS;
+            uint16_t* const out_hi = reinterpret_cast<uint16_t*>(p.out);
+            const int n0 = half * p.Cout;                 // first output channel of this pass
+            f32x4 bias[4 * NB];
+#pragma unroll
+            for (int r4 = 0; r4 < 4 * NB; ++r4) bias[r4] = *reinterpret_cast<const f32x4*>(sbias + n0 + 8 * r4 + 4 * fk);
+            if (p.pool) {
+                // fused 2x2 max pool: vertical max across the wave's two rows (same lane), horizontal across lane pairs
+                // (pixel = lane & 31), THEN bias + activation (monotonic) on a quarter of the values
+                uint2 pp[3][4 * NB];
+#pragma unroll
+                for (int r4 = 0; r4 < 4 * NB; ++r4) {
+                    if (8 * r4 >= p.Cout) continue;
+                    const int nb = r4 >> 2, q4 = r4 & 3;
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float m = fmaxf(acc[0][nb][4 * q4 + r], acc[1][nb][4 * q4 + r]);
+                        v[r] = fmaxf(m, __shfl_xor(m, 1));
+                    }
+                    v += bias[r4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = act_f32<ACT>(v[r]);
+                    split4_x3(v, pp[0][r4], pp[1][r4], pp[2][r4]);
+                }
+                const int pq = frow >> 1;                    // pooled pixel of this lane pair
+                const int yp = (cur.ty0 >> 1) + wave, Hp = p.H >> 1, Wp = p.W >> 1;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    if (!(lane & 1)) {
+#pragma unroll
+                        for (int r4 = 0; r4 < 4 * NB; ++r4) {
+                            if (8 * r4 >= p.Cout) continue;
+                            *reinterpret_cast<uint2*>(sh + pq * ROW + (8 * r4 + 4 * fk) * 2) = pp[pl][r4];
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int ps = 0; ps < (16 + PPP - 1) / PPP; ++ps) {
+                        const int pix = ps * PPP + prow;
+                        if (pix < 16 && yp < Hp && seg * 8 < p.Cout) {
+                            uint16_t* o = out_hi + ((size_t)(cur.img * Hp + yp) * Wp + (cur.tx0 >> 1) + pix) * p.Cstride + n0 + seg * 8;
+                            *reinterpret_cast<u32x4*>(o + pl * p.out_plane) = *reinterpret_cast<const u32x4*>(sh + pix * ROW + seg * 16);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                return;
+            }
+#pragma unroll
+            for (int a = 0; a < T3_MT; ++a) {
+                const int y = cur.ty0 + T3_MT * wave + a;
+                uint2 pp[3][4 * NB];
+#pragma unroll
+                for (int r4 = 0; r4 < 4 * NB; ++r4) {
+                    if (8 * r4 >= p.Cout) continue;         // rows past Cout are padding, never stored
+                    const int nb = r4 >> 2, q4 = r4 & 3;
+                    f32x4 v = {acc[a][nb][4 * q4], acc[a][nb][4 * q4 + 1], acc[a][nb][4 * q4 + 2], acc[a][nb][4 * q4 + 3]};
+                    v += bias[r4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = act_f32<ACT>(v[r]);
+                    split4_x3(v, pp[0][r4], pp[1][r4], pp[2][r4]);
+                }
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4 * NB; ++r4) {
+                        if (8 * r4 >= p.Cout) continue;
+                        *reinterpret_cast<uint2*>(sh + frow * ROW + (8 * r4 + 4 * fk) * 2) = pp[pl][r4];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int ps = 0; ps < 32 / PPP; ++ps) {
+                        const int pix = ps * PPP + prow;
+                        if (y < p.H && seg * 8 < p.Cout) {
+                            uint16_t* o = out_hi + ((size_t)(cur.img * p.H + y) * p.W + cur.tx0 + pix) * p.Cstride + n0 + seg * 8;
+                            *reinterpret_cast<u32x4*>(o + pl * p.out_plane) = *reinterpret_cast<const u32x4*>(sh + pix * ROW + seg * 16);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            }
+        };
+        if (p.act == ACT_RELU) epilogue(ActTag<ACT_RELU>{});
+        else if (p.act == ACT_ELU) epilogue(ActTag<ACT_ELU>{});
+        else epilogue(ActTag<ACT_NONE>{});
+        if (tid + (int)gridDim.x < items) cur = tile_of(tid + gridDim.x);
+    }
+}
+
+hipError_t launch_conv_direct3(const ConvDirectParams& p, hipStream_t s) {
+    if (p.act == ACT_SIGMOID03 || p.nreal || p.out_planar16 || p.f16 || p.out_f16) return hipErrorInvalidValue;   // (heads run as small-N kernels)
+    if (p.W % T3_TW || p.Cout > 64 || p.Cout % 8 || p.nsplit < 1 || p.nsplit > 8 || (p.nsplit > 1 && p.Cout != 64)) return hipErrorInvalidValue;
+    if (p.pool && ((p.H & 1) || (p.W & 1))) return hipErrorInvalidValue;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        cus = prop.multiProcessorCount;
+    }
+    const bool up = p.all_up && !(p.H & 1) && !(p.W & 1) && !(p.sw & SW_NO_UPTILE);
+    const int tiles = (p.W / T3_TW) * ((p.H + T3_TH - 1) / T3_TH) * p.N * p.nsplit;
+    const dim3 grid((unsigned)(tiles < cus ? tiles : cus));        // persistent: one workgroup per CU (158 KB of LDS)
+    if (p.Cout <= 32) {
+        if (up) hipLaunchKernelGGL((conv_direct3_kernel<1, true>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv_direct3_kernel<1, false>), grid, dim3(512), 0, s, p);
+    } else {
+        if (up) hipLaunchKernelGGL((conv_direct3_kernel<2, true>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv_direct3_kernel<2, false>), grid, dim3(512), 0, s, p);
+    }
+    return hipGetLastError();
+}
+
+const char* conv_direct3_kernel_name(const ConvDirectParams& p) {
+    return p.Cout <= 32 ? "conv_direct_x3_kernel<1,2>" : "conv_direct_x3_kernel<2,2>";
+}
+
+}  // namespace sd

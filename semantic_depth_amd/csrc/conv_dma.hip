@@ -67,22 +67,25 @@ __device__ __forceinline__ KEntry load_kentry(const KEntry* ptr) {
 // SIMPLE = 2: the two-source 1x1 GEMM of a ResNet block tail (conv3 over its 3x3 output + projection over the block input,
 // each with its own stride): two base pointers per lane, the k-tile index selects the source.
 // W1 (with F16): ONE MFMA product per product -- the w_lo plane is neither fetched nor multiplied (plain fp16 x fp16, f32 accumulate)
-template <int WAVES_M, int WAVES_N, int MT, int NT, int SIMPLE, int STAGES, bool F16 = false, bool W1 = false>
+// X3 (SD_PREC_BF16X3): three bf16 planes per operand, six MFMA products per product, three output planes; two 72-KiB stages for the
+// 128 x 256 / 256 x 128 blocks (a k-tile moves 72 KB through the 16 B/clk L2 -> LDS path against 48 MFMAs per wave: the DMA bounds it)
+template <int WAVES_M, int WAVES_N, int MT, int NT, int SIMPLE, int STAGES, bool F16 = false, bool W1 = false, bool X3 = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 : 1) void conv_dma_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
+    static_assert(!X3 || (!F16 && !W1), "bf16 x 3 is a form of its own");
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
+    constexpr int NPX = F16 ? 1 : X3 ? 3 : 2, NPW = W1 ? 1 : X3 ? 3 : 2;      // planes of a stage per operand
     // 16-B units of a stage: Xh [4][BM] | Xl [4][BM] | Wh [4][BN] | Wl [4][BN]; the fp16 forms drop the planes they do not read
     // (Xl; W1: Wl too), so the same LDS holds a deeper ring: more k-tiles in flight against the L2 -> LDS latency
-    constexpr int X_UNITS = (F16 ? 4 : 8) * BM, W_UNITS = (W1 ? 4 : 8) * BN;
+    constexpr int X_UNITS = NPX * 4 * BM, W_UNITS = NPW * 4 * BN;
     constexpr int STAGE_UNITS = X_UNITS + W_UNITS;
     static_assert(STAGES * STAGE_UNITS * 16 <= 160 * 1024, "ring fits in the LDS of a CU");
-    constexpr int XI = 8 * BM / 64 / NW;                      // activation DMA instructions per wave and tile (2 or 4), hi first then lo
-    constexpr int WI_ALL = 8 * BN / 64;                       // weight instructions of a tile, both planes (32, 16 or 8)
-    constexpr int WI = W1 ? WI_ALL / 2 : WI_ALL;              // both weight planes in either format (fp16: w_hi, w_lo); W1: w_hi only
+    constexpr int XI = 8 * BM / 64 / NW;                      // activation DMA instructions per wave and tile for TWO planes (2 or 4)
+    constexpr int WI = NPW * 4 * BN / 64;                     // weight instructions of a tile, every plane the form reads
     constexpr int WPW = (WI + NW - 1) / NW;                   // per wave (a short last round re-fetches earlier units: equal counts)
-    constexpr int NDMA = (F16 ? XI / 2 : XI) + WPW;           // DMA instructions per wave per tile (6; fp16 activations have ONE plane: 4 or 5)
+    constexpr int NDMA = NPX * (XI / 2) + WPW;                // DMA instructions per wave per tile (6; fp16 activations have ONE plane: 4 or 5; bf16 x 3: 9)
     constexpr int EPI_ROW = NT * 64 + 16;
-    static_assert(NW * 2 * 32 * EPI_ROW <= STAGES * STAGE_UNITS * 16, "epilogue slabs fit in the ring");
+    static_assert(NW * (X3 ? 3 : 2) * 32 * EPI_ROW <= STAGES * STAGE_UNITS * 16, "epilogue slabs fit in the ring");
     static_assert((8 * BM / 64) % (2 * NW) == 0 && ((8 * BN / 64) % NW == 0 || NW % (8 * BN / 64 / 2) == 0), "whole DMA instructions per wave and plane (fewer weight instructions than waves: duplicate fetches)");
     __shared__ __attribute__((aligned(16))) u32x4 ring[STAGES * STAGE_UNITS];
 
@@ -179,10 +182,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
             for (int i = 0; i < XH; ++i) {
                 const bool ok = smask[i] != 0;
                 const uint16_t* px = (first ? sbase[i] : sbaseB[i]) + coff;
-                const u32x4* gh = ok ? reinterpret_cast<const u32x4*>(px) : zero;
-                const u32x4* gl = ok ? reinterpret_cast<const u32x4*>(px + pln) : zero;
-                dma16(gh, sbyte + (unsigned)((wave + NW * i) * 1024));
-                if constexpr (!F16) dma16(gl, sbyte + (unsigned)((4 * BM + (wave + NW * i) * 64) * 16));
+#pragma unroll
+                for (int pl = 0; pl < NPX; ++pl)
+                    dma16(ok ? reinterpret_cast<const u32x4*>(px + pl * pln) : zero, sbyte + (unsigned)((pl * 4 * BM + (wave + NW * i) * 64) * 16));
             }
         } else if constexpr (SIMPLE == 1) {
             const int tap = s_ty * p.kw + s_tx;
@@ -191,10 +193,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
             for (int i = 0; i < XH; ++i) {
                     const bool ok = (smask[i] >> tap) & 1;
                 const uint16_t* px = sbase[i] + soff;
-                const u32x4* gh = ok ? reinterpret_cast<const u32x4*>(px) : zero;
-                const u32x4* gl = ok ? reinterpret_cast<const u32x4*>(px + splane) : zero;
-                dma16(gh, sbyte + (unsigned)((wave + NW * i) * 1024));
-                if constexpr (!F16) dma16(gl, sbyte + (unsigned)((4 * BM + (wave + NW * i) * 64) * 16));
+#pragma unroll
+                for (int pl = 0; pl < NPX; ++pl)
+                    dma16(ok ? reinterpret_cast<const u32x4*>(px + pl * splane) : zero, sbyte + (unsigned)((pl * 4 * BM + (wave + NW * i) * 64) * 16));
             }
             if (++s_tx == p.kw) { s_tx = 0; if (++s_ty == p.kh) { s_ty = 0; ++s_cb; } }
         } else {
@@ -207,10 +208,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
                 const bool ok = pok[i] && iy >= 0 && ix >= 0 && iy < (e.H << up) && ix < (e.W << up);
                 iy >>= up; ix >>= up;
                 const uint16_t* px = reinterpret_cast<const uint16_t*>(e.base) + ((size_t)(pimg[i] * e.H + iy) * e.W + ix) * e.C + pkg[i] * 8;
-                const u32x4* gh = ok ? reinterpret_cast<const u32x4*>(px) : zero;
-                const u32x4* gl = ok ? reinterpret_cast<const u32x4*>(px + plane) : zero;
-                dma16(gh, sbyte + (unsigned)((wave + NW * i) * 1024));
-                if constexpr (!F16) dma16(gl, sbyte + (unsigned)((4 * BM + (wave + NW * i) * 64) * 16));
+#pragma unroll
+                for (int pl = 0; pl < NPX; ++pl)
+                    dma16(ok ? reinterpret_cast<const u32x4*>(px + pl * plane) : zero, sbyte + (unsigned)((pl * 4 * BM + (wave + NW * i) * 64) * 16));
             }
         }
         // ---- weights: the stage image is the global image ----
@@ -249,28 +249,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * NDMA) : "memory");
         }
         __builtin_amdgcn_s_barrier();
-        const u32x4* Xh = ring + (kt % STAGES) * STAGE_UNITS;
-        const u32x4* Xl = Xh + 4 * BM;                         // (not read by the fp16 forms)
+        const u32x4* Xh = ring + (kt % STAGES) * STAGE_UNITS;  // X planes [NPX][4][BM], then W planes [NPW][4][BN]
         const u32x4* Wh = Xh + X_UNITS;
-        const u32x4* Wl = Wh + 4 * BN;                         // (not read by W1)
         // schedule of one k-tile, pinned with sched_barriers (left alone, hipcc hoists the DMA issue to the top and sinks
         // every LDS read to just before its first use, which exposes the LDS latency four times per tile):
         //   fragments of k-step 0 -> DMA issue of tile kt+2 (its address arithmetic runs under the LDS latency) ->
         //   fragments of k-step 1 -> 12 MFMAs of k-step 0 -> 12 MFMAs of k-step 1
-        u32x4 wh[2][NT], wl[2][NT], xh[2][MT], xl[2][MT];
+        u32x4 w[NPW][2][NT], x[NPX][2][MT];
         auto fragments = [&](int s) {
             const int kg = 2 * s + fk;
 #pragma unroll
-            for (int b = 0; b < NT; ++b) {
-                wh[s][b] = Wh[kg * BN + wn0 + b * 32 + frow];
-                wl[s][b] = W1 ? wh[s][b] : Wl[kg * BN + wn0 + b * 32 + frow];
-            }
+            for (int pl = 0; pl < NPW; ++pl)
+#pragma unroll
+                for (int b = 0; b < NT; ++b) w[pl][s][b] = Wh[pl * 4 * BN + kg * BN + wn0 + b * 32 + frow];
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
                 const int mrow = wm0 + a * 32 + frow;
                 const int slot = mrow * 4 + (kg ^ ((mrow >> 2) & 3));        // [pixel][octet ^ swizzle]
-                xh[s][a] = Xh[slot];
-                xl[s][a] = F16 ? xh[s][a] : Xl[slot];
+#pragma unroll
+                for (int pl = 0; pl < NPX; ++pl) x[pl][s][a] = Xh[pl * 4 * BM + slot];
             }
         };
         fragments(0);
@@ -279,23 +276,77 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
         __builtin_amdgcn_sched_barrier(0);
         fragments(1);
         __builtin_amdgcn_sched_barrier(0);
+        // (x plane, w plane) per product, small terms first.  bf16 x 3: hi*lo, lo*hi, mid*mid, hi*mid, mid*hi, hi*hi; bf16 x 2: hi*lo,
+        // lo*hi, hi*hi; fp16 activations have no lo plane (hi*lo, hi*hi); W1: hi*hi only
+        constexpr int NPR = X3 ? 6 : 3;
+        constexpr int xp3[6] = {0, 2, 1, 0, 1, 0}, wp3[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int xp2[3] = {0, 1, 0}, wp2[3] = {1, 0, 0};
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
-            for (int pr = 0; pr < 3; ++pr) {      // x_hi*w_lo, x_lo*w_hi, x_hi*w_hi; fp16 activations have no lo plane
-                if ((F16 && pr == 1) || (W1 && pr == 0)) continue;
+            for (int pr = 0; pr < NPR; ++pr) {
+                if (!X3 && ((F16 && pr == 1) || (W1 && pr == 0))) continue;
+                const int xi = X3 ? xp3[pr] : (F16 ? 0 : xp2[pr]), wi = X3 ? wp3[pr] : (W1 ? 0 : wp2[pr]);
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
 #pragma unroll
                     for (int a = 0; a < MT; ++a)
-                        acc[a][b] = mfma_frag<F16>(pr == 0 ? wl[s][b] : wh[s][b], pr == 1 ? xl[s][a] : xh[s][a], acc[a][b]);
+                        acc[a][b] = mfma_frag<F16>(w[wi][s][b], x[xi][s][a], acc[a][b]);
             }
         }
     }
 
     // ---- epilogue (as conv_split.hip): bias + activation, split once, LDS transpose, 16-byte runs per pixel ----
     __syncthreads();
-    unsigned sat = 0;                                          // values the fp16 output format clamped (split_fmt.hpp)
+    if constexpr (X3) {
+        // bf16 x 3 output: the exact three-way split, one slab per plane and wave
+        auto ep3 = [&](auto tag) {
+            constexpr int ACT = decltype(tag)::value;
+            constexpr int ROW = EPI_ROW;
+            unsigned char* slab = reinterpret_cast<unsigned char*>(ring) + wave * (3 * 32 * ROW);
+            constexpr int SEGS = NT * 4, PPP = 64 / SEGS;
+            const int seg = lane % SEGS, prow = lane / SEGS;
+            uint16_t* const out_hi = reinterpret_cast<uint16_t*>(p.out);
+            const int m0 = bm0 + wm0, n0 = bn0 + wn0;
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int nl = b * 32 + 8 * r4 + 4 * (lane >> 5);
+                        f32x4 v = {acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
+                        v += *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = act_f32<ACT>(v[r]);
+                        uint2 h, m, l;
+                        split4_x3(v, h, m, l);
+                        *reinterpret_cast<uint2*>(slab + (lane & 31) * ROW + nl * 2) = h;
+                        *reinterpret_cast<uint2*>(slab + 32 * ROW + (lane & 31) * ROW + nl * 2) = m;
+                        *reinterpret_cast<uint2*>(slab + 64 * ROW + (lane & 31) * ROW + nl * 2) = l;
+                    }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int ps = 0; ps < 32 / PPP; ++ps) {
+                    const int pix = ps * PPP + prow;
+                    const int mo = m0 + a * 32 + pix;
+                    if (mo < M) {
+                        uint16_t* o = out_hi + (size_t)mo * p.Cout + n0 + seg * 8;
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            *reinterpret_cast<u32x4*>(o + pl * p.out_plane) = *reinterpret_cast<const u32x4*>(slab + pl * 32 * ROW + pix * ROW + seg * 16);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        };
+        if (p.act == ACT_RELU) ep3(ActTag<ACT_RELU>{});
+        else if (p.act == ACT_ELU) ep3(ActTag<ACT_ELU>{});
+        else ep3(ActTag<ACT_NONE>{});
+        return;
+    }
     auto epilogue = [&](auto tag, auto otag) {
         constexpr int ACT = decltype(tag)::value;
         constexpr bool O16 = decltype(otag)::value;            // output planes: fp16 or bf16 (the consumers' format)
@@ -333,7 +384,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
                         uint2 h, l;
-                        split4_t<O16>(v, h, l, sat);
+                        split4_t<O16>(v, h, l, p.sat);
                         if ((lane & 3) == 0) {
                             *reinterpret_cast<uint2*>(sh + ((lane & 31) >> 2) * ROW + nl * 2) = h;
                             if constexpr (!O16) *reinterpret_cast<uint2*>(sl + ((lane & 31) >> 2) * ROW + nl * 2) = l;
@@ -369,7 +420,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
                     uint2 h, l;
-                    split4_t<O16>(v, h, l, sat);
+                    split4_t<O16>(v, h, l, p.sat);
                     *reinterpret_cast<uint2*>(sh + (lane & 31) * ROW + nl * 2) = h;
                     if constexpr (!O16) *reinterpret_cast<uint2*>(sl + (lane & 31) * ROW + nl * 2) = l;
                 }
@@ -394,7 +445,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
     if (p.act == ACT_RELU) ep(ActTag<ACT_RELU>{});
     else if (p.act == ACT_ELU) ep(ActTag<ACT_ELU>{});
     else ep(ActTag<ACT_NONE>{});
-    sat_report(p.sat, sat);
 }
 
 // which layers take the DMA pipeline: vec layers with Cout a multiple of 64 and enough tiles to occupy the chip
@@ -408,7 +458,8 @@ int conv_dma_variant(const ConvParams& p) {
     // form of 128 x 256 / 256 x 128 fits TWO workgroups per CU (72 KB of ring, 124 VGPRs): one's epilogue and pipeline fill run under
     // the other's k-loop, which wins below ~32 k-tiles (measured: K <= 640 +5..14 %, K = 768..1280 equal, K >= 1536 and fc6 -2..4 %)
     const bool shortk = p.f16 == 2 && p.Kpad < 1024;
-    if (big && !shortk && !p.pool && p.Cout % 256 == 0 && ((M + 255) / 256) * (p.Cout / 256) >= 512) return 5;
+    if (p.x3 && (p.pool || p.out_planar16)) return 0;         // (bf16 x 3: plain outputs only)
+    if (big && !p.x3 && !shortk && !p.pool && p.Cout % 256 == 0 && ((M + 255) / 256) * (p.Cout / 256) >= 512) return 5;
     if (p.Cout % 256 == 0 && ((M + 127) / 128) * (p.Cout / 256) >= thr) return 1;     // 128 x 256
     if (p.Cout % 128 == 0 && ((M + 255) / 256) * (p.Cout / 128) >= thr) return 2;     // 256 x 128
     if (p.Cout % 64 == 0 && p.Cout % 128 != 0 && ((M + 255) / 256) * (p.Cout / 64) >= thr) return 3;      // 256 x 64
@@ -422,6 +473,13 @@ static void launch_dma_variant(const ConvParams& p, long M, hipStream_t s) {
     const int tilesM = (int)((M + WM * MT * 32 - 1) / (WM * MT * 32)), tilesN = p.Cout / (WN * NT * 32);
     const dim3 grid((unsigned)(tilesM * tilesN)), block(64 * WM * WN);
     const int mode = (p.dbg & 16) ? 0 : p.simple;
+    constexpr bool x3_fits = 2 * 12 * (WM * MT * 32 + WN * NT * 32) * 16 <= 160 * 1024;
+    if constexpr (x3_fits) if (p.x3) {               // bf16 x 3: two stages
+        if (mode == 2) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 2, 2, false, false, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+        else if (mode == 1) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 1, 2, false, false, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+        else hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 0, 2, false, false, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+        return;
+    }
     if (p.f16 == 2) {
         if (mode == 2) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 2, S1, true, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
         else if (mode == 1) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 1, S1, true, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
@@ -444,13 +502,16 @@ hipError_t launch_conv_dma(const ConvParams& p0, hipStream_t s) {
     else if (v == 2) launch_dma_variant<4, 2, 2, 2, 3, 3, 3>(p, M, s);       // 48 / 32 / 24
     else if (v == 3) launch_dma_variant<4, 2, 2, 1, 3, 3, 4>(p, M, s);       // 40 / 24 / 20
     else if (v == 4) launch_dma_variant<8, 1, 1, 1, 3, 3, 3>(p, M, s);
-    else if (v == 5) launch_dma_variant<2, 4, 4, 2, 2, 2, 4>(p, M, s);       // 64 / 48 / 32
+    else if (v == 5 && !p.x3) launch_dma_variant<2, 4, 4, 2, 2, 2, 4>(p, M, s);       // 64 / 48 / 32
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
 const char* conv_dma_kernel_name(const ConvParams& p) {
     // f16w: fp16 activations x two fp16 weight planes (2 products); f16x1: fp16 x fp16 (1 product)
+    static const char* const names3[5] = {"conv_dma_x3_kernel<2,4,2,2>", "conv_dma_x3_kernel<4,2,2,2>", "conv_dma_x3_kernel<4,2,2,1>", "conv_dma_x3_kernel<8,1,1,1>",
+                                          "conv_dma_x3_kernel<2,4,2,2>"};
+    if (p.x3) { const int v3 = conv_dma_variant(p); return names3[v3 >= 1 && v3 <= 5 ? v3 - 1 : 2]; }
     static const char* const names[3][5] = {
         {"conv_dma_kernel<2,4,2,2>", "conv_dma_kernel<4,2,2,2>", "conv_dma_kernel<4,2,2,1>", "conv_dma_kernel<8,1,1,1>", "conv_dma_kernel<2,4,4,2>"},
         {"conv_dma_f16w_kernel<2,4,2,2>", "conv_dma_f16w_kernel<4,2,2,2>", "conv_dma_f16w_kernel<4,2,2,1>", "conv_dma_f16w_kernel<8,1,1,1>",

@@ -40,7 +40,6 @@ __device__ __forceinline__ void split_epilogue_act(f32x16 (&acc)[MT][NT], unsign
     constexpr int PPP = 64 / SEGS;                // pixels per read pass
     const int seg = lane % SEGS, prow = lane / SEGS;
     uint16_t* const out_hi = reinterpret_cast<uint16_t*>(p.out);
-    unsigned sat = 0;                             // values the fp16 output format clamped (split_fmt.hpp)
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
 #pragma unroll
@@ -54,7 +53,7 @@ __device__ __forceinline__ void split_epilogue_act(f32x16 (&acc)[MT][NT], unsign
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
                 uint2 h, l;
-                split4_t<F16>(v, h, l, sat);
+                split4_t<F16>(v, h, l, p.sat);
                 *reinterpret_cast<uint2*>(sh + (lane & 31) * ROW + nl * 2) = h;
                 *reinterpret_cast<uint2*>(sl + (lane & 31) * ROW + nl * 2) = l;
             }
@@ -76,7 +75,6 @@ __device__ __forceinline__ void split_epilogue_act(f32x16 (&acc)[MT][NT], unsign
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    sat_report(p.sat, sat);
 }
 // bf16 x 3 output (SD_PREC_BF16X3): the exact three-way split, one slab per plane
 template <int ACT, int MT, int NT>

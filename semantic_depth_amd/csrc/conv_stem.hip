@@ -153,7 +153,6 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
         }
 
         // ---- epilogue: bias + activation, split once, LDS transpose one plane at a time, 16-byte runs per pixel ----
-        unsigned sat = 0;                                    // values the fp16 output format clamped (split_fmt.hpp)
         auto epilogue = [&](auto tag, auto otag) {
             constexpr int ACT = decltype(tag)::value;
             constexpr bool O16 = decltype(otag)::value;
@@ -177,7 +176,7 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
-                        split4_t<O16>(v, hh[r4], ll[r4], sat);
+                        split4_t<O16>(v, hh[r4], ll[r4], p.sat);
                         mm[r4] = ll[r4];
                     }
                 }
@@ -208,7 +207,6 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
         if (p.act == ACT_RELU) ep(ActTag<ACT_RELU>{});
         else if (p.act == ACT_ELU) ep(ActTag<ACT_ELU>{});
         else ep(ActTag<ACT_NONE>{});
-        sat_report(p.sat, sat);
         cur = nxt;
     }
 }
@@ -220,7 +218,9 @@ bool conv_stem_eligible(const ConvParams& p) {
     if (p.out_planar16 && p.Cout % 16) return false;
     const int rw = p.stride == 1 ? 2 : 1, th = 8 * rw;
     const int ih = (th - 1) * p.stride + p.kh, iw = (ST_TW - 1) * p.stride + p.kh;
-    return ih * iw <= ST_MAXPIX && !(p.sw & SW_NO_STEM);
+    const int npl = p.x3 ? 3 : 2, nb = p.Cout / 32;
+    const size_t lds = (size_t)npl * ST_MAXPIX * 8 + (size_t)(p.Kpad / 8) * p.Cout * 16 * npl + (size_t)8 * 32 * (64 * nb + 16);
+    return ih * iw <= ST_MAXPIX && lds <= 160 * 1024 && !(p.sw & SW_NO_STEM);
 }
 
 hipError_t launch_conv_stem(const ConvParams& p, hipStream_t s) {

@@ -101,15 +101,21 @@ template <bool F16> __device__ __forceinline__ f32x4_t recon4_t(uint2 h, uint2 l
     const f32x2_t a = recon2_t<F16>(h.x, l.x), b = recon2_t<F16>(h.y, l.y);
     return f32x4_t{a[0], a[1], b[0], b[1]};
 }
-// `sat` (the conv epilogues): counts the values the fp16 formats had to clamp (or that were NaN) -- the layer's output left the fp16
-// range, i.e. the precision plan does not fit these weights; the conv kernels add it to a device counter the host reads through
-// sd_saturation_count (a silent clamp must not pass for a result)
-template <bool F16> __device__ __forceinline__ void split2_t(f32x2_t v, unsigned& h, unsigned& l, unsigned& sat) {
+// `sat` (the conv epilogues): the device counter of the values the fp16 formats had to clamp (or that were NaN) -- the layer's output
+// left the fp16 range, i.e. the precision plan does not fit these weights; the host reads it through sd_saturation_count (a silent
+// clamp must not pass for a result).  A compare and a never-taken branch per value pair: a per-lane count carried through the
+// epilogue instead costs the register-capped kernels (two workgroups per CU at 128 VGPRs) hundreds of spilled registers.
+typedef unsigned long long* sat_ptr_t;
+__device__ __forceinline__ void sat_check(f32x2_t c, f32x2_t v, sat_ptr_t sat) {
+    if (__builtin_expect((c[0] != v[0]) | (c[1] != v[1]), 0))
+        if (sat) atomicAdd(sat, (unsigned long long)((c[0] != v[0] ? 1 : 0) + (c[1] != v[1] ? 1 : 0)));
+}
+template <bool F16> __device__ __forceinline__ void split2_t(f32x2_t v, unsigned& h, unsigned& l, sat_ptr_t sat) {
     if constexpr (F16) {
         // saturate at the largest finite fp16 (v_med3_f32): an activation beyond 65504 must not become inf and poison the layers
         // behind it (NaN passes through); then round to nearest even.  There is no lo plane.
         const f32x2_t c = {__builtin_amdgcn_fmed3f(v[0], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v[1], -65504.f, 65504.f)};
-        sat += (c[0] != v[0] ? 1u : 0u) + (c[1] != v[1] ? 1u : 0u);
+        sat_check(c, v, sat);
         const f16x2_t hb = __builtin_convertvector(c, f16x2_t);
         h = __builtin_bit_cast(unsigned, hb);
         l = 0u;
@@ -118,27 +124,21 @@ template <bool F16> __device__ __forceinline__ void split2_t(f32x2_t v, unsigned
     }
 }
 template <bool F16> __device__ __forceinline__ void split2_t(f32x2_t v, unsigned& h, unsigned& l) {
-    unsigned sat = 0;
-    split2_t<F16>(v, h, l, sat);
+    split2_t<F16>(v, h, l, (sat_ptr_t) nullptr);
 }
-template <bool F16> __device__ __forceinline__ void split4_t(f32x4_t v, uint2& h, uint2& l, unsigned& sat) {
+template <bool F16> __device__ __forceinline__ void split4_t(f32x4_t v, uint2& h, uint2& l, sat_ptr_t sat) {
     split2_t<F16>(f32x2_t{v[0], v[1]}, h.x, l.x, sat);
     split2_t<F16>(f32x2_t{v[2], v[3]}, h.y, l.y, sat);
 }
 template <bool F16> __device__ __forceinline__ void split4_t(f32x4_t v, uint2& h, uint2& l) {
-    unsigned sat = 0;
-    split4_t<F16>(v, h, l, sat);
-}
-// end of an epilogue: the lanes that clamped something add their counts to the handle's counter (rare path: one branch otherwise)
-__device__ __forceinline__ void sat_report(unsigned long long* counter, unsigned sat) {
-    if (sat && counter) atomicAdd(counter, (unsigned long long)sat);
+    split4_t<F16>(v, h, l, (sat_ptr_t) nullptr);
 }
 // output format of an epilogue: 0 = bf16 hi + lo, 1 = ONE fp16 plane, 2 = fp16 hi + lo (the hi plane is bit for bit the one of format
 // 1, so every fp16 layer can read such a tensor; the lo plane serves the layers that multiply x_hi and x_lo by ONE weight plane)
-template <int FMT> __device__ __forceinline__ void split2_fmt(f32x2_t v, unsigned& h, unsigned& l, unsigned& sat) {
+template <int FMT> __device__ __forceinline__ void split2_fmt(f32x2_t v, unsigned& h, unsigned& l, sat_ptr_t sat) {
     if constexpr (FMT == 2) {
         const f32x2_t c = {__builtin_amdgcn_fmed3f(v[0], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v[1], -65504.f, 65504.f)};
-        sat += (c[0] != v[0] ? 1u : 0u) + (c[1] != v[1] ? 1u : 0u);
+        sat_check(c, v, sat);
         const f16x2_t hb = __builtin_convertvector(c, f16x2_t);
         const f32x2_t r = c - __builtin_convertvector(hb, f32x2_t);               // exact
         const f16x2_t lb = __builtin_convertvector(r, f16x2_t);
@@ -148,7 +148,7 @@ template <int FMT> __device__ __forceinline__ void split2_fmt(f32x2_t v, unsigne
         split2_t<FMT == 1>(v, h, l, sat);
     }
 }
-template <int FMT> __device__ __forceinline__ void split4_fmt(f32x4_t v, uint2& h, uint2& l, unsigned& sat) {
+template <int FMT> __device__ __forceinline__ void split4_fmt(f32x4_t v, uint2& h, uint2& l, sat_ptr_t sat) {
     split2_fmt<FMT>(f32x2_t{v[0], v[1]}, h.x, l.x, sat);
     split2_fmt<FMT>(f32x2_t{v[2], v[3]}, h.y, l.y, sat);
 }

@@ -26,7 +26,8 @@ def _frames(B, H, W, seed=0):
 
 
 # exact f32 MFMA / split-bf16 MFMA (3 bf16 products per product) / the built-in per-layer precision plan (3-, 2- and 1-product layers)
-PRECISIONS = ["f32", "bf16x2", "plan"]
+# "bf16x3": the fp32-grade split engine (three bf16 planes per operand, exact; 6 MFMA products)
+PRECISIONS = ["f32", "bf16x3", "bf16x2", "plan"]
 # "mixed": FCN-8s as bf16x2, every monodepth layer on fp16 activations x split fp16 weights (2 products): only the monodepth tests
 # gain a case, at the same 1e-3 budget
 MONO_PRECISIONS = PRECISIONS + ["mixed"]
@@ -194,7 +195,7 @@ def test_full_size_split_engine_matches_the_exact_f32_engine(H, W, B, enc):
     wm = Wt.make_monodepth_weights(enc, 2, bias_std=0.05)
     fr = dev(_frames(B, H, W, seed=H + W))
     res = {}
-    for prec in ("f32", "bf16x2"):
+    for prec in ("f32", "bf16x2", "bf16x3"):
         eng = Engine(H, W, B, enc, precision=prec)
         eng.load_weights(L.SD_NET_FCN8S, wf)
         eng.load_weights(L.SD_NET_MONODEPTH, wm)
@@ -204,6 +205,10 @@ def test_full_size_split_engine_matches_the_exact_f32_engine(H, W, B, enc):
         del eng
     assert relerr(res["bf16x2"][0], res["f32"][0]) < 1e-4
     assert relerr(res["bf16x2"][1], res["f32"][1]) < 1e-4
+    # the fp32-grade split engine differs from the f32 MFMA engine by what two f32 summation orders differ by
+    print(H, W, enc, "bf16x3 vs f32:", relerr(res["bf16x3"][0], res["f32"][0]), relerr(res["bf16x3"][1], res["f32"][1]))
+    assert relerr(res["bf16x3"][0], res["f32"][0]) < 5e-6
+    assert relerr(res["bf16x3"][1], res["f32"][1]) < 5e-6
 
 
 def test_fp16_activation_planes_saturate_instead_of_overflowing():

@@ -53,7 +53,7 @@ def oracle_full():
     return dict(wf=wf, wm=wm, frames=fr, logits=logits, taps=taps, scales=scales)
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x2", "plan"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x2", "plan"])
 def test_fcn8s_full_size_matches_oracle(precision, oracle_full, keep_taps):
     o = oracle_full
     eng = Engine(H, W, 1, "resnet50", precision=precision)
@@ -74,7 +74,7 @@ def test_fcn8s_full_size_matches_oracle(precision, oracle_full, keep_taps):
     assert 0.02 < road_r.mean() < 0.98
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x2", "mixed", "plan"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x2", "mixed", "plan"])
 def test_monodepth_full_size_matches_oracle(precision, oracle_full, keep_taps):
     o = oracle_full
     eng = Engine(H, W, 1, "resnet50", precision=precision)
@@ -134,7 +134,7 @@ def test_nets_b8_full_size_match_oracle(precision, oracle_b8):
     assert worst_l < TOL and worst_d < TOL
 
 
-@pytest.mark.parametrize("precision", ["f32", "plan"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "plan"])
 def test_nets_b32_as_benchmarked_match_oracle(precision, oracle_b8):
     """configs[3] as bench.py runs it: ONE pass of B = 32 frames per network on the benchmarked engines; frames 0, 9, 22 and 31 of the
     batch (= frames 0..3 of the oracle batch, placed there) against the CPU oracle: logits, masks, raw and post-processed disparity.
@@ -202,7 +202,7 @@ def _check_records_against_oracle(eng, frames_np, out, raw, cam, prm, colours=Tr
     return recs, found
 
 
-@pytest.mark.parametrize("B,precision", [(8, "bf16x2"), (32, "bf16x2"), (8, "f32"), (32, "plan"), (32, "f32")])
+@pytest.mark.parametrize("B,precision", [(8, "bf16x2"), (32, "bf16x2"), (8, "f32"), (32, "plan"), (32, "f32"), (32, "bf16x3")])
 def test_process_batch_records_equal_oracle_tail(B, precision):
     """configs[3] (B = 32: the benchmarked configuration, on the engines bench.py times -- f32 headline, plan leg) and the B = 8 batch
     of configs[1]/[2] through Engine.process_batch"""
