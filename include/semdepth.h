@@ -152,6 +152,17 @@ sd_status sd_resize_cubic_u8(sd_handle* h, const uint8_t* src, int B, int src_h,
  * memory; no handle, no GPU (semantic_depth_amd/frame_io.py inflates with zlib and calls this from a thread pool). */
 sd_status sd_png_unfilter_bgr(const uint8_t* filtered_host, int height, int width, int channels, uint8_t* bgr_out_host);
 
+/* HOST: a whole PNG file (8-bit, non-interlaced; gray, gray+alpha, RGB, RGBA, palette) -> cv2.imread(path) = u8 [height,width,3] BGR:
+ * chunk walk, zlib inflate, scanline reconstruction, channel shuffle, palette expansion in one native call (no interpreter lock held).
+ * bgr_out_host NULL: only *height_out / *width_out are written (size query).  SD_ERR_INVALID: not such a PNG / corrupt / buffer too small. */
+sd_status sd_png_decode_bgr(const uint8_t* file_host, size_t len, uint8_t* bgr_out_host, size_t out_capacity, int* height_out, int* width_out);
+/* HOST: the batch reader behind frame_io.FrameFeeder (the loop over sorted(glob(...)) of seq:689-701, `cv2.imread` at seq:123): reads and
+ * decodes n PNG files of height x width on `threads` native threads (<= 0: one per host CPU) into out_host + i * frame_stride (e.g. a
+ * pinned staging buffer).  status_out (nullable, int[n]): per-file sd_status (SD_ERR_NOTFOUND: unreadable file; SD_ERR_INVALID: not a
+ * PNG of that shape).  Returns SD_OK when every file decoded. */
+sd_status sd_decode_files_bgr(const char* const* paths, int n, int height, int width, uint8_t* out_host, size_t frame_stride, int threads,
+                              int* status_out);
+
 /* HOST helper of the PLY writer that replaces semantic_depth_lib/point_cloud_2_ply.py:70 (numpy.savetxt(fh, rows, "%f %f %f %d %d %d")):
  * n vertex rows "x y z r g b\n" -- coordinates as "%f" % float(v) prints them (fixed, six decimals, correctly rounded; nan / inf /
  * -inf), colours as integers -- into out[0 .. cap).  xyz f64 [n,3], rgb int64 [n,3], HOST memory; threads <= 0: one per core, at most

@@ -53,8 +53,25 @@ def source_hash() -> str:
         h.update(f.encode() + b"\0")
         h.update(open(os.path.join(CSRC, f), "rb").read())
     h.update(open(os.path.join(HERE, "..", "include", "semdepth.h"), "rb").read())
-    h.update(repr(SOURCES).encode() + ARCH.encode())
+    h.update(repr(SOURCES).encode() + ARCH.encode() + repr(LINK_FLAGS).encode())
     return h.hexdigest()[:16]
+
+
+LINK_FLAGS = ["-lz", "-lpthread"]      # zlib: host_png.cpp inflates PNG streams natively
+
+
+def _deps(path: str, seen=None) -> list:
+    """the file and every header it includes with quotes, recursively: an object is rebuilt when one of THESE changed (editing the
+    C-ABI header recompiles capi / host_* only, not the ten kernel files)"""
+    import re
+    seen = seen if seen is not None else []
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.append(path)
+    for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(path, encoding="utf-8", errors="replace").read(), flags=re.M):
+        _deps(os.path.join(os.path.dirname(path), inc), seen)
+    return seen
 
 
 def _stale(target: str, deps) -> bool:
@@ -67,7 +84,6 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
-    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     # a library built from exactly this tree (hash sidecar written after a successful link; _lib.load() checks the hash
     # embedded in the library itself) needs nothing, even when the object directory did not travel with the tree
     # (gpurun ships the .so but not csrc/build/): no one-minute rebuild at the start of every GPU-box command
@@ -83,7 +99,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         sp = os.path.join(CSRC, src)
         op = os.path.join(OBJ, src + ".o")
         objs.append(op)
-        if force or _stale(op, [sp] + hdrs) or (src == "capi.cpp" and hash_changed):
+        if force or _stale(op, _deps(sp)) or (src.endswith(".hip") and not os.path.exists(op + ".remarks")) or (src == "capi.cpp" and hash_changed):
             cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", sp, "-o", op] + extra
             if src.endswith(".hip"):
                 cmd.append("-Rpass-analysis=kernel-resource-usage")      # registers / spills / LDS per kernel -> <obj>.remarks
@@ -108,9 +124,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if jobs or _stale(LIB, objs):
+    if jobs or _stale(LIB, objs) or hash_changed:
         tmp = LIB + f".tmp{os.getpid()}"          # link aside, then rename: no process ever maps a half-written library
-        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + objs)
+        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + objs + LINK_FLAGS)
         os.replace(tmp, LIB)
     with open(hash_obj, "w") as f:
         f.write(digest)

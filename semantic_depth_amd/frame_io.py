@@ -1,11 +1,11 @@
 """Input stage, host side: the frame reader that replaces ``cv2.imread`` (semantic_depth.py:105; seq:123) and a
 feeder that keeps the GPU supplied.
 
-    imread(path)            8-bit PNG -> u8 [h,w,3] BGR, exactly cv2.imread's IMREAD_COLOR result (PNG is lossless); zlib inflates
-                            (GIL released), libsemdepth's sd_png_unfilter_bgr reconstructs the scanlines and shuffles to BGR
-    FrameFeeder             thread pool decoding the sorted file list (seq:689) into pinned staging buffers, batch by batch,
-                            one batch ahead of the GPU; the cubic resize to the network shape happens ON the GPU
-                            (Engine.resize_cubic), so the host never touches a pixel after the decode
+    imread(path)            8-bit PNG -> u8 [h,w,3] BGR, exactly cv2.imread's IMREAD_COLOR result (PNG is lossless): ONE native call
+                            (sd_png_decode_bgr: chunk walk, zlib inflate, scanline reconstruction, BGR shuffle, palette)
+    FrameFeeder             the sorted file list (seq:689) batch by batch: ONE native call per batch (sd_decode_files_bgr, C++ threads)
+                            reads and decodes straight into a pinned staging buffer, one batch ahead of the GPU; the cubic resize to
+                            the network shape happens ON the GPU (Engine.resize_cubic), so the host never touches a pixel after the decode
 
 Decode stays on the host on purpose: DEFLATE and the PNG predictors are serial byte recurrences; a frame costs a few
 milliseconds of one core and the GPU box has hundreds (scripts/feed_rate.py measures decode, pinned H2D and resize rates
@@ -26,41 +26,25 @@ _SIG = b"\x89PNG\r\n\x1a\n"
 _CHANNELS = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}
 
 
+def png_size(buf: bytes) -> tuple[int, int]:
+    """(height, width) of a PNG this reader takes (8-bit, non-interlaced); ValueError otherwise"""
+    lib = L.load()
+    h, w = C.c_int(), C.c_int()
+    if lib.sd_png_decode_bgr(buf, len(buf), None, 0, C.byref(h), C.byref(w)) != L.SD_OK:
+        if bytes(buf[:8]) != _SIG:
+            raise ValueError("not a PNG file")
+        raise ValueError("unsupported or corrupt PNG (8-bit, non-interlaced gray / gray+alpha / RGB / RGBA / palette only)")
+    return h.value, w.value
+
+
 def decode_png(buf: bytes) -> np.ndarray:
-    """PNG bytes -> u8 [h,w,3] BGR (cv2.IMREAD_COLOR semantics: 3 channels, alpha dropped, gray replicated, palette expanded)"""
-    if buf[:8] != _SIG:
-        raise ValueError("not a PNG file")
-    p, idat, hdr, plte = 8, [], None, None
-    while p < len(buf):
-        n, tag = struct.unpack_from(">I4s", buf, p)
-        body = buf[p + 8:p + 8 + n]
-        if tag == b"IHDR":
-            hdr = struct.unpack(">IIBBBBB", body)
-        elif tag == b"PLTE":
-            plte = np.frombuffer(body, np.uint8).reshape(-1, 3)
-        elif tag == b"IDAT":
-            idat.append(body)
-        elif tag == b"IEND":
-            break
-        p += 12 + n
-    if hdr is None:
-        raise ValueError("PNG without IHDR")
-    w, h, depth, ctype, _, _, interlace = hdr
-    if depth != 8 or interlace != 0 or ctype not in _CHANNELS:
-        raise ValueError(f"unsupported PNG (bit depth {depth}, colour type {ctype}, interlace {interlace}): 8-bit non-interlaced only")
-    ch = _CHANNELS[ctype]
-    raw = zlib.decompress(b"".join(idat))
-    if len(raw) != h * (1 + w * ch):
-        raise ValueError("PNG: inflated size does not match the header")
+    """PNG bytes -> u8 [h,w,3] BGR (cv2.IMREAD_COLOR semantics: 3 channels, alpha dropped, gray replicated, palette expanded).
+    One native call (sd_png_decode_bgr: chunk walk, zlib inflate, scanline reconstruction, shuffle), the interpreter lock released."""
+    h, w = png_size(buf)
     out = np.empty((h, w, 3), np.uint8)
     lib = L.load()
-    st = lib.sd_png_unfilter_bgr(C.c_char_p(raw), h, w, ch, out.ctypes.data_as(C.c_void_p))
-    if st != L.SD_OK:
-        raise ValueError("PNG: bad filter type")
-    if ctype == 3:                      # palette indices (replicated into 3 channels by the helper) -> BGR palette entries
-        if plte is None:
-            raise ValueError("PNG: palette image without PLTE")
-        out = plte[out[..., 0]][..., ::-1].copy()
+    if lib.sd_png_decode_bgr(buf, len(buf), out.ctypes.data_as(C.c_void_p), out.nbytes, None, None) != L.SD_OK:
+        raise ValueError("PNG: corrupt stream (inflate / filter type / palette index)")
     return out
 
 
@@ -70,18 +54,21 @@ def imread(path: str) -> np.ndarray:
 
 
 class FrameFeeder:
-    """iterate over (frames u8 [n,h,w,3] on ``device``, first global index) for the sorted ``paths``: decode on ``workers`` host
-    threads into pinned buffers, upload asynchronously, one batch ahead of the consumer (double buffering)."""
+    """iterate over (frames u8 [n,h,w,3] on ``device``, first global index) for the sorted ``paths``: every batch is read and decoded
+    by ONE native call (sd_decode_files_bgr: ``workers`` C++ threads, no interpreter lock) straight into a pinned staging buffer,
+    uploaded asynchronously, one batch ahead of the consumer (two staging buffers)."""
 
-    def __init__(self, paths, batch: int, device="cuda", workers: int = 16):
+    def __init__(self, paths, batch: int, device="cuda", workers: int = 0):
+        import os
         import torch
         self.paths, self.batch, self.device = list(paths), batch, torch.device(device)
-        self.pool = ThreadPoolExecutor(max_workers=workers)
+        self.workers = workers if workers > 0 else min(os.cpu_count() or 8, 128)
         self._torch = torch
         self._pinned = [None, None]
+        self._lib = L.load()
 
     def close(self):
-        self.pool.shutdown(wait=False)
+        self._pinned = [None, None]
 
     def __enter__(self):
         return self
@@ -91,19 +78,19 @@ class FrameFeeder:
 
     def _decode_into(self, slot: int, lo: int, hi: int):
         torch = self._torch
-        first = imread(self.paths[lo])
-        h, w = first.shape[:2]
+        with open(self.paths[lo], "rb") as f:
+            h, w = png_size(f.read())
         buf = self._pinned[slot]
         if buf is None or tuple(buf.shape[1:3]) != (h, w) or buf.shape[0] < hi - lo:
             buf = self._pinned[slot] = torch.empty((self.batch, h, w, 3), dtype=torch.uint8, pin_memory=self.device.type == "cuda")
-        view = buf.numpy()
-        view[0] = first
-
-        def one(i):
-            view[i - lo] = imread(self.paths[i])
-
-        list(self.pool.map(one, range(lo + 1, hi)))
-        return buf[:hi - lo]
+        n = hi - lo
+        arr = (C.c_char_p * n)(*[os_fsencode(p) for p in self.paths[lo:hi]])
+        status = (C.c_int * n)()
+        st = self._lib.sd_decode_files_bgr(arr, n, h, w, C.c_void_p(buf.data_ptr()), h * w * 3, self.workers, status)
+        if st != L.SD_OK:
+            bad = [(self.paths[lo + i], status[i]) for i in range(n) if status[i] != L.SD_OK]
+            raise ValueError(f"FrameFeeder: {len(bad)} frame(s) of the batch could not be read as {h}x{w} PNGs: {bad[:3]}")
+        return buf[:n]
 
     def __iter__(self):
         torch = self._torch
@@ -113,11 +100,21 @@ class FrameFeeder:
             return
         with ThreadPoolExecutor(max_workers=1) as ahead:
             fut = ahead.submit(self._decode_into, 0, *ranges[0])
+            events = [None, None]
             for k, (lo, hi) in enumerate(ranges):
                 host = fut.result()
                 if k + 1 < len(ranges):
-                    fut = ahead.submit(self._decode_into, (k + 1) & 1, *ranges[k + 1])
+                    slot = (k + 1) & 1
+                    if events[slot] is not None:
+                        events[slot].synchronize()          # the upload out of that staging buffer (two batches ago) has finished
+                    fut = ahead.submit(self._decode_into, slot, *ranges[k + 1])
                 dev = host.to(self.device, non_blocking=True)
                 if self.device.type == "cuda":
-                    torch.cuda.current_stream().synchronize()      # the pinned buffer is reused two batches later
+                    events[k & 1] = torch.cuda.Event()
+                    events[k & 1].record()
                 yield dev, lo
+
+
+def os_fsencode(p) -> bytes:
+    import os
+    return os.fsencode(p)

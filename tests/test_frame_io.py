@@ -125,3 +125,28 @@ def test_frame_feeder_uploads_through_pinned_buffers(tmp_path):
     assert got.shape == (5, 64, 128, 3)
     for i in range(5):
         assert np.array_equal(got[i], oresize.resize_cubic_u8(frames[i], 64, 128))
+
+
+def test_batch_reader_reports_the_files_it_could_not_decode(tmp_path):
+    """sd_decode_files_bgr (the native batch reader under FrameFeeder): a missing file and a frame of another shape are reported per
+    file; the frames around them are still decoded."""
+    import ctypes as C
+    from semantic_depth_amd import _lib as L
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, (3, 10, 12, 3), dtype=np.uint8)
+    paths = [outputs.write_png(str(tmp_path / f"a{i}.png"), f) for i, f in enumerate(frames)]
+    other = outputs.write_png(str(tmp_path / "other_shape.png"), rng.integers(0, 256, (8, 12, 3), dtype=np.uint8))
+    lst = [paths[0], str(tmp_path / "missing.png"), paths[1], other, paths[2]]
+    out = np.zeros((5, 10, 12, 3), np.uint8)
+    status = (C.c_int * 5)()
+    arr = (C.c_char_p * 5)(*[p.encode() for p in lst])
+    st = L.load().sd_decode_files_bgr(arr, 5, 10, 12, out.ctypes.data_as(C.c_void_p), 10 * 12 * 3, 3, status)
+    assert st == -1 and list(status) == [0, -4, 0, -1, 0]                  # SD_ERR_NOTFOUND = -4, SD_ERR_INVALID = -1
+    assert np.array_equal(out[[0, 2, 4]], frames)
+    with pytest.raises(ValueError, match="could not be read"):
+        list(frame_io.FrameFeeder(lst, batch=5, device="cpu", workers=2))
+    # size query of the single-file entry point, and a truncated stream
+    buf = open(paths[0], "rb").read()
+    assert frame_io.png_size(buf) == (10, 12)
+    with pytest.raises(ValueError):
+        frame_io.decode_png(buf[:len(buf) // 2])

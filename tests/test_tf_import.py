@@ -176,3 +176,139 @@ def test_reader_against_a_table_assembled_from_the_format_description(tmp_path):
     open(prefix + ".index", "wb").write(bytes(bad))
     with pytest.raises(ValueError, match="crc"):
         T.read_tensor_bundle(prefix)
+
+
+def test_two_shard_bundle_with_many_blocks_assembled_by_hand(tmp_path):
+    """what a real multi-device checkpoint looks like -- 40 variables spread over TWO data shards
+    (``.data-00000-of-00002`` / ``.data-00001-of-00002``, BundleHeaderProto.num_shards = 2, BundleEntryProto.shard_id / offset per
+    entry), the index cut into NINE data blocks of at most 5 entries (restart interval 3, so every block has shared-prefix entries
+    behind two restart points), alternate blocks snappy-compressed, a multi-entry index block -- assembled here from the format
+    descriptions with an independent CRC, NOT with the module's writer."""
+    import struct
+    vi = T._put_varint
+
+    def msg(*fields):           # (number, wire type, value): 0 varint, 2 length-delimited, 5 fixed32
+        out = b""
+        for n, wt, v in fields:
+            out += vi((n << 3) | wt)
+            out += vi(v) if wt == 0 else (v if wt == 5 else vi(len(v)) + v)
+        return out
+
+    rng = np.random.default_rng(11)
+    names = sorted([f"model/encoder/Conv_{i}/weights" for i in range(20)] + [f"model/encoder/Conv_{i}/biases" for i in range(19)] + ["global_step"])
+    tensors, shard_of, off_of = {}, {}, {}
+    shards = [b"", b""]
+    for j, n in enumerate(names):
+        a = (np.array(987654321, np.int64) if n == "global_step" else
+             rng.standard_normal((3, 3, 2, 1 + j % 5) if n.endswith("weights") else (1 + j % 7,)).astype(np.float32))
+        sh = (j * 7 // 3) % 2                                   # an irregular assignment to the two shards
+        tensors[n], shard_of[n], off_of[n] = a, sh, len(shards[sh])
+        shards[sh] += a.tobytes() + b"\xee" * (j % 3)           # (padding between tensors: offsets, not order, locate a tensor)
+    shape = lambda s: b"".join(msg((2, 2, msg((1, 0, d)))) for d in s)
+    entries = [(b"", msg((1, 0, 2), (2, 0, 0), (3, 2, msg((1, 0, 1)))))]      # header: num_shards 2, little endian, version {producer 1}
+    for n in names:
+        a = tensors[n]
+        entries.append((n.encode(), msg((1, 0, 9 if a.dtype == np.int64 else 1), (2, 2, shape(a.shape)), (3, 0, shard_of[n]), (4, 0, off_of[n]),
+                                        (5, 0, a.nbytes), (6, 5, struct.pack("<I", 0)))))     # (+ fixed32 crc32c field, ignored by the reader)
+
+    def block(items, interval):
+        out, restarts, prev = b"", [], b""
+        for i, (k, v) in enumerate(items):
+            sh = 0
+            if i % interval == 0:
+                restarts.append(len(out))
+            else:
+                while sh < min(len(k), len(prev)) and k[sh] == prev[sh]:
+                    sh += 1
+            out += vi(sh) + vi(len(k) - sh) + vi(len(v)) + k[sh:] + v
+            prev = k
+        return out + b"".join(struct.pack("<I", r) for r in restarts) + struct.pack("<I", len(restarts)), len(restarts)
+
+    def snappy_literals(raw):
+        out = vi(len(raw))
+        for i in range(0, len(raw), 60):
+            piece = raw[i:i + 60]
+            out += bytes([(len(piece) - 1) << 2]) + piece
+        return out
+
+    f, handles, nblocks, nrestarts = b"", [], 0, 0
+    for i in range(0, len(entries), 5):
+        items = entries[i:i + 5]
+        raw, nr = block(items, 3)
+        nrestarts += nr
+        compress = (nblocks % 2) == 1
+        body, ctype = (snappy_literals(raw), 1) if compress else (raw, 0)
+        handles.append((items[-1][0], vi(len(f)) + vi(len(body))))
+        f += body + bytes([ctype]) + struct.pack("<I", T.crc_mask(_crc32c_bitwise(body + bytes([ctype]))))
+        nblocks += 1
+    assert nblocks == 9 and nrestarts == 17
+    meta, _ = block([], 1)
+    meta_h = vi(len(f)) + vi(len(meta))
+    f += meta + b"\x00" + struct.pack("<I", T.crc_mask(_crc32c_bitwise(meta + b"\x00")))
+    idx, _ = block(handles, 1)
+    idx_h = vi(len(f)) + vi(len(idx))
+    f += idx + b"\x00" + struct.pack("<I", T.crc_mask(_crc32c_bitwise(idx + b"\x00")))
+    footer = meta_h + idx_h
+    f += footer + bytes(40 - len(footer)) + struct.pack("<Q", 0xDB4775248B80FB57)
+    prefix = str(tmp_path / "model_two_shards")
+    open(prefix + ".index", "wb").write(f)
+    for s in (0, 1):
+        open(f"{prefix}.data-{s:05d}-of-00002", "wb").write(shards[s])
+    got = T.read_tensor_bundle(prefix)
+    assert list(got) == names                                  # table order = sorted keys
+    for n in names:
+        assert got[n].dtype == tensors[n].dtype and got[n].shape == tensors[n].shape and np.array_equal(got[n], tensors[n]), n
+    assert len({shard_of[n] for n in names}) == 2
+    # a missing shard file is an error, not a silent skip
+    import os
+    os.remove(f"{prefix}.data-00001-of-00002")
+    with pytest.raises(FileNotFoundError):
+        T.read_tensor_bundle(prefix)
+
+
+# The CREATION order of the slim.conv2d layers in mrharicot/monodepth's monodepth_model.py, written out from the upstream source
+# (build_resnet50 / build_vgg, resconv, conv_block, upconv = upsample_nn + conv, get_disp) -- slim names them Conv, Conv_1, ... per
+# variable scope in exactly this order, which is all that identifies a variable in model_cityscapes / model_kitti (many layers share
+# shapes, so a wrong map would pass every shape check).
+#   resconv(x, n, stride): conv1 = conv(x, n, 1, 1); conv2 = conv(conv1, n, 3, stride); conv3 = conv(conv2, 4n, 1, 1, None);
+#                          shortcut = conv(x, 4n, 1, stride, None)        -> four layers per block: conv1, conv2, conv3, proj
+#   resblock(x, n, blocks): blocks - 1 x resconv(., n, 1), then resconv(., n, 2)
+#   encoder scope: conv1 = conv(input, 64, 7, 2); resblock(pool1, 64, 3); resblock(., 128, 4); resblock(., 256, 6); resblock(., 512, 3)
+#   decoder scope: upconv6, iconv6, upconv5, iconv5, upconv4, iconv4, disp4, upconv3, iconv3, disp3, upconv2, iconv2, disp2,
+#                  upconv1, iconv1, disp1
+_RESNET50_ENCODER_ORDER = (["enc/conv1"] +
+                           [f"enc/res2_{b}/{l}" for b in (1, 2, 3) for l in ("conv1", "conv2", "conv3", "proj")] +
+                           [f"enc/res3_{b}/{l}" for b in (1, 2, 3, 4) for l in ("conv1", "conv2", "conv3", "proj")] +
+                           [f"enc/res4_{b}/{l}" for b in (1, 2, 3, 4, 5, 6) for l in ("conv1", "conv2", "conv3", "proj")] +
+                           [f"enc/res5_{b}/{l}" for b in (1, 2, 3) for l in ("conv1", "conv2", "conv3", "proj")])
+_RESNET50_DECODER_ORDER = ["dec/upconv6", "dec/iconv6", "dec/upconv5", "dec/iconv5", "dec/upconv4", "dec/iconv4", "dec/disp4", "dec/upconv3", "dec/iconv3",
+                           "dec/disp3", "dec/upconv2", "dec/iconv2", "dec/disp2", "dec/upconv1", "dec/iconv1", "dec/disp1"]
+#   build_vgg: conv_block(x, n, k) = conv(x, n, k, 1) then conv(., n, k, 2): conv1 .. conv7 -> a, b of each; decoder from upconv7 down
+_VGG_ENCODER_ORDER = [f"enc/conv{i}{ab}" for i in range(1, 8) for ab in ("a", "b")]
+_VGG_DECODER_ORDER = ["dec/upconv7", "dec/iconv7", "dec/upconv6", "dec/iconv6", "dec/upconv5", "dec/iconv5", "dec/upconv4", "dec/iconv4", "dec/disp4",
+                      "dec/upconv3", "dec/iconv3", "dec/disp3", "dec/upconv2", "dec/iconv2", "dec/disp2", "dec/upconv1", "dec/iconv1", "dec/disp1"]
+# spot values a reader of the upstream code can check by counting: the literal names of a few layers
+_RESNET50_LITERALS = {"enc/conv1": "Conv", "enc/res2_1/conv1": "Conv_1", "enc/res2_1/proj": "Conv_4", "enc/res2_3/conv2": "Conv_10", "enc/res3_1/conv1": "Conv_13",
+                      "enc/res3_4/proj": "Conv_28", "enc/res4_1/conv1": "Conv_29", "enc/res4_6/proj": "Conv_52", "enc/res5_1/conv1": "Conv_53", "enc/res5_3/proj": "Conv_64",
+                      "dec/upconv6": "Conv", "dec/iconv4": "Conv_5", "dec/disp4": "Conv_6", "dec/upconv3": "Conv_7", "dec/disp2": "Conv_12", "dec/iconv1": "Conv_14",
+                      "dec/disp1": "Conv_15"}
+
+
+@pytest.mark.parametrize("encoder", ["resnet50", "vgg"])
+def test_slim_creation_order_against_the_upstream_construction_order(encoder):
+    nm = T.monodepth_name_map(encoder)
+    enc, dec = (_RESNET50_ENCODER_ORDER, _RESNET50_DECODER_ORDER) if encoder == "resnet50" else (_VGG_ENCODER_ORDER, _VGG_DECODER_ORDER)
+    assert len(enc) == (65 if encoder == "resnet50" else 14) and len(dec) == (16 if encoder == "resnet50" else 18)
+    want = {}
+    for scope, order in (("model/encoder", enc), ("model/decoder", dec)):
+        for i, layer in enumerate(order):
+            for leaf in ("weights", "biases"):
+                want[f"{layer}/{leaf}"] = f"{scope}/Conv{'' if i == 0 else '_' + str(i)}/{leaf}"
+    assert nm == want                                          # every slot, both scopes, no extras
+    if encoder == "resnet50":
+        for layer, conv in _RESNET50_LITERALS.items():
+            scope = "model/encoder" if layer.startswith("enc/") else "model/decoder"
+            assert nm[layer + "/weights"] == f"{scope}/{conv}/weights", layer
+    # the slot table itself lists the layers in that order (the engine's plan and the importer agree on what 'res3_2/proj' is)
+    slots = [s[:-len("/weights")] for s in W.monodepth_weight_shapes(encoder) if s.endswith("/weights")]
+    assert slots == enc + dec
