@@ -20,7 +20,8 @@ One step = one pass of the whole hot path over one batch of synthetic frames alr
      world size must equal --gpus, and the JSON carries `ranks_seen` (an all_reduce of ones over RCCL).
 
 The HEADLINE engine (`value`, `dtype`, `roofline`) computes at the reference's precision (fp32: semantic_depth.py:550-552,675 run the
-TF graphs in float32); the reduced-precision engines are LEGS of the same line, timed for the same --steps in the same process.
+TF graphs in float32): the bf16 x 3 split engine (f32 operands carried exactly, f32 accumulation) by default, the exact-f32 MFMA engine
+with --precision f32; the other engines are LEGS of the same line, timed for the same --steps in the same process.
 
 Prints ONE JSON line on rank 0 (contract in the round prompt) with
   `value`        frames/s of the headline engine: EXACTLY --steps steps between barrier + synchronize, max over ranks; the region is
@@ -51,9 +52,12 @@ H, W = 512, 1024
 # split-bf16 (3 products): every algorithmic product costs three dense-bf16 MFMA products (hi*hi + hi*lo + lo*hi), so the
 # ceiling for ALGORITHMIC flops is the dense bf16 peak / 3; split-fp16 x fp16 weights (2 products): dense fp16 peak / 2.
 PEAK_F32, PEAK_3P, PEAK_2P, PEAK_1P, PEAK_6P = 157.3, 2500.0 / 3.0, 2500.0 / 2.0, 2500.0, 2500.0 / 6.0
-# the HEADLINE engine computes at the reference's precision (the reference runs its TF graphs in float32, semantic_depth.py:550-552,675);
-# the reduced-precision engines (within north_star's 1e-3, see `legs[*].parity_vs_f32_engine`) are reported beside it
-DEFAULT_PRECISION = "f32"
+# the HEADLINE engine computes at the reference's precision (the reference runs its TF graphs in float32, semantic_depth.py:550-552,675):
+# 'bf16x3' carries every f32 operand EXACTLY (three bf16 planes) and accumulates in f32; its outputs differ from the exact-f32 MFMA
+# engine's by what two f32 summation orders differ by (`parity.vs_f32_engine`; against a float64 oracle both have the same error:
+# profiles/r03_f32_grade_check.txt).  The exact-f32 MFMA engine is timed beside it for the same --steps (`f32_exact`), and so is the
+# reduced-precision plan (within north_star's 1e-3: `legs.plan.parity_vs_f32_engine`).
+DEFAULT_PRECISION = "bf16x3"
 DTYPE = {
     "f32": "f32 (exact: v_mfma_f32_16x16x4_f32)",
     "bf16x3": "f32 operands carried EXACTLY as three bf16 planes each (v = hi + mid + lo, 8+8+8 significand bits), 6 bf16 MFMA products per "

@@ -342,9 +342,11 @@ __device__ __forceinline__ void sn_dma16(const void* gsrc, unsigned lds_dst) {
 constexpr int SN_TH = 8, SN_TW = 32, SN_HW = SN_TW + 2, SN_HH = SN_TH + 2;
 constexpr int SN_XI = (SN_HH * SN_HW * 2 + 63) / 64;        // 11 DMA instructions per plane
 constexpr int SN_XUNITS = SN_XI * 64;
-template <int NOUT, bool F16>
+// NPL = planes of the input: 1 ONE fp16 plane, 2 bf16 hi + lo, 3 bf16 hi + mid + lo (SD_PREC_BF16X3: exact f32 values, f32 FMAs)
+template <int NOUT, int NPL>
 __global__ __launch_bounds__(256) void conv_smalln_tile_kernel(const SmallNParams p) {
-    __shared__ __attribute__((aligned(16))) u32x4_t X[(F16 ? 1 : 2) * SN_XUNITS];       // one plane for fp16 inputs
+    constexpr bool F16 = NPL == 1;
+    __shared__ __attribute__((aligned(16))) u32x4_t X[NPL * SN_XUNITS];
     extern __shared__ __attribute__((aligned(16))) float wl[];   // [NOUT][9 C]
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -365,15 +367,15 @@ __global__ __launch_bounds__(256) void conv_smalln_tile_kernel(const SmallNParam
     for (int c0 = 0; c0 < p.C; c0 += 16) {
         const int nvalid = (p.C - c0) >= 16 ? 2 : 1;
         __syncthreads();                                   // the previous chunk is consumed (and the weights are staged)
-        for (int j = wave; j < (F16 ? 1 : 2) * SN_XI; j += 4) {        // wave-uniform: instruction j of [hi plane | lo plane]; fp16: ONE plane
-            const int pl = j >= SN_XI ? 1 : 0;
+        for (int j = wave; j < NPL * SN_XI; j += 4) {        // wave-uniform: instruction j of [hi plane | lo plane ...]; fp16: ONE plane
+            const int pl = j / SN_XI;
             const int u = (j - pl * SN_XI) * 64 + lane;
             const int pix = u >> 1;
             const int oct = (u & 1) ^ ((pix >> 3) & 1);
             const int ry = pix / SN_HW, rx = pix - ry * SN_HW;
             const int gy = ty0 - 1 + ry, gx = tx0 - 1 + rx;
             const bool ok = pix < SN_HH * SN_HW && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && oct < nvalid;
-            const uint16_t* src = img_hi + (pl ? p.in_plane : (size_t)0) + ((size_t)gy * p.W + gx) * pstride +
+            const uint16_t* src = img_hi + (size_t)pl * p.in_plane + ((size_t)gy * p.W + gx) * pstride +
                                   (p.in_sub ? (size_t)(c0 >> 4) * p.in_sub : (size_t)c0) + oct * 8;
             sn_dma16(ok ? (const void*)src : p.zero16, lds0 + (unsigned)(j * 1024));
         }
@@ -385,8 +387,15 @@ __global__ __launch_bounds__(256) void conv_smalln_tile_kernel(const SmallNParam
             for (int oct = 0; oct < nvalid; ++oct) {
                 const int idx = lp * 2 + (oct ^ ((lp >> 3) & 1));
                 const u32x4_t h = X[idx], l = F16 ? h : X[SN_XUNITS + idx];
-                const f32x4 v0 = recon4_t<F16>(uint2{h[0], h[1]}, uint2{l[0], l[1]});
-                const f32x4 v1 = recon4_t<F16>(uint2{h[2], h[3]}, uint2{l[2], l[3]});
+                f32x4 v0, v1;
+                if constexpr (NPL == 3) {
+                    const u32x4_t m3 = X[2 * SN_XUNITS + idx];            // (l = the mid plane, m3 = the lo plane: memory order)
+                    v0 = recon4_x3(uint2{h[0], h[1]}, uint2{l[0], l[1]}, uint2{m3[0], m3[1]});
+                    v1 = recon4_x3(uint2{h[2], h[3]}, uint2{l[2], l[3]}, uint2{m3[2], m3[3]});
+                } else {
+                    v0 = recon4_t<F16>(uint2{h[0], h[1]}, uint2{l[0], l[1]});
+                    v1 = recon4_t<F16>(uint2{h[2], h[3]}, uint2{l[2], l[3]});
+                }
 #pragma unroll
                 for (int j = 0; j < NOUT; ++j) {
                     const f32x4* wp = reinterpret_cast<const f32x4*>(wl + j * K + tap * p.C + c0 + oct * 8);
@@ -401,15 +410,24 @@ __global__ __launch_bounds__(256) void conv_smalln_tile_kernel(const SmallNParam
     if (y >= p.H) return;
     const long pix = ((long)img * p.H + y) * p.W + tx0 + col;
     if (p.out_split) {            // NOUT == 2: one bf16 pair per plane
-        unsigned h, l;
-        if (p.out_f16) split2_t<true>(f32x2_t{smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)}, h, l);
-        else split2_t<false>(f32x2_t{smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)}, h, l);
+        unsigned h, l, m = 0u;
+        const f32x2_t v2 = {smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)};
+        if (NPL == 3) split2_x3(v2, h, m, l);
+        else if (p.out_f16) split2_t<true>(v2, h, l);
+        else split2_t<false>(v2, h, l);
+        uint16_t* const o16 = reinterpret_cast<uint16_t*>(p.out);
         if (p.out_c == 8) {
-            reinterpret_cast<u32x4_t*>(p.out)[pix] = (u32x4_t){h, 0u, 0u, 0u};
-            if (!p.out_f16) reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(p.out) + p.out_plane)[pix] = (u32x4_t){l, 0u, 0u, 0u};
+            reinterpret_cast<u32x4_t*>(o16)[pix] = (u32x4_t){h, 0u, 0u, 0u};
+            if (NPL == 3) {
+                reinterpret_cast<u32x4_t*>(o16 + p.out_plane)[pix] = (u32x4_t){m, 0u, 0u, 0u};
+                reinterpret_cast<u32x4_t*>(o16 + 2 * p.out_plane)[pix] = (u32x4_t){l, 0u, 0u, 0u};
+            } else if (!p.out_f16) reinterpret_cast<u32x4_t*>(o16 + p.out_plane)[pix] = (u32x4_t){l, 0u, 0u, 0u};
         } else {
-            reinterpret_cast<unsigned*>(p.out)[pix] = h;
-            if (!p.out_f16) reinterpret_cast<unsigned*>(reinterpret_cast<uint16_t*>(p.out) + p.out_plane)[pix] = l;
+            reinterpret_cast<unsigned*>(o16)[pix] = h;
+            if (NPL == 3) {
+                reinterpret_cast<unsigned*>(o16 + p.out_plane)[pix] = m;
+                reinterpret_cast<unsigned*>(o16 + 2 * p.out_plane)[pix] = l;
+            } else if (!p.out_f16) reinterpret_cast<unsigned*>(o16 + p.out_plane)[pix] = l;
         }
     } else {
         float* o = p.out + pix * NOUT;
@@ -426,12 +444,15 @@ static void launch_smalln_t(const SmallNParams& p, hipStream_t s) {
         !(p.sw & SW_NO_SMALLN_TILE)) {
         const dim3 grid((unsigned)((p.W / SN_TW) * ((p.H + SN_TH - 1) / SN_TH) * p.N));
         const size_t lds = (size_t)K * 4 * p.nout;
-        if (IN_SPLIT == 2) {
-            if (p.nout == 1) hipLaunchKernelGGL((conv_smalln_tile_kernel<1, true>), grid, dim3(256), lds, s, p);
-            else hipLaunchKernelGGL((conv_smalln_tile_kernel<2, true>), grid, dim3(256), lds, s, p);
+        if (IN_SPLIT == 4) {
+            if (p.nout == 1) hipLaunchKernelGGL((conv_smalln_tile_kernel<1, 3>), grid, dim3(256), lds, s, p);
+            else hipLaunchKernelGGL((conv_smalln_tile_kernel<2, 3>), grid, dim3(256), lds, s, p);
+        } else if (IN_SPLIT == 2) {
+            if (p.nout == 1) hipLaunchKernelGGL((conv_smalln_tile_kernel<1, 1>), grid, dim3(256), lds, s, p);
+            else hipLaunchKernelGGL((conv_smalln_tile_kernel<2, 1>), grid, dim3(256), lds, s, p);
         } else {
-            if (p.nout == 1) hipLaunchKernelGGL((conv_smalln_tile_kernel<1, false>), grid, dim3(256), lds, s, p);
-            else hipLaunchKernelGGL((conv_smalln_tile_kernel<2, false>), grid, dim3(256), lds, s, p);
+            if (p.nout == 1) hipLaunchKernelGGL((conv_smalln_tile_kernel<1, 2>), grid, dim3(256), lds, s, p);
+            else hipLaunchKernelGGL((conv_smalln_tile_kernel<2, 2>), grid, dim3(256), lds, s, p);
         }
         return;
     }
@@ -455,11 +476,9 @@ bool conv_smalln_tiled(int in_split, int k, int W, int C, int nout, unsigned sw)
 hipError_t launch_conv_smalln(const SmallNParams& p, hipStream_t s) {
     if (p.in_sub && !(conv_smalln_tiled(p.in_split, p.k, p.W, p.C, p.nout, p.sw) && p.zero16)) return hipErrorInvalidValue;   // sub-planes: tiled kernel only
     if (p.out_split && (p.nout != 2 || p.k * p.k * p.C > 2048)) return hipErrorInvalidValue;
-    if (p.in_split && p.x3) {            // bf16 x 3 input: the per-thread / per-wave kernels (exact f32 arithmetic on the reconstructed values)
+    if (p.in_split && p.x3) {            // bf16 x 3 input: exact f32 arithmetic on the reconstructed values (tiled or per-thread / per-wave)
         if (p.in_sub) return hipErrorInvalidValue;
-        SmallNParams q = p;
-        q.sw |= SW_NO_SMALLN_TILE;
-        launch_smalln_t<4>(q, s);
+        launch_smalln_t<4>(p, s);
     } else if (p.in_split && p.f16 == 2) {      // fp16 hi + lo input: the per-thread / per-wave kernels only
         if (p.in_sub || p.out_split) return hipErrorInvalidValue;
         SmallNParams q = p;
