@@ -156,8 +156,16 @@ sd_status sd_png_unfilter_bgr(const uint8_t* filtered_host, int height, int widt
  * chunk walk, zlib inflate, scanline reconstruction, channel shuffle, palette expansion in one native call (no interpreter lock held).
  * bgr_out_host NULL: only *height_out / *width_out are written (size query).  SD_ERR_INVALID: not such a PNG / corrupt / buffer too small. */
 sd_status sd_png_decode_bgr(const uint8_t* file_host, size_t len, uint8_t* bgr_out_host, size_t out_capacity, int* height_out, int* width_out);
+/* HOST: a baseline / extended-sequential Huffman JPEG (8-bit; gray or YCbCr with 4:4:4, 4:2:2 or 4:2:0 chroma; restart intervals) ->
+ * cv2.imread(path): libjpeg's default decode path restated (jidctint "ISLOW" inverse DCT, "fancy" triangle chroma upsampling, jdcolor's
+ * fixed-point YCbCr -> RGB) followed by the EXIF orientation OpenCV's imread applies; u8 [height,width,3] BGR.  The reference's own example
+ * frames are JPEGs (assets/images/test_munich/test_3.jpg, semantic_depth.py:105).  Same calling convention as sd_png_decode_bgr;
+ * *height_out / *width_out are the dimensions AFTER the orientation.  Progressive / arithmetic / 12-bit / CMYK: SD_ERR_INVALID. */
+sd_status sd_jpeg_decode_bgr(const uint8_t* file_host, size_t len, uint8_t* bgr_out_host, size_t out_capacity, int* height_out, int* width_out);
+/* HOST: either of the two, by file signature */
+sd_status sd_image_decode_bgr(const uint8_t* file_host, size_t len, uint8_t* bgr_out_host, size_t out_capacity, int* height_out, int* width_out);
 /* HOST: the batch reader behind frame_io.FrameFeeder (the loop over sorted(glob(...)) of seq:689-701, `cv2.imread` at seq:123): reads and
- * decodes n PNG files of height x width on `threads` native threads (<= 0: one per host CPU) into out_host + i * frame_stride (e.g. a
+ * decodes n PNG / JPEG files of height x width on `threads` native threads (<= 0: one per host CPU) into out_host + i * frame_stride (e.g. a
  * pinned staging buffer).  status_out (nullable, int[n]): per-file sd_status (SD_ERR_NOTFOUND: unreadable file; SD_ERR_INVALID: not a
  * PNG of that shape).  Returns SD_OK when every file decoded. */
 sd_status sd_decode_files_bgr(const char* const* paths, int n, int height, int width, uint8_t* out_host, size_t frame_stride, int threads,

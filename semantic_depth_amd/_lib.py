@@ -69,6 +69,8 @@ SIGNATURES = {
     "sd_monodepth_forward": (C.c_int, [_H, _P, C.c_int, _P, _P, _P]),
     "sd_png_unfilter_bgr": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "sd_png_decode_bgr": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sd_jpeg_decode_bgr": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sd_image_decode_bgr": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sd_decode_files_bgr": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, _P, C.c_size_t, C.c_int, C.POINTER(C.c_int)]),
     "sd_ply_format_rows": (C.c_int64, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int]),
     "sd_post_process": (C.c_int, [_H, _P, C.c_int, _P, _P]),

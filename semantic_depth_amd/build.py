@@ -30,6 +30,7 @@ SOURCES = [
     ("plan.cpp", []),
     ("capi.cpp", []),
     ("host_png.cpp", []),
+    ("host_jpeg.cpp", []),
     ("host_ply.cpp", []),
 ]
 HEADERS = ["kernels.hpp", "plan.hpp", "split_fmt.hpp", os.path.join("..", "..", "include", "semdepth.h")]

@@ -137,6 +137,12 @@ sd_status png_decode(const uint8_t* f, size_t len, uint8_t* out, size_t out_cap,
     return SD_OK;
 }
 
+// PNG or baseline JPEG (host_jpeg.cpp), by signature
+sd_status image_decode(const uint8_t* f, size_t len, uint8_t* out, size_t out_cap, int* h_out, int* w_out) {
+    if (f && len >= 2 && f[0] == 0xFF && f[1] == 0xD8) return sd_jpeg_decode_bgr(f, len, out, out_cap, h_out, w_out);
+    return png_decode(f, len, out, out_cap, h_out, w_out);
+}
+
 bool read_file(const char* path, std::vector<uint8_t>& buf) {
     FILE* fp = std::fopen(path, "rb");
     if (!fp) return false;
@@ -157,6 +163,11 @@ extern "C" sd_status sd_png_decode_bgr(const uint8_t* file_host, size_t len, uin
     return png_decode(file_host, len, bgr_out_host, out_capacity, height_out, width_out);
 }
 
+extern "C" sd_status sd_image_decode_bgr(const uint8_t* file_host, size_t len, uint8_t* bgr_out_host, size_t out_capacity, int* height_out,
+                                         int* width_out) {
+    return image_decode(file_host, len, bgr_out_host, out_capacity, height_out, width_out);
+}
+
 extern "C" sd_status sd_decode_files_bgr(const char* const* paths, int n, int height, int width, uint8_t* out_host, size_t frame_stride,
                                          int threads, int* status_out) {
     if (!paths || n < 0 || height <= 0 || width <= 0 || !out_host || frame_stride < (size_t)height * width * 3) return SD_ERR_INVALID;
@@ -171,9 +182,9 @@ extern "C" sd_status sd_decode_files_bgr(const char* const* paths, int n, int he
             sd_status st = SD_ERR_NOTFOUND;
             if (paths[i] && read_file(paths[i], file)) {
                 int h = 0, w = 0;
-                st = png_decode(file.data(), file.size(), nullptr, 0, &h, &w);
+                st = image_decode(file.data(), file.size(), nullptr, 0, &h, &w);
                 if (st == SD_OK && (h != height || w != width)) st = SD_ERR_INVALID;         // every frame of a batch has the batch's shape
-                if (st == SD_OK) st = png_decode(file.data(), file.size(), out_host + (size_t)i * frame_stride, frame_stride, nullptr, nullptr);
+                if (st == SD_OK) st = image_decode(file.data(), file.size(), out_host + (size_t)i * frame_stride, frame_stride, nullptr, nullptr);
             }
             if (status_out) status_out[i] = st;
             if (st != SD_OK) failed.fetch_add(1);

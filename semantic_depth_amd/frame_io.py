@@ -48,9 +48,37 @@ def decode_png(buf: bytes) -> np.ndarray:
     return out
 
 
+def image_size(buf: bytes) -> tuple[int, int]:
+    """(height, width) of a PNG or baseline JPEG as cv2.imread would return it (JPEG: after the EXIF orientation)"""
+    lib = L.load()
+    h, w = C.c_int(), C.c_int()
+    if lib.sd_image_decode_bgr(buf, len(buf), None, 0, C.byref(h), C.byref(w)) != L.SD_OK:
+        raise ValueError("not a PNG / baseline JPEG this reader takes (PNG: 8-bit non-interlaced; JPEG: baseline Huffman, 8-bit, "
+                         "gray or YCbCr 4:4:4 / 4:2:2 / 4:2:0)")
+    return h.value, w.value
+
+
+def decode_jpeg(buf: bytes) -> np.ndarray:
+    """baseline JPEG bytes -> u8 [h,w,3] BGR = cv2.imread: libjpeg's default decode path (ISLOW inverse DCT, fancy chroma upsampling,
+    fixed-point YCbCr -> RGB) and the EXIF orientation, restated natively (sd_jpeg_decode_bgr)"""
+    if bytes(buf[:2]) != b"\xff\xd8":
+        raise ValueError("not a JPEG file")
+    return decode_image(buf)
+
+
+def decode_image(buf: bytes) -> np.ndarray:
+    h, w = image_size(buf)
+    out = np.empty((h, w, 3), np.uint8)
+    if L.load().sd_image_decode_bgr(buf, len(buf), out.ctypes.data_as(C.c_void_p), out.nbytes, None, None) != L.SD_OK:
+        raise ValueError("corrupt image stream")
+    return out
+
+
 def imread(path: str) -> np.ndarray:
+    """cv2.imread(path) for 8-bit PNG and baseline JPEG files (semantic_depth.py:105; seq:123)"""
     with open(path, "rb") as f:
-        return decode_png(f.read())
+        buf = f.read()
+    return decode_png(buf) if buf[:8] == _SIG else decode_image(buf)
 
 
 class FrameFeeder:
@@ -79,7 +107,7 @@ class FrameFeeder:
     def _decode_into(self, slot: int, lo: int, hi: int):
         torch = self._torch
         with open(self.paths[lo], "rb") as f:
-            h, w = png_size(f.read())
+            h, w = image_size(f.read())
         buf = self._pinned[slot]
         if buf is None or tuple(buf.shape[1:3]) != (h, w) or buf.shape[0] < hi - lo:
             buf = self._pinned[slot] = torch.empty((self.batch, h, w, 3), dtype=torch.uint8, pin_memory=self.device.type == "cuda")
@@ -89,7 +117,7 @@ class FrameFeeder:
         st = self._lib.sd_decode_files_bgr(arr, n, h, w, C.c_void_p(buf.data_ptr()), h * w * 3, self.workers, status)
         if st != L.SD_OK:
             bad = [(self.paths[lo + i], status[i]) for i in range(n) if status[i] != L.SD_OK]
-            raise ValueError(f"FrameFeeder: {len(bad)} frame(s) of the batch could not be read as {h}x{w} PNGs: {bad[:3]}")
+            raise ValueError(f"FrameFeeder: {len(bad)} frame(s) of the batch could not be read as {h}x{w} PNG / JPEG frames: {bad[:3]}")
         return buf[:n]
 
     def __iter__(self):

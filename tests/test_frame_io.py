@@ -150,3 +150,109 @@ def test_batch_reader_reports_the_files_it_could_not_decode(tmp_path):
     assert frame_io.png_size(buf) == (10, 12)
     with pytest.raises(ValueError):
         frame_io.decode_png(buf[:len(buf) // 2])
+
+
+# ------------------------------------------------------------------------------------------------ JPEG (the reference's own frames)
+def _jpeg_golden():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_golden.json")))
+
+
+def test_jpeg_reader_against_the_committed_golden_vectors():
+    """frames decoded by Pillow / libjpeg-turbo at libjpeg's default settings (= cv2.imread, semantic_depth.py:105) in the build
+    container (tests/golden/make_jpeg_golden.py): baseline, optimised-Huffman and progressive files, 4:4:4 / 4:2:2 / 4:2:0, gray,
+    odd sizes -- bit for bit"""
+    import base64
+    import hashlib
+    g = _jpeg_golden()
+    assert len(g["files"]) >= 6
+    for f in g["files"]:
+        buf = base64.b64decode(f["jpeg_base64"])
+        got = frame_io.decode_image(buf)
+        want = np.asarray(f["bgr"], np.uint8).reshape(f["height"], f["width"], 3)
+        assert got.shape == want.shape and np.array_equal(got, want), f["name"]
+        assert hashlib.sha256(got.tobytes()).hexdigest() == f["bgr_sha256"]
+        assert frame_io.image_size(buf) == (f["height"], f["width"])
+
+
+def test_jpeg_reader_on_the_references_example_frame():
+    """assets/images/test_munich/test_3.jpg (progressive, 4032 x 3024): the frame the reference's README runs on.  Runs where the
+    reference tree exists (the build container); the expected digest was made there with Pillow."""
+    import hashlib
+    ref = _jpeg_golden()["reference_frame"]
+    path = os.path.join("/root/reference", ref["path"])
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present")
+    buf = open(path, "rb").read()
+    assert hashlib.sha256(buf).hexdigest() == ref["file_sha256"]
+    got = frame_io.imread(path)
+    assert list(got.shape) == ref["shape"]
+    for k, v in ref["probe_pixels_bgr"].items():
+        y, x = map(int, k.split(","))
+        assert got[y, x].tolist() == v, k
+    assert hashlib.sha256(got.tobytes()).hexdigest() == ref["bgr_sha256"]
+
+
+def test_jpeg_matrix_against_pillow_and_exif_orientation(tmp_path):
+    """every combination of size x subsampling x quality x entropy mode Pillow writes, decoded by both; the EXIF orientations 1..8 as
+    cv2.imread applies them (= ImageOps.exif_transpose); restart intervals; what the reader refuses"""
+    import io
+    PILImage = pytest.importorskip("PIL.Image")
+    from PIL import ImageOps
+    rng = np.random.default_rng(5)
+
+    def img(h, w):
+        yy, xx = np.mgrid[0:h, 0:w]
+        a = np.stack([(yy * 3 + xx * 2) % 256, (xx * 5 + yy) % 256, (yy * yy // 7 + xx) % 256], -1).astype(np.uint8)
+        return a ^ rng.integers(0, 32, a.shape, dtype=np.uint8)
+
+    n = 0
+    for (h, w) in [(16, 16), (17, 23), (64, 48), (8, 9), (57, 130)]:
+        for ss in (0, 1, 2):
+            for q in (35, 90, 100):
+                for kw in ({}, {"optimize": True}, {"progressive": True}):
+                    b = io.BytesIO()
+                    try:
+                        PILImage.fromarray(img(h, w)).save(b, "JPEG", quality=q, subsampling=ss, **kw)
+                    except OSError:
+                        continue            # (Pillow's encoder refuses some tiny optimised files on an in-memory stream)
+                    want = np.asarray(PILImage.open(io.BytesIO(b.getvalue())).convert("RGB"))[..., ::-1]
+                    assert np.array_equal(frame_io.decode_image(b.getvalue()), want), (h, w, ss, q, kw)
+                    n += 1
+    assert n > 100
+    # restart intervals (DRI / RSTn)
+    for ss in (0, 2):
+        b = io.BytesIO()
+        PILImage.fromarray(img(50, 70)).save(b, "JPEG", quality=80, subsampling=ss, restart_marker_blocks=3)
+        assert b"\xff\xdd" in b.getvalue()
+        want = np.asarray(PILImage.open(io.BytesIO(b.getvalue())).convert("RGB"))[..., ::-1]
+        assert np.array_equal(frame_io.decode_image(b.getvalue()), want)
+    # EXIF orientation: cv2.imread rotates / flips, Pillow does so on request
+    base = PILImage.fromarray(img(24, 40))
+    for o in range(1, 9):
+        ex = PILImage.Exif()
+        ex[0x0112] = o
+        p = str(tmp_path / f"o{o}.jpg")
+        base.save(p, "JPEG", quality=90, subsampling=0, exif=ex)
+        want = np.asarray(ImageOps.exif_transpose(PILImage.open(p)).convert("RGB"))[..., ::-1]
+        got = frame_io.imread(p)
+        assert got.shape == want.shape and np.array_equal(got, want), o
+        assert frame_io.image_size(open(p, "rb").read()) == want.shape[:2]
+    # a feeder batch of JPEG frames
+    paths = []
+    for i in range(3):
+        p = str(tmp_path / f"frame{i}.jpg")
+        PILImage.fromarray(img(32, 48)).save(p, "JPEG", quality=85)
+        paths.append(p)
+    got = [d.numpy().copy() for d, _ in frame_io.FrameFeeder(paths, batch=2, device="cpu", workers=2)]
+    for i, p in enumerate(paths):
+        assert np.array_equal(np.concatenate(got)[i], np.asarray(PILImage.open(p).convert("RGB"))[..., ::-1])
+    # refused: CMYK, truncated
+    b = io.BytesIO()
+    PILImage.fromarray(img(16, 16)).convert("CMYK").save(b, "JPEG")
+    with pytest.raises(ValueError):
+        frame_io.decode_image(b.getvalue())
+    b = io.BytesIO()
+    PILImage.fromarray(img(32, 32)).save(b, "JPEG")
+    with pytest.raises(ValueError):
+        frame_io.decode_image(b.getvalue()[:200])
