@@ -342,8 +342,8 @@ def main():
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dts.append(float(tmax.item()))
             for b_ in eng.profile_read():                          # HIP-event buckets of this region (read outside the timed region)
-                a_ = buckets.setdefault(b_["kernel"], dict(kernel=b_["kernel"], launches=0, ms=0.0, flops=0.0))
-                a_["launches"] += b_["launches"]; a_["ms"] += b_["ms"]; a_["flops"] += b_["flops"]
+                a_ = buckets.setdefault(b_["kernel"], dict(kernel=b_["kernel"], launches=0, ms=0.0, flops=0.0, bytes=0.0))
+                a_["launches"] += b_["launches"]; a_["ms"] += b_["ms"]; a_["flops"] += b_["flops"]; a_["bytes"] += b_.get("bytes", 0.0)
         eng.profile(False)
         if args.config == 5:                                       # stage split + report tensors from one more (untimed) instrumented step
             out, _ = instrumented_step()
@@ -530,6 +530,8 @@ def conv_roofline(buckets, precision, dt):
         "frac": round(ach(dom) / dpk, 4), "traffic": traffic, "traffic_source": traffic_src,
         "launches": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
         "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
+        "algorithmic_bytes_per_launch": round(dom.get("bytes", 0.0) / dom["launches"]),
+        "traffic_over_algorithmic": (round(traffic / (dom["bytes"] / dom["launches"]), 3) if traffic and dom.get("bytes") else None),
         "peak_note": "f32 MFMA dense peak 157.3 (v_mfma_f32_16x16x4_f32: 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz); split engines: dense bf16/fp16 "
                      "MFMA peak 2500 / MFMA products per algorithmic product (kernels named _x3: 6, plain: 3, f16w: 2, f16x1: 1).  `achieved` "
                      "counts ALGORITHMIC flops (2*M*N*K of the layer, padding not counted).  Measured on this pool: with random operands the "

@@ -281,6 +281,8 @@ typedef struct {
     int64_t launches;
     double ms;
     double flops;
+    double bytes;      /* algorithmic HBM bytes of those launches: every source tensor, the weights and the output tensor ONCE, in the
+                          formats the engine stores them in (what a launch cannot avoid moving; the PMC traffic is compared with it) */
 } sd_profile_bucket;
 sd_status sd_profile(sd_handle* h, int enable);
 sd_status sd_profile_read(sd_handle* h, sd_profile_bucket* out_host, int cap_buckets, int* n_out);

@@ -45,7 +45,7 @@ class sd_f2f_result(C.Structure):
 
 
 class sd_profile_bucket(C.Structure):
-    _fields_ = [("kernel", C.c_char * 64), ("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double)]
+    _fields_ = [("kernel", C.c_char * 64), ("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
 
 
 # every symbol include/semdepth.h declares: name -> (restype, argtypes)

@@ -41,7 +41,7 @@ struct sd_handle {
     std::string err;
     // profiling (sd_profile): event pairs around conv launches
     bool prof = false;
-    struct ProfRec { const char* kernel; double flops; hipEvent_t a, b; const char* op; int M, N, K; };
+    struct ProfRec { const char* kernel; double flops; hipEvent_t a, b; const char* op; int M, N, K; double bytes; };
     std::vector<ProfRec> prof_recs;
     // one event per conv launch: the end event of a conv is the start event of the conv launched right behind it (two events per
     // launch cost 1.8 % of a step: every record is a barrier packet on the stream)
@@ -132,6 +132,15 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
     auto T = [&](int t) -> float* { return reinterpret_cast<float*>(abase + p.tensors[t].offset); };
     auto Wp = [&](int w) -> const float* { return reinterpret_cast<const float*>(wbase + p.weights[w].offset); };
     auto PL = [&](int t) -> size_t { const TensorDesc& d = p.tensors[t]; return (size_t)p.images * d.H * d.W * d.C; };   // lo-plane offset
+    // algorithmic HBM bytes of a conv op for N of the plan's images: sources + output once, + the weights (sd_profile_bucket::bytes)
+    auto op_bytes = [&](const OpDesc& op) -> double {
+        double b = 0;
+        for (int j = 0; j < op.nsrc; ++j) b += (double)p.tensors[op.src[j]].bytes;
+        if (op.dst >= 0) b += (double)p.tensors[op.dst].bytes;
+        b = b * N / p.images;
+        if (op.w >= 0) b += (double)p.weights[op.w].bytes;
+        return b;
+    };
     auto FMT = [&](int t) -> int { return p.tensors[t].fmt ? (p.tensors[t].x3 ? 4 : p.tensors[t].f16 ? 2 : 1) : 0; };     // (fp16 hi+lo tensors never reach the ops that take this)     // 0 f32, 1 split bf16, 2 split fp16
     for (const WeightSlot& wsl : p.weights)
         if (!wsl.loaded) return fail(h, SD_ERR_STATE, "weight not loaded: " + wsl.name);
@@ -191,7 +200,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                     hipEventRecord(eb, s);
                     h->prof_last = eb; conv_op = true;
                     h->prof_recs.push_back({dma ? conv_dma_kernel_name(c) : stem ? (c.x3 ? "conv_stem_x3_kernel" : c.f16 ? "conv_stem_f16w_kernel" : "conv_stem_kernel") : split ? conv_split_kernel_name(c) : conv_igemm_kernel_name(c), op.flops * N / p.images, ea, eb,
-                                            op.name.c_str(), N * c.Hout * c.Wout, d.C, op.K});
+                                            op.name.c_str(), N * c.Hout * c.Wout, d.C, op.K, op_bytes(op)});
                 }
                 break;
             }
@@ -223,7 +232,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 if (h->prof) {
                     hipEventRecord(eb, s);
                     h->prof_last = eb; conv_op = true;
-                    h->prof_recs.push_back({p.x3 ? conv_direct3_kernel_name(c) : conv_direct_kernel_name(c), op.flops * N / p.images, ea, eb, op.name.c_str(), N * c.H * c.W, d.C, op.K});
+                    h->prof_recs.push_back({p.x3 ? conv_direct3_kernel_name(c) : conv_direct_kernel_name(c), op.flops * N / p.images, ea, eb, op.name.c_str(), N * c.H * c.W, d.C, op.K, op_bytes(op)});
                 }
                 break;
             }
@@ -823,6 +832,7 @@ sd_status sd_profile_read(sd_handle* h, sd_profile_bucket* out, int cap_buckets,
         out[b].launches += 1;
         out[b].ms += ms;
         out[b].flops += r.flops;
+        out[b].bytes += r.bytes;
     }
     *n_out = n;
     h->prof_recs.clear();

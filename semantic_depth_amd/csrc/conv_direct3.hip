@@ -5,14 +5,14 @@
 // Same tiling as conv_direct.hip (a workgroup of 8 waves owns a 16 x 32 pixel tile, passes of 64 output channels, per 16-channel chunk
 // the 18 x 34 halo tile is DMAed into LDS once and serves all nine taps), but three planes of X (60 KB) plus three of W (54 KB) per chunk
 // do not fit twice into 160 KB.  The products are therefore grouped BY WEIGHT PLANE into three phases per chunk,
-//        phase hi : W_hi  x (X_hi, X_mid, X_lo)      108 MFMAs per wave (NB = 2)
-//        phase mid: W_mid x (X_hi, X_mid)              72
-//        phase lo : W_lo  x (X_hi)                     36
+//        phase lo : W_lo  x (X_hi)                     36 MFMAs per wave (NB = 2)
+//        phase mid: W_mid x (X_mid, X_hi)              72
+//        phase hi : W_hi  x (X_lo, X_mid, X_hi)       108
 // X is double-buffered per chunk (2 x 60 KB) and the weight planes stream through a two-slot ring (2 x 18 KB): 156 KB + 2 KB of bias.
 // While a phase multiplies, the LDS-DMA brings the next weight plane and, spread over the hi / mid phases, the next chunk's X planes:
-//        phase hi issues  W_mid(c) + X_hi(c+1) + X_mid(c+1)      58 KB under 108 MFMAs
-//        phase mid issues W_lo(c)  + X_lo(c+1)                   38 KB under  72
-//        phase lo issues  W_hi(c+1)                              18 KB under  36
+//        phase lo issues  W_mid(c)                               18 KB under  36 MFMAs
+//        phase mid issues W_hi(c)   + X_hi(c+1)                  38 KB under  72
+//        phase hi issues  W_lo(c+1) + X_mid(c+1) + X_lo(c+1)     58 KB under 108
 // so every phase moves at most ~0.55 of the bytes the 16 B/clk L2 -> LDS path could move in its MFMA time.  One barrier per phase.
 // The (tile, pass, chunk, phase) sequence is one software pipeline across tiles (persistent workgroups, XCD-aware tile order).
 // Epilogue: bias + activation in f32 (the f32 engine's own ELU), the exact three-way split, LDS transpose in the consumed X buffer,
@@ -47,7 +47,10 @@ constexpr int T3_TW = 32, T3_HW = T3_TW + 2, T3_WAVES = 8, T3_TH = 16, T3_HH = T
 
 // NB = 32-channel blocks of output channels per pass (Cout <= 32 NB).  UP: every source is read through a x2 nearest-neighbour
 // upsample (the upconv layers): the LDS tile holds the 10 x 18 SOURCE pixels under the halo (conv_direct.hip).
-template <int NB, bool UP>
+// KEEP: X planes (hi first) whose MFMA fragments stay in VGPRs across the phases of a chunk instead of being re-read from LDS: the
+// kernel issues 0.58 ds_read_b128 per MFMA without it (x: 72, w: 54 per 216 MFMAs and wave) and the LDS read path (128 B/clk/CU),
+// not the MFMA pipe, bounds it; KEEP = 2 reads every X fragment once (x: 36).
+template <int NB, bool UP, int KEEP>
 __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectParams p) {
     constexpr int S_HH = UP ? T3_HH / 2 + 1 : T3_HH, S_HW = UP ? T3_HW / 2 + 1 : T3_HW;      // stored tile
     constexpr int XI = (S_HH * S_HW * 2 + 63) / 64;            // DMA instructions per halo plane (2 octet slots per pixel)
@@ -98,16 +101,16 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
         const int ry = pix / S_HW, rx = pix - ry * S_HW;
         geo[i] = ry | (rx << 8) | (oct << 19) | ((pix < S_HH * S_HW ? 1 : 0) << 20);
     }
-    int sgy[XS], sgx[XS];
     unsigned okA = 0, okB = 0;            // bit i: slot i reads an existing pixel (okB: ... and the first channel octet of a chunk)
+    int tgy = 0, tgx = 0;                 // source coordinates of halo pixel (0, 0) of the cursor tile (wave-uniform)
     auto set_tile = [&](const Tile& tl) {
         okA = 0; okB = 0;
+        tgy = (UP ? (tl.ty0 >> 1) : tl.ty0) - 1; tgx = (UP ? (tl.tx0 >> 1) : tl.tx0) - 1;
 #pragma unroll
         for (int i = 0; i < XS; ++i) {
             const int ry = geo[i] & 0xff, rx = (geo[i] >> 8) & 0xff;
-            const int gy = (UP ? (tl.ty0 >> 1) : tl.ty0) - 1 + ry, gx = (UP ? (tl.tx0 >> 1) : tl.tx0) - 1 + rx;
+            const int gy = tgy + ry, gx = tgx + rx;
             const bool in = ((geo[i] >> 20) & 1) && (unsigned)gy < (unsigned)(UP ? p.H >> 1 : p.H) && (unsigned)gx < (unsigned)(UP ? p.W >> 1 : p.W);
-            sgy[i] = gy; sgx[i] = gx;
             okA |= (in ? 1u : 0u) << i;
             okB |= ((in && !((geo[i] >> 19) & 1)) ? 1u : 0u) << i;
         }
@@ -127,7 +130,8 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
     auto xslot = [&](const ChunkCtx& k, int pl, int i) {       // X-DMA instruction wave + 8 i of plane pl
         const int j = wave + T3_WAVES * i;
         if (j >= XI) return;
-        const unsigned off = (unsigned)(sgy[i] >> k.up) * k.rowel + ((unsigned)(sgx[i] >> k.up) * k.C + ((unsigned)(geo[i] >> 16) & 8u));
+        const int gy = tgy + (geo[i] & 0xff), gx = tgx + ((geo[i] >> 8) & 0xff);      // (recomputed per slot: two VALU operations, no registers held)
+        const unsigned off = (unsigned)(gy >> k.up) * k.rowel + ((unsigned)(gx >> k.up) * k.C + ((unsigned)(geo[i] >> 16) & 8u));
         const uint16_t* src = k.img + (size_t)pl * k.plane + off;
         d3dma16(((k.okm >> i) & 1u) ? reinterpret_cast<const u32x4*>(src) : zero, k.xbyte + (unsigned)((pl * XUNITS + j * 64) * 16));
     };
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
 #pragma unroll
             for (int i = 0; i < XS; ++i) xslot(k, pl, i);
 #pragma unroll
-        for (int i = 0; i < WS; ++i) wslot(k.w, 0, i, 0);
+        for (int i = 0; i < WS; ++i) wslot(k.w, 2, i, 0);         // the first phase of a chunk multiplies W_lo
         wcur = k.w;
         advance();
     }
@@ -176,21 +180,31 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
             const bool more = itid < items;        // the cursor item exists: its X goes into buffer (g + 1) & 1 during this chunk
             ChunkCtx kn;
             const u32x4* const Xb = lds + (g & 1) * XBUF;
-            // one phase: NPX products of the weight plane in ring slot q & 1 with the first NPX planes of X; `issue(grp)` is called
-            // behind MFMA group grp (one DMA instruction per call)
-            auto phase = [&](auto npx_tag, auto&& issue) {
-                constexpr int NPX = decltype(npx_tag)::value;
+            auto xload = [&](int pl, int dx, int r) {
+                const int lp = hpix(T3_MT * wave + r, frow + dx);
+                return Xb[pl * XUNITS + lp * 2 + (fk ^ ((lp >> 3) & 1))];
+            };
+            // the X fragments of the first KEEP planes stay in registers from the phase that first reads them to the end of the chunk
+            u32x4 xk[KEEP > 0 ? KEEP : 1][3][T3_MT + 2];
+            // one phase: the weight plane in ring slot q & 1 times X planes PH .. 0 (phase 0: W_lo x X_hi; 1: W_mid x (X_mid, X_hi);
+            // 2: W_hi x (X_lo, X_mid, X_hi)); `issue(grp)` is called behind MFMA group grp (one DMA instruction per call)
+            auto phase = [&](auto ph_tag, auto&& issue) {
+                constexpr int PH = decltype(ph_tag)::value, NPX = PH + 1;
                 const u32x4* const Wq = lds + 2 * XBUF + (q & 1) * WUNITS;
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     u32x4 x[NPX][T3_MT + 2];
 #pragma unroll
-                    for (int r = 0; r < T3_MT + 2; ++r) {
-                        const int lp = hpix(T3_MT * wave + r, frow + dx);
-                        const int idx = lp * 2 + (fk ^ ((lp >> 3) & 1));
+                    for (int pl = 0; pl < NPX; ++pl)
 #pragma unroll
-                        for (int pl = 0; pl < NPX; ++pl) x[pl][r] = Xb[pl * XUNITS + idx];
-                    }
+                        for (int r = 0; r < T3_MT + 2; ++r) {
+                            if (pl < KEEP) {
+                                if (pl == PH) xk[pl][dx][r] = xload(pl, dx, r);      // first use: from LDS, then kept
+                                x[pl][r] = xk[pl][dx][r];
+                            } else {
+                                x[pl][r] = xload(pl, dx, r);
+                            }
+                        }
 #pragma unroll
                     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -207,28 +221,29 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
                         }
                 }
             };
-            // ---- phase hi: W_hi x (X_hi, X_mid, X_lo); brings W_mid of this chunk and X_hi, X_mid of the cursor chunk
+            // ---- phase lo: W_lo x X_hi (36 MFMAs per wave at NB = 2); brings W_mid of this chunk
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            phase(IntTag<0>{}, [&](int grp) {
+                if (grp < WS) wslot(wcur, 1, grp, (q + 1) & 1);
+            });
+            ++q;
+            // ---- phase mid: W_mid x (X_mid, X_hi) (72); brings W_hi of this chunk and X_hi of the cursor chunk
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (more) kn = begin_chunk(d3load_chunk(p.chunks + ic), icur, ic, (g + 1) & 1);
-            phase(IntTag<3>{}, [&](int grp) {
-                if (grp < WS) wslot(wcur, 1, grp, (q + 1) & 1);
-                else if (more && grp < WS + 2 * XS) { const int s_ = grp - WS; xslot(kn, s_ / XS, s_ % XS); }
+            phase(IntTag<1>{}, [&](int grp) {
+                if (grp < WS) wslot(wcur, 0, grp, (q + 1) & 1);
+                else if (more && grp < WS + XS) xslot(kn, 0, grp - WS);
             });
             ++q;
-            // ---- phase mid: W_mid x (X_hi, X_mid); brings W_lo of this chunk and X_lo of the cursor chunk
+            // ---- phase hi: W_hi x (X_lo, X_mid, X_hi) (108); brings W_lo and X_mid, X_lo of the cursor chunk
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             phase(IntTag<2>{}, [&](int grp) {
-                if (grp < WS) wslot(wcur, 2, grp, (q + 1) & 1);
-                else if (more && grp < WS + XS) xslot(kn, 2, grp - WS);
-            });
-            ++q;
-            // ---- phase lo: W_lo x X_hi; brings W_hi of the cursor chunk
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            phase(IntTag<1>{}, [&](int grp) {
-                if (more && grp < WS) wslot(kn.w, 0, grp, (q + 1) & 1);
+                if (!more) return;
+                if (grp < WS) wslot(kn.w, 2, grp, (q + 1) & 1);
+                else if (grp < WS + 2 * XS) { const int s_ = grp - WS; xslot(kn, 1 + s_ / XS, s_ % XS); }
             });
             ++q;
             if (more) { wcur = kn.w; advance(); }
@@ -349,13 +364,16 @@ hipError_t launch_conv_direct3(const ConvDirectParams& p, hipStream_t s) {
     const bool up = p.all_up && !(p.H & 1) && !(p.W & 1) && !(p.sw & SW_NO_UPTILE);
     const int tiles = (p.W / T3_TW) * ((p.H + T3_TH - 1) / T3_TH) * p.N * p.nsplit;
     const dim3 grid((unsigned)(tiles < cus ? tiles : cus));        // persistent: one workgroup per CU (158 KB of LDS)
+    static const int keep = [] { const char* e = std::getenv("SEMDEPTH_X3_KEEP"); return e ? atoi(e) : 2; }();   // (A/B switch, latched once)
+#define SD_D3(NB_, UP_) do { if (keep >= 2) hipLaunchKernelGGL((conv_direct3_kernel<NB_, UP_, 2>), grid, dim3(512), 0, s, p); \
+                             else if (keep == 1) hipLaunchKernelGGL((conv_direct3_kernel<NB_, UP_, 1>), grid, dim3(512), 0, s, p); \
+                             else hipLaunchKernelGGL((conv_direct3_kernel<NB_, UP_, 0>), grid, dim3(512), 0, s, p); } while (0)
     if (p.Cout <= 32) {
-        if (up) hipLaunchKernelGGL((conv_direct3_kernel<1, true>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((conv_direct3_kernel<1, false>), grid, dim3(512), 0, s, p);
+        if (up) SD_D3(1, true); else SD_D3(1, false);
     } else {
-        if (up) hipLaunchKernelGGL((conv_direct3_kernel<2, true>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((conv_direct3_kernel<2, false>), grid, dim3(512), 0, s, p);
+        if (up) SD_D3(2, true); else SD_D3(2, false);
     }
+#undef SD_D3
     return hipGetLastError();
 }
 

@@ -329,7 +329,7 @@ class Engine:
         buf = (L.sd_profile_bucket * 32)()
         n = C.c_int()
         L.check(self.lib, self.h, self.lib.sd_profile_read(self.h, buf, 32, C.byref(n)), "sd_profile_read")
-        return [dict(kernel=b.kernel.decode(), launches=int(b.launches), ms=float(b.ms), flops=float(b.flops)) for b in buf[:n.value]]
+        return [dict(kernel=b.kernel.decode(), launches=int(b.launches), ms=float(b.ms), flops=float(b.flops), bytes=float(b.bytes)) for b in buf[:n.value]]
 
     def precision_plan(self) -> dict:
         """{net: (layers that run the 2-product fp16 scheme, their share of the net's FLOPs)} after the consistency closure"""
