@@ -260,6 +260,30 @@ def save_frame_outputs(output_name: str, res: dict, depth: float, approach: str 
     return files
 
 
+# ------------------------------------------------------------------------------------------------ per-frame metrics log
+def append_metrics_jsonl(path: str, name: str, res: dict, times: dict | None = None, extra: dict | None = None) -> str:
+    """one JSON line per processed frame (SURVEY §5 "Metrics / logging": the reference only prints): frame name, both distances, the
+    kept-point count after every stage of the road chain, the plane, the end points, the stage times when given.  ``res`` is the dict
+    api.FrameProcessor.process_frame returns."""
+    rec = res["record"]
+    line = {"frame": name, "dist_rw": res.get("dist_rw"), "dist_f2f": res.get("dist_f2f"), "found": bool(rec["found"]),
+            "points": {k: int(rec[k]) for k in ("n_road", "n_zcut", "n_mad_y", "n_mad_x", "n_plane", "n_sor", "n_ror")},
+            "road_plane": [float(v) for v in rec["plane"]],
+            "left_pt": [float(v) for v in rec["left_pt"]] if rec["found"] else None,
+            "right_pt": [float(v) for v in rec["right_pt"]] if rec["found"] else None}
+    if res.get("f2f_record") is not None:
+        f2 = res["f2f_record"]
+        line["fence"] = {"ok": bool(f2["ok"]), "counts": [int(c) for c in f2["counts"]], "plane_left": [float(v) for v in f2["plane_left"]],
+                         "plane_right": [float(v) for v in f2["plane_right"]]}
+    if times is not None:
+        line["times_s"] = {k: float(times[k]) for k in TIME_KEYS if k in times}
+    if extra:
+        line.update(extra)
+    with open(path, "a") as f:
+        f.write(json.dumps(line) + "\n")
+    return path
+
+
 # ------------------------------------------------------------------------------------------------ focal-length sweep
 def write_sweep_data(f_directory: str, all_data, n_frames: int):
     """semantic_depth.py:907-936: rows (real, rw, f2f, |real-rw|, |real-f2f|) + a last row holding the two MAEs in columns

@@ -93,6 +93,26 @@ def test_monodepth_full_size_matches_oracle(precision, oracle_full, keep_taps):
     assert np.array_equal(pp.cpu().numpy()[0], fusion.post_processing(raw).astype(np.float32))
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x2", "plan"])
+def test_monodepth_vgg_full_size_matches_oracle(precision):
+    """the reference's DEFAULT monodepth encoder (--monodepth_encoder vgg, semantic_depth.py:721-722) at BASELINE's frame size against
+    the CPU oracle: raw disparity pair and the post-processed map (this encoder had only a 128 x 256 oracle test).
+    Under SD_PREC_PLAN the vgg encoder keeps three products (the built-in monodepth plan names ResNet-50 layers)."""
+    wm = Wt.make_monodepth_weights("vgg", 2, gain=1.0, bias_std=0.05)
+    fr = _smooth_frames(1, seed=45)
+    f = fr[0].astype(np.float32) / 255
+    ref_raw = nets.monodepth_forward(np.stack((f, np.fliplr(f)), 0), wm, "vgg")[..., 0]
+    eng = Engine(H, W, 1, "vgg", precision=precision)
+    eng.load_weights(L.SD_NET_MONODEPTH, wm)
+    eng.load_weights(L.SD_NET_FCN8S, Wt.make_fcn8s_weights(1, decoder_std=0.05))
+    pp, raw = eng.monodepth_forward(dev(fr), want_raw=True)
+    raw = raw.cpu().numpy()[0]
+    rep = assert_close(raw, ref_raw, "bf16x2" if precision == "plan" else precision, TOL, "raw disparity pair (vgg encoder)", kind="disp")
+    print("monodepth-vgg 512x1024 disparity", precision, rep)
+    assert np.array_equal(pp.cpu().numpy()[0], fusion.post_processing(raw).astype(np.float32))
+    assert relerr(pp.cpu().numpy()[0], fusion.post_processing(ref_raw.astype(np.float32)).astype(np.float32)) < TOL
+
+
 @pytest.fixture(scope="module")
 def oracle_b8():
     """BASELINE.json configs[1] / configs[2] as written: B = 8 frames of 512 x 1024 through the CPU oracle (once per module)"""
@@ -368,6 +388,12 @@ def test_api_classes_built_like_the_reference_main(tmp_path):
         assert seg_big.shape == (2 * h, 2 * w, 3) and np.array_equal(seg_big, oresize.resize_cubic_u8(overlay, 2 * h, 2 * w))
         assert str(tmp_path / "big.png") in files2 and frame_io.imread(str(tmp_path / "big.png")).shape == (2 * h, 2 * w, 3)
         assert open(tmp_path / "frame_output_distances.txt").read().startswith("rw distance:    {}\n".format(res["dist_rw"]))
+        import json as _json
+        outputs.append_metrics_jsonl(str(tmp_path / "metrics.jsonl"), "frame_output", res, times={k: 0.0 for k in outputs.TIME_KEYS})
+        outputs.append_metrics_jsonl(str(tmp_path / "metrics.jsonl"), "frame_output_again", res)
+        lines = [_json.loads(l) for l in open(tmp_path / "metrics.jsonl")]
+        assert len(lines) == 2 and lines[0]["dist_rw"] == res["dist_rw"] and lines[0]["points"]["n_ror"] == int(res["record"]["n_ror"])
+        assert lines[0]["fence"]["counts"][0] == int(res["f2f_record"]["counts"][0]) and "times_s" in lines[0] and "times_s" not in lines[1]
         head = open(tmp_path / "frame_output_ROAD.ply").read().split("\n")
         assert head[0] == "ply" and head[2].strip().startswith("element vertex")
     # DepthFrame.disp_to_image (semantic_depth.py:681-683): a gray PNG of the original frame size, min -> 0, max -> 255
