@@ -499,7 +499,7 @@ def pmc_traffic(label: str, pattern: str):
 def peak_of(kernel: str, precision: str) -> float:
     if "igemm" in kernel:
         return PEAK_F32
-    if "_x3" in kernel:
+    if "_x3" in kernel or "dma3" in kernel:
         return PEAK_6P
     if "f16x1" in kernel:
         return PEAK_1P

@@ -20,6 +20,7 @@ SOURCES = [
     ("conv_igemm.hip", []),
     ("conv_split.hip", []),
     ("conv_dma.hip", []),
+    ("conv_dma3.hip", []),
     ("conv_direct.hip", []),
     ("conv_direct3.hip", []),
     ("conv_stem.hip", []),

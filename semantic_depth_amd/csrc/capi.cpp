@@ -191,15 +191,16 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                     if (!ea) { if (!(ea = prof_event(h))) return fail(h, SD_ERR_HIP, "hipEventCreate"); hipEventRecord(ea, s); }
                     if (!(eb = prof_event(h))) return fail(h, SD_ERR_HIP, "hipEventCreate");
                 }
-                const bool dma = split && conv_dma_variant(c) != 0 && !(h->sw & SW_NO_DMA);
-                const bool stem = split && !dma && conv_stem_eligible(c);
+                const bool dma3 = split && conv_dma3_eligible(c) && !(h->sw & SW_NO_DMA);
+                const bool dma = !dma3 && split && conv_dma_variant(c) != 0 && !(h->sw & SW_NO_DMA);
+                const bool stem = split && !dma && !dma3 && conv_stem_eligible(c);
                 if (c.out_planar16 && !stem && !dma) return fail(h, SD_ERR_STATE, "sub-planar output needs the LDS-DMA or the stem conv kernel");
                 if (c.pool && !dma) return fail(h, SD_ERR_STATE, "fused pool needs the LDS-DMA conv kernel");
-                e = dma ? launch_conv_dma(c, s) : stem ? launch_conv_stem(c, s) : split ? launch_conv_split(c, s) : launch_conv_igemm(c, s);
+                e = dma3 ? launch_conv_dma3(c, s) : dma ? launch_conv_dma(c, s) : stem ? launch_conv_stem(c, s) : split ? launch_conv_split(c, s) : launch_conv_igemm(c, s);
                 if (h->prof) {
                     hipEventRecord(eb, s);
                     h->prof_last = eb; conv_op = true;
-                    h->prof_recs.push_back({dma ? conv_dma_kernel_name(c) : stem ? (c.x3 ? "conv_stem_x3_kernel" : c.f16 ? "conv_stem_f16w_kernel" : "conv_stem_kernel") : split ? conv_split_kernel_name(c) : conv_igemm_kernel_name(c), op.flops * N / p.images, ea, eb,
+                    h->prof_recs.push_back({dma3 ? "conv_dma3_kernel" : dma ? conv_dma_kernel_name(c) : stem ? (c.x3 ? "conv_stem_x3_kernel" : c.f16 ? "conv_stem_f16w_kernel" : "conv_stem_kernel") : split ? conv_split_kernel_name(c) : conv_igemm_kernel_name(c), op.flops * N / p.images, ea, eb,
                                             op.name.c_str(), N * c.Hout * c.Wout, d.C, op.K, op_bytes(op)});
                 }
                 break;

@@ -1,0 +1,251 @@
+// Implicit-GEMM convolution of the fp32-grade split engine (SD_PREC_BF16X3) for the layers with Cout % 256 == 0: fc6 / fc7, the ResNet
+// block tails (conv3 + projection as one GEMM) and the wide 1x1 / strided layers.  Three bf16 planes per operand, six MFMA products per
+// product (split_fmt.hpp), everything staged by LDS-DMA like conv_dma.hip.
+//
+// The 128 x 256 two-stage block of conv_dma.hip<X3> moves 72 KB per k-tile through the 16 B/clk L2 -> LDS path (4608 clk) for 48 MFMAs per
+// wave (3072 clk): the DMA bounds it at 0.67 of the MFMA rate (measured 0.46-0.55).  Here the block is 256 x 256 -- 96 KB for 96 MFMAs per
+// wave: 1 : 1 -- which fits LDS because the six products are grouped BY WEIGHT PLANE into three phases per k-tile, as in conv_direct3.hip:
+//        phase lo : W_lo  x X_hi                16 MFMAs per wave
+//        phase mid: W_mid x (X_mid, X_hi)       32
+//        phase hi : W_hi  x (X_lo, X_mid, X_hi) 48
+// X (three planes of 256 pixels x 32 k = 48 KB) is double-buffered per k-tile, the weight planes (16 KB each) stream through a THREE-slot
+// ring: 144 KB.  Every phase issues the weight plane needed TWO phases later plus one X plane that is first read two phases later
+// (lo(t): X_lo(t); mid(t): X_hi(t+1); hi(t): X_mid(t+1)) -- four DMA instructions per wave and phase, so a phase waits with a counted
+// s_waitcnt vmcnt(4) for what was issued two phases ago while the previous phase's DMAs stay in flight.  The X fragments of the hi and mid
+// planes stay in VGPRs across the phases of a k-tile (36 instead of 60 ds_read_b128 per 96 MFMAs).
+// 8 waves as 2 x 4, wave tile 128 pixels x 64 channels (acc 128 VGPRs); general gather through the KEntry table (any kernel size, stride,
+// concatenated sources); epilogue = conv_dma.hip's X3 epilogue.
+#include <cstdlib>
+#include "kernels.hpp"
+#include "split_fmt.hpp"
+
+namespace sd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void g3dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+typedef int i32x8g __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ KEntry g3load_kentry(const KEntry* ptr) {
+    i32x8g v;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ptr) : "memory");
+    KEntry e;
+    e.base = reinterpret_cast<const float*>(((unsigned long long)(unsigned)v[1] << 32) | (unsigned)v[0]);
+    e.H = v[2]; e.W = v[3]; e.C = v[4]; e.dy = v[5]; e.dx = v[6]; e.flags = v[7];
+    return e;
+}
+
+constexpr int G3_BM = 256, G3_BN = 256, G3_NW = 8, G3_MT = 4, G3_NT = 2;
+constexpr int G3_XPL = 4 * G3_BM;            // 16-B units of one X plane of a k-tile: [pixel][octet ^ swizzle]
+constexpr int G3_WPL = 4 * G3_BN;            // units of one weight plane of a k-tile: [k-octet][channel]
+constexpr int G3_XBUF = 3 * G3_XPL;
+constexpr int G3_LDS = 2 * G3_XBUF + 3 * G3_WPL;       // units (144 KB)
+constexpr int G3_ROW = G3_NT * 64 + 16;
+
+__global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
+    static_assert(G3_NW * 3 * 32 * G3_ROW <= G3_LDS * 16, "epilogue slabs fit in the ring");
+    __shared__ __attribute__((aligned(16))) u32x4 lds[G3_LDS];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm0 = (wave & 1) * (G3_MT * 32), wn0 = (wave >> 1) * (G3_NT * 32);
+    int tid_;
+    {
+        const int nwg = tilesM * tilesN, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        tid_ = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = tid_ % tilesM, tn = tid_ / tilesM;
+    const int bm0 = tm * G3_BM, bn0 = tn * G3_BN;
+
+    // X DMA: instruction j (16 per plane) covers pixels [16 j, 16 j + 16) x 4 octets; this wave issues j = wave and wave + 8
+    int pimg[2], poy[2], pox[2], pkg[2];
+    bool pok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m_l = (wave + G3_NW * i) * 16 + (lane >> 2);
+        const int m = bm0 + m_l;
+        pok[i] = m < M;
+        const int hw = p.Hout * p.Wout;
+        const int mm = pok[i] ? m : 0;
+        pimg[i] = mm / hw;
+        const int r = mm - pimg[i] * hw;
+        poy[i] = r / p.Wout;
+        pox[i] = r - poy[i] * p.Wout;
+        pkg[i] = (lane & 3) ^ ((m_l >> 2) & 3);               // the octet this lane fetches into slot lane % 4
+    }
+    const KEntry* __restrict__ const ktab = p.ktab;
+    const int CoutPad = p.CoutPad, Nmax = p.Nmax;
+    const u32x4* __restrict__ const wt_hi = reinterpret_cast<const u32x4*>(p.wt);
+    const size_t wplane = (size_t)(p.Kpad / 8) * CoutPad;     // units
+    const u32x4* const zero = reinterpret_cast<const u32x4*>(p.zero16);
+    const int ktiles = p.Kpad / 32;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds;
+
+    auto issue_x = [&](int kt, int pl) {                       // X plane pl of k-tile kt -> X buffer kt & 1
+        const KEntry e = g3load_kentry(ktab + kt);
+        const int st = (e.flags >> 4) & 3, up = e.flags & 1;
+        const size_t plane = (size_t)Nmax * e.H * e.W * e.C;
+        const unsigned dst = lds0 + (unsigned)(((kt & 1) * G3_XBUF + pl * G3_XPL) * 16);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int iy = poy[i] * st + e.dy, ix = pox[i] * st + e.dx;
+            const bool ok = pok[i] && iy >= 0 && ix >= 0 && iy < (e.H << up) && ix < (e.W << up);
+            iy >>= up; ix >>= up;
+            const uint16_t* px = reinterpret_cast<const uint16_t*>(e.base) + ((size_t)(pimg[i] * e.H + iy) * e.W + ix) * e.C + pkg[i] * 8 + (size_t)pl * plane;
+            g3dma16(ok ? reinterpret_cast<const u32x4*>(px) : zero, dst + (unsigned)((wave + G3_NW * i) * 1024));
+        }
+    };
+    auto issue_w = [&](int kt, int pl, int slot) {             // weight plane pl of k-tile kt -> ring slot
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int wu = (wave + G3_NW * i) * 64 + lane;     // unit inside the plane: [kg][n]
+            const int kg = wu / G3_BN, n_l = wu % G3_BN;
+            g3dma16(wt_hi + (size_t)pl * wplane + (size_t)(kt * 4 + kg) * CoutPad + bn0 + n_l,
+                    lds0 + (unsigned)((2 * G3_XBUF + slot * G3_WPL + (wave + G3_NW * i) * 64) * 16));
+        }
+    };
+
+    f32x16 acc[G3_MT][G3_NT];
+#pragma unroll
+    for (int a = 0; a < G3_MT; ++a)
+#pragma unroll
+        for (int b = 0; b < G3_NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // phase q = 3 kt + ph reads weight plane (2 - ph) of k-tile kt from ring slot q % 3 (ph 0: lo, 1: mid, 2: hi)
+    const int nphase = 3 * ktiles;
+    // prologue = the issues of the (virtual) phases -2 and -1: W for phases 0 and 1, X_hi(0) and X_mid(0)
+    issue_w(0, 2, 0); issue_x(0, 0);
+    issue_w(0, 1, 1); issue_x(0, 1);
+    int prev_issued = 4;                                      // DMA instructions this wave issued in the previous phase
+    const int frow = lane & 31, fk = lane >> 5;
+    int q = 0;
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const u32x4* const Xb = lds + (kt & 1) * G3_XBUF;
+        u32x4 xk[2][2][G3_MT];                                // X fragments of the hi and mid planes, kept for the k-tile: [plane][k-step][a]
+        auto xload = [&](int pl, int s, int a) {
+            const int mrow = wm0 + a * 32 + frow;
+            return Xb[pl * G3_XPL + mrow * 4 + ((2 * s + fk) ^ ((mrow >> 2) & 3))];
+        };
+        auto phase = [&](auto ph_tag) {
+            constexpr int PH = decltype(ph_tag)::value, NPX = PH + 1;
+            // everything issued two phases ago has landed once at most the previous phase's DMAs are outstanding
+            if (prev_issued == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (prev_issued == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // issue for phase q + 2: its weight plane, and the X plane that is first read then
+            int issued = 0;
+            {
+                const int q2 = q + 2;
+                if (q2 < nphase) { issue_w(q2 / 3, 2 - q2 % 3, q2 % 3); issued += 2; }
+                // phase (kt', ph') first reads X plane ph' of k-tile kt'
+                if (q2 < nphase) { issue_x(q2 / 3, q2 % 3); issued += 2; }
+            }
+            prev_issued = issued;
+            const u32x4* const Wq = lds + 2 * G3_XBUF + (q % 3) * G3_WPL;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int kg = 2 * s + fk;
+                u32x4 w[G3_NT], x[NPX][G3_MT];
+#pragma unroll
+                for (int b = 0; b < G3_NT; ++b) w[b] = Wq[kg * G3_BN + wn0 + b * 32 + frow];
+#pragma unroll
+                for (int pl = 0; pl < NPX; ++pl)
+#pragma unroll
+                    for (int a = 0; a < G3_MT; ++a) {
+                        if (pl < 2) {
+                            if (pl == PH) xk[pl][s][a] = xload(pl, s, a);
+                            x[pl][a] = xk[pl][s][a];
+                        } else {
+                            x[pl][a] = xload(pl, s, a);
+                        }
+                    }
+#pragma unroll
+                for (int pl = NPX - 1; pl >= 0; --pl)          // the smaller planes first
+#pragma unroll
+                    for (int b = 0; b < G3_NT; ++b)
+#pragma unroll
+                        for (int a = 0; a < G3_MT; ++a)
+                            acc[a][b] = mfma_frag<false>(w[b], x[pl][a], acc[a][b]);
+            }
+            ++q;
+        };
+        phase(IntTag<0>{});
+        phase(IntTag<1>{});
+        phase(IntTag<2>{});
+    }
+
+    // ---- epilogue: bias + activation in f32, exact three-way split, LDS transpose (one slab per plane and wave), 16-byte runs ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    auto ep3 = [&](auto tag) {
+        constexpr int ACT = decltype(tag)::value;
+        constexpr int ROW = G3_ROW;
+        unsigned char* slab = reinterpret_cast<unsigned char*>(lds) + wave * (3 * 32 * ROW);
+        constexpr int SEGS = G3_NT * 4, PPP = 64 / SEGS;
+        const int seg = lane % SEGS, prow = lane / SEGS;
+        uint16_t* const out_hi = reinterpret_cast<uint16_t*>(p.out);
+        const int m0 = bm0 + wm0, n0 = bn0 + wn0;
+#pragma unroll
+        for (int a = 0; a < G3_MT; ++a) {
+#pragma unroll
+            for (int b = 0; b < G3_NT; ++b)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int nl = b * 32 + 8 * r4 + 4 * (lane >> 5);
+                    f32x4 v = {acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
+                    v += *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = act_f32<ACT>(v[r]);
+                    uint2 h, m, l;
+                    split4_x3(v, h, m, l);
+                    *reinterpret_cast<uint2*>(slab + (lane & 31) * ROW + nl * 2) = h;
+                    *reinterpret_cast<uint2*>(slab + 32 * ROW + (lane & 31) * ROW + nl * 2) = m;
+                    *reinterpret_cast<uint2*>(slab + 64 * ROW + (lane & 31) * ROW + nl * 2) = l;
+                }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ps = 0; ps < 32 / PPP; ++ps) {
+                const int pix = ps * PPP + prow;
+                const int mo = m0 + a * 32 + pix;
+                if (mo < M) {
+                    uint16_t* o = out_hi + (size_t)mo * p.Cout + n0 + seg * 8;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        *reinterpret_cast<u32x4*>(o + pl * p.out_plane) = *reinterpret_cast<const u32x4*>(slab + pl * 32 * ROW + pix * ROW + seg * 16);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    };
+    if (p.act == ACT_RELU) ep3(ActTag<ACT_RELU>{});
+    else if (p.act == ACT_ELU) ep3(ActTag<ACT_ELU>{});
+    else ep3(ActTag<ACT_NONE>{});
+}
+
+// layers the 256 x 256 phased block takes: bf16 x 3, all-vec K axis, Cout a multiple of 256 and enough blocks to occupy the chip
+bool conv_dma3_eligible(const ConvParams& p) {
+    if (!p.x3 || !p.vec || !p.zero16 || p.pool || p.out_planar16 || p.residual || p.Cout % G3_BN || p.Kpad < 64 || p.CoutPad != p.Cout) return false;
+    static const bool off = std::getenv("SEMDEPTH_NO_DMA3") != nullptr;      // (A/B switch, latched once per process)
+    if (off) return false;
+    const long M = (long)p.N * p.Hout * p.Wout;
+    return ((M + G3_BM - 1) / G3_BM) * (p.Cout / G3_BN) >= 128;
+}
+
+hipError_t launch_conv_dma3(const ConvParams& p, hipStream_t s) {
+    if (!conv_dma3_eligible(p)) return hipErrorInvalidValue;
+    const long M = (long)p.N * p.Hout * p.Wout;
+    const int tilesM = (int)((M + G3_BM - 1) / G3_BM), tilesN = p.Cout / G3_BN;
+    hipLaunchKernelGGL(conv_dma3_kernel, dim3((unsigned)(tilesM * tilesN)), dim3(512), 0, s, p, (int)M, tilesM, tilesN);
+    return hipGetLastError();
+}
+
+}  // namespace sd
