@@ -205,10 +205,11 @@ def test_full_size_split_engine_matches_the_exact_f32_engine(H, W, B, enc):
         del eng
     assert relerr(res["bf16x2"][0], res["f32"][0]) < 1e-4
     assert relerr(res["bf16x2"][1], res["f32"][1]) < 1e-4
-    # the fp32-grade split engine differs from the f32 MFMA engine by what two f32 summation orders differ by
+    # the fp32-grade split engine differs from the f32 MFMA engine by what two f32 summation orders differ by (measured 2e-6 .. 6e-6 on
+    # these uniform-noise frames; either engine is 2e-6 .. 3e-6 from a float64 oracle, profiles/r03_f32_grade_check.txt)
     print(H, W, enc, "bf16x3 vs f32:", relerr(res["bf16x3"][0], res["f32"][0]), relerr(res["bf16x3"][1], res["f32"][1]))
-    assert relerr(res["bf16x3"][0], res["f32"][0]) < 5e-6
-    assert relerr(res["bf16x3"][1], res["f32"][1]) < 5e-6
+    assert relerr(res["bf16x3"][0], res["f32"][0]) < 1e-5
+    assert relerr(res["bf16x3"][1], res["f32"][1]) < 1e-5
 
 
 def test_fp16_activation_planes_saturate_instead_of_overflowing():
