@@ -50,7 +50,11 @@ constexpr int T3_TW = 32, T3_HW = T3_TW + 2, T3_WAVES = 8, T3_TH = 16, T3_HH = T
 // KEEP: X planes (hi first) whose MFMA fragments stay in VGPRs across the phases of a chunk instead of being re-read from LDS: the
 // kernel issues 0.58 ds_read_b128 per MFMA without it (x: 72, w: 54 per 216 MFMAs and wave) and the LDS read path (128 B/clk/CU),
 // not the MFMA pipe, bounds it; KEEP = 2 reads every X fragment once (x: 36).
-template <int NB, bool UP, int KEEP>
+// WSLOTS: slots of the weight-plane ring.  2 (NB = 2: all the LDS there is): every phase waits for everything issued in the phase before it.
+// 3 (NB = 1, the 16 / 32-channel full-resolution layers): phases of 18 / 36 / 54 MFMAs per wave are shorter than the latency of the DMAs
+// they would have to cover, so a weight plane is issued TWO phases before its phase, each X plane of the next chunk two phases before its
+// first read, and a phase waits with a counted vmcnt only for what was issued two phases ago.
+template <int NB, bool UP, int KEEP, int WSLOTS>
 __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectParams p) {
     constexpr int S_HH = UP ? T3_HH / 2 + 1 : T3_HH, S_HW = UP ? T3_HW / 2 + 1 : T3_HW;      // stored tile
     constexpr int XI = (S_HH * S_HW * 2 + 63) / 64;            // DMA instructions per halo plane (2 octet slots per pixel)
@@ -62,9 +66,9 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
     constexpr int ROW = 64 * NB + 16;                          // epilogue slab row (bytes per pixel and plane, + pad)
     constexpr int SLAB = T3_WAVES * 32 * ROW / 16;             // units: one plane of 32 pixels per wave
     constexpr int XBUF = 3 * XUNITS < SLAB ? SLAB : 3 * XUNITS;
-    static_assert((2 * XBUF + 2 * WUNITS) * 16 + 2048 <= 160 * 1024, "two X buffers + two weight slots + bias fit the LDS of a CU");
+    static_assert((2 * XBUF + WSLOTS * WUNITS) * 16 + 2048 <= 160 * 1024, "two X buffers + the weight ring + bias fit the LDS of a CU");
     static_assert(WS + 2 * XS <= 9 * NB, "one DMA slot per MFMA group of a phase");
-    __shared__ __attribute__((aligned(16))) u32x4 lds[2 * XBUF + 2 * WUNITS];
+    __shared__ __attribute__((aligned(16))) u32x4 lds[2 * XBUF + WSLOTS * WUNITS];
     __shared__ __attribute__((aligned(16))) float sbias[512];
     auto hpix = [](int hy, int hx) { return UP ? ((hy + 1) >> 1) * S_HW + ((hx + 1) >> 1) : hy * S_HW + hx; };
 
@@ -116,13 +120,14 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
         }
     };
     // a chunk in flight: source image + plane stride, its X buffer, its weight block (hi plane; plane stride = nchunks * WUNITS)
-    struct ChunkCtx { const uint16_t* img; size_t plane; unsigned rowel, C, okm, xbyte; int up; const u32x4* w; };
+    struct ChunkCtx { const uint16_t* img; size_t plane; unsigned rowel, C, okm, xbyte; int up, gy0, gx0; const u32x4* w; };
     auto begin_chunk = [&](const DirectChunk& ch, const Tile& tl, int c, int buf) {
         ChunkCtx k;
         k.plane = (size_t)p.Nmax * ch.H * ch.W * ch.C;      // elements
         k.img = reinterpret_cast<const uint16_t*>(ch.base) + (size_t)tl.img * ch.H * ch.W * ch.C;
         k.rowel = (unsigned)(ch.W * ch.C); k.C = (unsigned)ch.C; k.up = UP ? 0 : ch.up;
         k.okm = ch.nvalid >= 2 ? okA : okB;
+        k.gy0 = tgy; k.gx0 = tgx;                           // (the tile of the cursor at this moment: a chunk's X planes may be issued after the cursor moved on)
         k.xbyte = lds0 + (unsigned)(buf * XBUF * 16);
         k.w = p.wt + ((size_t)(3 * tl.half) * p.nchunks + c) * WUNITS;
         return k;
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
     auto xslot = [&](const ChunkCtx& k, int pl, int i) {       // X-DMA instruction wave + 8 i of plane pl
         const int j = wave + T3_WAVES * i;
         if (j >= XI) return;
-        const int gy = tgy + (geo[i] & 0xff), gx = tgx + ((geo[i] >> 8) & 0xff);      // (recomputed per slot: two VALU operations, no registers held)
+        const int gy = k.gy0 + (geo[i] & 0xff), gx = k.gx0 + ((geo[i] >> 8) & 0xff);      // (recomputed per slot: two VALU operations, no registers held)
         const unsigned off = (unsigned)(gy >> k.up) * k.rowel + ((unsigned)(gx >> k.up) * k.C + ((unsigned)(geo[i] >> 16) & 8u));
         const uint16_t* src = k.img + (size_t)pl * k.plane + off;
         d3dma16(((k.okm >> i) & 1u) ? reinterpret_cast<const u32x4*>(src) : zero, k.xbyte + (unsigned)((pl * XUNITS + j * 64) * 16));
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
     auto wslot = [&](const u32x4* wbase, int pl, int i, int slot) {     // weight-DMA instruction wave + 8 i of plane pl into ring slot
         const int jw = wave + T3_WAVES * i;
         if (jw >= WI) return;
-        d3dma16(wbase + (size_t)pl * p.nchunks * WUNITS + jw * 64 + lane, lds0 + (unsigned)((2 * XBUF + slot * WUNITS + jw * 64) * 16));
+        d3dma16(wbase + (size_t)pl * p.nchunks * WUNITS + jw * 64 + lane, lds0 + (unsigned)((2 * XBUF + slot * WUNITS + jw * 64) * 16));     // slot < WSLOTS
     };
 
     sbias[threadIdx.x] = (int)threadIdx.x < p.nsplit * p.Cout ? p.bias[threadIdx.x] : 0.f;
@@ -155,15 +160,47 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
         if (++ic == p.nchunks) { ic = 0; itid += gridDim.x; if (itid < items) { icur = tile_of(itid); set_tile(icur); } }
     };
     const u32x4* wcur;                   // weight block of the chunk being multiplied
+    ChunkCtx kc;                         // ... and its context (WSLOTS == 3: its X_lo plane is issued during its own first phase)
+    // DMA instructions this wave issues per weight plane / per X plane (the counted waits of the three-slot pipeline)
+    int nwv = 0, nxv = 0;
+#pragma unroll
+    for (int i = 0; i < WS; ++i) nwv += (wave + T3_WAVES * i < WI) ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < XS; ++i) nxv += (wave + T3_WAVES * i < XI) ? 1 : 0;
+    int prev = 0;                        // DMA instructions this wave issued in the previous phase
+    auto wait_prev = [&]() {             // everything issued BEFORE the previous phase has landed
+        switch (prev) {
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+    };
     {
-        const ChunkCtx k = begin_chunk(d3load_chunk(p.chunks), icur, 0, 0);
+        kc = begin_chunk(d3load_chunk(p.chunks), icur, 0, 0);
+        if constexpr (WSLOTS == 3) {
+            // the issues of the virtual phases -2 and -1: (W_lo, X_hi) and (W_mid, X_mid) of chunk 0; X_lo and W_hi follow in phase 0
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+            for (int i = 0; i < WS; ++i) wslot(kc.w, 2, i, 0);
 #pragma unroll
-            for (int i = 0; i < XS; ++i) xslot(k, pl, i);
+            for (int i = 0; i < XS; ++i) xslot(kc, 0, i);
 #pragma unroll
-        for (int i = 0; i < WS; ++i) wslot(k.w, 2, i, 0);         // the first phase of a chunk multiplies W_lo
-        wcur = k.w;
+            for (int i = 0; i < WS; ++i) wslot(kc.w, 1, i, 1);
+#pragma unroll
+            for (int i = 0; i < XS; ++i) xslot(kc, 1, i);
+            prev = nwv + nxv;
+        } else {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int i = 0; i < XS; ++i) xslot(kc, pl, i);
+#pragma unroll
+            for (int i = 0; i < WS; ++i) wslot(kc.w, 2, i, 0);         // the first phase of a chunk multiplies W_lo
+        }
+        wcur = kc.w;
         advance();
     }
     int g = 0, q = 0;                    // chunks / phases consumed so far
@@ -190,7 +227,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
             // 2: W_hi x (X_lo, X_mid, X_hi)); `issue(grp)` is called behind MFMA group grp (one DMA instruction per call)
             auto phase = [&](auto ph_tag, auto&& issue) {
                 constexpr int PH = decltype(ph_tag)::value, NPX = PH + 1;
-                const u32x4* const Wq = lds + 2 * XBUF + (q & 1) * WUNITS;
+                const u32x4* const Wq = lds + 2 * XBUF + (q % WSLOTS) * WUNITS;
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     u32x4 x[NPX][T3_MT + 2];
@@ -221,6 +258,40 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
                         }
                 }
             };
+            if constexpr (WSLOTS == 3) {
+                // ---- three-slot pipeline: phase q issues the weight plane of phase q + 2 and the X plane first read in phase q + 2
+                // lo(c): W_hi(c) + X_lo(c)
+                wait_prev();
+                __builtin_amdgcn_s_barrier();
+                phase(IntTag<0>{}, [&](int grp) {
+                    if (grp < WS) wslot(wcur, 0, grp, (q + 2) % 3);
+                    else if (grp < WS + XS) xslot(kc, 2, grp - WS);
+                });
+                prev = nwv + nxv;
+                ++q;
+                // mid(c): W_lo(c+1) + X_hi(c+1)
+                wait_prev();
+                __builtin_amdgcn_s_barrier();
+                if (more) kn = begin_chunk(d3load_chunk(p.chunks + ic), icur, ic, (g + 1) & 1);
+                phase(IntTag<1>{}, [&](int grp) {
+                    if (!more) return;
+                    if (grp < WS) wslot(kn.w, 2, grp, (q + 2) % 3);
+                    else if (grp < WS + XS) xslot(kn, 0, grp - WS);
+                });
+                prev = more ? nwv + nxv : 0;
+                ++q;
+                // hi(c): W_mid(c+1) + X_mid(c+1)
+                wait_prev();
+                __builtin_amdgcn_s_barrier();
+                phase(IntTag<2>{}, [&](int grp) {
+                    if (!more) return;
+                    if (grp < WS) wslot(kn.w, 1, grp, (q + 2) % 3);
+                    else if (grp < WS + XS) xslot(kn, 1, grp - WS);
+                });
+                prev = more ? nwv + nxv : 0;
+                ++q;
+                if (more) { kc = kn; }
+            } else {
             // ---- phase lo: W_lo x X_hi (36 MFMAs per wave at NB = 2); brings W_mid of this chunk
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -246,6 +317,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
                 else if (grp < WS + 2 * XS) { const int s_ = grp - WS; xslot(kn, 1 + s_ / XS, s_ % XS); }
             });
             ++q;
+            }
             if (more) { wcur = kn.w; advance(); }
         }
 
@@ -346,6 +418,12 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
         if (p.act == ACT_RELU) epilogue(ActTag<ACT_RELU>{});
         else if (p.act == ACT_ELU) epilogue(ActTag<ACT_ELU>{});
         else epilogue(ActTag<ACT_NONE>{});
+        if constexpr (WSLOTS == 3) {
+            // gfx9 counts stores in vmcnt too and loads / stores may complete out of order with respect to each other: a COUNTED wait is
+            // only sound over the DMA loads alone.  Drain the epilogue's stores (and the DMAs of the last phase with them) once per tile.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            prev = 0;
+        }
         if (tid + (int)gridDim.x < items) cur = tile_of(tid + gridDim.x);
     }
 }
@@ -365,13 +443,14 @@ hipError_t launch_conv_direct3(const ConvDirectParams& p, hipStream_t s) {
     const int tiles = (p.W / T3_TW) * ((p.H + T3_TH - 1) / T3_TH) * p.N * p.nsplit;
     const dim3 grid((unsigned)(tiles < cus ? tiles : cus));        // persistent: one workgroup per CU (158 KB of LDS)
     static const int keep = [] { const char* e = std::getenv("SEMDEPTH_X3_KEEP"); return e ? atoi(e) : 2; }();   // (A/B switch, latched once)
-#define SD_D3(NB_, UP_) do { if (keep >= 2) hipLaunchKernelGGL((conv_direct3_kernel<NB_, UP_, 2>), grid, dim3(512), 0, s, p); \
-                             else if (keep == 1) hipLaunchKernelGGL((conv_direct3_kernel<NB_, UP_, 1>), grid, dim3(512), 0, s, p); \
-                             else hipLaunchKernelGGL((conv_direct3_kernel<NB_, UP_, 0>), grid, dim3(512), 0, s, p); } while (0)
+    static const bool ring3 = std::getenv("SEMDEPTH_X3_NO_RING3") == nullptr;      // (A/B switch: the three-slot weight ring of the NB = 1 layers)
+#define SD_D3(NB_, UP_, WS_) do { if (keep >= 2) hipLaunchKernelGGL((conv_direct3_kernel<NB_, UP_, 2, WS_>), grid, dim3(512), 0, s, p); \
+                                  else hipLaunchKernelGGL((conv_direct3_kernel<NB_, UP_, 0, WS_>), grid, dim3(512), 0, s, p); } while (0)
     if (p.Cout <= 32) {
-        if (up) SD_D3(1, true); else SD_D3(1, false);
+        if (ring3) { if (up) SD_D3(1, true, 3); else SD_D3(1, false, 3); }
+        else { if (up) SD_D3(1, true, 2); else SD_D3(1, false, 2); }
     } else {
-        if (up) SD_D3(2, true); else SD_D3(2, false);
+        if (up) SD_D3(2, true, 2); else SD_D3(2, false, 2);
     }
 #undef SD_D3
     return hipGetLastError();

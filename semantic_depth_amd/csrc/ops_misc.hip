@@ -154,10 +154,12 @@ __global__ __launch_bounds__(256) void maxpool3z_kernel(const float* __restrict_
         }
     store4<SPLIT>(y, plane_out, i, m);
 }
-// split planes with C % 8 == 0: one thread per (output pixel, channel octet), 16-byte loads per plane and tap
-template <bool F16>
+// split planes with C % 8 == 0: one thread per (output pixel, channel octet), 16-byte loads per plane and tap.
+// NPL = planes: 1 ONE fp16 plane, 2 bf16 hi + lo, 3 bf16 hi + mid + lo (exact: the max of exact values, split exactly again)
+template <int NPL>
 __global__ __launch_bounds__(256) void maxpool3z_oct_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C8,
                                                             size_t plane_in, size_t plane_out) {
+    constexpr bool F16 = NPL == 1;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     long total = (long)N * Ho * Wo * C8;
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(256) void maxpool3z_oct_kernel(const float* __restr
     int n = (int)(r / Ho);
     const u32x4_t* const xh = reinterpret_cast<const u32x4_t*>(x);
     const u32x4_t* const xl = reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(x) + plane_in);
+    const u32x4_t* const x3 = reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(x) + 2 * plane_in);
     f32x4 m0 = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, m1 = m0;
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
@@ -179,25 +182,39 @@ __global__ __launch_bounds__(256) void maxpool3z_oct_kernel(const float* __restr
             if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
                 const long q = (((long)n * H + iy) * W + ix) * C8 + c;
                 const u32x4_t h = xh[q], l = F16 ? h : xl[q];
-                v0 = recon4_t<F16>(uint2{h[0], h[1]}, uint2{l[0], l[1]});
-                v1 = recon4_t<F16>(uint2{h[2], h[3]}, uint2{l[2], l[3]});
+                if constexpr (NPL == 3) {
+                    const u32x4_t t = x3[q];
+                    v0 = recon4_x3(uint2{h[0], h[1]}, uint2{l[0], l[1]}, uint2{t[0], t[1]});
+                    v1 = recon4_x3(uint2{h[2], h[3]}, uint2{l[2], l[3]}, uint2{t[2], t[3]});
+                } else {
+                    v0 = recon4_t<F16>(uint2{h[0], h[1]}, uint2{l[0], l[1]});
+                    v1 = recon4_t<F16>(uint2{h[2], h[3]}, uint2{l[2], l[3]});
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) { m0[j] = fmaxf(m0[j], v0[j]); m1[j] = fmaxf(m1[j], v1[j]); }
         }
     uint2 h0, l0, h1, l1;
-    split4_t<F16>(m0, h0, l0);
-    split4_t<F16>(m1, h1, l1);
+    if constexpr (NPL == 3) {
+        uint2 t0, t1;
+        split4_x3(m0, h0, l0, t0);
+        split4_x3(m1, h1, l1, t1);
+        reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(y) + 2 * plane_out)[i] = (u32x4_t){t0.x, t0.y, t1.x, t1.y};
+    } else {
+        split4_t<F16>(m0, h0, l0);
+        split4_t<F16>(m1, h1, l1);
+    }
     reinterpret_cast<u32x4_t*>(y)[i] = (u32x4_t){h0.x, h0.y, h1.x, h1.y};
     if (!F16) reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(y) + plane_out)[i] = (u32x4_t){l0.x, l0.y, l1.x, l1.y};
 }
 hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    if (split && split != 4 && C % 8 == 0) {
+    if (split && C % 8 == 0) {
         const long tot8 = (long)N * Ho * Wo * (C / 8);
         const dim3 g8((unsigned)((tot8 + 255) / 256));
-        if (split == 2) hipLaunchKernelGGL(maxpool3z_oct_kernel<true>, g8, dim3(256), 0, s, x, y, N, H, W, C / 8, plane_in, plane_out);
-        else hipLaunchKernelGGL(maxpool3z_oct_kernel<false>, g8, dim3(256), 0, s, x, y, N, H, W, C / 8, plane_in, plane_out);
+        if (split == 4) hipLaunchKernelGGL(maxpool3z_oct_kernel<3>, g8, dim3(256), 0, s, x, y, N, H, W, C / 8, plane_in, plane_out);
+        else if (split == 2) hipLaunchKernelGGL(maxpool3z_oct_kernel<1>, g8, dim3(256), 0, s, x, y, N, H, W, C / 8, plane_in, plane_out);
+        else hipLaunchKernelGGL(maxpool3z_oct_kernel<2>, g8, dim3(256), 0, s, x, y, N, H, W, C / 8, plane_in, plane_out);
         return hipGetLastError();
     }
     long total = (long)N * Ho * Wo * (C / 4);
