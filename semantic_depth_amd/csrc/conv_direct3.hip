@@ -79,6 +79,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
     const u32x4* const zero = reinterpret_cast<const u32x4*>(p.zero16);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds;      // LDS byte address
     const int frow = lane & 31, fk = lane >> 5;
+    const int diag = p.rows_per_wave >> 8;       // SEMDEPTH_X3_DIAG (decomposition runs): 1 no output stores, 2 no MFMAs; 0 in production
 
     // work item = (tile, pass of <= 64 output channels); the passes of a tile are neighbouring items
     const int items = total * p.nsplit;
@@ -247,11 +248,13 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) {
                             const u32x4 wv = Wq[((dy * 3 + dx) * 2 + fk) * (32 * NB) + nb * 32 + frow];
+                            if (!(diag & 2)) {
 #pragma unroll
                             for (int pl = NPX - 1; pl >= 0; --pl)          // the smaller planes first
 #pragma unroll
                                 for (int a = 0; a < T3_MT; ++a)
                                     acc[a][nb] = mfma_frag<false>(wv, x[pl][a + dy], acc[a][nb]);
+                            }
                             __builtin_amdgcn_sched_barrier(0);
                             issue((dx * 3 + dy) * NB + nb);
                             __builtin_amdgcn_sched_barrier(0);
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
 #pragma unroll
                     for (int ps = 0; ps < (16 + PPP - 1) / PPP; ++ps) {
                         const int pix = ps * PPP + prow;
-                        if (pix < 16 && yp < Hp && seg * 8 < p.Cout) {
+                        if (pix < 16 && yp < Hp && seg * 8 < p.Cout && !(diag & 1)) {
                             uint16_t* o = out_hi + ((size_t)(cur.img * Hp + yp) * Wp + (cur.tx0 >> 1) + pix) * p.Cstride + n0 + seg * 8;
                             *reinterpret_cast<u32x4*>(o + pl * p.out_plane) = *reinterpret_cast<const u32x4*>(sh + pix * ROW + seg * 16);
                         }
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
 #pragma unroll
                     for (int ps = 0; ps < 32 / PPP; ++ps) {
                         const int pix = ps * PPP + prow;
-                        if (y < p.H && seg * 8 < p.Cout) {
+                        if (y < p.H && seg * 8 < p.Cout && !(diag & 1)) {
                             uint16_t* o = out_hi + ((size_t)(cur.img * p.H + y) * p.W + cur.tx0 + pix) * p.Cstride + n0 + seg * 8;
                             *reinterpret_cast<u32x4*>(o + pl * p.out_plane) = *reinterpret_cast<const u32x4*>(sh + pix * ROW + seg * 16);
                         }
@@ -443,9 +446,15 @@ hipError_t launch_conv_direct3(const ConvDirectParams& p, hipStream_t s) {
     const int tiles = (p.W / T3_TW) * ((p.H + T3_TH - 1) / T3_TH) * p.N * p.nsplit;
     const dim3 grid((unsigned)(tiles < cus ? tiles : cus));        // persistent: one workgroup per CU (158 KB of LDS)
     static const int keep = [] { const char* e = std::getenv("SEMDEPTH_X3_KEEP"); return e ? atoi(e) : 2; }();   // (A/B switch, latched once)
-    static const bool ring3 = std::getenv("SEMDEPTH_X3_NO_RING3") == nullptr;      // (A/B switch: the three-slot weight ring of the NB = 1 layers)
-#define SD_D3(NB_, UP_, WS_) do { if (keep >= 2) hipLaunchKernelGGL((conv_direct3_kernel<NB_, UP_, 2, WS_>), grid, dim3(512), 0, s, p); \
-                                  else hipLaunchKernelGGL((conv_direct3_kernel<NB_, UP_, 0, WS_>), grid, dim3(512), 0, s, p); } while (0)
+    static const int diagv = [] { const char* e = std::getenv("SEMDEPTH_X3_DIAG"); return e ? atoi(e) : 0; }();
+    ConvDirectParams pd = p;
+    pd.rows_per_wave = (p.rows_per_wave & 0xff) | (diagv << 8);
+    // (A/B switch: the three-slot weight ring of the NB = 1 layers.  Measured equal or 3-6 % slower than the two-slot form on upconv1 /
+    //  iconv1 / upconv2 / iconv2 -- profiles/r03g_conv_direct3_ring3_ab.txt: what these layers wait for is not the latency a deeper
+    //  prefetch hides -- so it is off by default)
+    static const bool ring3 = std::getenv("SEMDEPTH_X3_RING3") != nullptr;
+#define SD_D3(NB_, UP_, WS_) do { if (keep >= 2) hipLaunchKernelGGL((conv_direct3_kernel<NB_, UP_, 2, WS_>), grid, dim3(512), 0, s, pd); \
+                                  else hipLaunchKernelGGL((conv_direct3_kernel<NB_, UP_, 0, WS_>), grid, dim3(512), 0, s, pd); } while (0)
     if (p.Cout <= 32) {
         if (ring3) { if (up) SD_D3(1, true, 3); else SD_D3(1, false, 3); }
         else { if (up) SD_D3(1, true, 2); else SD_D3(1, false, 2); }

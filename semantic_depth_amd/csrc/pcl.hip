@@ -1111,14 +1111,12 @@ template <int CAPK>
 struct TopK {
     double v[CAPK];
     double kth;      // v[k-1]
-    float kf;        // f32 upper bound of kth (kth (1 + 2e-6), far outside the f32 rounding of that product): the candidate pre-test
     int k;
-    __device__ __forceinline__ void set_kth(double d) { kth = d; kf = (float)(d * 1.000002); }
     __device__ __forceinline__ void init(int k_) {
         k = k_;
 #pragma unroll
         for (int t = 0; t < CAPK; ++t) v[t] = INFINITY;
-        set_kth(INFINITY);
+        kth = INFINITY;
     }
     __device__ __forceinline__ void push(double d) {
         if (!(d < kth)) return;
@@ -1129,12 +1127,12 @@ struct TopK {
             v[t] = lo; d = hi;
         }
         if (k == CAPK) {
-            set_kth(v[CAPK - 1]);
+            kth = v[CAPK - 1];
         } else {
             double kv = v[0];
 #pragma unroll
             for (int t = 1; t < CAPK; ++t) kv = (t == k - 1) ? v[t] : kv;
-            set_kth(kv);
+            kth = kv;
         }
     }
 };
@@ -1176,14 +1174,12 @@ __device__ __forceinline__ void shell_row(const GridMeta& g, const int* st, int 
 }
 // the candidates [t0, t1) of a range, four at a time: the twelve coordinate loads are issued together, so the search pays
 // one memory latency per four candidates instead of one each.
-// `kf` = an f32 upper bound of the caller's current k-th squared distance (TopK::kf; push() ignores anything not below kth).  Round 3: an f32 candidate test in front of
-// the f64 distance -- d32 (three f32 subtractions, squares and adds of the f32 coordinates, no contraction) is within 3e-7 relative of the
-// exact d, so a candidate with d32 > kth (1 + 2e-6) cannot enter the list and its f64 distance (nine half-rate operations) is never
-// formed; everything else goes through the unchanged f64 path: the list, and so the result, are bit for bit what they were.
+// (Round 3, measured and taken out again: an f32 candidate test in front of the f64 distance -- d32 within 3e-7 of the exact d, so
+//  d32 > kth (1 + 2e-6) rejects without the nine half-rate f64 operations, exactness untouched -- made the statistical filter SLOWER,
+//  2.15 -> 2.42 ms per 32 frames (2.96 with the bound converted per candidate), and left the radius filter at 1.50: the search waits
+//  for its gathers, not for its arithmetic; the extra compare + branch per candidate only lengthens the dependent chain.)
 template <class F>
-__device__ __forceinline__ void visit_points(const float* __restrict__ pts, double qx, double qy, double qz, int t0, int t1, F&& push,
-                                             const float& kf) {
-    const float qxf = (float)qx, qyf = (float)qy, qzf = (float)qz;     // (the queries ARE f32 coordinates: exact)
+__device__ __forceinline__ void visit_points(const float* __restrict__ pts, double qx, double qy, double qz, int t0, int t1, F&& push) {
     for (int t = t0; t < t1; t += 4) {
         float c[4][3];
 #pragma unroll
@@ -1192,12 +1188,8 @@ __device__ __forceinline__ void visit_points(const float* __restrict__ pts, doub
             { const float4 v4 = reinterpret_cast<const float4*>(pts)[tt]; c[u][0] = v4.x; c[u][1] = v4.y; c[u][2] = v4.z; }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (t + u >= t1) continue;
-            const float dx = qxf - c[u][0], dy = qyf - c[u][1], dz = qzf - c[u][2];
-            const float d32 = (dx * dx + dy * dy) + dz * dz;
-            if (d32 <= kf) push(dist2(qx, qy, qz, c[u]));               // (kf: TopK::kf, refreshed by every successful push; inf stays inf; NaN fails like d < kth)
-        }
+        for (int u = 0; u < 4; ++u)
+            if (t + u < t1) push(dist2(qx, qy, qz, c[u]));
     }
 }
 
@@ -1245,18 +1237,18 @@ __global__ __launch_bounds__(256) void sor_knn_kernel(CloudView in, int cap, con
             const int slot = i < 4 ? i + 1 : i;
             t0[slot] = st[rb + x0]; t1[slot] = st[rb + x1 + 1];
         }
-        visit_points(pts, qx, qy, qz, t0[0], t1[0], [&](double d) { top.push(d); }, top.kf);       // shell 0
+        visit_points(pts, qx, qy, qz, t0[0], t1[0], [&](double d) { top.push(d); });       // shell 0
         if (top.kth <= 0.0 || rall == 0) done = true;      // (the bound of shell 0 is zero)
         if (!done) {
             // shell 1 in the order of the generic walk below: (dz, dy) rows ascending, centre row = its two end cells
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
                 if (i == 4) {
-                    visit_points(pts, qx, qy, qz, t0[9], t1[9], [&](double d) { top.push(d); }, top.kf);
-                    visit_points(pts, qx, qy, qz, t0[10], t1[10], [&](double d) { top.push(d); }, top.kf);
+                    visit_points(pts, qx, qy, qz, t0[9], t1[9], [&](double d) { top.push(d); });
+                    visit_points(pts, qx, qy, qz, t0[10], t1[10], [&](double d) { top.push(d); });
                 } else {
                     const int slot = i < 4 ? i + 1 : i;
-                    visit_points(pts, qx, qy, qz, t0[slot], t1[slot], [&](double d) { top.push(d); }, top.kf);
+                    visit_points(pts, qx, qy, qz, t0[slot], t1[slot], [&](double d) { top.push(d); });
                 }
             }
             const double bound = g.cell * (1.0 - 1e-9);
@@ -1275,7 +1267,7 @@ __global__ __launch_bounds__(256) void sor_knn_kernel(CloudView in, int cap, con
                     if (ymin * ymin + zmin * zmin >= top.kth) continue;
                 }
                 shell_row(g, st, cx, cy, cz, r, dz, dy, [&](int t0, int t1) {
-                    visit_points(pts, qx, qy, qz, t0, t1, [&](double d) { top.push(d); }, top.kf);
+                    visit_points(pts, qx, qy, qz, t0, t1, [&](double d) { top.push(d); });
                 });
             }
         }
@@ -1338,7 +1330,7 @@ __global__ __launch_bounds__(256) void sor_knn_hard_kernel(CloudView in, int cap
             for (int t = 0; t < CAPK; ++t) nb[t] = INFINITY;
             if (lane == 0) {     // lane 0 also offers the previous best list: merge it into its own list first
 #pragma unroll
-                for (int t = 0; t < CAPK; ++t) { top.set_kth(INFINITY); if (best[t] < INFINITY) top.push(best[t]); }
+                for (int t = 0; t < CAPK; ++t) { top.kth = INFINITY; if (best[t] < INFINITY) top.push(best[t]); }
             }
 #pragma unroll
             for (int t = 0; t < CAPK; ++t) {
@@ -1363,7 +1355,7 @@ __global__ __launch_bounds__(256) void sor_knn_hard_kernel(CloudView in, int cap
         bool done = false;
         for (int r = SOR_RSOFT + 1; r <= SOR_RMAX && !done; ++r) {
             top.init(kk);
-            top.set_kth(gk);                    // prune by the wave's k-th distance; lists hold only this shell's candidates
+            top.kth = gk;                       // prune by the wave's k-th distance; lists hold only this shell's candidates
             const int side = 2 * r + 1;
             for (int t = lane; t < side * side; t += 64) {
                 const int dz = t / side - r, dy = t % side - r;
@@ -1372,7 +1364,7 @@ __global__ __launch_bounds__(256) void sor_knn_hard_kernel(CloudView in, int cap
                 if (cy + dy >= 0 && cy + dy < g.gy) axis_bounds(qy, g.oy, g.cell, cy + dy, g.gy, ymin, dmax);
                 if (ymin * ymin + zmin * zmin >= gk) continue;
                 shell_row(g, st, cx, cy, cz, r, dz, dy, [&](int t0, int t1) {
-                    visit_points(pts, qx, qy, qz, t0, t1, [&](double d) { if (d < gk) top.push(d); }, top.kf);
+                    visit_points(pts, qx, qy, qz, t0, t1, [&](double d) { if (d < gk) top.push(d); });
                 });
             }
             merge();
@@ -1433,10 +1425,6 @@ __global__ __launch_bounds__(256) void ror_count_kernel(CloudView in, int cap, c
     const float* pts = sxyz + (size_t)b * cap * 4;      // float4 per point
     const float* q = pts + (size_t)j * 4;
     const double qx = q[0], qy = q[1], qz = q[2];
-    const float qxf = q[0], qyf = q[1], qzf = q[2];
-    // (a radius so small that f32 squares of the differences could underflow gets no fast "inside": every candidate in reach goes exact)
-    // (margins of 4e-6: the f32 distance is within 3e-7 of the exact one and the casts below round by 6e-8)
-    const float r2lo = r2 > 1e-20 ? (float)(r2 * (1.0 - 4e-6)) : -1.f, r2hi = (float)(r2 * (1.0 + 4e-6));
     const int cx = cell_coord(qx, g.ox, g.inv, g.gx), cy = cell_coord(qy, g.oy, g.inv, g.gy), cz = cell_coord(qz, g.oz, g.inv, g.gz);
     int cnt = 0;
     // fast accept: every point of the 3 x 3 x 3 cells around the query's cell is closer than 2 sqrt(3) cell = 0.866 (r / 4) (1 + 1e-6)
@@ -1494,15 +1482,7 @@ __global__ __launch_bounds__(256) void ror_count_kernel(CloudView in, int cap, c
                             { const float4 v4 = reinterpret_cast<const float4*>(pts)[tt]; c4[u][0] = v4.x; c4[u][1] = v4.y; c4[u][2] = v4.z; }
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            // f32 test first (within 3e-7 relative of the exact squared distance): surely inside / surely outside the ball
-                            // are decided without the f64 distance; the band around r2 takes the exact path -- same count as before
-                            const float dxf = qxf - c4[u][0], dyf = qyf - c4[u][1], dzf = qzf - c4[u][2];
-                            const float d32 = (dxf * dxf + dyf * dyf) + dzf * dzf;
-                            bool inside = d32 < r2lo;
-                            if (!inside && !(d32 > r2hi)) inside = dist2(qx, qy, qz, c4[u]) < r2;
-                            cnt += (t + u < e) && inside;
-                        }
+                        for (int u = 0; u < 4; ++u) cnt += (t + u < e) && dist2(qx, qy, qz, c4[u]) < r2;
                     }
                 }
             }
