@@ -79,7 +79,8 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
     const u32x4* const zero = reinterpret_cast<const u32x4*>(p.zero16);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds;      // LDS byte address
     const int frow = lane & 31, fk = lane >> 5;
-    const int diag = p.rows_per_wave >> 8;       // SEMDEPTH_X3_DIAG (decomposition runs): 1 no output stores, 2 no MFMAs; 0 in production
+    // SEMDEPTH_X3_DIAG (decomposition runs, latched in the handle's switches): 1 no output stores, 2 no MFMAs; 0 in production
+    const int diag = ((p.sw & SW_X3_DIAG_NOSTORE) ? 1 : 0) | ((p.sw & SW_X3_DIAG_NOMFMA) ? 2 : 0);
 
     // work item = (tile, pass of <= 64 output channels); the passes of a tile are neighbouring items
     const int items = total * p.nsplit;
@@ -445,14 +446,12 @@ hipError_t launch_conv_direct3(const ConvDirectParams& p, hipStream_t s) {
     const bool up = p.all_up && !(p.H & 1) && !(p.W & 1) && !(p.sw & SW_NO_UPTILE);
     const int tiles = (p.W / T3_TW) * ((p.H + T3_TH - 1) / T3_TH) * p.N * p.nsplit;
     const dim3 grid((unsigned)(tiles < cus ? tiles : cus));        // persistent: one workgroup per CU (158 KB of LDS)
-    static const int keep = [] { const char* e = std::getenv("SEMDEPTH_X3_KEEP"); return e ? atoi(e) : 2; }();   // (A/B switch, latched once)
-    static const int diagv = [] { const char* e = std::getenv("SEMDEPTH_X3_DIAG"); return e ? atoi(e) : 0; }();
-    ConvDirectParams pd = p;
-    pd.rows_per_wave = (p.rows_per_wave & 0xff) | (diagv << 8);
-    // (A/B switch: the three-slot weight ring of the NB = 1 layers.  Measured equal or 3-6 % slower than the two-slot form on upconv1 /
-    //  iconv1 / upconv2 / iconv2 -- profiles/r03g_conv_direct3_ring3_ab.txt: what these layers wait for is not the latency a deeper
-    //  prefetch hides -- so it is off by default)
-    static const bool ring3 = std::getenv("SEMDEPTH_X3_RING3") != nullptr;
+    // A/B switches of the handle (plan.cpp latch_switches): the X fragments of the hi / mid planes kept in registers or re-read; the
+    // three-slot weight ring of the NB = 1 layers (measured equal or 3-6 % slower than the two-slot form on upconv1 / iconv1 / upconv2 /
+    // iconv2 -- profiles/r03g_conv_direct3_ring3_ab.txt -- so it is off by default)
+    const int keep = (p.sw & SW_X3_NOKEEP) ? 0 : 2;
+    const bool ring3 = (p.sw & SW_X3_RING3) != 0;
+    const ConvDirectParams& pd = p;
 #define SD_D3(NB_, UP_, WS_) do { if (keep >= 2) hipLaunchKernelGGL((conv_direct3_kernel<NB_, UP_, 2, WS_>), grid, dim3(512), 0, s, pd); \
                                   else hipLaunchKernelGGL((conv_direct3_kernel<NB_, UP_, 0, WS_>), grid, dim3(512), 0, s, pd); } while (0)
     if (p.Cout <= 32) {

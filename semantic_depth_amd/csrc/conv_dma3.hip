@@ -234,8 +234,7 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
 // layers the 256 x 256 phased block takes: bf16 x 3, all-vec K axis, Cout a multiple of 256 and enough blocks to occupy the chip
 bool conv_dma3_eligible(const ConvParams& p) {
     if (!p.x3 || !p.vec || !p.zero16 || p.pool || p.out_planar16 || p.residual || p.Cout % G3_BN || p.Kpad < 64 || p.CoutPad != p.Cout) return false;
-    static const bool off = std::getenv("SEMDEPTH_NO_DMA3") != nullptr;      // (A/B switch, latched once per process)
-    if (off) return false;
+    if (p.sw & SW_NO_DMA3) return false;                       // (A/B switch of the handle)
     const long M = (long)p.N * p.Hout * p.Wout;
     return ((M + G3_BM - 1) / G3_BM) * (p.Cout / G3_BN) >= 128;
 }

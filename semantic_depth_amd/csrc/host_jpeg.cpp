@@ -262,6 +262,7 @@ struct Decoder {
                 if (sn < 6 || s[0] != 8) return SD_ERR_INVALID;
                 H = rd16(s + 1); W = rd16(s + 3); ncomp = s[5];
                 if (H <= 0 || W <= 0 || (ncomp != 1 && ncomp != 3) || sn < 6 + 3 * (size_t)ncomp) return SD_ERR_INVALID;
+                if ((size_t)H * (size_t)W > ((size_t)1 << 28)) return SD_ERR_INVALID;      // (256 Mpixel: refuse absurd headers before allocating planes)
                 for (int i = 0; i < ncomp; ++i) {
                     comp[i].id = s[6 + 3 * i]; comp[i].h = s[7 + 3 * i] >> 4; comp[i].v = s[7 + 3 * i] & 15; comp[i].tq = s[8 + 3 * i];
                     if (comp[i].h < 1 || comp[i].v < 1 || comp[i].tq > 3) return SD_ERR_INVALID;

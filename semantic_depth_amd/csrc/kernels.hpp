@@ -12,7 +12,11 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 enum Switch : unsigned {
     SW_NO_N16 = 1u << 0, SW_NO_UPTILE = 1u << 1, SW_NO_N16_MT1 = 1u << 2, SW_NO_DMA_BIG = 1u << 3, SW_NO_DMA32 = 1u << 4,
     SW_NO_STEM = 1u << 5, SW_NO_FUSE4 = 1u << 6, SW_NO_SMALLN_TILE = 1u << 7, SW_NO_DMA = 1u << 8, SW_DMA_DBG16 = 1u << 9,
-    SW_PROFILE_VERBOSE = 1u << 10, SW_NO_FUSE1 = 1u << 11
+    SW_PROFILE_VERBOSE = 1u << 10, SW_NO_FUSE1 = 1u << 11,
+    // bf16 x 3 engine (round 3): SEMDEPTH_X3_KEEP=0 (no register-cached X fragments), SEMDEPTH_X3_RING3 (three-slot weight ring of the
+    // NB = 1 layers), SEMDEPTH_NO_DMA3 (128 x 256 two-stage GEMM block instead of the phased 256 x 256 one), SEMDEPTH_X3_DIAG=1|2|3
+    // (decomposition runs of conv_direct3: no output stores / no MFMAs)
+    SW_X3_NOKEEP = 1u << 12, SW_X3_RING3 = 1u << 13, SW_NO_DMA3 = 1u << 14, SW_X3_DIAG_NOSTORE = 1u << 15, SW_X3_DIAG_NOMFMA = 1u << 16
 };
 unsigned latch_switches();      // plan.cpp
 

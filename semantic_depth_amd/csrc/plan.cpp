@@ -14,12 +14,14 @@ unsigned latch_switches() {
         {"SEMDEPTH_NO_N16", SW_NO_N16}, {"SEMDEPTH_NO_UPTILE", SW_NO_UPTILE}, {"SEMDEPTH_NO_N16_MT1", SW_NO_N16_MT1},
         {"SEMDEPTH_NO_DMA_BIG", SW_NO_DMA_BIG}, {"SEMDEPTH_NO_DMA32", SW_NO_DMA32}, {"SEMDEPTH_NO_STEM", SW_NO_STEM},
         {"SEMDEPTH_NO_FUSE4", SW_NO_FUSE4}, {"SEMDEPTH_NO_SMALLN_TILE", SW_NO_SMALLN_TILE}, {"SEMDEPTH_NO_DMA", SW_NO_DMA},
-        {"SEMDEPTH_NO_FUSE1", SW_NO_FUSE1}};
+        {"SEMDEPTH_NO_FUSE1", SW_NO_FUSE1}, {"SEMDEPTH_X3_RING3", SW_X3_RING3}, {"SEMDEPTH_NO_DMA3", SW_NO_DMA3}};
     unsigned sw = 0;
     for (const auto& e : tab)
         if (std::getenv(e.name)) sw |= e.bit;
     if (const char* d = std::getenv("SEMDEPTH_DMA_DBG")) if (atoi(d) & 16) sw |= SW_DMA_DBG16;
     if (const char* v = std::getenv("SEMDEPTH_PROFILE_VERBOSE")) if (v[0] == '1') sw |= SW_PROFILE_VERBOSE;
+    if (const char* v = std::getenv("SEMDEPTH_X3_KEEP")) if (atoi(v) == 0) sw |= SW_X3_NOKEEP;
+    if (const char* v = std::getenv("SEMDEPTH_X3_DIAG")) sw |= ((atoi(v) & 1) ? SW_X3_DIAG_NOSTORE : 0u) | ((atoi(v) & 2) ? SW_X3_DIAG_NOMFMA : 0u);
     return sw;
 }
 

@@ -230,3 +230,47 @@ def test_fp16_activation_planes_saturate_instead_of_overflowing():
     assert np.isfinite(lg).all()
     ref = nets.fcn8s_forward(fr, wf)                      # f32: the same activations are ~1e5, far outside fp16
     assert np.isfinite(ref).all() and np.abs(ref).max() > 1e3
+
+
+def test_bf16x3_is_fp32_grade_against_a_float64_oracle():
+    """The headline engine's claim: carrying every f32 operand exactly as three bf16 planes and forming each product from six
+    MFMA products (f32 accumulation) is fp32-grade arithmetic.  One 256 x 512 frame through the oracle in FLOAT64 (the check value) and
+    through the float32 oracle, the exact-f32 MFMA engine and the bf16x3 engine: against float64 the bf16x3 engine must be no worse than
+    1.5 x the f32 MFMA engine (max-normalised and rms), and both within a few 1e-6 -- while bf16x2 is an order of magnitude away."""
+    import torch as _torch
+    from semantic_depth_amd.engine import Engine
+    from semantic_depth_amd import weights as Wt
+    H, W = 256, 512
+    rng = np.random.default_rng(77)
+    base = rng.integers(0, 256, (1, H // 8, W // 8, 3), dtype=np.uint8)
+    fr = np.repeat(np.repeat(base, 8, axis=1), 8, axis=2)
+    fr = (fr.astype(np.int16) + rng.integers(-16, 17, fr.shape, dtype=np.int16)).clip(0, 255).astype(np.uint8)
+    wf = Wt.make_fcn8s_weights(1, decoder_std=0.05, bias_std=0.1)
+    wm = Wt.make_monodepth_weights("resnet50", 2, bias_std=0.05)
+    f = fr[0].astype(np.float32) / 255
+    pair = np.stack((f, np.fliplr(f)), 0)
+    ref_l = nets.fcn8s_forward(fr, wf, dtype=_torch.float64)
+    ref_d = nets.monodepth_forward(pair, wm, "resnet50", dtype=_torch.float64)[..., 0]
+
+    def errs(lg, dp):
+        out = []
+        for x, r in ((lg, ref_l), (dp, ref_d)):
+            d = np.abs(np.asarray(x, np.float64) - np.asarray(r, np.float64))
+            sc = np.abs(r).max()
+            out += [d.max() / sc, np.sqrt((d * d).mean()) / sc]
+        return out          # logits max, logits rms, disparity max, disparity rms
+
+    res = {"oracle_f32": errs(nets.fcn8s_forward(fr, wf), nets.monodepth_forward(pair, wm, "resnet50")[..., 0])}
+    for prec in ("f32", "bf16x3", "bf16x2"):
+        eng = Engine(H, W, 1, "resnet50", precision=prec)
+        eng.load_weights(L.SD_NET_FCN8S, wf)
+        eng.load_weights(L.SD_NET_MONODEPTH, wm)
+        lg = eng.fcn8s_forward(dev(fr), want_logits=True)["logits"].cpu().numpy()
+        _, raw = eng.monodepth_forward(dev(fr), want_raw=True)
+        res[prec] = errs(lg, raw[0].cpu().numpy())
+        del eng
+    print("against float64 (logits max / rms, disparity max / rms):", {k: [f"{v:.2e}" for v in e] for k, e in res.items()})
+    for i in range(4):
+        assert res["bf16x3"][i] <= 1.5 * res["f32"][i] + 1e-7, (i, res)       # no worse than the f32 MFMA engine
+        assert res["bf16x3"][i] < 1e-5 and res["f32"][i] < 1e-5, (i, res)      # both fp32-grade
+    assert res["bf16x2"][0] > 3 * res["bf16x3"][0]                             # and the 16-bit split is visibly not
