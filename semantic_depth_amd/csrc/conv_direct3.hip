@@ -226,48 +226,68 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
             // the X fragments of the first KEEP planes stay in registers from the phase that first reads them to the end of the chunk
             u32x4 xk[KEEP > 0 ? KEEP : 1][3][T3_MT + 2];
             // one phase: the weight plane in ring slot q & 1 times X planes PH .. 0 (phase 0: W_lo x X_hi; 1: W_mid x (X_mid, X_hi);
-            // 2: W_hi x (X_lo, X_mid, X_hi)); `issue(grp)` is called behind MFMA group grp (one DMA instruction per call)
-            auto phase = [&](auto ph_tag, auto&& issue) {
-                constexpr int PH = decltype(ph_tag)::value, NPX = PH + 1;
+            // 2: W_hi x (X_lo, X_mid, X_hi)); `issue(grp)` is called behind MFMA group grp (one DMA instruction per call).
+            // The LDS reads run AHEAD of the MFMAs that consume them (an explicit software pipeline: left to itself the compiler puts every
+            // weight fragment's ds_read + s_waitcnt directly in front of its 2 NPX MFMAs, and in the lo / mid phases the two waves of a
+            // SIMD do not have enough MFMAs per group to cover an LDS round trip): the weight fragment of group g + 2 and the X rows of the
+            // plane this phase reads for the first time (row dy + 2 / the first two rows of the next dx) are issued before group g's MFMAs.
+            auto phase = [&](auto ph_tag, auto nomfma_tag, auto&& issue) {
+                constexpr int PH = decltype(ph_tag)::value, NPX = PH + 1, G = 9 * NB;
+                constexpr bool NOMFMA = decltype(nomfma_tag)::value != 0;
+                constexpr bool NEWKEPT = PH < KEEP;              // the plane first read in this phase stays in xk
                 const u32x4* const Wq = lds + 2 * XBUF + (q % WSLOTS) * WUNITS;
+                auto wfrag = [&](int grp) {
+                    const int dx = grp / (3 * NB), dy = (grp / NB) % 3, nb = grp % NB;
+                    return Wq[((dy * 3 + dx) * 2 + fk) * (32 * NB) + nb * 32 + frow];
+                };
+                u32x4 xn[T3_MT + 2];                             // rows of the new plane when it is not kept
+                u32x4 xo[KEEP < PH ? PH - KEEP : 1][T3_MT + 2];  // older planes that are not kept: re-read per dx
+                auto xnew = [&](int dx, int r) {
+                    if constexpr (NEWKEPT) xk[PH][dx][r] = xload(PH, dx, r);
+                    else xn[r] = xload(PH, dx, r);
+                };
+                u32x4 wq[3];
+                wq[0] = wfrag(0);
+                wq[1] = wfrag(1);
+                xnew(0, 0); xnew(0, 1);
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    u32x4 x[NPX][T3_MT + 2];
+                for (int grp = 0; grp < G; ++grp) {
+                    const int dx = grp / (3 * NB), dy = (grp / NB) % 3, nb = grp % NB;
+                    if (dy == 0 && nb == 0) {
 #pragma unroll
-                    for (int pl = 0; pl < NPX; ++pl)
+                        for (int pl = KEEP; pl < PH; ++pl)
 #pragma unroll
-                        for (int r = 0; r < T3_MT + 2; ++r) {
-                            if (pl < KEEP) {
-                                if (pl == PH) xk[pl][dx][r] = xload(pl, dx, r);      // first use: from LDS, then kept
-                                x[pl][r] = xk[pl][dx][r];
-                            } else {
-                                x[pl][r] = xload(pl, dx, r);
+                            for (int r = 0; r < T3_MT + 2; ++r) xo[pl - KEEP][r] = xload(pl, dx, r);
+                    }
+                    if (grp + 2 < G) wq[(grp + 2) % 3] = wfrag(grp + 2);
+                    if (nb == 0) {
+                        if (dy < 2) xnew(dx, dy + 2);
+                        else if (dx < 2) { xnew(dx + 1, 0); xnew(dx + 1, 1); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (!NOMFMA) {
+                        const u32x4 wv = wq[grp % 3];
+#pragma unroll
+                        for (int pl = NPX - 1; pl >= 0; --pl)          // the smaller planes first
+#pragma unroll
+                            for (int a = 0; a < T3_MT; ++a) {
+                                const u32x4 xv = pl < KEEP ? xk[pl < KEEP ? pl : 0][dx][a + dy] : (pl == PH ? xn[a + dy] : xo[pl >= KEEP && pl < PH ? pl - KEEP : 0][a + dy]);
+                                acc[a][nb] = mfma_frag<false>(wv, xv, acc[a][nb]);
                             }
-                        }
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            const u32x4 wv = Wq[((dy * 3 + dx) * 2 + fk) * (32 * NB) + nb * 32 + frow];
-                            if (!(diag & 2)) {
-#pragma unroll
-                            for (int pl = NPX - 1; pl >= 0; --pl)          // the smaller planes first
-#pragma unroll
-                                for (int a = 0; a < T3_MT; ++a)
-                                    acc[a][nb] = mfma_frag<false>(wv, x[pl][a + dy], acc[a][nb]);
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                            issue((dx * 3 + dy) * NB + nb);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue(grp);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             };
+            // (SEMDEPTH_X3_DIAG & 2 selects the copy of a phase without MFMAs; production runs the branch-free one)
+#define SD_PHASE(PH_, ...) do { if (diag & 2) phase(IntTag<PH_>{}, IntTag<1>{}, __VA_ARGS__); else phase(IntTag<PH_>{}, IntTag<0>{}, __VA_ARGS__); } while (0)
             if constexpr (WSLOTS == 3) {
                 // ---- three-slot pipeline: phase q issues the weight plane of phase q + 2 and the X plane first read in phase q + 2
                 // lo(c): W_hi(c) + X_lo(c)
                 wait_prev();
                 __builtin_amdgcn_s_barrier();
-                phase(IntTag<0>{}, [&](int grp) {
+                SD_PHASE(0, [&](int grp) {
                     if (grp < WS) wslot(wcur, 0, grp, (q + 2) % 3);
                     else if (grp < WS + XS) xslot(kc, 2, grp - WS);
                 });
@@ -277,7 +297,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
                 wait_prev();
                 __builtin_amdgcn_s_barrier();
                 if (more) kn = begin_chunk(d3load_chunk(p.chunks + ic), icur, ic, (g + 1) & 1);
-                phase(IntTag<1>{}, [&](int grp) {
+                SD_PHASE(1, [&](int grp) {
                     if (!more) return;
                     if (grp < WS) wslot(kn.w, 2, grp, (q + 2) % 3);
                     else if (grp < WS + XS) xslot(kn, 0, grp - WS);
@@ -287,7 +307,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
                 // hi(c): W_mid(c+1) + X_mid(c+1)
                 wait_prev();
                 __builtin_amdgcn_s_barrier();
-                phase(IntTag<2>{}, [&](int grp) {
+                SD_PHASE(2, [&](int grp) {
                     if (!more) return;
                     if (grp < WS) wslot(kn.w, 1, grp, (q + 2) % 3);
                     else if (grp < WS + XS) xslot(kn, 1, grp - WS);
@@ -299,7 +319,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
             // ---- phase lo: W_lo x X_hi (36 MFMAs per wave at NB = 2); brings W_mid of this chunk
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            phase(IntTag<0>{}, [&](int grp) {
+            SD_PHASE(0, [&](int grp) {
                 if (grp < WS) wslot(wcur, 1, grp, (q + 1) & 1);
             });
             ++q;
@@ -307,7 +327,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (more) kn = begin_chunk(d3load_chunk(p.chunks + ic), icur, ic, (g + 1) & 1);
-            phase(IntTag<1>{}, [&](int grp) {
+            SD_PHASE(1, [&](int grp) {
                 if (grp < WS) wslot(wcur, 0, grp, (q + 1) & 1);
                 else if (more && grp < WS + XS) xslot(kn, 0, grp - WS);
             });
@@ -315,7 +335,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
             // ---- phase hi: W_hi x (X_lo, X_mid, X_hi) (108); brings W_lo and X_mid, X_lo of the cursor chunk
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            phase(IntTag<2>{}, [&](int grp) {
+            SD_PHASE(2, [&](int grp) {
                 if (!more) return;
                 if (grp < WS) wslot(kn.w, 2, grp, (q + 1) & 1);
                 else if (grp < WS + 2 * XS) { const int s_ = grp - WS; xslot(kn, 1 + s_ / XS, s_ % XS); }
@@ -430,6 +450,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
         }
         if (tid + (int)gridDim.x < items) cur = tile_of(tid + gridDim.x);
     }
+#undef SD_PHASE
 }
 
 hipError_t launch_conv_direct3(const ConvDirectParams& p, hipStream_t s) {

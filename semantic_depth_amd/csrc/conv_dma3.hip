@@ -149,30 +149,49 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
             }
             prev_issued = issued;
             const u32x4* const Wq = lds + 2 * G3_XBUF + (q % 3) * G3_WPL;
+            // LDS reads ahead of the MFMAs (left to itself the compiler emits, per k-step, 6 ds_reads + a wait + the MFMAs -- two exposed LDS
+            // round trips per phase): both k-steps' weight fragments and the fragments of the plane this phase reads for the first time
+            // are issued at the top (the hi / mid planes land in their kept registers, so that costs none), and the products on the kept
+            // planes come first, so the hi phase's X_lo reads have 16 MFMAs of cover.
+            u32x4 w[2][G3_NT], xl[G3_MT];
+#pragma unroll
+            for (int s = 0; s < (PH < 2 ? 2 : 1); ++s)         // (hi phase: the second k-step's weights follow its first kept-plane MFMAs -- registers)
+#pragma unroll
+                for (int b = 0; b < G3_NT; ++b) w[s][b] = Wq[(2 * s + fk) * G3_BN + wn0 + b * 32 + frow];
+            if constexpr (PH < 2) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int a = 0; a < G3_MT; ++a) xk[PH][s][a] = xload(PH, s, a);
+            } else {
+#pragma unroll
+                for (int a = 0; a < G3_MT; ++a) xl[a] = xload(2, 0, a);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const int kg = 2 * s + fk;
-                u32x4 w[G3_NT], x[NPX][G3_MT];
 #pragma unroll
-                for (int b = 0; b < G3_NT; ++b) w[b] = Wq[kg * G3_BN + wn0 + b * 32 + frow];
-#pragma unroll
-                for (int pl = 0; pl < NPX; ++pl)
-#pragma unroll
-                    for (int a = 0; a < G3_MT; ++a) {
-                        if (pl < 2) {
-                            if (pl == PH) xk[pl][s][a] = xload(pl, s, a);
-                            x[pl][a] = xk[pl][s][a];
-                        } else {
-                            x[pl][a] = xload(pl, s, a);
-                        }
-                    }
-#pragma unroll
-                for (int pl = NPX - 1; pl >= 0; --pl)          // the smaller planes first
+                for (int pl = 0; pl < (PH < 2 ? NPX : 2); ++pl)          // the kept planes
 #pragma unroll
                     for (int b = 0; b < G3_NT; ++b)
 #pragma unroll
                         for (int a = 0; a < G3_MT; ++a)
-                            acc[a][b] = mfma_frag<false>(w[b], x[pl][a], acc[a][b]);
+                            acc[a][b] = mfma_frag<false>(w[s][b], xk[pl][s][a], acc[a][b]);
+                if constexpr (PH == 2) {
+#pragma unroll
+                    for (int b = 0; b < G3_NT; ++b)
+#pragma unroll
+                        for (int a = 0; a < G3_MT; ++a)
+                            acc[a][b] = mfma_frag<false>(w[s][b], xl[a], acc[a][b]);
+                    if (s == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int b = 0; b < G3_NT; ++b) w[1][b] = Wq[(2 + fk) * G3_BN + wn0 + b * 32 + frow];
+#pragma unroll
+                        for (int a = 0; a < G3_MT; ++a) xl[a] = xload(2, 1, a);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
             ++q;
         };
