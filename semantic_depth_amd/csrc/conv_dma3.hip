@@ -8,11 +8,12 @@
 //        phase lo : W_lo  x X_hi                16 MFMAs per wave
 //        phase mid: W_mid x (X_mid, X_hi)       32
 //        phase hi : W_hi  x (X_lo, X_mid, X_hi) 48
-// X (three planes of 256 pixels x 32 k = 48 KB) is double-buffered per k-tile, the weight planes (16 KB each) stream through a THREE-slot
-// ring: 144 KB.  Every phase issues the weight plane needed TWO phases later plus one X plane that is first read two phases later
-// (lo(t): X_lo(t); mid(t): X_hi(t+1); hi(t): X_mid(t+1)) -- four DMA instructions per wave and phase, so a phase waits with a counted
-// s_waitcnt vmcnt(4) for what was issued two phases ago while the previous phase's DMAs stay in flight.  The X fragments of the hi and mid
-// planes stay in VGPRs across the phases of a k-tile (36 instead of 60 ds_read_b128 per 96 MFMAs).
+// The X fragments of the hi and mid planes stay in VGPRs across the phases of a k-tile (36 instead of 60 ds_read_b128 per 96 MFMAs), so
+// every X plane is read from LDS in ONE phase only -- the phase that uses it first: lo reads X_hi, mid X_mid, hi X_lo -- exactly like the
+// weight planes.  LDS is therefore a ring of four (X plane, weight plane) pairs of 16 + 16 KB (128 KB): the pair being read and the pairs
+// of the next THREE phases in flight.  Phase q issues the pair of phase q + 3 (four DMA instructions per wave) and waits with a counted
+// s_waitcnt vmcnt(8) for what was issued three phases ago.  (Round 3's first form double-buffered whole X k-tiles beside a three-slot
+// weight ring -- 144 KB, two phases of look-ahead; PMC showed the MFMA pipes 56 % busy with a third of the wave cycles parked in waits.)
 // 8 waves as 2 x 4, wave tile 128 pixels x 64 channels (acc 128 VGPRs); general gather through the KEntry table (any kernel size, stride,
 // concatenated sources); epilogue = conv_dma.hip's X3 epilogue.
 #include <cstdlib>
@@ -43,8 +44,9 @@ __device__ __forceinline__ KEntry g3load_kentry(const KEntry* ptr) {
 constexpr int G3_BM = 256, G3_BN = 256, G3_NW = 8, G3_MT = 4, G3_NT = 2;
 constexpr int G3_XPL = 4 * G3_BM;            // 16-B units of one X plane of a k-tile: [pixel][octet ^ swizzle]
 constexpr int G3_WPL = 4 * G3_BN;            // units of one weight plane of a k-tile: [k-octet][channel]
-constexpr int G3_XBUF = 3 * G3_XPL;
-constexpr int G3_LDS = 2 * G3_XBUF + 3 * G3_WPL;       // units (144 KB)
+constexpr int G3_RING = 4;                   // ring slots, one (X plane, weight plane) pair each: the phase being read + three in flight
+constexpr int G3_PAIR = G3_XPL + G3_WPL;
+constexpr int G3_LDS = G3_RING * G3_PAIR;    // units (128 KB)
 constexpr int G3_ROW = G3_NT * 64 + 16;
 
 __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
@@ -85,28 +87,27 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
     const int ktiles = p.Kpad / 32;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds;
 
-    auto issue_x = [&](int kt, int pl) {                       // X plane pl of k-tile kt -> X buffer kt & 1
-        const KEntry e = g3load_kentry(ktab + kt);
+    // one DMA instruction of a pair: piece 0, 1 = the weight plane's two instructions of this wave, 2, 3 = the X plane's
+    auto issue_x1 = [&](const KEntry& e, int pl, int slot, int i) {     // X plane pl of the k-tile of entry e -> ring slot
         const int st = (e.flags >> 4) & 3, up = e.flags & 1;
         const size_t plane = (size_t)Nmax * e.H * e.W * e.C;
-        const unsigned dst = lds0 + (unsigned)(((kt & 1) * G3_XBUF + pl * G3_XPL) * 16);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int iy = poy[i] * st + e.dy, ix = pox[i] * st + e.dx;
-            const bool ok = pok[i] && iy >= 0 && ix >= 0 && iy < (e.H << up) && ix < (e.W << up);
-            iy >>= up; ix >>= up;
-            const uint16_t* px = reinterpret_cast<const uint16_t*>(e.base) + ((size_t)(pimg[i] * e.H + iy) * e.W + ix) * e.C + pkg[i] * 8 + (size_t)pl * plane;
-            g3dma16(ok ? reinterpret_cast<const u32x4*>(px) : zero, dst + (unsigned)((wave + G3_NW * i) * 1024));
-        }
+        const unsigned dst = lds0 + (unsigned)(slot * G3_PAIR * 16);
+        int iy = poy[i] * st + e.dy, ix = pox[i] * st + e.dx;
+        const bool ok = pok[i] && iy >= 0 && ix >= 0 && iy < (e.H << up) && ix < (e.W << up);
+        iy >>= up; ix >>= up;
+        const uint16_t* px = reinterpret_cast<const uint16_t*>(e.base) + ((size_t)(pimg[i] * e.H + iy) * e.W + ix) * e.C + pkg[i] * 8 + (size_t)pl * plane;
+        g3dma16(ok ? reinterpret_cast<const u32x4*>(px) : zero, dst + (unsigned)((wave + G3_NW * i) * 1024));
     };
-    auto issue_w = [&](int kt, int pl, int slot) {             // weight plane pl of k-tile kt -> ring slot
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int wu = (wave + G3_NW * i) * 64 + lane;     // unit inside the plane: [kg][n]
-            const int kg = wu / G3_BN, n_l = wu % G3_BN;
-            g3dma16(wt_hi + (size_t)pl * wplane + (size_t)(kt * 4 + kg) * CoutPad + bn0 + n_l,
-                    lds0 + (unsigned)((2 * G3_XBUF + slot * G3_WPL + (wave + G3_NW * i) * 64) * 16));
-        }
+    auto issue_w1 = [&](int kt, int pl, int slot, int i) {              // weight plane pl of k-tile kt -> ring slot
+        const int wu = (wave + G3_NW * i) * 64 + lane;         // unit inside the plane: [kg][n]
+        const int kg = wu / G3_BN, n_l = wu % G3_BN;
+        g3dma16(wt_hi + (size_t)pl * wplane + (size_t)(kt * 4 + kg) * CoutPad + bn0 + n_l,
+                lds0 + (unsigned)((slot * G3_PAIR + G3_XPL + (wave + G3_NW * i) * 64) * 16));
+    };
+    auto issue_pair = [&](int kt, int ph, int slot) {          // (prologue: all four instructions at once)
+        const KEntry e = g3load_kentry(ktab + kt);
+        issue_w1(kt, 2 - ph, slot, 0); issue_w1(kt, 2 - ph, slot, 1);
+        issue_x1(e, ph, slot, 0); issue_x1(e, ph, slot, 1);
     };
 
     f32x16 acc[G3_MT][G3_NT];
@@ -117,38 +118,44 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // phase q = 3 kt + ph reads weight plane (2 - ph) of k-tile kt from ring slot q % 3 (ph 0: lo, 1: mid, 2: hi)
+    // phase q = 3 kt + ph reads weight plane (2 - ph) and, for the first and only time, X plane ph of k-tile kt from ring slot q % 4
+    // (ph 0: lo, 1: mid, 2: hi)
     const int nphase = 3 * ktiles;
-    // prologue = the issues of the (virtual) phases -2 and -1: W for phases 0 and 1, X_hi(0) and X_mid(0)
-    issue_w(0, 2, 0); issue_x(0, 0);
-    issue_w(0, 1, 1); issue_x(0, 1);
-    int prev_issued = 4;                                      // DMA instructions this wave issued in the previous phase
+    // prologue = the issues of the (virtual) phases -3 .. -1: the pairs of phases 0, 1, 2
+    issue_pair(0, 0, 0);
+    issue_pair(0, 1, 1);
+    issue_pair(0, 2, 2);
+    int prev1 = 4, prev2 = 4;                                 // DMA instructions this wave issued in the previous phase / the one before
     const int frow = lane & 31, fk = lane >> 5;
     int q = 0;
     for (int kt = 0; kt < ktiles; ++kt) {
-        const u32x4* const Xb = lds + (kt & 1) * G3_XBUF;
         u32x4 xk[2][2][G3_MT];                                // X fragments of the hi and mid planes, kept for the k-tile: [plane][k-step][a]
-        auto xload = [&](int pl, int s, int a) {
-            const int mrow = wm0 + a * 32 + frow;
-            return Xb[pl * G3_XPL + mrow * 4 + ((2 * s + fk) ^ ((mrow >> 2) & 3))];
-        };
         auto phase = [&](auto ph_tag) {
             constexpr int PH = decltype(ph_tag)::value, NPX = PH + 1;
-            // everything issued two phases ago has landed once at most the previous phase's DMAs are outstanding
-            if (prev_issued == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (prev_issued == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            // everything issued three phases ago has landed once at most the last two phases' DMAs are outstanding
+            if (prev1 + prev2 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (prev1 + prev2 == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            // issue for phase q + 2: its weight plane, and the X plane that is first read then
-            int issued = 0;
-            {
-                const int q2 = q + 2;
-                if (q2 < nphase) { issue_w(q2 / 3, 2 - q2 % 3, q2 % 3); issued += 2; }
-                // phase (kt', ph') first reads X plane ph' of k-tile kt'
-                if (q2 < nphase) { issue_x(q2 / 3, q2 % 3); issued += 2; }
-            }
-            prev_issued = issued;
-            const u32x4* const Wq = lds + 2 * G3_XBUF + (q % 3) * G3_WPL;
+            // the pair of phase q + 3 goes into the slot phase q - 1 has just finished reading -- its four DMA instructions are spread
+            // BEHIND the first four MFMA groups of this phase (at the top of the phase, with the MFMA pipe drained by the barrier, each
+            // of them would cost its full issue latency)
+            const bool doissue = q + 3 < nphase;               // = 3 (kt + 1) + ph
+            KEntry e3;
+            if (doissue) e3 = g3load_kentry(ktab + kt + 1);
+            const int issued = doissue ? 4 : 0;
+            auto piece = [&](int n) {
+                if (!doissue) return;
+                if (n < 2) issue_w1(kt + 1, 2 - PH, (q + 3) & 3, n);
+                else issue_x1(e3, PH, (q + 3) & 3, n - 2);
+            };
+            prev2 = prev1; prev1 = issued;
+            const u32x4* const Xq = lds + (q & 3) * G3_PAIR;
+            const u32x4* const Wq = Xq + G3_XPL;
+            auto xload = [&](int, int s, int a) {             // (the plane this phase reads for the first time)
+                const int mrow = wm0 + a * 32 + frow;
+                return Xq[mrow * 4 + ((2 * s + fk) ^ ((mrow >> 2) & 3))];
+            };
             // LDS reads ahead of the MFMAs (left to itself the compiler emits, per k-step, 6 ds_reads + a wait + the MFMAs -- two exposed LDS
             // round trips per phase): both k-steps' weight fragments and the fragments of the plane this phase reads for the first time
             // are issued at the top (the hi / mid planes land in their kept registers, so that costs none), and the products on the kept
@@ -173,10 +180,17 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
 #pragma unroll
                 for (int pl = 0; pl < (PH < 2 ? NPX : 2); ++pl)          // the kept planes
 #pragma unroll
-                    for (int b = 0; b < G3_NT; ++b)
+                    for (int b = 0; b < G3_NT; ++b) {
 #pragma unroll
                         for (int a = 0; a < G3_MT; ++a)
                             acc[a][b] = mfma_frag<false>(w[s][b], xk[pl][s][a], acc[a][b]);
+                        const int grp = (s * (PH < 2 ? NPX : 2) + pl) * G3_NT + b;      // MFMA groups of four so far (lo phase: 4 in all)
+                        if (PH == 0 ? true : (s == 0 && grp < 4)) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            piece(grp);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
                 if constexpr (PH == 2) {
 #pragma unroll
                     for (int b = 0; b < G3_NT; ++b)
