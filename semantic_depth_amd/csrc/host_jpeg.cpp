@@ -216,6 +216,7 @@ struct Decoder {
         if (w_out) *w_out = swap ? H : W;
     }
 
+    size_t cap_bytes = 0;                                  // capacity of the caller's output buffer (checked at the frame header)
     sd_status parse(bool decode) {
         if (len < 4 || f[0] != 0xFF || f[1] != 0xD8) return SD_ERR_INVALID;
         size_t p = 2;
@@ -263,6 +264,7 @@ struct Decoder {
                 H = rd16(s + 1); W = rd16(s + 3); ncomp = s[5];
                 if (H <= 0 || W <= 0 || (ncomp != 1 && ncomp != 3) || sn < 6 + 3 * (size_t)ncomp) return SD_ERR_INVALID;
                 if ((size_t)H * (size_t)W > ((size_t)1 << 28)) return SD_ERR_INVALID;      // (256 Mpixel: refuse absurd headers before allocating planes)
+                if (decode && cap_bytes < (size_t)H * W * 3) return SD_ERR_INVALID;       // the caller's buffer bounds what a header can make us allocate
                 for (int i = 0; i < ncomp; ++i) {
                     comp[i].id = s[6 + 3 * i]; comp[i].h = s[7 + 3 * i] >> 4; comp[i].v = s[7 + 3 * i] & 15; comp[i].tq = s[8 + 3 * i];
                     if (comp[i].h < 1 || comp[i].v < 1 || comp[i].tq > 3) return SD_ERR_INVALID;
@@ -532,6 +534,7 @@ struct Decoder {
     }
 
     sd_status decode(uint8_t* out, size_t cap) {
+        cap_bytes = cap;
         const sd_status st = parse(true);
         if (st != SD_OK) return st;
         for (int i = 0; i < ncomp; ++i) if (comp[i].plane.empty()) return SD_ERR_INVALID;
@@ -604,10 +607,14 @@ struct Decoder {
 extern "C" sd_status sd_jpeg_decode_bgr(const uint8_t* file_host, size_t len, uint8_t* bgr_out_host, size_t out_capacity, int* height_out,
                                         int* width_out) {
     if (!file_host) return SD_ERR_INVALID;
-    Decoder d;
-    d.f = file_host; d.len = len;
-    if (!bgr_out_host) return d.header_only(height_out, width_out);
-    const sd_status st = d.decode(bgr_out_host, out_capacity);
-    if (st == SD_OK) d.dims(height_out, width_out);
-    return st;
+    try {                                                  // (no exception crosses the C ABI: an allocation failure is a refused file)
+        Decoder d;
+        d.f = file_host; d.len = len;
+        if (!bgr_out_host) return d.header_only(height_out, width_out);
+        const sd_status st = d.decode(bgr_out_host, out_capacity);
+        if (st == SD_OK) d.dims(height_out, width_out);
+        return st;
+    } catch (...) {
+        return SD_ERR_INVALID;
+    }
 }

@@ -140,7 +140,11 @@ sd_status png_decode(const uint8_t* f, size_t len, uint8_t* out, size_t out_cap,
 // PNG or baseline JPEG (host_jpeg.cpp), by signature
 sd_status image_decode(const uint8_t* f, size_t len, uint8_t* out, size_t out_cap, int* h_out, int* w_out) {
     if (f && len >= 2 && f[0] == 0xFF && f[1] == 0xD8) return sd_jpeg_decode_bgr(f, len, out, out_cap, h_out, w_out);
-    return png_decode(f, len, out, out_cap, h_out, w_out);
+    try {                                                       // (no exception crosses the C ABI or a worker thread: an allocation failure is a refused file)
+        return png_decode(f, len, out, out_cap, h_out, w_out);
+    } catch (...) {
+        return SD_ERR_INVALID;
+    }
 }
 
 bool read_file(const char* path, std::vector<uint8_t>& buf) {
@@ -160,7 +164,11 @@ bool read_file(const char* path, std::vector<uint8_t>& buf) {
 
 extern "C" sd_status sd_png_decode_bgr(const uint8_t* file_host, size_t len, uint8_t* bgr_out_host, size_t out_capacity, int* height_out,
                                        int* width_out) {
-    return png_decode(file_host, len, bgr_out_host, out_capacity, height_out, width_out);
+    try {
+        return png_decode(file_host, len, bgr_out_host, out_capacity, height_out, width_out);
+    } catch (...) {
+        return SD_ERR_INVALID;
+    }
 }
 
 extern "C" sd_status sd_image_decode_bgr(const uint8_t* file_host, size_t len, uint8_t* bgr_out_host, size_t out_capacity, int* height_out,
@@ -180,18 +188,25 @@ extern "C" sd_status sd_decode_files_bgr(const char* const* paths, int n, int he
             const int i = next.fetch_add(1);
             if (i >= n) break;
             sd_status st = SD_ERR_NOTFOUND;
-            if (paths[i] && read_file(paths[i], file)) {
-                int h = 0, w = 0;
-                st = image_decode(file.data(), file.size(), nullptr, 0, &h, &w);
-                if (st == SD_OK && (h != height || w != width)) st = SD_ERR_INVALID;         // every frame of a batch has the batch's shape
-                if (st == SD_OK) st = image_decode(file.data(), file.size(), out_host + (size_t)i * frame_stride, frame_stride, nullptr, nullptr);
+            try {
+                if (paths[i] && read_file(paths[i], file)) {
+                    int h = 0, w = 0;
+                    st = image_decode(file.data(), file.size(), nullptr, 0, &h, &w);
+                    if (st == SD_OK && (h != height || w != width)) st = SD_ERR_INVALID;     // every frame of a batch has the batch's shape
+                    if (st == SD_OK) st = image_decode(file.data(), file.size(), out_host + (size_t)i * frame_stride, frame_stride, nullptr, nullptr);
+                }
+            } catch (...) {
+                st = SD_ERR_INVALID;
             }
             if (status_out) status_out[i] = st;
             if (st != SD_OK) failed.fetch_add(1);
         }
     };
     std::vector<std::thread> pool;
-    for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+    try {
+        for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+    } catch (...) {                                             // (thread creation refused: the calling thread and the workers that exist do the batch)
+    }
     work();
     for (auto& th : pool) th.join();
     return failed.load() ? SD_ERR_INVALID : SD_OK;
