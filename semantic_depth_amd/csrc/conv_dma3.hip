@@ -31,6 +31,13 @@ __device__ __forceinline__ void g3dma16(const void* gsrc, unsigned lds_dst) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// the same with a uniform base in SGPRs and a 32-bit per-lane byte offset (the weight panels: one VGPR per piece instead of a 64-bit
+// pointer per piece and plane)
+__device__ __forceinline__ void g3dma16s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
 typedef int i32x8g __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ KEntry g3load_kentry(const KEntry* ptr) {
     i32x8g v;
@@ -64,20 +71,20 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
     const int bm0 = tm * G3_BM, bn0 = tn * G3_BN;
 
     // X DMA: instruction j (16 per plane) covers pixels [16 j, 16 j + 16) x 4 octets; this wave issues j = wave and wave + 8
-    int pimg[2], poy[2], pox[2], pkg[2];
-    bool pok[2];
+    // per-lane geometry of its two X-DMA pixels, packed (registers): pyx = oy | ox << 16, pik = image | octet << 26 | inside << 30
+    int pyx[2], pik[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m_l = (wave + G3_NW * i) * 16 + (lane >> 2);
         const int m = bm0 + m_l;
-        pok[i] = m < M;
+        const bool ok = m < M;
         const int hw = p.Hout * p.Wout;
-        const int mm = pok[i] ? m : 0;
-        pimg[i] = mm / hw;
-        const int r = mm - pimg[i] * hw;
-        poy[i] = r / p.Wout;
-        pox[i] = r - poy[i] * p.Wout;
-        pkg[i] = (lane & 3) ^ ((m_l >> 2) & 3);               // the octet this lane fetches into slot lane % 4
+        const int mm = ok ? m : 0;
+        const int img = mm / hw;
+        const int r = mm - img * hw;
+        const int oy = r / p.Wout;
+        pyx[i] = oy | ((r - oy * p.Wout) << 16);
+        pik[i] = img | (((lane & 3) ^ ((m_l >> 2) & 3)) << 26) | ((ok ? 1 : 0) << 30);      // (octet: the one this lane fetches into slot lane % 4)
     }
     const KEntry* __restrict__ const ktab = p.ktab;
     const int CoutPad = p.CoutPad, Nmax = p.Nmax;
@@ -92,17 +99,22 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
         const int st = (e.flags >> 4) & 3, up = e.flags & 1;
         const size_t plane = (size_t)Nmax * e.H * e.W * e.C;
         const unsigned dst = lds0 + (unsigned)(slot * G3_PAIR * 16);
-        int iy = poy[i] * st + e.dy, ix = pox[i] * st + e.dx;
-        const bool ok = pok[i] && iy >= 0 && ix >= 0 && iy < (e.H << up) && ix < (e.W << up);
+        int iy = (pyx[i] & 0xffff) * st + e.dy, ix = (pyx[i] >> 16) * st + e.dx;
+        const bool ok = ((pik[i] >> 30) & 1) && iy >= 0 && ix >= 0 && iy < (e.H << up) && ix < (e.W << up);
         iy >>= up; ix >>= up;
-        const uint16_t* px = reinterpret_cast<const uint16_t*>(e.base) + ((size_t)(pimg[i] * e.H + iy) * e.W + ix) * e.C + pkg[i] * 8 + (size_t)pl * plane;
+        const uint16_t* px = reinterpret_cast<const uint16_t*>(e.base) + ((size_t)((pik[i] & 0x3ffffff) * e.H + iy) * e.W + ix) * e.C + ((pik[i] >> 26) & 3) * 8 + (size_t)pl * plane;
         g3dma16(ok ? reinterpret_cast<const u32x4*>(px) : zero, dst + (unsigned)((wave + G3_NW * i) * 1024));
     };
-    auto issue_w1 = [&](int kt, int pl, int slot, int i) {              // weight plane pl of k-tile kt -> ring slot
+    // weight DMA: piece i of a plane covers units [(wave + 8 i) 64, + 64) of [k-octet][BN channels]; per-lane byte offset into the panel
+    unsigned woff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
         const int wu = (wave + G3_NW * i) * 64 + lane;         // unit inside the plane: [kg][n]
-        const int kg = wu / G3_BN, n_l = wu % G3_BN;
-        g3dma16(wt_hi + (size_t)pl * wplane + (size_t)(kt * 4 + kg) * CoutPad + bn0 + n_l,
-                lds0 + (unsigned)((slot * G3_PAIR + G3_XPL + (wave + G3_NW * i) * 64) * 16));
+        woff[i] = (unsigned)(((wu / G3_BN) * CoutPad + wu % G3_BN) * 16);
+    }
+    auto issue_w1 = [&](int kt, int pl, int slot, int i) {              // weight plane pl of k-tile kt -> ring slot
+        const u32x4* base = wt_hi + (size_t)pl * wplane + (size_t)(kt * 4) * CoutPad + bn0;       // (wave-uniform: SGPRs)
+        g3dma16s(base, woff[i], lds0 + (unsigned)((slot * G3_PAIR + G3_XPL + (wave + G3_NW * i) * 64) * 16));
     };
     auto issue_pair = [&](int kt, int ph, int slot) {          // (prologue: all four instructions at once)
         const KEntry e = g3load_kentry(ktab + kt);
@@ -125,60 +137,77 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
     issue_pair(0, 0, 0);
     issue_pair(0, 1, 1);
     issue_pair(0, 2, 2);
-    int prev1 = 4, prev2 = 4;                                 // DMA instructions this wave issued in the previous phase / the one before
+    int prev1 = 4;                                            // DMA instructions this wave issued in the previous phase
     const int frow = lane & 31, fk = lane >> 5;
+    // Fragment registers that live across phase boundaries: the LDS reads a phase starts with are issued in the TAIL of the phase before
+    // it (pair q + 1 is complete and visible from barrier q on: every wave waits for it there), so a phase's first MFMAs follow its barrier
+    // directly instead of waiting out an LDS round trip with the MFMA pipes drained.
+    u32x4 xk[2][2][G3_MT];                                    // X fragments of the hi and mid planes, kept for the k-tile: [plane][k-step][a]
+    u32x4 wn[G3_NT], xl[G3_MT];                               // the next phase's first-k-step weight fragments; X_lo fragments of a k-step
+    auto wfrag = [&](int slot, int s, int b) { return lds[slot * G3_PAIR + G3_XPL + (2 * s + fk) * G3_BN + wn0 + b * 32 + frow]; };
+    auto xfrag = [&](int slot, int s, int a) {
+        const int mrow = wm0 + a * 32 + frow;
+        return lds[slot * G3_PAIR + mrow * 4 + ((2 * s + fk) ^ ((mrow >> 2) & 3))];
+    };
+    // heads of phase 0: pairs 0 and 1 have landed once only the third prologue pair is outstanding
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int b = 0; b < G3_NT; ++b) wn[b] = wfrag(0, 0, b);
+#pragma unroll
+    for (int a = 0; a < G3_MT; ++a) xk[0][0][a] = xfrag(0, 0, a);
     int q = 0;
+    KEntry e3 = g3load_kentry(ktab + 1);                      // (Kpad >= 64: at least two k-tiles) gather entry of the k-tile whose pairs are being issued (kt + 1)
     for (int kt = 0; kt < ktiles; ++kt) {
-        u32x4 xk[2][2][G3_MT];                                // X fragments of the hi and mid planes, kept for the k-tile: [plane][k-step][a]
         auto phase = [&](auto ph_tag) {
             constexpr int PH = decltype(ph_tag)::value, NPX = PH + 1;
-            // everything issued three phases ago has landed once at most the last two phases' DMAs are outstanding
-            if (prev1 + prev2 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (prev1 + prev2 == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            // pairs q and q + 1 have landed once at most the previous phase's DMAs are outstanding (pair q + 1 feeds the tail's prefetch)
+            if (prev1 == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             // the pair of phase q + 3 goes into the slot phase q - 1 has just finished reading -- its four DMA instructions are spread
             // BEHIND the first four MFMA groups of this phase (at the top of the phase, with the MFMA pipe drained by the barrier, each
             // of them would cost its full issue latency)
             const bool doissue = q + 3 < nphase;               // = 3 (kt + 1) + ph
-            KEntry e3;
-            if (doissue) e3 = g3load_kentry(ktab + kt + 1);
-            const int issued = doissue ? 4 : 0;
             auto piece = [&](int n) {
                 if (!doissue) return;
                 if (n < 2) issue_w1(kt + 1, 2 - PH, (q + 3) & 3, n);
                 else issue_x1(e3, PH, (q + 3) & 3, n - 2);
             };
-            prev2 = prev1; prev1 = issued;
-            const u32x4* const Xq = lds + (q & 3) * G3_PAIR;
-            const u32x4* const Wq = Xq + G3_XPL;
-            auto xload = [&](int, int s, int a) {             // (the plane this phase reads for the first time)
-                const int mrow = wm0 + a * 32 + frow;
-                return Xq[mrow * 4 + ((2 * s + fk) ^ ((mrow >> 2) & 3))];
+            prev1 = doissue ? 4 : 0;
+            const int sq = q & 3, sn = (q + 1) & 3;            // this phase's ring slot, the next one's
+            const bool next = q + 1 < nphase;
+            // this phase's first k-step runs on fragments the phase before prefetched; its second k-step's are read now (lo / mid: behind
+            // the barrier, under the first k-step's MFMAs; hi: between its k-steps, registers)
+            u32x4 w[2][G3_NT];
+#pragma unroll
+            for (int b = 0; b < G3_NT; ++b) w[0][b] = wn[b];
+            auto second_step = [&]() {                         // (issued behind the phase's first MFMA group)
+                if constexpr (PH < 2) {
+#pragma unroll
+                    for (int b = 0; b < G3_NT; ++b) w[1][b] = wfrag(sq, 1, b);
+#pragma unroll
+                    for (int a = 0; a < G3_MT; ++a) xk[PH][1][a] = xfrag(sq, 1, a);
+                }
             };
-            // LDS reads ahead of the MFMAs (left to itself the compiler emits, per k-step, 6 ds_reads + a wait + the MFMAs -- two exposed LDS
-            // round trips per phase): both k-steps' weight fragments and the fragments of the plane this phase reads for the first time
-            // are issued at the top (the hi / mid planes land in their kept registers, so that costs none), and the products on the kept
-            // planes come first, so the hi phase's X_lo reads have 16 MFMAs of cover.
-            u32x4 w[2][G3_NT], xl[G3_MT];
+            // the tail's prefetch for phase q + 1: its first k-step's weight fragments and the first-k-step fragments of the X plane it
+            // reads for the first time (lo -> mid: X_mid, mid -> hi: X_lo, hi -> lo of the next k-tile: X_hi, once the kept X_hi
+            // fragments of this k-tile's first k-step have been used)
+            auto tail = [&]() {
+                if (!next) return;
 #pragma unroll
-            for (int s = 0; s < (PH < 2 ? 2 : 1); ++s)         // (hi phase: the second k-step's weights follow its first kept-plane MFMAs -- registers)
+                for (int b = 0; b < G3_NT; ++b) wn[b] = wfrag(sn, 0, b);
 #pragma unroll
-                for (int b = 0; b < G3_NT; ++b) w[s][b] = Wq[(2 * s + fk) * G3_BN + wn0 + b * 32 + frow];
-            if constexpr (PH < 2) {
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int a = 0; a < G3_MT; ++a) xk[PH][s][a] = xload(PH, s, a);
-            } else {
-#pragma unroll
-                for (int a = 0; a < G3_MT; ++a) xl[a] = xload(2, 0, a);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+                for (int a = 0; a < G3_MT; ++a) {
+                    if constexpr (PH == 0) xk[1][0][a] = xfrag(sn, 0, a);
+                    else if constexpr (PH == 1) xl[a] = xfrag(sn, 0, a);
+                    else xk[0][0][a] = xfrag(sn, 0, a);
+                }
+            };
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
 #pragma unroll
-                for (int pl = 0; pl < (PH < 2 ? NPX : 2); ++pl)          // the kept planes
+                for (int pl = 0; pl < (PH < 2 ? NPX : 2); ++pl) {        // the kept planes
 #pragma unroll
                     for (int b = 0; b < G3_NT; ++b) {
 #pragma unroll
@@ -187,11 +216,28 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
                         const int grp = (s * (PH < 2 ? NPX : 2) + pl) * G3_NT + b;      // MFMA groups of four so far (lo phase: 4 in all)
                         if (PH == 0 ? true : (s == 0 && grp < 4)) {
                             __builtin_amdgcn_sched_barrier(0);
+                            if (grp == 0) second_step();
                             piece(grp);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
+                    if (PH == 1 && s == 1 && pl == 0) {                  // mid: before its last eight MFMAs
+                        __builtin_amdgcn_sched_barrier(0);
+                        tail();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (PH == 0 && s == 0) {                                 // lo: between its two k-steps
+                    __builtin_amdgcn_sched_barrier(0);
+                    tail();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if constexpr (PH == 2) {
+                    if (s == 1) {                                        // hi: before its last eight MFMAs (X_hi(0) of this k-tile is done with)
+                        __builtin_amdgcn_sched_barrier(0);
+                        tail();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
 #pragma unroll
                     for (int b = 0; b < G3_NT; ++b)
 #pragma unroll
@@ -200,9 +246,9 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
                     if (s == 0) {
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int b = 0; b < G3_NT; ++b) w[1][b] = Wq[(2 + fk) * G3_BN + wn0 + b * 32 + frow];
+                        for (int b = 0; b < G3_NT; ++b) w[1][b] = wfrag(sq, 1, b);
 #pragma unroll
-                        for (int a = 0; a < G3_MT; ++a) xl[a] = xload(2, 1, a);
+                        for (int a = 0; a < G3_MT; ++a) xl[a] = xfrag(sq, 1, a);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -212,6 +258,7 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
         phase(IntTag<0>{});
         phase(IntTag<1>{});
         phase(IntTag<2>{});
+        if (kt + 2 < ktiles) e3 = g3load_kentry(ktab + kt + 2);       // (one scalar load per k-tile, behind the hi phase's MFMAs)
     }
 
     // ---- epilogue: bias + activation in f32, exact three-way split, LDS transpose (one slab per plane and wave), 16-byte runs ----
