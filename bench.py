@@ -98,6 +98,7 @@ def parse_args():
                     help="'both' adds the fence chain + fence-to-fence distance (semantic_depth.py:273-334; SURVEY §8f-1) to every frame; "
                          "the metric's configuration is 'rw'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-cloud", default=None, help="dev: save the raw road cloud of frame 0 (before the road chain) as .npy and exit")
     ap.add_argument("--no-f32-leg", action="store_true", help="(kept for old command lines) same as --legs none")
     ap.add_argument("--no-colours", action="store_true", help="do not carry the RGB of the points through the road chain")
     return ap.parse_args()
@@ -383,6 +384,12 @@ def main():
                 **({"fp16_saturated_values": sat} if sat is not None else {}), **pl, "roofline": rl}
 
     eng = make_engine(args.precision)
+    if args.dump_cloud:
+        o_ = eng.process_batch(state["frames"], cams, prm, approach=args.approach, colours=False)
+        n0 = int(o_["fuse"]["n_road"][0].item())
+        np.save(args.dump_cloud, o_["fuse"]["road_xyz"][0, :n0].cpu().numpy())
+        log(f"road cloud of frame 0: {n0} points -> {args.dump_cloud}")
+        return
     if rank == 0:
         log(f"setup {time.time() - t_setup:.1f}s; arenas: " + ", ".join(f"{k} {v / 2**30:.2f} GiB" for k, v in eng.bytes.items()))
     head = measure(eng, args.precision)

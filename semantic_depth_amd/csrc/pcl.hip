@@ -1447,14 +1447,49 @@ __global__ __launch_bounds__(256) void ror_count_kernel(CloudView in, int cap, c
             }
         if (c27 > nb) { keep[(size_t)b * cap + sidx[(size_t)b * cap + j]] = 1; return; }
     }
-    for (int r = 0; r <= ROR_RINGS && cnt <= nb; ++r) {
-        for (int dz = -r; dz <= r && cnt <= nb; ++dz) {
+    // The exact walk over the (2 ROR_RINGS + 1)^3 cells around the query, ROW by row (dz, dy fixed, the nine x cells of the row), rows in
+    // rings of growing max(|dz|, |dy|).  A row's points are one range of the cell-sorted array: an empty row costs two loads, a row of a
+    // few points is tested point by point.  Otherwise the cells wholly inside the ball are one x interval around cx (the per-axis far
+    // bound grows with |x - cx|; clamped face layers are never "inside") and are counted with ONE difference of the prefix array; only the
+    // cells the sphere cuts are read point by point.  The x bounds of the nine cells do not depend on the row: they are computed once.
+    // Same conservative bounds and the same strict d2 < r2 test per candidate as a cell-by-cell walk, and only the decision count > nb
+    // leaves the kernel: the same decision.
+    // (Round 3.  SQ counters of the cell-by-cell form of this walk: 684 M wave-level VALU instructions per 32 frames, ~9000 per wave -- a
+    // wave is as slow as its slowest lane, 64 % of the bench cloud's queries fail the fast accept above, 2 % are true outliers that walk all
+    // 729 cells, and every lane is on a path of its own: 1.52 ms.  Row-wise with one prefix difference per run of inside cells 1.36 ms, x
+    // bounds hoisted 1.32 ms.  Measured and dropped: batched row loads (1.53: it is not latency); a wave per undecided query (6.7 + 0.8 ms
+    // after the fast accept, 1.9 + 0.8 after ring 1, 0.42 + 1.02 after ring 2 with a row per lane); a 57-cell accept + compaction of the
+    // rest in front of the walk (0.40 + 0.88 ms: the 42 gathers per query into the 2-MB-per-frame prefix array cost what they save).)
+    const int xa = max(cx - ROR_RINGS, 0), xb = min(cx + ROR_RINGS, g.gx - 1);
+    constexpr int NX = 2 * ROR_RINGS + 1;
+    double xmn2[NX], xmx2[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        double xmin = 0.0, xmax = 0.0;
+        if (xa + i <= xb) axis_bounds(qx, g.ox, g.cell, xa + i, g.gx, xmin, xmax);
+        xmn2[i] = xmin * xmin; xmx2[i] = xmax * xmax;
+    }
+    auto test_points = [&](int t0, int t1) {                     // four candidates per memory latency
+        for (int t = t0; t < t1 && cnt <= nb; t += 4) {
+            float c4[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int tt = min(t + u, t1 - 1);
+                { const float4 v4 = reinterpret_cast<const float4*>(pts)[tt]; c4[u][0] = v4.x; c4[u][1] = v4.y; c4[u][2] = v4.z; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cnt += (t + u < t1) && dist2(qx, qy, qz, c4[u]) < r2;
+        }
+    };
+    for (int rr = 0; rr <= ROR_RINGS && cnt <= nb; ++rr) {
+        for (int dz = -rr; dz <= rr && cnt <= nb; ++dz) {
             const int z = cz + dz;
             if (z < 0 || z >= g.gz) continue;
             double zmin, zmax;
             axis_bounds(qz, g.oz, g.cell, z, g.gz, zmin, zmax);
             if (zmin * zmin > r2) continue;
-            for (int dy = -r; dy <= r && cnt <= nb; ++dy) {
+            const int dystep = (dz == -rr || dz == rr || rr == 0) ? 1 : 2 * rr;      // rows of this ring: the two faces in z, else dy = -rr, +rr
+            for (int dy = -rr; dy <= rr && cnt <= nb; dy += dystep) {
                 const int y = cy + dy;
                 if (y < 0 || y >= g.gy) continue;
                 double ymin, ymax;
@@ -1462,28 +1497,27 @@ __global__ __launch_bounds__(256) void ror_count_kernel(CloudView in, int cap, c
                 const double yzmin = ymin * ymin + zmin * zmin;
                 if (yzmin > r2) continue;
                 const double yzmax = ymax * ymax + zmax * zmax;
-                const bool face = (dz == -r || dz == r || dy == -r || dy == r);
-                const int step = face ? 1 : (r == 0 ? 1 : 2 * r);
-                for (int dx = -r; dx <= r && cnt <= nb; dx += step) {
-                    const int x = cx + dx;
-                    if (x < 0 || x >= g.gx) continue;
-                    const int c = (z * g.gy + y) * g.gx + x;
-                    const int s0 = st[c], e = st[c + 1];
-                    if (s0 == e) continue;
-                    double xmin, xmax;
-                    axis_bounds(qx, g.ox, g.cell, x, g.gx, xmin, xmax);
-                    if (xmin * xmin + yzmin > r2) continue;            // the whole cell is outside the ball
-                    if (xmax * xmax + yzmax < r2) { cnt += e - s0; continue; }   // the whole cell is inside
-                    for (int t = s0; t < e && cnt <= nb; t += 4) {       // four candidates per memory latency
-                        float c4[4][3];
+                const int rb = (z * g.gy + y) * g.gx;
+                const int rs = st[rb + xa], re = st[rb + xb + 1];
+                if (rs == re) continue;
+                if (re - rs <= 8) { test_points(rs, re); continue; }
+                // classify the row's cells from the bounds alone: the inside interval [i0, i1], the cut cells as a bit mask
+                int i0 = NX, i1 = -1;
+                unsigned cut = 0;
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int tt = min(t + u, e - 1);
-                            { const float4 v4 = reinterpret_cast<const float4*>(pts)[tt]; c4[u][0] = v4.x; c4[u][1] = v4.y; c4[u][2] = v4.z; }
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) cnt += (t + u < e) && dist2(qx, qy, qz, c4[u]) < r2;
-                    }
+                for (int i = 0; i < NX; ++i) {
+                    if (xa + i > xb) continue;
+                    // (the same two comparisons as the cell-by-cell walk, with the row's terms moved to the other side: xmin^2 + yzmin > r2
+                    //  and xmax^2 + yzmax < r2 are evaluated as written there to keep the decisions bit-identical)
+                    if (xmn2[i] + yzmin > r2) continue;
+                    if (xmx2[i] + yzmax < r2) { i0 = i < i0 ? i : i0; i1 = i; }
+                    else cut |= 1u << i;
+                }
+                if (i1 >= i0) cnt += st[rb + xa + i1 + 1] - st[rb + xa + i0];
+                while (cut && cnt <= nb) {
+                    const int x = xa + __builtin_ctz(cut);
+                    cut &= cut - 1;
+                    test_points(st[rb + x], st[rb + x + 1]);
                 }
             }
         }
