@@ -64,7 +64,11 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
     constexpr int WUNITS = 9 * 2 * 32 * NB;                    // taps x octets x output channels
     constexpr int WS = (WI + T3_WAVES - 1) / T3_WAVES;         // weight-DMA slots per wave and plane
     constexpr int ROW = 64 * NB + 16;                          // epilogue slab row (bytes per pixel and plane, + pad)
-    constexpr int SLAB = T3_WAVES * 32 * ROW / 16;             // units: one plane of 32 pixels per wave
+    // planes per epilogue round: with 32 output channels a wave's three planes of 32 pixels fit the consumed X buffer side by side, so a
+    // row of outputs costs ONE LDS write -> read round trip instead of three (the 16 / 32-channel layers have two or three chunks per
+    // tile: their epilogue is a third of the tile's time and is a chain of LDS round trips with the MFMA pipes idle)
+    constexpr int EPL = NB == 1 ? 3 : 1;
+    constexpr int SLAB = T3_WAVES * EPL * 32 * ROW / 16;       // units: EPL planes of 32 pixels per wave
     constexpr int XBUF = 3 * XUNITS < SLAB ? SLAB : 3 * XUNITS;
     static_assert((2 * XBUF + WSLOTS * WUNITS) * 16 + 2048 <= 160 * 1024, "two X buffers + the weight ring + bias fit the LDS of a CU");
     static_assert(WS + 2 * XS <= 9 * NB, "one DMA slot per MFMA group of a phase");
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
         auto epilogue = [&](auto tag) {
             constexpr int ACT = decltype(tag)::value;
             constexpr int SEGS = 4 * NB, PPP = 64 / SEGS;        // 16-byte segments per pixel, pixels per store pass
-            unsigned char* sh = reinterpret_cast<unsigned char*>(lds + ((g - 1) & 1) * XBUF) + wave * (32 * ROW);
+            unsigned char* sh = reinterpret_cast<unsigned char*>(lds + ((g - 1) & 1) * XBUF) + wave * (EPL * 32 * ROW);
             const int seg = lane % SEGS, prow = lane / SEGS;
             uint16_t* const out_hi = reinterpret_cast<uint16_t*>(p.out);
             const int n0 = half * p.Cout;                 // first output channel of this pass
@@ -418,12 +422,14 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
                     split4_x3(v, pp[0][r4], pp[1][r4], pp[2][r4]);
                 }
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
+                for (int pl0 = 0; pl0 < 3; pl0 += EPL) {
 #pragma unroll
-                    for (int r4 = 0; r4 < 4 * NB; ++r4) {
-                        if (8 * r4 >= p.Cout) continue;
-                        *reinterpret_cast<uint2*>(sh + frow * ROW + (8 * r4 + 4 * fk) * 2) = pp[pl][r4];
-                    }
+                    for (int e = 0; e < EPL; ++e)
+#pragma unroll
+                        for (int r4 = 0; r4 < 4 * NB; ++r4) {
+                            if (8 * r4 >= p.Cout) continue;
+                            *reinterpret_cast<uint2*>(sh + e * (32 * ROW) + frow * ROW + (8 * r4 + 4 * fk) * 2) = pp[pl0 + e][r4];
+                        }
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -431,7 +437,9 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
                         const int pix = ps * PPP + prow;
                         if (y < p.H && seg * 8 < p.Cout && !(diag & 1)) {
                             uint16_t* o = out_hi + ((size_t)(cur.img * p.H + y) * p.W + cur.tx0 + pix) * p.Cstride + n0 + seg * 8;
-                            *reinterpret_cast<u32x4*>(o + pl * p.out_plane) = *reinterpret_cast<const u32x4*>(sh + pix * ROW + seg * 16);
+#pragma unroll
+                            for (int e = 0; e < EPL; ++e)
+                                *reinterpret_cast<u32x4*>(o + (pl0 + e) * p.out_plane) = *reinterpret_cast<const u32x4*>(sh + e * (32 * ROW) + pix * ROW + seg * 16);
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
