@@ -268,43 +268,63 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
             } else {
             constexpr int NGRP = 9 * NB;               // MFMA groups of a chunk; the DMA slots follow groups 1 .. NSLOT
             static_assert(NSLOT <= NGRP, "one DMA slot per MFMA group");
+            // The LDS reads run AHEAD of the MFMAs that consume them (an explicit software pipeline: left to itself hipcc puts every weight
+            // fragment's ds_read + s_waitcnt directly in front of its 1-3 products x MT MFMAs, and the two waves of a SIMD then do not have
+            // enough MFMAs per group to cover an LDS round trip -- the one-product layers least of all): the weight fragment(s) of group
+            // g + 2 and the next X row(s) (row dy + 2 / the first two rows of the next dx) are issued before group g's MFMAs.
+            constexpr bool HASWL = !(W1 || X2), HASXL = !(F16 && !X2);
+            u32x4 xh[MT + 2], xl[HASXL ? MT + 2 : 1];
+            u32x4 wqh[3], wql[HASWL ? 3 : 1];
+            auto wload = [&](int grp) {
+                const int dx = grp / (3 * NB), dy = (grp / NB) % 3, nb = grp % NB;
+                const int wi = ((dy * 3 + dx) * 2 + fk) * (32 * NB) + nb * 32 + frow;
+                wqh[grp % 3] = Wh[wi];
+                if constexpr (HASWL) wql[grp % 3] = Wl[wi];
+            };
+            auto xrow = [&](int dx, int r) {
+                const int lp = hpix(MT * wave + r, frow + dx);
+                const int idx = lp * 2 + (fk ^ ((lp >> 3) & 1));
+                xh[r] = Xh[idx];
+                if constexpr (HASXL) xl[r] = Xl[idx];
+            };
+            wload(0);
+            wload(1);
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                u32x4 xh[MT + 2], xl[MT + 2];
+            for (int r = 0; r < MT; ++r) xrow(0, r);
 #pragma unroll
-                for (int r = 0; r < MT + 2; ++r) {
-                    const int lp = hpix(MT * wave + r, frow + dx);
-                    const int idx = lp * 2 + (fk ^ ((lp >> 3) & 1));
-                    xh[r] = Xh[idx];
-                    xl[r] = (F16 && !X2) ? xh[r] : Xl[idx];
-                }
+            for (int grp = 0; grp < NGRP; ++grp) {
+                const int dx = grp / (3 * NB), dy = (grp / NB) % 3, nb = grp % NB;
+                if (grp + 2 < NGRP) wload(grp + 2);
+                if (nb == 0) {
+                    if (dy < 2) xrow(dx, dy + MT);
+                    else if (dx < 2) {
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        const int wi = ((dy * 3 + dx) * 2 + fk) * (32 * NB) + nb * 32 + frow;
-                        const u32x4 wh = Wh[wi];
-                        const u32x4 wl = (W1 || X2) ? wh : Wl[wi];
-#pragma unroll
-                        for (int pr = 0; pr < 3; ++pr) {          // x_hi*w_lo, x_lo*w_hi, x_hi*w_hi; fp16 activations have no lo plane
-                            if ((F16 && !X2 && pr == 1) || ((W1 || X2) && pr == 0)) continue;
-#pragma unroll
-                            for (int a = 0; a < MT; ++a)
-                                acc[a][nb] = mfma_frag<F16>(pr == 0 ? wl : wh, pr == 1 ? xl[a + dy] : xh[a + dy], acc[a][nb]);
-                        }
-                        const int grp = (dx * 3 + dy) * NB + nb;
-                        if (grp == 0 && more) {
-                            // the descriptor's scalar load is issued AND waited for here, behind the first MFMA group (whose execution it
-                            // overlaps); kept in one piece: SGPRs of a load in flight must not be live across code the compiler may spill in
-                            __builtin_amdgcn_sched_barrier(0);
-                            k = begin_chunk(load_chunk(p.chunks + ic), icur, ic, (g + 1) & 1);
-                        }
-                        if (grp < NSLOT && more) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            slot(k, grp);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
+                        for (int r = 0; r < MT; ++r) xrow(dx + 1, r);
                     }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const u32x4 wh = wqh[grp % 3];
+                    const u32x4 wl = HASWL ? wql[HASWL ? grp % 3 : 0] : wh;
+#pragma unroll
+                    for (int pr = 0; pr < 3; ++pr) {          // x_hi*w_lo, x_lo*w_hi, x_hi*w_hi; fp16 activations have no lo plane
+                        if ((F16 && !X2 && pr == 1) || ((W1 || X2) && pr == 0)) continue;
+#pragma unroll
+                        for (int a = 0; a < MT; ++a)
+                            acc[a][nb] = mfma_frag<F16>(pr == 0 ? wl : wh, pr == 1 ? xl[HASXL ? a + dy : 0] : xh[a + dy], acc[a][nb]);
+                    }
+                }
+                if (grp == 0 && more) {
+                    // the descriptor's scalar load is issued AND waited for here, behind the first MFMA group (whose execution it
+                    // overlaps); kept in one piece: SGPRs of a load in flight must not be live across code the compiler may spill in
+                    __builtin_amdgcn_sched_barrier(0);
+                    k = begin_chunk(load_chunk(p.chunks + ic), icur, ic, (g + 1) & 1);
+                }
+                if (grp < NSLOT && more) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    slot(k, grp);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             }
             if (more) advance();
