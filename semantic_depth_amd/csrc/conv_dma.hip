@@ -224,6 +224,45 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
         }
     };
 
+    // the same DMA instructions one at a time (n = 0 .. NDMA - 1: the X pieces (i, plane), then the weight pieces), for the main loop: it
+    // issues them BEHIND its MFMA groups -- at the top of a k-tile, with the MFMA pipes drained by the barrier, each cost its full issue
+    // latency (PMC of the bf16 x 3 form of this loop: pipes 56 % busy, a third of the wave cycles parked)
+    KEntry pe;                                                 // (SIMPLE == 0: the gather entry of the tile being issued)
+    auto piece = [&](int kt, int stage, int n) {
+        const unsigned sbyte = ring_lds + (unsigned)(stage * STAGE_UNITS * 16);
+        if (n < XH * NPX) {
+            const int i = n / NPX, pl = n % NPX;
+            if constexpr (SIMPLE == 2) {
+                const bool first = kt < nA;
+                const int coff = (first ? kt : kt - nA) * 32;
+                const size_t pln = first ? splane : splaneB;
+                const uint16_t* px = (first ? sbase[i] : sbaseB[i]) + coff;
+                dma16(smask[i] != 0 ? reinterpret_cast<const u32x4*>(px + pl * pln) : zero, sbyte + (unsigned)((pl * 4 * BM + (wave + NW * i) * 64) * 16));
+            } else if constexpr (SIMPLE == 1) {
+                const int tap = s_ty * p.kw + s_tx;
+                const long soff = (long)(s_ty * sW + s_tx) * sC + s_cb * 32;
+                const uint16_t* px = sbase[i] + soff;
+                dma16(((smask[i] >> tap) & 1) ? reinterpret_cast<const u32x4*>(px + pl * splane) : zero, sbyte + (unsigned)((pl * 4 * BM + (wave + NW * i) * 64) * 16));
+                if (n == XH * NPX - 1) { if (++s_tx == p.kw) { s_tx = 0; if (++s_ty == p.kh) { s_ty = 0; ++s_cb; } } }
+            } else {
+                if (n == 0) pe = load_kentry(ktab + kt);
+                const int st = (pe.flags >> 4) & 3, up = pe.flags & 1;
+                const size_t plane = (size_t)Nmax * pe.H * pe.W * pe.C;
+                int iy = poy[i] * st + pe.dy, ix = pox[i] * st + pe.dx;
+                const bool ok = pok[i] && iy >= 0 && ix >= 0 && iy < (pe.H << up) && ix < (pe.W << up);
+                iy >>= up; ix >>= up;
+                const uint16_t* px = reinterpret_cast<const uint16_t*>(pe.base) + ((size_t)(pimg[i] * pe.H + iy) * pe.W + ix) * pe.C + pkg[i] * 8;
+                dma16(ok ? reinterpret_cast<const u32x4*>(px + pl * plane) : zero, sbyte + (unsigned)((pl * 4 * BM + (wave + NW * i) * 64) * 16));
+            }
+        } else {
+            const int i = n - XH * NPX;
+            const int jw = (wave + NW * i) % WI;
+            const int wu = jw * 64 + lane;
+            const int pl = wu / (4 * BN), r = wu % (4 * BN), kg = r / BN, n_l = r % BN;
+            dma16(wt_hi + pl * wplane + (size_t)(kt * 4 + kg) * CoutPad + bn0 + n_l, sbyte + (unsigned)(X_UNITS * 16 + jw * 1024));
+        }
+    };
+
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int a = 0; a < MT; ++a)
@@ -271,16 +310,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
             }
         };
         fragments(0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + AHEAD < ktiles) issue(kt + AHEAD, (kt + AHEAD) % STAGES);
-        __builtin_amdgcn_sched_barrier(0);
         fragments(1);
         __builtin_amdgcn_sched_barrier(0);
+        const bool doissue = kt + AHEAD < ktiles;
         // (x plane, w plane) per product, small terms first.  bf16 x 3: hi*lo, lo*hi, mid*mid, hi*mid, mid*hi, hi*hi; bf16 x 2: hi*lo,
         // lo*hi, hi*hi; fp16 activations have no lo plane (hi*lo, hi*hi); W1: hi*hi only
         constexpr int NPR = X3 ? 6 : 3;
         constexpr int xp3[6] = {0, 2, 1, 0, 1, 0}, wp3[6] = {2, 0, 1, 1, 0, 0};
         constexpr int xp2[3] = {0, 1, 0}, wp2[3] = {1, 0, 0};
+        constexpr int NPRA = X3 ? 6 : (3 - (F16 ? 1 : 0) - (W1 ? 1 : 0));      // products actually formed
+        constexpr int NGROUPS = 2 * NPRA * NT;                                  // MFMA groups (MT MFMAs each) of a k-tile
+        constexpr int PPG = (NDMA + NGROUPS - 1) / NGROUPS;                     // DMA pieces behind each of the first groups
+        int gidx = 0;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
@@ -288,10 +329,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
                 if (!X3 && ((F16 && pr == 1) || (W1 && pr == 0))) continue;
                 const int xi = X3 ? xp3[pr] : (F16 ? 0 : xp2[pr]), wi = X3 ? wp3[pr] : (W1 ? 0 : wp2[pr]);
 #pragma unroll
-                for (int b = 0; b < NT; ++b)
+                for (int b = 0; b < NT; ++b) {
 #pragma unroll
                     for (int a = 0; a < MT; ++a)
                         acc[a][b] = mfma_frag<F16>(w[wi][s][b], x[xi][s][a], acc[a][b]);
+                    if (gidx * PPG < NDMA) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (doissue) {
+#pragma unroll
+                            for (int n = gidx * PPG; n < (gidx + 1) * PPG && n < NDMA; ++n) piece(kt + AHEAD, (kt + AHEAD) % STAGES, n);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    ++gidx;
+                }
             }
         }
     }
