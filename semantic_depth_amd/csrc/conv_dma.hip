@@ -276,8 +276,46 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
     for (int a = 0; a < AHEAD; ++a)
         if (a < ktiles) issue(a, a);
     const int frow = lane & 31, fk = lane >> 5;
+    // With four stages (three k-tiles in flight) a k-tile waits until only AHEAD - 2 later tiles are outstanding: then tile kt + 1 is
+    // complete -- and, behind the tile's barrier, visible -- as well, and the first k-step's fragments of tile kt + 1 are read in the TAIL of
+    // tile kt (into the registers its own first k-step has released), so that a tile's first MFMAs follow its barrier directly instead of an
+    // LDS round trip with the MFMA pipes drained (conv_dma3.hip).
+    constexpr bool PRE = STAGES >= 4;
+    u32x4 w[NPW][2][NT], x[NPX][2][MT];
+    auto fragments_of = [&](int stage, int s) {
+        const u32x4* Xs = ring + stage * STAGE_UNITS;
+        const u32x4* Ws = Xs + X_UNITS;
+        const int kg = 2 * s + fk;
+#pragma unroll
+        for (int pl = 0; pl < NPW; ++pl)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) w[pl][s][b] = Ws[pl * 4 * BN + kg * BN + wn0 + b * 32 + frow];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const int mrow = wm0 + a * 32 + frow;
+            const int slot = mrow * 4 + (kg ^ ((mrow >> 2) & 3));        // [pixel][octet ^ swizzle]
+#pragma unroll
+            for (int pl = 0; pl < NPX; ++pl) x[pl][s][a] = Xs[pl * 4 * BM + slot];
+        }
+    };
+    auto wait_later = [&](int later) {
+        static_assert((AHEAD - 1) * NDMA < 64 && AHEAD <= 6, "vmcnt is a 6-bit counter");
+        if (later <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+        else if (later == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NDMA) : "memory");
+        else if (later == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * NDMA) : "memory");
+    };
+    if constexpr (PRE) {
+        wait_later(min(AHEAD - 1, ktiles - 1));       // tile 0 has landed
+        __builtin_amdgcn_s_barrier();
+        fragments_of(0, 0);
+    }
     for (int kt = 0; kt < ktiles; ++kt) {
-        {   // tile kt has landed once at most the DMAs of the tiles issued after it are outstanding
+        if constexpr (PRE) {
+            wait_later(min(AHEAD - 2, ktiles - 2 - kt));       // tiles kt and kt + 1 have landed
+        } else {   // tile kt has landed once at most the DMAs of the tiles issued after it are outstanding
             const int later = min(AHEAD - 1, ktiles - 1 - kt);
             static_assert((AHEAD - 1) * NDMA < 64 && AHEAD <= 6, "vmcnt is a 6-bit counter");
             if (later == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -288,29 +326,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * NDMA) : "memory");
         }
         __builtin_amdgcn_s_barrier();
-        const u32x4* Xh = ring + (kt % STAGES) * STAGE_UNITS;  // X planes [NPX][4][BM], then W planes [NPW][4][BN]
-        const u32x4* Wh = Xh + X_UNITS;
-        // schedule of one k-tile, pinned with sched_barriers (left alone, hipcc hoists the DMA issue to the top and sinks
-        // every LDS read to just before its first use, which exposes the LDS latency four times per tile):
-        //   fragments of k-step 0 -> DMA issue of tile kt+2 (its address arithmetic runs under the LDS latency) ->
-        //   fragments of k-step 1 -> 12 MFMAs of k-step 0 -> 12 MFMAs of k-step 1
-        u32x4 w[NPW][2][NT], x[NPX][2][MT];
-        auto fragments = [&](int s) {
-            const int kg = 2 * s + fk;
-#pragma unroll
-            for (int pl = 0; pl < NPW; ++pl)
-#pragma unroll
-                for (int b = 0; b < NT; ++b) w[pl][s][b] = Wh[pl * 4 * BN + kg * BN + wn0 + b * 32 + frow];
-#pragma unroll
-            for (int a = 0; a < MT; ++a) {
-                const int mrow = wm0 + a * 32 + frow;
-                const int slot = mrow * 4 + (kg ^ ((mrow >> 2) & 3));        // [pixel][octet ^ swizzle]
-#pragma unroll
-                for (int pl = 0; pl < NPX; ++pl) x[pl][s][a] = Xh[pl * 4 * BM + slot];
-            }
-        };
-        fragments(0);
-        fragments(1);
+        // schedule of one k-tile, pinned with sched_barriers (left alone, hipcc hoists the DMA issue to the top and sinks every LDS read to
+        // just before its first use, which exposes the LDS latency four times per tile): the fragments of both k-steps (four stages: of
+        // the second one only, the first came with the previous tile's tail) -> the MFMA groups, one or two DMA instructions of tile
+        // kt + AHEAD behind each of the first ones -> (four stages) the next tile's first fragments before the last group.
+        // Stage image: X planes [NPX][4][BM], then W planes [NPW][4][BN].
+        if constexpr (!PRE) fragments_of(kt % STAGES, 0);
+        fragments_of(kt % STAGES, 1);
         __builtin_amdgcn_sched_barrier(0);
         const bool doissue = kt + AHEAD < ktiles;
         // (x plane, w plane) per product, small terms first.  bf16 x 3: hi*lo, lo*hi, mid*mid, hi*mid, mid*hi, hi*hi; bf16 x 2: hi*lo,
@@ -330,6 +352,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
                 const int xi = X3 ? xp3[pr] : (F16 ? 0 : xp2[pr]), wi = X3 ? wp3[pr] : (W1 ? 0 : wp2[pr]);
 #pragma unroll
                 for (int b = 0; b < NT; ++b) {
+                    if (PRE && gidx == NGROUPS - 1 && kt + 1 < ktiles) {      // (the first k-step's registers are free by now)
+                        __builtin_amdgcn_sched_barrier(0);
+                        fragments_of((kt + 1) % STAGES, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
 #pragma unroll
                     for (int a = 0; a < MT; ++a)
                         acc[a][b] = mfma_frag<F16>(w[wi][s][b], x[xi][s][a], acc[a][b]);
