@@ -331,10 +331,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
         // the second one only, the first came with the previous tile's tail) -> the MFMA groups, one or two DMA instructions of tile
         // kt + AHEAD behind each of the first ones -> (four stages) the next tile's first fragments before the last group.
         // Stage image: X planes [NPX][4][BM], then W planes [NPW][4][BN].
+        // (bf16 x 3, nine DMA instructions and 24-48 MFMAs per k-tile: the round-2 order -- the whole issue between the two fragment reads --
+        //  measured faster than the spread one on the strided 3x3 layers of the vgg-encoder monodepth: 53.7 vs 56.3 ms per 32 frames)
+        constexpr bool SPREAD = !X3;
         if constexpr (!PRE) fragments_of(kt % STAGES, 0);
+        if constexpr (!SPREAD) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + AHEAD < ktiles) issue(kt + AHEAD, (kt + AHEAD) % STAGES);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         fragments_of(kt % STAGES, 1);
         __builtin_amdgcn_sched_barrier(0);
-        const bool doissue = kt + AHEAD < ktiles;
+        const bool doissue = SPREAD && kt + AHEAD < ktiles;
         // (x plane, w plane) per product, small terms first.  bf16 x 3: hi*lo, lo*hi, mid*mid, hi*mid, mid*hi, hi*hi; bf16 x 2: hi*lo,
         // lo*hi, hi*hi; fp16 activations have no lo plane (hi*lo, hi*hi); W1: hi*hi only
         constexpr int NPR = X3 ? 6 : 3;
