@@ -156,11 +156,12 @@ sd_status sd_png_unfilter_bgr(const uint8_t* filtered_host, int height, int widt
  * chunk walk, zlib inflate, scanline reconstruction, channel shuffle, palette expansion in one native call (no interpreter lock held).
  * bgr_out_host NULL: only *height_out / *width_out are written (size query).  SD_ERR_INVALID: not such a PNG / corrupt / buffer too small. */
 sd_status sd_png_decode_bgr(const uint8_t* file_host, size_t len, uint8_t* bgr_out_host, size_t out_capacity, int* height_out, int* width_out);
-/* HOST: a baseline / extended-sequential Huffman JPEG (8-bit; gray or YCbCr with 4:4:4, 4:2:2 or 4:2:0 chroma; restart intervals) ->
+/* HOST: a baseline / extended-sequential / progressive Huffman JPEG (SOF0 / SOF1 / SOF2, 8-bit; gray or YCbCr with 4:4:4, 4:2:2 or 4:2:0 chroma; restart intervals) ->
  * cv2.imread(path): libjpeg's default decode path restated (jidctint "ISLOW" inverse DCT, "fancy" triangle chroma upsampling, jdcolor's
  * fixed-point YCbCr -> RGB) followed by the EXIF orientation OpenCV's imread applies; u8 [height,width,3] BGR.  The reference's own example
  * frames are JPEGs (assets/images/test_munich/test_3.jpg, semantic_depth.py:105).  Same calling convention as sd_png_decode_bgr;
- * *height_out / *width_out are the dimensions AFTER the orientation.  Progressive / arithmetic / 12-bit / CMYK: SD_ERR_INVALID. */
+ * *height_out / *width_out are the dimensions AFTER the orientation.  Arithmetic-coded / lossless / 12-bit / CMYK files, Huffman tables that
+ * are not a prefix code and files with more than one frame header: SD_ERR_INVALID. */
 sd_status sd_jpeg_decode_bgr(const uint8_t* file_host, size_t len, uint8_t* bgr_out_host, size_t out_capacity, int* height_out, int* width_out);
 /* HOST: either of the two, by file signature */
 sd_status sd_image_decode_bgr(const uint8_t* file_host, size_t len, uint8_t* bgr_out_host, size_t out_capacity, int* height_out, int* width_out);

@@ -29,13 +29,16 @@ struct Huff {
     // canonical decoding tables (T.81 F.2.2.3)
     int mincode[17], maxcode[18], valptr[17];
     uint16_t look[512];      // 9-bit lookahead: (length << 8) | symbol, 0 = longer than 9 bits
-    void build() {
+    // false when the code-length counts do not form a prefix code (libjpeg's JERR_BAD_HUFF_TABLE: more codes of length l than 2^l
+    // leaves free) -- an over-subscribed table would index look[] past its 512 entries
+    bool build() {
         int code = 0, k = 0;
         for (int l = 1; l <= 16; ++l) {
             valptr[l] = k;
             mincode[l] = code;
             code += bits[l];
             k += bits[l];
+            if (code > (1 << l) || k > 256) { present = false; return false; }
             maxcode[l] = bits[l] ? code - 1 : -1;
             code <<= 1;
         }
@@ -45,10 +48,12 @@ struct Huff {
         for (int l = 1; l <= 9; ++l) {
             for (int i = 0; i < bits[l]; ++i, ++k, ++code) {
                 const int first = code << (9 - l), n = 1 << (9 - l);
+                if (first + n > 512) { present = false; return false; }
                 for (int j = 0; j < n; ++j) look[first + j] = (uint16_t)((l << 8) | vals[k]);
             }
             code <<= 1;
         }
+        return true;
     }
 };
 
@@ -204,7 +209,7 @@ struct Decoder {
     const uint8_t* f; size_t len;
     int W = 0, H = 0, ncomp = 0, hmax = 1, vmax = 1, restart = 0, orientation = 1, adobe_transform = -1;
     bool sof = false, progressive = false;
-    uint16_t qt[4][64];
+    uint16_t qt[4][64] = {};
     bool qt_ok[4] = {false, false, false, false};
     Huff dc[4], ac[4];
     Comp comp[3];
@@ -256,10 +261,12 @@ struct Decoder {
                     std::memcpy(h.vals, s + o, (size_t)total);
                     o += total;
                     h.present = true;
-                    h.build();
+                    if (!h.build()) return SD_ERR_INVALID;
                 }
             } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {     // SOF0 / SOF1 / SOF2: baseline / extended sequential / progressive, Huffman
+                if (sof) return SD_ERR_INVALID;                  // one frame header per file: a second one would re-shape planes already allocated
                 progressive = m == 0xC2;
+                hmax = vmax = 1;
                 if (sn < 6 || s[0] != 8) return SD_ERR_INVALID;
                 H = rd16(s + 1); W = rd16(s + 3); ncomp = s[5];
                 if (H <= 0 || W <= 0 || (ncomp != 1 && ncomp != 3) || sn < 6 + 3 * (size_t)ncomp) return SD_ERR_INVALID;
@@ -325,6 +332,7 @@ struct Decoder {
             const int t = decode_sym(br, hd);
             if (t < 0 || t > 15) return false;
             c.pred += t ? extend(br.get(t), t) : 0;
+            if (c.pred < -32767 || c.pred > 32767) return false;      // (a valid 8-bit stream stays within 11 bits)
             if (blk) blk[0] = (int16_t)(c.pred * (1 << Al));
         } else if (br.get(1)) {
             if (blk) blk[0] = (int16_t)(blk[0] | (1 << Al));
@@ -409,6 +417,7 @@ struct Decoder {
         if (t < 0 || t > 15) return false;
         const int diff = t ? extend(br.get(t), t) : 0;
         c.pred += diff;
+        if (c.pred < -32767 || c.pred > 32767) return false;          // (keeps pred * qt inside int32 on crafted streams)
         coef[0] = c.pred * (int32_t)qt[c.tq][0];
         for (int k = 1; k < 64;) {
             const int rs = decode_sym(br, ha);
@@ -539,7 +548,10 @@ struct Decoder {
         if (st != SD_OK) return st;
         for (int i = 0; i < ncomp; ++i) if (comp[i].plane.empty()) return SD_ERR_INVALID;
         if (cap < (size_t)W * H * 3) return SD_ERR_INVALID;
-        if (progressive) prog_finish();
+        if (progressive) {
+            for (int i = 0; i < ncomp; ++i) if (!qt_ok[comp[i].tq] || comp[i].coef.empty()) return SD_ERR_INVALID;
+            prog_finish();
+        }
         std::vector<uint8_t> bgr;
         const bool direct = orientation == 1;
         uint8_t* dst = out;

@@ -49,17 +49,17 @@ def decode_png(buf: bytes) -> np.ndarray:
 
 
 def image_size(buf: bytes) -> tuple[int, int]:
-    """(height, width) of a PNG or baseline JPEG as cv2.imread would return it (JPEG: after the EXIF orientation)"""
+    """(height, width) of a PNG or Huffman JPEG (SOF0 / SOF1 / SOF2) as cv2.imread would return it (JPEG: after the EXIF orientation)"""
     lib = L.load()
     h, w = C.c_int(), C.c_int()
     if lib.sd_image_decode_bgr(buf, len(buf), None, 0, C.byref(h), C.byref(w)) != L.SD_OK:
-        raise ValueError("not a PNG / baseline JPEG this reader takes (PNG: 8-bit non-interlaced; JPEG: baseline Huffman, 8-bit, "
+        raise ValueError("not a PNG / JPEG this reader takes (PNG: 8-bit non-interlaced; JPEG: baseline, extended-sequential or progressive Huffman, 8-bit, "
                          "gray or YCbCr 4:4:4 / 4:2:2 / 4:2:0)")
     return h.value, w.value
 
 
 def decode_jpeg(buf: bytes) -> np.ndarray:
-    """baseline JPEG bytes -> u8 [h,w,3] BGR = cv2.imread: libjpeg's default decode path (ISLOW inverse DCT, fancy chroma upsampling,
+    """JPEG bytes (baseline / extended-sequential / progressive Huffman) -> u8 [h,w,3] BGR = cv2.imread: libjpeg's default decode path (ISLOW inverse DCT, fancy chroma upsampling,
     fixed-point YCbCr -> RGB) and the EXIF orientation, restated natively (sd_jpeg_decode_bgr)"""
     if bytes(buf[:2]) != b"\xff\xd8":
         raise ValueError("not a JPEG file")
@@ -75,7 +75,7 @@ def decode_image(buf: bytes) -> np.ndarray:
 
 
 def imread(path: str) -> np.ndarray:
-    """cv2.imread(path) for 8-bit PNG and baseline JPEG files (semantic_depth.py:105; seq:123)"""
+    """cv2.imread(path) for 8-bit PNG and Huffman JPEG (SOF0 / SOF1 / SOF2) files (semantic_depth.py:105; seq:123)"""
     with open(path, "rb") as f:
         buf = f.read()
     return decode_png(buf) if buf[:8] == _SIG else decode_image(buf)

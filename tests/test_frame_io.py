@@ -316,3 +316,64 @@ def test_readers_survive_mutated_files():
             else:
                 refused += 1
     assert decoded > 50 and refused > 50
+
+
+def _seg(marker, payload):
+    return bytes([0xFF, marker]) + (len(payload) + 2).to_bytes(2, "big") + bytes(payload)
+
+
+def _crafted_jpegs():
+    """hand-built files for the structural holes random byte flips do not reach"""
+    out = {}
+    # (1) DHT whose code-length counts are not a prefix code: 200 codes of length 1
+    bits = [200] + [0] * 15
+    out["dht_oversubscribed"] = b"\xff\xd8" + _seg(0xC4, [0x00] + bits + list(range(200)))
+    bits = [0, 0, 0, 0, 0, 0, 0, 0, 255] + [0] * 7            # 255 codes of length 9 fit; 1 + 255 of lengths 1 and 9 do not
+    out["dht_len9_ok_header_only"] = b"\xff\xd8" + _seg(0xC4, [0x00] + bits + list(range(255)))
+    bits = [1, 0, 0, 0, 0, 0, 0, 0, 255] + [0] * 7
+    out["dht_len1_plus_len9"] = b"\xff\xd8" + _seg(0xC4, [0x00] + bits + list(range(256)))
+    dqt = _seg(0xDB, [0x00] + [1] * 64)
+    dht_dc = _seg(0xC4, [0x00] + [1] + [0] * 15 + [0])       # one code "0" -> category 0
+    dht_ac = _seg(0xC4, [0x10] + [1] + [0] * 15 + [0])       # one code "0" -> EOB
+
+    def sof(m, h, w):
+        return _seg(m, [8] + list(h.to_bytes(2, "big")) + list(w.to_bytes(2, "big")) + [1, 1, 0x11, 0])
+    sos = _seg(0xDA, [1, 1, 0x00, 0, 63, 0]) + b"\x00" * 4
+    # (2) a second frame header of another shape after the planes exist (8x8 gray, then 64x1: same H*W*3)
+    out["two_sof_reshaped"] = b"\xff\xd8" + dqt + dht_dc + dht_ac + sof(0xC0, 8, 8) + sos + sof(0xC0, 1, 64) + sos + b"\xff\xd9"
+    # (3) baseline scan first, then a progressive frame header: prog_dc would run on an empty coefficient vector
+    sos_p = _seg(0xDA, [1, 1, 0x00, 0, 0, 0]) + b"\x00" * 4
+    out["sof0_then_sof2"] = b"\xff\xd8" + dqt + dht_dc + dht_ac + sof(0xC0, 8, 8) + sos + sof(0xC2, 8, 8) + sos_p + b"\xff\xd9"
+    # (4) progressive file without a DQT: prog_finish would dequantise with an undefined table
+    out["progressive_without_dqt"] = b"\xff\xd8" + dht_dc + dht_ac + sof(0xC2, 8, 8) + sos_p + b"\xff\xd9"
+    # control: the same skeleton, well-formed (gray 8x8, all-zero coefficients -> level 128)
+    out["control_ok"] = b"\xff\xd8" + dqt + dht_dc + dht_ac + sof(0xC0, 8, 8) + sos + b"\xff\xd9"
+    return out
+
+
+def test_jpeg_reader_refuses_structurally_hostile_files():
+    """over-subscribed Huffman tables (libjpeg: JERR_BAD_HUFF_TABLE), a second frame header, a progressive file without quantisation
+    tables: SD_ERR_INVALID from the size query and from the decode, nothing written past the buffer.  The same files run under
+    ASan + UBSan in scripts/fuzz_decoders.cpp (structure-aware mutations)"""
+    import ctypes as C
+    from semantic_depth_amd import _lib as L
+    lib = L.load()
+    files = _crafted_jpegs()
+    for name, f in files.items():
+        h, w = C.c_int(0), C.c_int(0)
+        st_q = lib.sd_image_decode_bgr(f, len(f), None, 0, C.byref(h), C.byref(w))
+        cap = 64 * 64 * 3
+        buf = np.full(cap + 64, 0xA5, np.uint8)
+        st_d = lib.sd_image_decode_bgr(f, len(f), buf.ctypes.data_as(C.c_void_p), cap, C.byref(h), C.byref(w))
+        assert (buf[cap:] == 0xA5).all(), name
+        if name == "control_ok":
+            assert st_q == L.SD_OK and st_d == L.SD_OK and (h.value, w.value) == (8, 8)
+            assert (buf[:8 * 8 * 3] == 128).all()
+        elif name == "dht_len9_ok_header_only":
+            assert st_q != L.SD_OK and st_d != L.SD_OK     # a valid table, but no frame header follows
+        elif name == "progressive_without_dqt":
+            assert st_d != L.SD_OK, name                   # (the size query only reads the header)
+        else:
+            assert st_d != L.SD_OK, name
+            if name.startswith("dht"):
+                assert st_q != L.SD_OK, name
