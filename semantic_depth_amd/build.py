@@ -23,6 +23,7 @@ SOURCES = [
     ("conv_dma3.hip", []),
     ("conv_direct.hip", []),
     ("conv_direct3.hip", []),
+    ("dec_tail.hip", []),
     ("conv_stem.hip", []),
     ("ops_misc.hip", []),
     ("resize.hip", []),

@@ -185,6 +185,9 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.sw = h->sw;
                 c.sat = reinterpret_cast<unsigned long long*>(h->ws + h->o_misc + SAT_OFF);
                 c.x3 = p.x3;
+                if (op.fold) {          // (conv_dma3.hip: the GEMM's pixel space is the source itself)
+                    c.fold = 1; c.simple = 0; c.Hin = s0.H; c.Win = s0.W; c.Hout = s0.H; c.Wout = s0.W; c.kh = c.kw = 2;
+                }
                 hipEvent_t ea = nullptr, eb = nullptr;
                 if (h->prof) {
                     ea = h->prof_last;
@@ -196,12 +199,13 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 const bool stem = split && !dma && !dma3 && conv_stem_eligible(c);
                 if (c.out_planar16 && !stem && !dma) return fail(h, SD_ERR_STATE, "sub-planar output needs the LDS-DMA or the stem conv kernel");
                 if (c.pool && !dma) return fail(h, SD_ERR_STATE, "fused pool needs the LDS-DMA conv kernel");
+                if (c.fold && !dma3) return fail(h, SD_ERR_STATE, "an upsample-folded conv needs the conv_dma3 kernel");
                 e = dma3 ? launch_conv_dma3(c, s) : dma ? launch_conv_dma(c, s) : stem ? launch_conv_stem(c, s) : split ? launch_conv_split(c, s) : launch_conv_igemm(c, s);
                 if (h->prof) {
                     hipEventRecord(eb, s);
                     h->prof_last = eb; conv_op = true;
                     h->prof_recs.push_back({dma3 ? "conv_dma3_kernel" : dma ? conv_dma_kernel_name(c) : stem ? (c.x3 ? "conv_stem_x3_kernel" : c.f16 ? "conv_stem_f16w_kernel" : "conv_stem_kernel") : split ? conv_split_kernel_name(c) : conv_igemm_kernel_name(c), op.flops * N / p.images, ea, eb,
-                                            op.name.c_str(), N * c.Hout * c.Wout, d.C, op.K, op_bytes(op)});
+                                            op.name.c_str(), N * c.Hout * c.Wout * (c.fold ? 4 : 1), d.C, op.K, op_bytes(op)});
                 }
                 break;
             }
@@ -234,6 +238,29 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                     hipEventRecord(eb, s);
                     h->prof_last = eb; conv_op = true;
                     h->prof_recs.push_back({p.x3 ? conv_direct3_kernel_name(c) : conv_direct_kernel_name(c), op.flops * N / p.images, ea, eb, op.name.c_str(), N * c.H * c.W, d.C, op.K, op_bytes(op)});
+                }
+                break;
+            }
+            case OP_DEC_TAIL1: {
+                const TensorDesc& d = p.tensors[op.dst];
+                DecTailParams c{};
+                c.a = T(op.src[0]); c.a_plane = PL(op.src[0]); c.d2 = T(op.src[1]); c.d_plane = PL(op.src[1]);
+                c.N = N; c.H = d.H; c.W = d.W;
+                c.w1 = reinterpret_cast<const u32x4_t*>(Wp(op.w)); c.b1 = Wp(op.b);
+                c.w2 = reinterpret_cast<const u32x4_t*>(Wp(op.w2)); c.b2 = Wp(op.b2);
+                c.wd = Wp(op.w3); c.bd = Wp(op.b3);
+                c.out = T(op.dst); c.sw = h->sw;
+                hipEvent_t ea = nullptr, eb = nullptr;
+                if (h->prof) {
+                    ea = h->prof_last;
+                    if (!ea) { if (!(ea = prof_event(h))) return fail(h, SD_ERR_HIP, "hipEventCreate"); hipEventRecord(ea, s); }
+                    if (!(eb = prof_event(h))) return fail(h, SD_ERR_HIP, "hipEventCreate");
+                }
+                e = launch_dec_tail1(c, s);
+                if (h->prof) {
+                    hipEventRecord(eb, s);
+                    h->prof_last = eb; conv_op = true;
+                    h->prof_recs.push_back({"dec_tail1_x3_kernel", op.flops * N / p.images, ea, eb, op.name.c_str(), N * d.H * d.W, 16, op.K, op_bytes(op)});
                 }
                 break;
             }

@@ -64,9 +64,12 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
     const int wm0 = (wave & 1) * (G3_MT * 32), wn0 = (wave >> 1) * (G3_NT * 32);
     int tid_;
     {
-        const int nwg = tilesM * tilesN, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int nwg = tilesM * tilesN * (p.fold ? 4 : 1), bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         tid_ = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
+    // upsample-folded conv (ConvParams::fold): the parity is the outermost tile index
+    const int par = tid_ / (tilesM * tilesN);
+    tid_ -= par * (tilesM * tilesN);
     const int tm = tid_ % tilesM, tn = tid_ / tilesM;
     const int bm0 = tm * G3_BM, bn0 = tn * G3_BN;
 
@@ -86,10 +89,10 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
         pyx[i] = oy | ((r - oy * p.Wout) << 16);
         pik[i] = img | (((lane & 3) ^ ((m_l >> 2) & 3)) << 26) | ((ok ? 1 : 0) << 30);      // (octet: the one this lane fetches into slot lane % 4)
     }
-    const KEntry* __restrict__ const ktab = p.ktab;
+    const KEntry* __restrict__ const ktab = p.ktab + par * (p.Kpad / 32);
     const int CoutPad = p.CoutPad, Nmax = p.Nmax;
-    const u32x4* __restrict__ const wt_hi = reinterpret_cast<const u32x4*>(p.wt);
-    const size_t wplane = (size_t)(p.Kpad / 8) * CoutPad;     // units
+    const u32x4* __restrict__ const wt_hi = reinterpret_cast<const u32x4*>(p.wt) + (size_t)par * (p.Kpad / 8) * CoutPad;
+    const size_t wplane = (size_t)(p.Kpad / 8) * CoutPad * (p.fold ? 4 : 1);     // units
     const u32x4* const zero = reinterpret_cast<const u32x4*>(p.zero16);
     const int ktiles = p.Kpad / 32;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds;
@@ -299,7 +302,12 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
                 const int pix = ps * PPP + prow;
                 const int mo = m0 + a * 32 + pix;
                 if (mo < M && !(diag & 1)) {
-                    uint16_t* o = out_hi + (size_t)mo * p.Cout + n0 + seg * 8;
+                    size_t opix = (size_t)mo;
+                    if (p.fold) {                // source pixel (img, i, j) of parity (py, px) -> output pixel (2 i + py, 2 j + px)
+                        const int hw = p.Hout * p.Wout, img = mo / hw, r = mo - img * hw, i = r / p.Wout, j = r - i * p.Wout;
+                        opix = ((size_t)(img * 2 * p.Hout + 2 * i + (par >> 1))) * (2 * p.Wout) + 2 * j + (par & 1);
+                    }
+                    uint16_t* o = out_hi + opix * p.Cout + n0 + seg * 8;
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl)
                         *reinterpret_cast<u32x4*>(o + pl * p.out_plane) = *reinterpret_cast<const u32x4*>(slab + pl * 32 * ROW + pix * ROW + seg * 16);
@@ -317,6 +325,7 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
 // layers the 256 x 256 phased block takes: bf16 x 3, all-vec K axis, Cout a multiple of 256 and enough blocks to occupy the chip
 bool conv_dma3_eligible(const ConvParams& p) {
     if (!p.x3 || !p.vec || !p.zero16 || p.pool || p.out_planar16 || p.residual || p.Cout % G3_BN || p.Kpad < 64 || p.CoutPad != p.Cout) return false;
+    if (p.fold) return true;                                   // (the folded form exists here only: its results must not depend on the batch)
     if (p.sw & SW_NO_DMA3) return false;                       // (A/B switch of the handle)
     const long M = (long)p.N * p.Hout * p.Wout;
     return ((M + G3_BM - 1) / G3_BM) * (p.Cout / G3_BN) >= 128;
@@ -326,7 +335,7 @@ hipError_t launch_conv_dma3(const ConvParams& p, hipStream_t s) {
     if (!conv_dma3_eligible(p)) return hipErrorInvalidValue;
     const long M = (long)p.N * p.Hout * p.Wout;
     const int tilesM = (int)((M + G3_BM - 1) / G3_BM), tilesN = p.Cout / G3_BN;
-    hipLaunchKernelGGL(conv_dma3_kernel, dim3((unsigned)(tilesM * tilesN)), dim3(512), 0, s, p, (int)M, tilesM, tilesN);
+    hipLaunchKernelGGL(conv_dma3_kernel, dim3((unsigned)(tilesM * tilesN * (p.fold ? 4 : 1))), dim3(512), 0, s, p, (int)M, tilesM, tilesN);
     return hipGetLastError();
 }
 

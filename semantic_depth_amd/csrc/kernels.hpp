@@ -16,7 +16,9 @@ enum Switch : unsigned {
     // bf16 x 3 engine (round 3): SEMDEPTH_X3_KEEP=0 (no register-cached X fragments), SEMDEPTH_X3_RING3 (three-slot weight ring of the
     // NB = 1 layers), SEMDEPTH_NO_DMA3 (128 x 256 two-stage GEMM block instead of the phased 256 x 256 one), SEMDEPTH_X3_DIAG=1|2|3
     // (decomposition runs of conv_direct3: no output stores / no MFMAs)
-    SW_X3_NOKEEP = 1u << 12, SW_X3_RING3 = 1u << 13, SW_NO_DMA3 = 1u << 14, SW_X3_DIAG_NOSTORE = 1u << 15, SW_X3_DIAG_NOMFMA = 1u << 16
+    SW_X3_NOKEEP = 1u << 12, SW_X3_RING3 = 1u << 13, SW_NO_DMA3 = 1u << 14, SW_X3_DIAG_NOSTORE = 1u << 15, SW_X3_DIAG_NOMFMA = 1u << 16,
+    SW_NO_FOLD = 1u << 17,       // SEMDEPTH_NO_FOLD: the upconv layers as 3x3 convs on the upsampled source (plan-time switch)
+    SW_NO_TAIL1 = 1u << 18       // SEMDEPTH_NO_TAIL1: upconv1 / iconv1 / disp1 of the bf16 x 3 monodepth as three launches (plan-time switch)
 };
 unsigned latch_switches();      // plan.cpp
 
@@ -71,6 +73,9 @@ struct ConvParams {
     unsigned sw;       // Switch bits of the handle
     unsigned long long* sat;   // DEVICE counter of fp16-saturated output values (split_fmt.hpp sat_report; sd_saturation_count)
     int x3;            // 1: bf16 x 3 planes in, out and in the weights (SD_PREC_BF16X3: six MFMA products per product, split_fmt.hpp)
+    int fold;          // 1 (conv_dma3.hip): upsample-folded 3x3 conv (OpDesc::fold).  Hout x Wout are the SOURCE dims (the GEMM's pixel space), the
+                       // grid carries four parities, parity q = 2 py + px reads weight rows [q Kpad, (q + 1) Kpad) and table entries [q Kpad/32, ...)
+                       // and writes source pixel (i, j) to output pixel (2 i + py, 2 j + px) of the [N, 2 Hout, 2 Wout, Cout] tensor
 };
 hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t s);
 const char* conv_igemm_kernel_name(const ConvParams& p);
@@ -157,6 +162,25 @@ hipError_t launch_conv_direct3(const ConvDirectParams& p, hipStream_t s);       
 const char* conv_direct3_kernel_name(const ConvDirectParams& p);
 hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s);
 const char* conv_direct_kernel_name(const ConvDirectParams& p);
+
+// the full-resolution decoder tail of the bf16 x 3 monodepth in one launch (dec_tail.hip): upconv1 -> iconv1 -> disp1[..., 0]
+struct DecTailParams {
+    const void* a;         // dec/iconv2: bf16 x 3 planes [N, H/2, W/2, 32]
+    size_t a_plane;        // element offset between its planes
+    const void* d2;        // dec/disp2: bf16 x 3 planes [N, H/2, W/2, 8] (2 real channels in a zero-padded octet)
+    size_t d_plane;
+    int N, H, W;           // full resolution
+    const u32x4_t* w1;     // upconv1, upsample-folded: MFMA A fragments [parity 4][2x2 tap 4][plane 3][lane 64] (plan.cpp WL_TAIL_UP)
+    const float* b1;       // [16]
+    const u32x4_t* w2;     // iconv1: A fragments [row block 3 x half 2][plane 3][lane 64] (WL_TAIL_ICONV)
+    const float* b2;       // [16]
+    const float* wd;       // disp1, output channel 0: [tap 9][16]
+    const float* bd;       // [1]
+    float* out;            // [N, H, W] f32
+    unsigned sw;
+};
+bool dec_tail1_eligible(int H, int W);
+hipError_t launch_dec_tail1(const DecTailParams& p, hipStream_t s);
 
 // small-N convolution (N <= 4 output channels: score 1x1 convs, monodepth disparity heads)
 struct SmallNParams {

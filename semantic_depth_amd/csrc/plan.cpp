@@ -14,7 +14,8 @@ unsigned latch_switches() {
         {"SEMDEPTH_NO_N16", SW_NO_N16}, {"SEMDEPTH_NO_UPTILE", SW_NO_UPTILE}, {"SEMDEPTH_NO_N16_MT1", SW_NO_N16_MT1},
         {"SEMDEPTH_NO_DMA_BIG", SW_NO_DMA_BIG}, {"SEMDEPTH_NO_DMA32", SW_NO_DMA32}, {"SEMDEPTH_NO_STEM", SW_NO_STEM},
         {"SEMDEPTH_NO_FUSE4", SW_NO_FUSE4}, {"SEMDEPTH_NO_SMALLN_TILE", SW_NO_SMALLN_TILE}, {"SEMDEPTH_NO_DMA", SW_NO_DMA},
-        {"SEMDEPTH_NO_FUSE1", SW_NO_FUSE1}, {"SEMDEPTH_X3_RING3", SW_X3_RING3}, {"SEMDEPTH_NO_DMA3", SW_NO_DMA3}};
+        {"SEMDEPTH_NO_FUSE1", SW_NO_FUSE1}, {"SEMDEPTH_X3_RING3", SW_X3_RING3}, {"SEMDEPTH_NO_DMA3", SW_NO_DMA3}, {"SEMDEPTH_NO_FOLD", SW_NO_FOLD},
+        {"SEMDEPTH_NO_TAIL1", SW_NO_TAIL1}};
     unsigned sw = 0;
     for (const auto& e : tab)
         if (std::getenv(e.name)) sw |= e.bit;
@@ -58,6 +59,8 @@ struct Builder {
             case WL_DIRECT_SPLIT: n = (size_t)Kpad * CoutPad * nsplit; break;     // Kpad = nchunks * 9 * 16, CoutPad = 32 or 64
             case WL_SMALLN: n = (size_t)s.shape[0] * s.shape[1] * s.shape[2] * 4; break;
             case WL_BIAS4: n = 4; break;
+            case WL_TAIL_UP: n = 4 * 4 * 3 * 64 * 4; break;         // [parity][tap][plane][lane] x 16 bytes
+            case WL_TAIL_ICONV: n = 6 * 3 * 64 * 4; break;          // [row block, half][plane][lane] x 16 bytes
             default: n = 1; for (int j = 0; j < s.rank; ++j) n *= (size_t)s.shape[j];
         }
         s.bytes = n * sizeof(float);
@@ -111,6 +114,24 @@ struct Builder {
                       !std::getenv("SEMDEPTH_NO_DIRECT");
         for (int i = 0; i < op.nsrc; ++i)
             if (p.tensors[op.src[i]].C % 8 || op.sstride[i] != 1) direct = false;
+        // bf16 x 3: an upconv layer (3x3 on a x2 nearest-neighbour upsampled source) with a wide output runs as four 2x2 convs on the source
+        // itself, one per output parity, on the 256 x 256 GEMM block (OpDesc::fold).  The choice depends on the layer alone, never on the batch.
+        if (p.x3 && k == 3 && stride == 1 && op.nsrc == 1 && op.up[0] && Cout % 256 == 0 && p.tensors[op.src[0]].C % 32 == 0 && residual < 0 &&
+            !(latch_switches() & SW_NO_FOLD)) {
+            const TensorDesc& t = p.tensors[op.src[0]];
+            op.fold = 1; op.vec = 1;
+            op.Ctot = t.C; op.K = 4 * t.C; op.Kpad = op.Kvec = 4 * t.C; op.CqPad = 0;
+            op.w = wslot(wname, {k, k, Ctf, Cout}, WL_IGEMM_SPLIT, 4 * op.Kpad, Cout);
+            WeightSlot& ws = p.weights[op.w];
+            ws.fold = 1; ws.nsrc = 1; ws.vec = 1; ws.Ktotal = 4 * op.Kpad; ws.srcCtf[0] = ws.srcCpad[0] = t.C; ws.srcVec[0] = 1;
+            op.b = wslot(bname, {Cout}, WL_RAW);
+            op.dst = tensor(name, N, Hout, Wout, Cout);
+            op.tab_bytes = (size_t)4 * (op.Kpad / 32) * sizeof(KEntry);
+            op.flops = 2.0 * (double)N * Hout * Wout * Cout * (double)(4 * Ctf);      // the multiplications that run (4/9 of the 3x3 form's)
+            op.m_fastest = 1;
+            push(op);
+            return op.dst;
+        }
         if (direct) {
             op.kind = OP_CONV_DIRECT;
             int nch = 0;
@@ -218,6 +239,28 @@ struct Builder {
         p.tensors[op.dst].Ctf = nout;
         if (!feeds_conv) p.tensors[op.dst].fmt = 0;      // consumed by f32 kernels (deconv ladder, post-processing)
         op.flops = 2.0 * p.tensors[src].N * p.tensors[src].H * p.tensors[src].W * nout * k * k * p.tensors[src].C;
+        push(op);
+        return op.dst;
+    }
+
+    // bf16 x 3: upconv1 -> iconv1 -> disp1 (channel 0) in one launch (dec_tail.hip).  a = dec/iconv2 (32 channels), d2 = dec/disp2 (octet)
+    int dec_tail1(int a, int d2) {
+        OpDesc op;
+        op.kind = OP_DEC_TAIL1; op.name = "dec/tail1"; op.nsrc = 2; op.src[0] = a; op.src[1] = d2; op.k = 3; op.pad = 1; op.act = ACT_SIGMOID03;
+        const TensorDesc ta = p.tensors[a];
+        if (ta.C != 32 || p.tensors[d2].C != 8 || p.tensors[d2].H != ta.H || p.tensors[d2].W != ta.W)
+            throw std::runtime_error("dec_tail1: needs a 32-channel source and a disparity octet of the same size");
+        op.w = wslot("dec/upconv1/weights", {3, 3, 32, 16}, WL_TAIL_UP);
+        op.b = wslot("dec/upconv1/biases", {16}, WL_RAW);
+        op.w2 = wslot("dec/iconv1/weights", {3, 3, 18, 16}, WL_TAIL_ICONV);
+        op.b2 = wslot("dec/iconv1/biases", {16}, WL_RAW);
+        op.w3 = wslot("dec/disp1/weights", {3, 3, 16, 2}, WL_SMALLN, 0, 0, 1);
+        op.b3 = wslot("dec/disp1/biases", {2}, WL_BIAS4, 0, 0, 1);
+        op.dst = tensor("dec/disp1", ta.N, 2 * ta.H, 2 * ta.W, 1);
+        p.tensors[op.dst].Ctf = 1; p.tensors[op.dst].fmt = 0; p.tensors[op.dst].x3 = 0;
+        p.tensors[op.dst].bytes = (size_t)ta.N * 2 * ta.H * 2 * ta.W * sizeof(float);
+        op.K = 4 * 32 + 9 * 18 + 9;        // multiplications per output pixel and channel that run: folded upconv1 + iconv1 (16 channels each) + the head
+        op.flops = 2.0 * ta.N * 4.0 * ta.H * ta.W * (16.0 * (4 * 32) + 16.0 * (9 * 18) + 9.0 * 16);
         push(op);
         return op.dst;
     }
@@ -563,6 +606,10 @@ NetPlan build_monodepth(int encoder, int frames, int H, int W, int prec, const c
     int disp_prev = -1;
     for (int lvl = top; lvl >= 1; --lvl) {
         const std::string L = std::to_string(lvl);
+        if (lvl == 1 && b.p.x3 && dec_tail1_eligible(H, W) && !(latch_switches() & SW_NO_TAIL1)) {
+            disp_prev = b.dec_tail1(x, disp_prev);
+            break;
+        }
         const int u = cv("dec/upconv" + L, {{x, 1}}, dec_ch[lvl], 3, 1);
         std::vector<Src> cat = {{u, 0}};
         if (skips.count(lvl)) cat.push_back({skips[lvl], 0});
@@ -640,6 +687,38 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
         };
         const bool f16 = s.f16 != 0;                   // two fp16 planes: hi = fp16(w) (RNE, subnormals kept), lo = fp16(w - hi)
         auto bf16_to_f = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; };
+        if (s.fold) {
+            // upsample-folded 3x3 (OpDesc::fold): parity q = 2 py + px, tap t = 2 a + b reads source pixel (i + a - 1 + py, j + b - 1 + px); the
+            // 3x3 taps dy that land on source row a of parity py are  py = 0: a = 0 <- {0}, a = 1 <- {1, 2};  py = 1: a = 0 <- {0, 1}, a = 1 <- {2}
+            // (the same for columns).  The taps are added in double and rounded once to f32 -- the grade of every other f32 operation of
+            // the layer -- and that f32 value is split exactly into its three bf16 planes like any other weight.
+            // K order inside a parity panel: (32-channel block, tap, channel), as the vec region of an ordinary layer.
+            const int64_t C = s.shape[2], Cout = s.shape[3];
+            const int64_t Kp = s.Kpad / 4;              // rows of one parity panel (4 C)
+            auto rows_of = [](int par, int a, int* d) { if (par == 0) { if (a == 0) { d[0] = 0; return 1; } d[0] = 1; d[1] = 2; return 2; }
+                                                         if (a == 0) { d[0] = 0; d[1] = 1; return 2; } d[0] = 2; return 1; };
+            for (int q = 0; q < 4; ++q)
+                for (int tp = 0; tp < 4; ++tp) {
+                    int dys[2], dxs[2];
+                    const int ny = rows_of(q >> 1, tp >> 1, dys), nx = rows_of(q & 1, tp & 1, dxs);
+                    for (int64_t c = 0; c < C; ++c) {
+                        const int64_t k = q * Kp + ((c / 32) * 4 + tp) * 32 + c % 32;
+                        const size_t base = (size_t)(k / 8) * s.CoutPad * 8 + (k % 8);
+                        for (int64_t n = 0; n < Cout; ++n) {
+                            double acc = 0.0;
+                            for (int iy = 0; iy < ny; ++iy)
+                                for (int ix = 0; ix < nx; ++ix) acc += (double)w[((int64_t)(dys[iy] * 3 + dxs[ix]) * C + c) * Cout + n];
+                            const float wf = (float)acc;
+                            const uint16_t h = bf16(wf);
+                            hi[base + n * 8] = h;
+                            const float r1 = wf - bf16_to_f(h);
+                            lo[base + n * 8] = bf16(r1);
+                            lo3[base + n * 8] = bf16(r1 - bf16_to_f(lo[base + n * 8]));
+                        }
+                    }
+                }
+            return;
+        }
         const int64_t taps = s.shape[0] * s.shape[1], Ctf = s.shape[2], Cout = s.shape[3];
         int CtotPad = 0;
         for (int i = 0; i < s.nsrc; ++i) CtotPad += s.srcCpad[i];
@@ -703,6 +782,54 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
                     }
             cb_tf += s.srcCtf[i];
         }
+    } else if (s.layout == WL_TAIL_UP || s.layout == WL_TAIL_ICONV) {
+        // MFMA A fragments of dec_tail.hip (v_mfma_f32_16x16x32_bf16: lane l = output channel l & 15, k group l >> 4 = eight consecutive k),
+        // three bf16 planes each: out = u32x4 [fragment][plane][lane]
+        auto bf16 = [](float v) -> uint16_t { uint32_t u; std::memcpy(&u, &v, 4); u += 0x7FFFu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
+        auto bf16_to_f = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; };
+        uint16_t* const o16 = reinterpret_cast<uint16_t*>(out.data());
+        auto put = [&](int frag, int lane, int e, float v) {             // element e of the lane's eight, all three planes
+            const uint16_t h = bf16(v);
+            const float r1 = v - bf16_to_f(h);
+            const uint16_t m = bf16(r1);
+            const uint16_t l = bf16(r1 - bf16_to_f(m));
+            o16[(((size_t)frag * 3 + 0) * 64 + lane) * 8 + e] = h;
+            o16[(((size_t)frag * 3 + 1) * 64 + lane) * 8 + e] = m;
+            o16[(((size_t)frag * 3 + 2) * 64 + lane) * 8 + e] = l;
+        };
+        const int64_t C = s.shape[2], Cout = s.shape[3];
+        if (s.layout == WL_TAIL_UP) {
+            // upsample-folded upconv1 (see the fold branch of WL_IGEMM_SPLIT above): fragment (parity q, tap a b) holds Wf[q][a][b][c = 8 kg + e][n]
+            auto rows_of = [](int par, int a, int* d) { if (par == 0) { if (a == 0) { d[0] = 0; return 1; } d[0] = 1; d[1] = 2; return 2; }
+                                                         if (a == 0) { d[0] = 0; d[1] = 1; return 2; } d[0] = 2; return 1; };
+            for (int q = 0; q < 4; ++q)
+                for (int tp = 0; tp < 4; ++tp) {
+                    int dys[2], dxs[2];
+                    const int ny = rows_of(q >> 1, tp >> 1, dys), nx = rows_of(q & 1, tp & 1, dxs);
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int n = lane & 15, c = 8 * (lane >> 4) + e;
+                            double acc = 0.0;
+                            for (int iy = 0; iy < ny; ++iy)
+                                for (int ix = 0; ix < nx; ++ix) acc += (double)w[((int64_t)(dys[iy] * 3 + dxs[ix]) * C + c) * Cout + n];
+                            put(q * 4 + tp, lane, e, (float)acc);
+                        }
+                }
+        } else {
+            // iconv1 on concat(u 16, up2(disp2) 2): fragment (row block dy, half): half 0 = [u(x-1) octets 0 1 | u(x) octets 0 1],
+            // half 1 = [u(x+1) octets 0 1 | disp2 (dx -1, 0, +1) x 2 channels + two zeros | zeros]
+            for (int dy = 0; dy < 3; ++dy)
+                for (int hf = 0; hf < 2; ++hf)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int n = lane & 15, sl = lane >> 4;
+                            float v = 0.f;
+                            if (hf == 0) v = w[((int64_t)(dy * 3 + (sl >> 1)) * C + 8 * (sl & 1) + e) * Cout + n];
+                            else if (sl < 2) v = w[((int64_t)(dy * 3 + 2) * C + 8 * sl + e) * Cout + n];
+                            else if (sl == 2 && e < 6) v = w[((int64_t)(dy * 3 + (e >> 1)) * C + 16 + (e & 1)) * Cout + n];
+                            put(dy * 2 + hf, lane, e, v);
+                        }
+        }
     } else if (s.layout == WL_SMALLN) {
         const int64_t K = s.shape[0] * s.shape[1] * s.shape[2], Cout = s.shape[3];
         for (int64_t k = 0; k < K; ++k)
@@ -715,6 +842,21 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
 }
 
 void build_conv_tables(const NetPlan& p, const OpDesc& op, const char* act_base, const char* tab_dev, std::vector<KEntry>& ktab) {
+    if (op.fold) {      // four parity tables of Kpad / 32 entries: k-tile = (32-channel block, 2x2 tap) on the source at its own resolution
+        const TensorDesc& t = p.tensors[op.src[0]];
+        const int kt_n = op.Kpad / 32;
+        ktab.assign((size_t)4 * kt_n, KEntry{nullptr, 1, 1, 1, 0, 0, 0});
+        for (int q = 0; q < 4; ++q)
+            for (int kt = 0; kt < kt_n; ++kt) {
+                const int cb = kt / 4, tp = kt % 4;
+                KEntry& e = ktab[(size_t)q * kt_n + kt];
+                e.base = reinterpret_cast<const float*>(act_base + t.offset + (size_t)cb * 32 * 2);
+                e.H = t.H; e.W = t.W; e.C = t.C;
+                e.dy = (tp >> 1) - 1 + (q >> 1); e.dx = (tp & 1) - 1 + (q & 1);
+                e.flags = (1 << 4) | (4 << 8) | 0x10000;
+            }
+        return;
+    }
     const int taps = op.k * op.k;
     // channel runs: vec sources concatenated (cv), the other sources concatenated with quad padding (cq)
     struct Run { int src, c0; };

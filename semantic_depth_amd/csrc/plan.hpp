@@ -27,8 +27,10 @@ struct TensorDesc {
     int first = -1, last = -1;   // op indices (liveness)
 };
 
-enum OpKind { OP_PRE_VGG, OP_PRE_MONO, OP_CONV, OP_CONV_DIRECT, OP_SMALLN, OP_POOL2, OP_POOL3Z, OP_DECONV4_ADD, OP_HEAD16 };
-enum WLayout { WL_RAW = 0, WL_IGEMM = 1, WL_SMALLN = 2, WL_BIAS4 = 3, WL_IGEMM_SPLIT = 4, WL_DIRECT_SPLIT = 5 };
+enum OpKind { OP_PRE_VGG, OP_PRE_MONO, OP_CONV, OP_CONV_DIRECT, OP_SMALLN, OP_POOL2, OP_POOL3Z, OP_DECONV4_ADD, OP_HEAD16,
+              OP_DEC_TAIL1 /* dec_tail.hip: upconv1 -> iconv1 -> disp1 of the bf16 x 3 monodepth in one launch */ };
+enum WLayout { WL_RAW = 0, WL_IGEMM = 1, WL_SMALLN = 2, WL_BIAS4 = 3, WL_IGEMM_SPLIT = 4, WL_DIRECT_SPLIT = 5,
+               WL_TAIL_UP = 6, WL_TAIL_ICONV = 7 /* MFMA A fragments of dec_tail.hip (DecTailParams::w1 / w2) */ };
 
 struct WeightSlot {
     std::string name;
@@ -46,6 +48,7 @@ struct WeightSlot {
     // (ResNet block: conv3 and the projection shortcut are one GEMM over the concatenated K axis); a bias view is ADDED
     // to its owner's bias
     int owner = -1, k_off = 0, Ktotal = 0;
+    int fold = 0;          // WL_IGEMM_SPLIT: upsample-folded 3x3 weights (OpDesc::fold): four parity panels of 4 C rows each, stacked along K
     int srcVec[3] = {0, 0, 0};   // mixed layers: sources with C % 32 == 0 live in the vec region of K, the others in the quad tail
     size_t offset = 0, bytes = 0;   // in the weight arena (re-laid-out form)
     bool loaded = false;
@@ -62,11 +65,16 @@ struct OpDesc {
     int residual = -1;     // OP_CONV: tensor added before the activation; OP_DECONV4_ADD: the skip tensor
     int k = 1, stride = 1, pad = 0, act = ACT_NONE, nout = 0;
     int w = -1, b = -1;    // weight slots
+    int w2 = -1, b2 = -1, w3 = -1, b3 = -1;      // OP_DEC_TAIL1: iconv1 and disp1 (w, b = upconv1)
     // conv engine
     int Ctot = 0;          // padded channels per tap (every source rounded up to a multiple of 4)
     int K = 0, Kpad = 0, vec = 0, m_fastest = 0;
     int f16 = 0;                 // conv ops: 1 = sources are single fp16 planes, weights two fp16 planes, TWO MFMA products per product;
                                  // 2 = the same sources, w_hi only, ONE product (plain fp16 x fp16)
+    int fold = 0;                // OP_CONV: a 3x3 stride-1 conv on a x2 nearest-neighbour upsampled source, run as FOUR 2x2 convs on the source itself
+                                 // (one per output parity (y & 1, x & 1)): out[2i+py, 2j+px] = sum_{a,b in 0..1} Wf[py][px][a][b] . src[i+a-1+py, j+b-1+px]
+                                 // with Wf = the 3x3 taps that read the same source pixel added up (plan.cpp relayout_weight).  4/9 of the
+                                 // multiplications; Kpad = 4 C is the K axis of ONE parity
     int fuse_pool = 0;           // OP_CONV_DIRECT / OP_CONV (LDS-DMA kernel): the 2x2 max pool that follows is applied in the epilogue
     int nchunks = 0;             // OP_CONV_DIRECT: 32-channel chunks over the concatenated sources
     int nsplit = 1;              // OP_CONV_DIRECT: passes of <= 64 output channels per tile

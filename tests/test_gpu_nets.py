@@ -183,6 +183,48 @@ def test_256x256_block_of_the_dma_pipeline_is_bit_identical_to_the_128x256_one()
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("H,W,B,enc", [(512, 1024, 2, "resnet50"), (128, 256, 3, "resnet50"), (256, 512, 1, "vgg")])
+def test_folded_upconvs_and_fused_decoder_tail_against_the_layer_by_layer_form(H, W, B, enc):
+    """bf16x3 runs the wide upconv layers upsample-FOLDED (four 2x2 convs on the source instead of a 3x3 conv on the upsampled source:
+    the taps that read the same source pixel are added, 4/9 of the multiplications) and upconv1 -> iconv1 -> disp1 as ONE kernel
+    (dec_tail.hip).  Both are the same function in another summation order: against the layer-by-layer form (SEMDEPTH_NO_FOLD,
+    SEMDEPTH_NO_TAIL1: 3x3 convs on the upsampled source, three launches) the raw disparities and every intermediate scale agree to a
+    few f32 roundings, and against the CPU oracle both are equally far away.  Matches upconv / iconv / get_disp of oracle/nets.py:138-160."""
+    from semantic_depth_amd.engine import Engine
+    from semantic_depth_amd import weights as Wt
+    wm = Wt.make_monodepth_weights(enc, 5, bias_std=0.05)
+    frn = _frames(B, H, W, seed=H + 3)
+    fr = dev(frn)
+    outs, kern = {}, {}
+    for mode, env in (("fused", {}), ("plain", {"SEMDEPTH_NO_FOLD": "1", "SEMDEPTH_NO_TAIL1": "1"})):
+        os.environ.update(env)
+        try:
+            eng = Engine(H, W, B, enc, precision="bf16x3")
+            eng.load_weights(L.SD_NET_MONODEPTH, wm)
+            eng.profile(True)
+            _, raw = eng.monodepth_forward(fr, want_raw=True)
+            kern[mode] = {(b["kernel"]) for b in eng.profile_read()}
+            eng.profile(False)
+            outs[mode] = (raw.clone().cpu().numpy(), [eng.net_tensor(L.SD_NET_MONODEPTH, f"dec/disp{lvl}").cpu().numpy() for lvl in (2, 3, 4)])
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        del eng
+    assert "dec_tail1_x3_kernel" in kern["fused"] and "dec_tail1_x3_kernel" not in kern["plain"], kern
+    e1 = relerr(outs["fused"][0], outs["plain"][0])
+    print(H, W, enc, "fused vs layer by layer:", e1, [relerr(a, b) for a, b in zip(outs["fused"][1], outs["plain"][1])])
+    assert e1 < 5e-6
+    for a, b in zip(outs["fused"][1], outs["plain"][1]):
+        assert relerr(a, b) < 5e-6
+    if H * W <= 128 * 256:
+        for i in range(B):
+            f = frn[i].astype(np.float32) / 255
+            ref = nets.monodepth_forward(np.stack((f, np.fliplr(f)), 0), wm, enc)[..., 0]
+            ef, ep = relerr(outs["fused"][0][i], ref), relerr(outs["plain"][0][i], ref)
+            print("  frame", i, "vs oracle: fused", ef, "layer by layer", ep)
+            assert ef < 1e-5 and ef < 2.0 * ep + 1e-6
+
+
 @pytest.mark.parametrize("H,W,B,enc", [(512, 1024, 2, "resnet50"), (384, 1280, 2, "resnet50"), (512, 1024, 1, "vgg")])
 def test_full_size_split_engine_matches_the_exact_f32_engine(H, W, B, enc):
     """BASELINE.json's frame size is out of the CPU oracle's reach, so the split-bf16 engine (direct conv passes,
