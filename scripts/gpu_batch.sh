@@ -1,10 +1,7 @@
 #!/bin/bash
-# GPU batch of the moment (rewritten per experiment; results land under gpurun_out/<tag>/)
-tag=${1:-r04c}
+tag=${1:-r04g}
 mkdir -p gpurun_out/$tag
 o=gpurun_out/$tag
-timeout 900 python -m pytest tests/test_gpu_nets.py -x -q -m gpu -s -k "folded or fp32_grade or full_size_split" > $o/pytest.txt 2>&1; tail -25 $o/pytest.txt
-timeout 300 python scripts/layer_times.py 32 resnet50 bf16x3 2> $o/layers.txt >/dev/null
-grep -h "dec/\|conv ms" $o/layers.txt
-timeout 600 python bench.py --legs none --steps 20 --warmup 5 --repeats 3 --no-cpu-baseline > $o/bench.json 2> $o/bench.log
-echo "$(grep 'frames/s' $o/bench.log | cut -c1-200)"
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats -d $o/prof -o trace --output-format csv -- python3 bench.py --legs none --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline > $o/bench_prof.json 2> $o/bench_prof.log
+ls -R $o/prof | head -20

@@ -63,6 +63,18 @@ __global__ __launch_bounds__(DT_NT, 1) void dec_tail1_x3_kernel(const DecTailPar
         const int arow = pix / DT_AC, acol = pix - arow * DT_AC;
         gd[k] = arow | (acol << 8) | (pl << 20) | ((d < 3 * DT_DPL ? 1 : 0) << 24);
     }
+    // e items of this thread: destination unit in U | disp2-tile word of dx = -1 .. the words of dx = 0, +1 are at + dc0, + dc1 (0 or 1)
+    int ge[DT_NE];          // ru | uc << 8 | valid << 24
+    int gew[DT_NE];         // word index of (drow, dcol(-1)) in Dt | step to dcol(0) << 16 | step from dcol(0) to dcol(+1) << 17
+#pragma unroll
+    for (int k = 0; k < DT_NE; ++k) {
+        const int e = t + DT_NT * k;
+        const int pl = e / (DT_UR * DT_UC), pix = e - pl * (DT_UR * DT_UC);
+        const int ru = pix / DT_UC, uc = pix - ru * DT_UC;
+        auto dcol = [&](int dx) { int c = ((uc + dx) >> 1) + 1; return c < 0 ? 0 : c > DT_AC - 1 ? DT_AC - 1 : c; };
+        ge[k] = ru | (uc << 8) | (pl << 16) | ((e < 3 * DT_UR * DT_UC ? 1 : 0) << 24);
+        gew[k] = (pl * DT_DPL + ((ru >> 1) + 1) * DT_AC + dcol(-1)) | ((dcol(0) - dcol(-1)) << 16) | ((dcol(1) - dcol(0)) << 17);
+    }
     struct Tile { int img, y0, x0; };
     auto tile_of = [&](int it) {
         Tile r;
@@ -118,7 +130,15 @@ __global__ __launch_bounds__(DT_NT, 1) void dec_tail1_x3_kernel(const DecTailPar
         return acc;
     };
 
-    for (int i = t; i < 3 * DT_UPL; i += DT_NT) U[i] = u32x4{0u, 0u, 0u, 0u};      // (columns 32, 33 of u are never computed: finite values)
+    for (int i = t; i < 3 * DT_UPL; i += DT_NT) U[i] = u32x4{0u, 0u, 0u, 0u};
+    // disp1 weights of channel 0 ([tap][16]) spread over the lanes of three registers: stage 3 broadcasts them with v_readlane (a read per
+    // weight from LDS instead costs more LDS time than the whole i tile)
+    const float wdr0 = p.wd[lane], wdr1 = p.wd[64 + lane], wdr2 = p.wd[lane < 16 ? 128 + lane : 0];
+    auto wd_at = [&](int i) {           // i: compile-time constant after unrolling
+        return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, i < 64 ? wdr0 : i < 128 ? wdr1 : wdr2), i & 63));
+    };      // (columns 32, 33 of u are never computed: finite values)
+    // SEMDEPTH_X3_DIAG (decomposition runs; 0 in production): 1 / 2 / 3 = without stage 1 / 2 / 3
+    const int diag = ((p.sw & SW_X3_DIAG_NOSTORE) ? 1 : 0) | ((p.sw & SW_X3_DIAG_NOMFMA) ? 2 : 0);
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
     Tile cur = tile_of(tile);
@@ -137,25 +157,20 @@ __global__ __launch_bounds__(DT_NT, 1) void dec_tail1_x3_kernel(const DecTailPar
         // ---- e = disp2(y, x - 1 .. x + 1) of every pixel of the u tile (zero outside the image)
 #pragma unroll
         for (int k = 0; k < DT_NE; ++k) {
-            const int e = t + DT_NT * k;
-            if (e < 3 * DT_UR * DT_UC) {
-                const int pl = e / (DT_UR * DT_UC), pix = e - pl * (DT_UR * DT_UC);
-                const int ru = pix / DT_UC, uc = pix - ru * DT_UC;
-                const int y = y0 - 2 + ru, x = x0 - 2 + uc;
-                const int drow = (ru >> 1) + 1;
-                u32x4 ev = {0u, 0u, 0u, 0u};
-#pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    int dcol = ((uc + dx) >> 1) + 1;
-                    dcol = dcol < 0 ? 0 : dcol > DT_AC - 1 ? DT_AC - 1 : dcol;
-                    const bool ok = (unsigned)y < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;
-                    ev[dx + 1] = ok ? Dt[pl * DT_DPL + drow * DT_AC + dcol] : 0u;
-                }
-                U[pl * DT_UPL + pix * 3 + 2] = ev;
-            }
+            const int ru = ge[k] & 0xff, uc = (ge[k] >> 8) & 0xff, pl = (ge[k] >> 16) & 3;
+            const int y = y0 - 2 + ru, x = x0 - 2 + uc;
+            const int wi = gew[k] & 0xffff, i0 = wi + ((gew[k] >> 16) & 1), i1 = i0 + ((gew[k] >> 17) & 1);
+            const unsigned a = Dt[wi], b0 = Dt[i0], c = Dt[i1];            // (unconditional loads of in-tile words, then selects)
+            const bool oky = (unsigned)y < (unsigned)H;
+            u32x4 ev;
+            ev[0] = oky && (unsigned)(x - 1) < (unsigned)W ? a : 0u;
+            ev[1] = oky && (unsigned)x < (unsigned)W ? b0 : 0u;
+            ev[2] = oky && (unsigned)(x + 1) < (unsigned)W ? c : 0u;
+            ev[3] = 0u;
+            if ((ge[k] >> 24) & 1) U[pl * DT_UPL + (ru * DT_UC + uc) * 3 + 2] = ev;
         }
         // ---- stage 1: u rows 2 n + py, n = 0 .. 9, columns 2 m + px (m = lane & 15) of the u tile
-        {
+        if (diag != 1) {
             constexpr int n0 = 0;
             // source fragment of tile row r, column shift b: pixel column m + px + b, octet lane >> 4
             auto frag = [&](int r, int b, int pl) {
@@ -194,8 +209,12 @@ __global__ __launch_bounds__(DT_NT, 1) void dec_tail1_x3_kernel(const DecTailPar
             }
         }
         __syncthreads();
+        // ---- the next tile's source pixels travel while stages 2 and 3 run
+        const int nxt = tile + (int)gridDim.x;
+        const Tile ntl = nxt < ntiles ? tile_of(nxt) : cur;
+        if (nxt < ntiles) prefetch(ntl);
         // ---- stage 2: i rows ri0 .. ri0 + 8 of the 16-pixel strip `strip`
-        {
+        if (diag != 2) {
             const int strip = wave & 1;
             const int ri0 = 9 * (wave >> 1);
             const int c = 16 * strip + lp;
@@ -234,28 +253,30 @@ __global__ __launch_bounds__(DT_NT, 1) void dec_tail1_x3_kernel(const DecTailPar
             }
         }
         __syncthreads();
-        // ---- the next tile's source pixels travel while the head runs
-        const int nxt = tile + (int)gridDim.x;
-        const Tile ntl = nxt < ntiles ? tile_of(nxt) : cur;
-        if (nxt < ntiles) prefetch(ntl);
-        // ---- stage 3: disp1 channel 0 on the f32 tile
+        // ---- stage 3: disp1 channel 0 on the f32 tile.  A thread owns the vertical pixel pair (2 rp, 2 rp + 1) x cx: the four i rows around
+        //      it are read once for both (consecutive lanes = consecutive pixels of a row: conflict-free 16-byte reads)
+        if (t < (DT_TH / 2) * DT_TW && diag != 3) {
+            const int rp = t / DT_TW, cx = t - rp * DT_TW;
+            float acc0 = p.bd[0], acc1 = acc0;
 #pragma unroll
-        for (int pp = 0; pp < (DT_TH * DT_TW + DT_NT - 1) / DT_NT; ++pp) {
-            const int tt = t + DT_NT * pp;
-            if (tt >= DT_TH * DT_TW) break;
-            const int ry = tt / DT_TW, cx = tt - ry * DT_TW;
-            float acc = p.bd[0];
+            for (int r = 0; r < 4; ++r) {
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const unsigned char* ip = reinterpret_cast<const unsigned char*>(R0) + ((ry + tap / 3) * DT_IC + cx + tap % 3) * DT_IPIX;
+                for (int dx = 0; dx < 3; ++dx) {
+                    const unsigned char* ip = reinterpret_cast<const unsigned char*>(R0) + ((2 * rp + r) * DT_IC + cx + dx) * DT_IPIX;
 #pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(ip + 16 * c4);
-                    const float* w = p.wd + tap * 16 + 4 * c4;
-                    acc += v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(ip + 16 * c4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (r < 3) acc0 += v[e] * wd_at((r * 3 + dx) * 16 + 4 * c4 + e);
+                            if (r > 0) acc1 += v[e] * wd_at(((r - 1) * 3 + dx) * 16 + 4 * c4 + e);
+                        }
+                    }
                 }
             }
-            p.out[((size_t)cur.img * H + y0 + ry) * W + x0 + cx] = 0.3f * (1.0f / (1.0f + expf(-acc)));
+            float* o = p.out + ((size_t)cur.img * H + y0 + 2 * rp) * W + x0 + cx;
+            o[0] = 0.3f * (1.0f / (1.0f + expf(-acc0)));
+            o[W] = 0.3f * (1.0f / (1.0f + expf(-acc1)));
         }
         __syncthreads();
         cur = ntl;
