@@ -1,7 +1,9 @@
 #!/bin/bash
-tag=${1:-r04g}
+tag=${1:-r04j}
 mkdir -p gpurun_out/$tag
 o=gpurun_out/$tag
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -d $o/prof -o trace --output-format csv -- python3 bench.py --legs none --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline > $o/bench_prof.json 2> $o/bench_prof.log
-ls -R $o/prof | head -20
+timeout 1500 python -m pytest tests -x -q -m gpu > $o/pytest.txt 2>&1; tail -5 $o/pytest.txt
+timeout 300 python scripts/layer_times.py 32 resnet50 bf16x3 2> $o/layers.txt >/dev/null
+grep -h "dec/tail1\|conv ms" $o/layers.txt
+timeout 900 python bench.py --steps 20 --warmup 5 --repeats 3 > $o/bench.json 2> $o/bench.log
+grep 'frames/s' $o/bench.log | cut -c1-220

@@ -18,7 +18,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 seen = collections.defaultdict(set)
 for r in csv.DictReader(open(cc)):
     k = r["Kernel_Name"]
-    if "sd::conv_" not in k:
+    if "sd::conv_" not in k and "sd::dec_" not in k:
         continue
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Dispatch_Id"] not in seen[k]:
