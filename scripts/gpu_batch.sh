@@ -1,9 +1,9 @@
 #!/bin/bash
-tag=${1:-r04j}
+tag=${1:-r04k}
 mkdir -p gpurun_out/$tag
 o=gpurun_out/$tag
-timeout 1500 python -m pytest tests -x -q -m gpu > $o/pytest.txt 2>&1; tail -5 $o/pytest.txt
+timeout 900 python -m pytest tests/test_gpu_nets.py -x -q -m gpu -s -k "row_grouped or fcn8s_matches or fp32_grade" > $o/pytest.txt 2>&1; tail -5 $o/pytest.txt
 timeout 300 python scripts/layer_times.py 32 resnet50 bf16x3 2> $o/layers.txt >/dev/null
-grep -h "dec/tail1\|conv ms" $o/layers.txt
-timeout 900 python bench.py --steps 20 --warmup 5 --repeats 3 > $o/bench.json 2> $o/bench.log
-grep 'frames/s' $o/bench.log | cut -c1-220
+grep -h "fc6 \|fc7 \|conv ms" $o/layers.txt
+SEMDEPTH_NO_ROWSKIP=1 timeout 300 python scripts/layer_times.py 32 resnet50 bf16x3 2> $o/layers_norowskip.txt >/dev/null
+grep -h "fc6 \|conv ms" $o/layers_norowskip.txt

@@ -185,6 +185,10 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.sw = h->sw;
                 c.sat = reinterpret_cast<unsigned long long*>(h->ws + h->o_misc + SAT_OFF);
                 c.x3 = p.x3;
+                // conv_dma3.hip, k x k stride-1 layers on one source (fc6): one output row of 256 / Wout images per tile, taps on padding rows skipped
+                if (p.x3 && !op.fold && op.nsrc == 1 && op.vec && op.Kvec == op.Kpad && op.k >= 3 && op.sstride[0] == 1 && !op.up[0] && !c.pool &&
+                    op.Kpad == op.k * op.k * s0.C && c.Wout > 0 && 256 % c.Wout == 0 && N % (256 / c.Wout) == 0 && !(h->sw & SW_NO_ROWSKIP))
+                    c.rowgrp = 256 / c.Wout;
                 if (op.fold) {          // (conv_dma3.hip: the GEMM's pixel space is the source itself)
                     c.fold = 1; c.simple = 0; c.Hin = s0.H; c.Win = s0.W; c.Hout = s0.H; c.Wout = s0.W; c.kh = c.kw = 2;
                 }

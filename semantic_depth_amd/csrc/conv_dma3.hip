@@ -70,7 +70,18 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
     // upsample-folded conv (ConvParams::fold): the parity is the outermost tile index
     const int par = tid_ / (tilesM * tilesN);
     tid_ -= par * (tilesM * tilesN);
-    const int tm = tid_ % tilesM, tn = tid_ / tilesM;
+    int tm = tid_ % tilesM, tn = tid_ / tilesM;
+    if (p.rowgrp && p.Hout >= 2 * p.pad) {
+        // row-grouped tiles differ in length (border rows skip taps): dispatch the longest first -- rows by decreasing distance from the
+        // border -- so that the CUs that finish early pick up the short ones (the workgroups start in blockIdx order)
+        const int per_row = (tilesM / p.Hout) * tilesN, rank = (int)blockIdx.x / per_row, rest = (int)blockIdx.x - rank * per_row;
+        const int full = p.Hout - 2 * p.pad;
+        int oy = p.pad + rank;
+        if (rank >= full) { const int j = rank - full, d = p.pad - 1 - (j >> 1); oy = (j & 1) ? p.Hout - 1 - d : d; }
+        const int groups = tilesM / p.Hout;
+        tn = rest / groups;
+        tm = (rest - tn * groups) * p.Hout + oy;
+    }
     const int bm0 = tm * G3_BM, bn0 = tn * G3_BN;
 
     // X DMA: instruction j (16 per plane) covers pixels [16 j, 16 j + 16) x 4 octets; this wave issues j = wave and wave + 8
@@ -83,9 +94,16 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
         const bool ok = m < M;
         const int hw = p.Hout * p.Wout;
         const int mm = ok ? m : 0;
-        const int img = mm / hw;
-        const int r = mm - img * hw;
-        const int oy = r / p.Wout;
+        int img = mm / hw;
+        int r = mm - img * hw;
+        int oy = r / p.Wout;
+        if (p.rowgrp) {                  // pixel order (image group, row, image of the group, column): a tile is ONE row of rowgrp images
+            const int q1 = mm / p.Wout, q2 = q1 / p.rowgrp;
+            r = mm - q1 * p.Wout;        // (column)
+            oy = q2 % p.Hout;
+            img = (q2 / p.Hout) * p.rowgrp + (q1 - q2 * p.rowgrp);
+            r += oy * p.Wout;
+        }
         pyx[i] = oy | ((r - oy * p.Wout) << 16);
         pik[i] = img | (((lane & 3) ^ ((m_l >> 2) & 3)) << 26) | ((ok ? 1 : 0) << 30);      // (octet: the one this lane fetches into slot lane % 4)
     }
@@ -94,7 +112,19 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
     const u32x4* __restrict__ const wt_hi = reinterpret_cast<const u32x4*>(p.wt) + (size_t)par * (p.Kpad / 8) * CoutPad;
     const size_t wplane = (size_t)(p.Kpad / 8) * CoutPad * (p.fold ? 4 : 1);     // units
     const u32x4* const zero = reinterpret_cast<const u32x4*>(p.zero16);
-    const int ktiles = p.Kpad / 32;
+    // the k-tiles this tile runs: all of them, or (ConvParams::rowgrp: the tile is one output row) only the taps whose input row exists --
+    // per 32-channel block the taps [t0, t0 + nt) of kh x kw; the skipped ones would multiply zero padding: the accumulators are bit for bit
+    // what the full loop leaves
+    int taps = p.Kpad / 32, t0 = 0, nt = taps;
+    if (p.rowgrp) {
+        const int oy_t = (bm0 / (p.rowgrp * p.Wout)) % p.Hout;
+        const int dlo = oy_t < p.pad ? -oy_t : -p.pad, dhi = p.Hout - 1 - oy_t < p.pad ? p.Hout - 1 - oy_t : p.pad;
+        taps = p.kh * p.kw; t0 = (dlo + p.pad) * p.kw; nt = (dhi - dlo + 1) * p.kw;
+    }
+    const int ktiles = (p.Kpad / 32 / taps) * nt;             // k-tiles this tile runs
+    // cursor over them: actual k-tile index and position inside the window
+    struct KCur { int idx, tt; };
+    auto knext = [&](KCur c) { ++c.idx; if (++c.tt == nt) { c.tt = 0; c.idx += taps - nt; } return c; };
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds;
 
     // one DMA instruction of a pair: piece 0, 1 = the weight plane's two instructions of this wave, 2, 3 = the X plane's
@@ -137,9 +167,9 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
     // (ph 0: lo, 1: mid, 2: hi)
     const int nphase = 3 * ktiles;
     // prologue = the issues of the (virtual) phases -3 .. -1: the pairs of phases 0, 1, 2
-    issue_pair(0, 0, 0);
-    issue_pair(0, 1, 1);
-    issue_pair(0, 2, 2);
+    issue_pair(t0, 0, 0);
+    issue_pair(t0, 1, 1);
+    issue_pair(t0, 2, 2);
     int prev1 = 4;                                            // DMA instructions this wave issued in the previous phase
     const int frow = lane & 31, fk = lane >> 5;
     // Fragment registers that live across phase boundaries: the LDS reads a phase starts with are issued in the TAIL of the phase before
@@ -160,7 +190,8 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
 #pragma unroll
     for (int a = 0; a < G3_MT; ++a) xk[0][0][a] = xfrag(0, 0, a);
     int q = 0;
-    KEntry e3 = g3load_kentry(ktab + 1);                      // (Kpad >= 64: at least two k-tiles) gather entry of the k-tile whose pairs are being issued (kt + 1)
+    KCur k1 = knext(KCur{t0, 0});                             // the k-tile whose pairs are being issued (the one after the k-tile being multiplied)
+    KEntry e3 = g3load_kentry(ktab + k1.idx);                 // (at least two k-tiles) its gather entry
     for (int kt = 0; kt < ktiles; ++kt) {
         auto phase = [&](auto ph_tag) {
             constexpr int PH = decltype(ph_tag)::value, NPX = PH + 1;
@@ -174,7 +205,7 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
             const bool doissue = q + 3 < nphase;               // = 3 (kt + 1) + ph
             auto piece = [&](int n) {
                 if (!doissue) return;
-                if (n < 2) issue_w1(kt + 1, 2 - PH, (q + 3) & 3, n);
+                if (n < 2) issue_w1(k1.idx, 2 - PH, (q + 3) & 3, n);
                 else issue_x1(e3, PH, (q + 3) & 3, n - 2);
             };
             prev1 = doissue ? 4 : 0;
@@ -261,7 +292,8 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
         phase(IntTag<0>{});
         phase(IntTag<1>{});
         phase(IntTag<2>{});
-        if (kt + 2 < ktiles) e3 = g3load_kentry(ktab + kt + 2);       // (one scalar load per k-tile, behind the hi phase's MFMAs)
+        k1 = knext(k1);
+        if (kt + 2 < ktiles) e3 = g3load_kentry(ktab + k1.idx);       // (one scalar load per k-tile, behind the hi phase's MFMAs)
     }
 
     // ---- epilogue: bias + activation in f32, exact three-way split, LDS transpose (one slab per plane and wave), 16-byte runs ----
@@ -303,6 +335,10 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
                 const int mo = m0 + a * 32 + pix;
                 if (mo < M && !(diag & 1)) {
                     size_t opix = (size_t)mo;
+                    if (p.rowgrp) {              // (image group, row, image of the group, column) -> (image, row, column)
+                        const int q1 = mo / p.Wout, q2 = q1 / p.rowgrp, g = q2 / p.Hout;
+                        opix = ((size_t)((g * p.rowgrp + (q1 - q2 * p.rowgrp)) * p.Hout + (q2 - g * p.Hout))) * p.Wout + (mo - q1 * p.Wout);
+                    }
                     if (p.fold) {                // source pixel (img, i, j) of parity (py, px) -> output pixel (2 i + py, 2 j + px)
                         const int hw = p.Hout * p.Wout, img = mo / hw, r = mo - img * hw, i = r / p.Wout, j = r - i * p.Wout;
                         opix = ((size_t)(img * 2 * p.Hout + 2 * i + (par >> 1))) * (2 * p.Wout) + 2 * j + (par & 1);

@@ -183,6 +183,30 @@ def test_256x256_block_of_the_dma_pipeline_is_bit_identical_to_the_128x256_one()
     assert torch.equal(outs[0], outs[1])
 
 
+def test_row_grouped_fc6_tiles_skip_padding_taps_bit_identically():
+    """bf16x3, fc6 (7x7 on the 16 x 32 pool5 map): conv_dma3 orders the GEMM's pixels (image group, row, image, column) so that a
+    256-pixel tile is one output row of eight images, and skips the k-tiles of the taps whose input row is zero padding (10.7 % of them).
+    Skipped terms are exact zeros: the logits must not change by a bit against the plain pixel order (SEMDEPTH_NO_ROWSKIP)."""
+    from semantic_depth_amd.engine import Engine
+    from semantic_depth_amd import weights as Wt
+    H, W, B = 512, 1024, 8
+    wf = Wt.make_fcn8s_weights(3, decoder_std=0.05, bias_std=0.1)
+    fr = dev(_frames(B, H, W, seed=5))
+    outs = []
+    for off in (False, True):
+        if off:
+            os.environ["SEMDEPTH_NO_ROWSKIP"] = "1"
+        try:
+            eng = Engine(H, W, B, "resnet50", precision="bf16x3")
+            eng.load_weights(L.SD_NET_FCN8S, wf)
+            outs.append((eng.fcn8s_forward(fr, want_logits=True)["logits"].clone(), eng.net_tensor(L.SD_NET_FCN8S, "layer7_out").clone()))
+        finally:
+            os.environ.pop("SEMDEPTH_NO_ROWSKIP", None)
+        del eng
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0])
+    assert float(outs[0][0].abs().max()) > 0
+
+
 @pytest.mark.parametrize("H,W,B,enc", [(512, 1024, 2, "resnet50"), (128, 256, 3, "resnet50"), (256, 512, 1, "vgg")])
 def test_folded_upconvs_and_fused_decoder_tail_against_the_layer_by_layer_form(H, W, B, enc):
     """bf16x3 runs the wide upconv layers upsample-FOLDED (four 2x2 convs on the source instead of a 3x3 conv on the upsampled source:
