@@ -224,6 +224,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.nreal = (d.Ctf > 0 && d.Ctf < d.C) ? d.Ctf : 0;
                 c.all_up = 1;
                 for (int i = 0; i < op.nsrc; ++i) c.all_up = c.all_up && op.up[i] == 1;
+                c.fold = op.fold;
                 c.wt = reinterpret_cast<const u32x4_t*>(Wp(op.w)); c.bias = Wp(op.b);
                 c.out = T(op.dst); c.out_plane = PL(op.dst); c.act = op.act; c.Nmax = p.images;
                 c.zero16 = h->ws + h->o_misc + 256;

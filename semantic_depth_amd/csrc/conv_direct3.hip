@@ -54,14 +54,20 @@ constexpr int T3_TW = 32, T3_HW = T3_TW + 2, T3_WAVES = 8, T3_TH = 16, T3_HH = T
 // 3 (NB = 1, the 16 / 32-channel full-resolution layers): phases of 18 / 36 / 54 MFMAs per wave are shorter than the latency of the DMAs
 // they would have to cover, so a weight plane is issued TWO phases before its phase, each X plane of the next chunk two phases before its
 // first read, and a phase waits with a counted vmcnt only for what was issued two phases ago.
-template <int NB, bool UP, int KEEP, int WSLOTS>
+// FOLD (UP layers with ONE source; ConvDirectParams::fold): the upsample-folded form -- per output parity (y & 1, x & 1) a 2x2 conv on the
+// source with the 3x3 taps that read the same source pixel added up (plan.hpp OpDesc::fold): 16 tap matrices per chunk instead of 9, but
+// 4 instead of 9 MFMAs per output pixel.  Wave w owns parity w & 3 and the source rows 4 (w >> 2) .. + 3 of the tile: its two 32-pixel MFMA
+// column groups are 2 source rows x 16 source columns each.
+template <int NB, bool UP, int KEEP, int WSLOTS, bool FOLD = false>
 __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectParams p) {
+    static_assert(!FOLD || (UP && WSLOTS == 2 && KEEP == 2), "the folded form: upconv layers, two-slot ring, kept X fragments");
+    constexpr int NTAP = FOLD ? 16 : 9;                        // tap matrices per chunk
     constexpr int S_HH = UP ? T3_HH / 2 + 1 : T3_HH, S_HW = UP ? T3_HW / 2 + 1 : T3_HW;      // stored tile
     constexpr int XI = (S_HH * S_HW * 2 + 63) / 64;            // DMA instructions per halo plane (2 octet slots per pixel)
     constexpr int XUNITS = XI * 64;
     constexpr int XS = (XI + T3_WAVES - 1) / T3_WAVES;         // X-DMA slots per wave and plane
-    constexpr int WI = 9 * NB;                                 // DMA instructions per weight plane
-    constexpr int WUNITS = 9 * 2 * 32 * NB;                    // taps x octets x output channels
+    constexpr int WI = NTAP * NB;                              // DMA instructions per weight plane
+    constexpr int WUNITS = NTAP * 2 * 32 * NB;                 // taps x octets x output channels
     constexpr int WS = (WI + T3_WAVES - 1) / T3_WAVES;         // weight-DMA slots per wave and plane
     constexpr int ROW = 64 * NB + 16;                          // epilogue slab row (bytes per pixel and plane, + pad)
     // planes per epilogue round: with 32 output channels a wave's three planes of 32 pixels fit the consumed X buffer side by side, so a
@@ -71,7 +77,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
     constexpr int SLAB = T3_WAVES * EPL * 32 * ROW / 16;       // units: EPL planes of 32 pixels per wave
     constexpr int XBUF = 3 * XUNITS < SLAB ? SLAB : 3 * XUNITS;
     static_assert((2 * XBUF + WSLOTS * WUNITS) * 16 + 2048 <= 160 * 1024, "two X buffers + the weight ring + bias fit the LDS of a CU");
-    static_assert(WS + 2 * XS <= 9 * NB, "one DMA slot per MFMA group of a phase");
+    static_assert(WS + 2 * XS <= (FOLD ? 4 : 9) * NB, "one DMA slot per MFMA group of a phase");
     __shared__ __attribute__((aligned(16))) u32x4 lds[2 * XBUF + WSLOTS * WUNITS];
     __shared__ __attribute__((aligned(16))) float sbias[512];
     auto hpix = [](int hy, int hx) { return UP ? ((hy + 1) >> 1) * S_HW + ((hx + 1) >> 1) : hy * S_HW + hx; };
@@ -83,6 +89,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
     const u32x4* const zero = reinterpret_cast<const u32x4*>(p.zero16);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds;      // LDS byte address
     const int frow = lane & 31, fk = lane >> 5;
+    const int fpar = wave & 3, fpy = fpar >> 1, fpx = fpar & 1, fhh = wave >> 2;     // FOLD: this wave's parity and half of the tile's source rows
     // SEMDEPTH_X3_DIAG (decomposition runs, latched in the handle's switches): 1 no output stores, 2 no MFMAs; 0 in production
     const int diag = ((p.sw & SW_X3_DIAG_NOSTORE) ? 1 : 0) | ((p.sw & SW_X3_DIAG_NOMFMA) ? 2 : 0);
 
@@ -227,6 +234,12 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
                 const int lp = hpix(T3_MT * wave + r, frow + dx);
                 return Xb[pl * XUNITS + lp * 2 + (fk ^ ((lp >> 3) & 1))];
             };
+            // FOLD: fragment (column shift tb, row offset ro = 2 a + ta) of plane pl: lane = (source row r2 = frow >> 4, source column frow & 15)
+            // -> halo pixel (4 hh + ro + r2 + py, column + tb + px) of the stored source tile
+            auto xloadf = [&](int pl, int tb, int ro) {
+                const int lp = (4 * fhh + ro + (frow >> 4) + fpy) * S_HW + (frow & 15) + tb + fpx;
+                return Xb[pl * XUNITS + lp * 2 + (fk ^ ((lp >> 3) & 1))];
+            };
             // the X fragments of the first KEEP planes stay in registers from the phase that first reads them to the end of the chunk
             u32x4 xk[KEEP > 0 ? KEEP : 1][3][T3_MT + 2];
             // one phase: the weight plane in ring slot q & 1 times X planes PH .. 0 (phase 0: W_lo x X_hi; 1: W_mid x (X_mid, X_hi);
@@ -284,8 +297,47 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
+            // the folded form of a phase: 4 NB groups (tap t = 2 ta + tb, block nb) of 2 NPX MFMAs; the eight fragments of the plane the phase
+            // reads for the first time go out before its first MFMA, the weight fragment of group g + 2 before group g's MFMAs
+            auto phase_fold = [&](auto ph_tag, auto&& issue) {
+                constexpr int PH = decltype(ph_tag)::value, NPX = PH + 1, G = 4 * NB;
+                const u32x4* const Wq = lds + 2 * XBUF + (q % WSLOTS) * WUNITS;
+                auto wfrag = [&](int grp) {
+                    const int tp = grp / NB, nb = grp % NB;
+                    return Wq[((fpar * 4 + tp) * 2 + fk) * (32 * NB) + nb * 32 + frow];
+                };
+                u32x4 xn[2][4];                                  // the lo plane (read in the hi phase only)
+                u32x4 wq[3];
+                wq[0] = wfrag(0);
+                wq[1] = wfrag(1);
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                    for (int ro = 0; ro < 4; ++ro) {
+                        if constexpr (PH < KEEP) xk[PH][tb][ro] = xloadf(PH, tb, ro);
+                        else xn[tb][ro] = xloadf(PH, tb, ro);
+                    }
+#pragma unroll
+                for (int grp = 0; grp < G; ++grp) {
+                    const int tp = grp / NB, ta = tp >> 1, tb = tp & 1, nb = grp % NB;
+                    if (grp + 2 < G) wq[(grp + 2) % 3] = wfrag(grp + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const u32x4 wv = wq[grp % 3];
+#pragma unroll
+                    for (int pl = NPX - 1; pl >= 0; --pl)          // the smaller planes first
+#pragma unroll
+                        for (int a = 0; a < T3_MT; ++a) {
+                            const u32x4 xv = pl < KEEP ? xk[pl < KEEP ? pl : 0][tb][2 * a + ta] : xn[tb][2 * a + ta];
+                            acc[a][nb] = mfma_frag<false>(wv, xv, acc[a][nb]);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue(grp);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
             // (SEMDEPTH_X3_DIAG & 2 selects the copy of a phase without MFMAs; production runs the branch-free one)
-#define SD_PHASE(PH_, ...) do { if (diag & 2) phase(IntTag<PH_>{}, IntTag<1>{}, __VA_ARGS__); else phase(IntTag<PH_>{}, IntTag<0>{}, __VA_ARGS__); } while (0)
+#define SD_PHASE(PH_, ...) do { if constexpr (FOLD) phase_fold(IntTag<PH_>{}, __VA_ARGS__); \
+                                else if (diag & 2) phase(IntTag<PH_>{}, IntTag<1>{}, __VA_ARGS__); else phase(IntTag<PH_>{}, IntTag<0>{}, __VA_ARGS__); } while (0)
             if constexpr (WSLOTS == 3) {
                 // ---- three-slot pipeline: phase q issues the weight plane of phase q + 2 and the X plane first read in phase q + 2
                 // lo(c): W_hi(c) + X_lo(c)
@@ -435,8 +487,11 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
 #pragma unroll
                     for (int ps = 0; ps < 32 / PPP; ++ps) {
                         const int pix = ps * PPP + prow;
-                        if (y < p.H && seg * 8 < p.Cout && !(diag & 1)) {
-                            uint16_t* o = out_hi + ((size_t)(cur.img * p.H + y) * p.W + cur.tx0 + pix) * p.Cstride + n0 + seg * 8;
+                        // FOLD: pixel pix of column group a = source (row 4 hh + 2 a + (pix >> 4), column pix & 15) of this wave's parity
+                        const int yo = FOLD ? cur.ty0 + 2 * (4 * fhh + 2 * a + (pix >> 4)) + fpy : y;
+                        const int xo = FOLD ? cur.tx0 + 2 * (pix & 15) + fpx : cur.tx0 + pix;
+                        if (yo < p.H && seg * 8 < p.Cout && !(diag & 1)) {
+                            uint16_t* o = out_hi + ((size_t)(cur.img * p.H + yo) * p.W + xo) * p.Cstride + n0 + seg * 8;
 #pragma unroll
                             for (int e = 0; e < EPL; ++e)
                                 *reinterpret_cast<u32x4*>(o + (pl0 + e) * p.out_plane) = *reinterpret_cast<const u32x4*>(sh + e * (32 * ROW) + pix * ROW + seg * 16);
@@ -478,6 +533,12 @@ hipError_t launch_conv_direct3(const ConvDirectParams& p, hipStream_t s) {
     // A/B switches of the handle (plan.cpp latch_switches): the X fragments of the hi / mid planes kept in registers or re-read; the
     // three-slot weight ring of the NB = 1 layers (measured equal or 3-6 % slower than the two-slot form on upconv1 / iconv1 / upconv2 /
     // iconv2 -- profiles/r03g_conv_direct3_ring3_ab.txt -- so it is off by default)
+    if (p.fold) {             // upsample-folded upconv layers: source-resolution tiles, two-slot ring, kept fragments
+        if (!up || p.pool) return hipErrorInvalidValue;
+        if (p.Cout <= 32) hipLaunchKernelGGL((conv_direct3_kernel<1, true, 2, 2, true>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv_direct3_kernel<2, true, 2, 2, true>), grid, dim3(512), 0, s, p);
+        return hipGetLastError();
+    }
     const int keep = (p.sw & SW_X3_NOKEEP) ? 0 : 2;
     const bool ring3 = (p.sw & SW_X3_RING3) != 0;
     const ConvDirectParams& pd = p;
@@ -494,6 +555,7 @@ hipError_t launch_conv_direct3(const ConvDirectParams& p, hipStream_t s) {
 }
 
 const char* conv_direct3_kernel_name(const ConvDirectParams& p) {
+    if (p.fold) return p.Cout <= 32 ? "conv_direct_x3_fold_kernel<1>" : "conv_direct_x3_fold_kernel<2>";
     return p.Cout <= 32 ? "conv_direct_x3_kernel<1,2>" : "conv_direct_x3_kernel<2,2>";
 }
 

@@ -148,6 +148,7 @@ struct ConvDirectParams {
     int nreal;                   // > 0: only the first nreal of the Cout stored channels are real, the rest are written as zeros
                                  // (disparity heads: 2 channels in a zero-padded octet; N16 kernel)
     int all_up;                  // every chunk has up == 1 (upconv layers): the kernel keeps source-resolution halo tiles
+    int fold;                    // conv_direct3.hip: upsample-folded weights [split][plane][chunk][parity 4][2x2 tap 4][octet 2][32 or 64][8] (OpDesc::fold)
     const u32x4_t* wt;           // [split][plane][chunk][tap 9][octet 2][32 or 64][8 bf16]
     const float* bias;
     float* out;                  // split planes [N,H,W,Cout]

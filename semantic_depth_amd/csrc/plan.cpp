@@ -138,14 +138,17 @@ struct Builder {
             for (int i = 0; i < op.nsrc; ++i) nch += (p.tensors[op.src[i]].C + 15) / 16;
             op.nchunks = nch;
             op.nsplit = Cout > 64 ? Cout / 64 : 1;
-            op.w = wslot(wname, {k, k, Ctf, Cout}, WL_DIRECT_SPLIT, nch * 9 * 16, Cout <= 32 ? 32 : 64, 0, op.nsplit);
+            // bf16 x 3, an upconv layer (one x2-upsampled source): the upsample-folded form of the direct kernel (OpDesc::fold)
+            op.fold = (p.x3 && op.nsrc == 1 && op.up[0] && p.tensors[op.src[0]].C % 16 == 0 && Hout % 2 == 0 && !(latch_switches() & (SW_NO_FOLD | SW_NO_UPTILE))) ? 1 : 0;
+            op.w = wslot(wname, {k, k, Ctf, Cout}, WL_DIRECT_SPLIT, nch * (op.fold ? 16 : 9) * 16, Cout <= 32 ? 32 : 64, 0, op.nsplit);
             WeightSlot& ws = p.weights[op.w];
-            ws.nsrc = op.nsrc;
+            ws.nsrc = op.nsrc; ws.fold = op.fold;
             for (int i = 0; i < 3; ++i) { ws.srcCtf[i] = srcCtf[i]; ws.srcCpad[i] = i < op.nsrc ? p.tensors[op.src[i]].C : 0; }
             op.b = wslot(bname, {Cout}, WL_RAW);
             op.dst = tensor(name, N, Hout, Wout, Cout);
             op.tab_bytes = (size_t)nch * sizeof(DirectChunk);
-            op.flops = 2.0 * (double)N * Hout * Wout * Cout * (double)(k * k * Ctf);
+            op.flops = 2.0 * (double)N * Hout * Wout * Cout * (double)((op.fold ? 4 : k * k) * Ctf);      // (folded: the multiplications that run)
+            if (op.fold) op.K = 4 * Ctot;
             push(op);
             return op.dst;
         }
@@ -762,6 +765,36 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
         uint16_t* const hi0 = reinterpret_cast<uint16_t*>(out.data());
         auto bf16 = [](float v) -> uint16_t { uint32_t u; std::memcpy(&u, &v, 4); u += 0x7FFFu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
         auto bf16_to_f = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; };
+        if (s.fold) {
+            // upsample-folded (OpDesc::fold): [split][plane][chunk][parity q][2x2 tap t][octet][CoutPad n][8]; the 3x3 taps that land on source
+            // row a of parity py are  py = 0: a = 0 <- {0}, a = 1 <- {1, 2};  py = 1: a = 0 <- {0, 1}, a = 1 <- {2}  (columns alike), added in
+            // double and rounded once to f32, then split exactly like any other weight
+            auto rows_of = [](int par, int a, int* d) { if (par == 0) { if (a == 0) { d[0] = 0; return 1; } d[0] = 1; d[1] = 2; return 2; }
+                                                         if (a == 0) { d[0] = 0; d[1] = 1; return 2; } d[0] = 2; return 1; };
+            for (int c0 = 0, chunk = 0; c0 < s.srcCpad[0]; c0 += 16, ++chunk)
+                for (int q = 0; q < 4; ++q)
+                    for (int tp = 0; tp < 4; ++tp) {
+                        int dys[2], dxs[2];
+                        const int ny = rows_of(q >> 1, tp >> 1, dys), nx = rows_of(q & 1, tp & 1, dxs);
+                        for (int c = c0; c < std::min(c0 + 16, s.srcCtf[0]); ++c) {
+                            const int oct = (c - c0) / 8, e = (c - c0) % 8;
+                            const size_t base = ((((size_t)chunk * 4 + q) * 4 + tp) * 2 + oct) * s.CoutPad * 8 + e;
+                            for (int64_t n = 0; n < Cout; ++n) {
+                                double acc = 0.0;
+                                for (int iy = 0; iy < ny; ++iy)
+                                    for (int ix = 0; ix < nx; ++ix) acc += (double)w[((int64_t)(dys[iy] * 3 + dxs[ix]) * Ctf + c) * Cout + n];
+                                const float wf = (float)acc;
+                                uint16_t* hi = hi0 + (size_t)(n / s.CoutPad) * 3 * plane + base + (n % s.CoutPad) * 8;
+                                const uint16_t h = bf16(wf);
+                                *hi = h;
+                                const float r1 = wf - bf16_to_f(h);
+                                hi[plane] = bf16(r1);
+                                hi[2 * plane] = bf16(r1 - bf16_to_f(hi[plane]));
+                            }
+                        }
+                    }
+            return;
+        }
         int chunk = 0, cb_tf = 0;
         for (int i = 0; i < s.nsrc; ++i) {
             for (int c0 = 0; c0 < s.srcCpad[i]; c0 += 16, ++chunk)
