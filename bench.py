@@ -84,6 +84,10 @@ def parse_args():
                          "HIP-event durations behind `roofline` come from one extra UNTIMED region of --steps steps without the overlap "
                          "(under it the tail's workgroups share CUs with the conv launches and their event durations stop being the kernels' own)")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false", help="everything on one stream")
+    ap.add_argument("--from-disk", action="store_true",
+                    help="--config 5 only: the frames are PNG files on disk and the input stage (native decode on this rank's share of the "
+                         "CPUs -> pinned staging -> upload) runs INSIDE the timed region, one batch ahead of the GPU "
+                         "(distributed.run_sequence_files: every rank decodes only its shard)")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--repeats", type=int, default=3, help="back-to-back timed regions of --steps steps each; value = mean over them")
@@ -117,7 +121,8 @@ def spawn_ranks(args) -> int:
         port = s.getsockname()[1]
     procs = []
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), SD_BENCH_SPAWNED="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     return wait_ranks(procs)
@@ -194,7 +199,7 @@ def main():
             time.sleep(1.0)
     from semantic_depth_amd import _lib as L
     from semantic_depth_amd import weights as Wt
-    from semantic_depth_amd.distributed import gather_records, make_engine_step, run_sequence
+    from semantic_depth_amd.distributed import gather_records, make_engine_step, run_sequence, run_sequence_files
     from semantic_depth_amd.engine import Camera, Engine, FenceParams, RoadWidthParams
 
     torch.cuda.set_device(local_rank)
@@ -246,6 +251,24 @@ def main():
     cams = [cam] * B
     prm = RoadWidthParams()
     state = {"bias": None, "frames": None}
+    disk_paths = None
+    if args.from_disk:
+        if args.config != 5:
+            raise SystemExit("--from-disk needs --config 5")
+        # this rank's frames as PNG files in a directory all ranks of the node share (untimed); every rank then sees the same sorted list
+        import glob
+        import tempfile
+        from semantic_depth_amd import outputs as sd_out
+        ddir = os.path.join(tempfile.gettempdir(), f"sd_bench_frames_{os.environ.get('MASTER_PORT', 'single')}_{os.getppid() if world > 1 else os.getpid()}")
+        os.makedirs(ddir, exist_ok=True)
+        for i in range(B):
+            sd_out.write_png(os.path.join(ddir, f"frame_{rank * B + i:06d}.png"), frames_np[i])
+        if world > 1:
+            dist.barrier()
+        files = sorted(glob.glob(os.path.join(ddir, "frame_*.png")))
+        assert len(files) == world * B, (len(files), world, B)
+        # K steps = K batches per rank: every file K times, adjacent in the sorted list, so that rank r's shard is its own B files x K
+        disk_paths = [f for f in files for _ in range(args.steps)]
 
     def make_engine(precision):
         eng = Engine(H, W, B, args.encoder, local_rank, precision=precision, plan=custom_plan if precision == "plan" else None)
@@ -336,11 +359,15 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(args.steps):
-                if args.config == 5:
-                    allrec = step()                                # distributed.run_sequence: shard -> resize -> process_batch -> all_gather
-                else:
-                    out, allrec = instrumented_step()
+            if disk_paths is not None:
+                # files -> FrameFeeder (decode + upload one batch ahead) -> resize -> whole path, --steps batches per rank, ONE all_gather
+                allrec = run_sequence_files(disk_paths, seq_step, batch=B, device="cuda")[:: args.steps][: world * B]
+            else:
+                for _ in range(args.steps):
+                    if args.config == 5:
+                        allrec = step()                            # distributed.run_sequence: shard -> resize -> process_batch -> all_gather
+                    else:
+                        out, allrec = instrumented_step()
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
@@ -504,6 +531,9 @@ def main():
                    "stage_ms_last_step": head_rec["stage_ms_last_step"],
                    "approach": args.approach, "engine": args.precision,
                    "colours_through_road_chain": colours, "overlap": bool(args.overlap),
+                   **({"from_disk": True, "decode_threads_per_rank": __import__("semantic_depth_amd.frame_io", fromlist=["x"]).default_decode_workers(),
+                       "input_stage": "PNG files on disk -> native decode (this rank's shard only) -> pinned staging -> upload, inside the timed region"}
+                      if args.from_disk else {}),
                    **({k: head_rec[k] for k in ("precision_plan", "built_in_plan") if k in head_rec}),
                    **({"fp16_saturated_values": head_rec["fp16_saturated_values"]} if "fp16_saturated_values" in head_rec else {}),
                    "road_fraction": round(road_frac, 4), "n_road_mean": float(recs["n_road"].mean()), "n_after_chain_mean": float(recs["n_ror"].mean()),

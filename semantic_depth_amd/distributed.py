@@ -91,6 +91,28 @@ def run_sequence(load_frames, n_frames: int, step, batch: int = 32, group=None, 
     return gather_records(local, n_frames, group)
 
 
+def run_sequence_files(paths, step, batch: int = 32, group=None, device="cuda", workers: int = 0) -> torch.Tensor:
+    """run_sequence on FILES (semantic_depth_cityscapes_sequence.py:689-701 reads ``sorted(glob(input_folder))`` frame by frame): rank r
+    decodes ONLY its shard of the sorted list -- frame_io.FrameFeeder: one native call per batch into pinned staging, upload one batch
+    ahead, ``workers`` decode threads (default: this rank's share of the node's CPUs, frame_io.default_decode_workers) -- and hands every
+    batch to ``step(frames_on_device, first_global_index)``; one all_gather of the records at the end."""
+    from .frame_io import FrameFeeder
+    paths = sorted(paths)
+    n_frames = len(paths)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_range(n_frames, rank, world)
+    parts = []
+    if hi > lo:
+        with FrameFeeder(paths[lo:hi], batch, device=device, workers=workers) as feeder:
+            for frames, first in feeder:
+                rec = step(frames, lo + first)
+                assert rec.dtype == torch.uint8 and tuple(rec.shape) == (frames.shape[0], RECORD_BYTES), (rec.dtype, rec.shape)
+                parts.append(rec)
+    local = torch.cat(parts, 0) if parts else torch.zeros((0, RECORD_BYTES), dtype=torch.uint8, device=device)
+    return gather_records(local, n_frames, group)
+
+
 def make_engine_step(engine, camera_of, params=None, approach: str = "rw"):
     """``step`` for run_sequence on a real Engine: host or device u8 frames of any size -> (cubic resize to the network shape on
     the GPU, semantic_depth_cityscapes_sequence.py:123-130) -> Engine.process_batch -> record buffer.

@@ -81,6 +81,25 @@ def imread(path: str) -> np.ndarray:
     return decode_png(buf) if buf[:8] == _SIG else decode_image(buf)
 
 
+def default_decode_workers() -> int:
+    """decode threads of ONE rank: the CPUs this process may run on (its affinity mask, capped by the cgroup CPU quota -- os.cpu_count()
+    reports the host's 256 whatever the container may use) divided by the ranks of the node (LOCAL_WORLD_SIZE, set by torch.distributed.run
+    and by bench.py's launcher), at least 1, at most 128.  Eight ranks on a 256-CPU node get 32 threads each instead of 8 x 128."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 8
+    try:                                                   # cgroup v2: "max 100000" or "<quota> <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    local = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+    return max(1, min(n // local, 128))
+
+
 class FrameFeeder:
     """iterate over (frames u8 [n,h,w,3] on ``device``, first global index) for the sorted ``paths``: every batch is read and decoded
     by ONE native call (sd_decode_files_bgr: ``workers`` C++ threads, no interpreter lock) straight into a pinned staging buffer,
@@ -90,7 +109,7 @@ class FrameFeeder:
         import os
         import torch
         self.paths, self.batch, self.device = list(paths), batch, torch.device(device)
-        self.workers = workers if workers > 0 else min(os.cpu_count() or 8, 128)
+        self.workers = workers if workers > 0 else default_decode_workers()
         self._torch = torch
         self._pinned = [None, None]
         self._lib = L.load()

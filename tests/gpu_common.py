@@ -52,6 +52,8 @@ def err_report(a, b):
             "rms_rel": float(np.sqrt((d * d).mean()) / scale)}
 
 
+# FROZEN at the round-3 values: these are not re-fitted when a kernel changes (round 4's folded upconvs / fused decoder tail had to pass them
+# as they stood) -- a change that needs them loosened is a numerical regression to be explained, not absorbed.
 # Bounds on the strict per-element figure |delta| / (|ref| + 1e-2 max|ref|), by engine and tensor kind, = 2 x the worst value measured at
 # 512 x 1024 (profiles/r03_strict_error_*.txt: the plan and bf16x2 over 10 / 4 weight + frame seeds against the f32 engine; the f32 engine
 # against the CPU oracle in the bench run and in test_gpu_pipeline): an element of magnitude >= 1 % of the tensor's maximum is then within

@@ -133,3 +133,79 @@ def test_run_sequence_single_process_equals_the_serial_loop():
     got = run_sequence(lambda lo, hi: frames[lo:hi], 9, _stub_step, batch=4).numpy().view(RW_DTYPE).reshape(-1)
     serial = np.concatenate([_stub_step(frames[i:i + 1], i).numpy().view(RW_DTYPE).reshape(-1) for i in range(9)])
     assert np.array_equal(got, serial)
+
+
+# ------------------------------------------------------------------------------------------------ files on disk -> FrameFeeder -> run_sequence_files
+def _files_worker(rank, world, port, paths, batch, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_WORLD_SIZE"] = str(world)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from semantic_depth_amd import frame_io
+        from semantic_depth_amd.distributed import run_sequence_files
+        from semantic_depth_amd.engine import RW_DTYPE
+        opened = []
+        real_decode = frame_io.FrameFeeder._decode_into
+
+        def spy(self, slot, lo, hi):                      # which files THIS rank's feeder decodes
+            opened.extend(self.paths[lo:hi])
+            return real_decode(self, slot, lo, hi)
+        frame_io.FrameFeeder._decode_into = spy
+        seen = []
+
+        def step(frames, first):                           # stub of the engine step: a record per frame that identifies it
+            assert frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[3] == 3
+            rec = np.zeros(frames.shape[0], RW_DTYPE)
+            rec["n_road"] = np.arange(first, first + frames.shape[0])
+            rec["width"] = frames.reshape(frames.shape[0], -1).double().mean(1).numpy()
+            rec["found"] = 1
+            seen.extend(range(first, first + frames.shape[0]))
+            return torch.from_numpy(rec.view(np.uint8).reshape(-1, RECORD_BYTES).copy())
+        allr = run_sequence_files(paths, step, batch=batch, device="cpu")
+        got = allr.numpy().view(RW_DTYPE).reshape(-1)
+        q.put((rank, sorted(opened), seen, got["n_road"].tolist(), got["width"].tolist(), frame_io.default_decode_workers()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_run_sequence_files_world2_each_rank_decodes_only_its_shard(tmp_path):
+    """semantic_depth_cityscapes_sequence.py:689-701 on two ranks: PNG and JPEG frames on disk, every rank's FrameFeeder decodes ONLY its
+    contiguous shard of the sorted list (ragged: 7 frames), the gathered records are in global frame order on both ranks, and the default
+    decode-thread count is this rank's share of the CPUs it may use (not os.cpu_count() per rank)."""
+    PILImage = pytest.importorskip("PIL.Image")
+    from semantic_depth_amd import outputs
+    rng = np.random.default_rng(4)
+    n, h, w = 7, 32, 48
+    frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    paths = []
+    for i in range(n):
+        if i % 3 == 2:                                    # a JPEG among the PNGs (the reference's own example frame is one)
+            p = str(tmp_path / f"frame_{i:03d}.jpg")
+            PILImage.fromarray(frames[i][..., ::-1]).save(p, "JPEG", quality=90)
+        else:
+            p = outputs.write_png(str(tmp_path / f"frame_{i:03d}.png"), frames[i])
+        paths.append(p)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_files_worker, args=(r, 2, port, paths[::-1], 2, q)) for r in range(2)]      # (unsorted on purpose)
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    srt = sorted(paths)
+    for rank, opened, seen, n_road, width, workers in res:
+        lo, hi = shard_range(n, rank, 2)
+        assert opened == srt[lo:hi] and seen == list(range(lo, hi))
+        assert n_road == list(range(n))
+        for i in range(n):
+            if srt[i].endswith(".png"):
+                assert abs(width[i] - frames[i].astype(np.float64).mean()) < 1e-9      # PNG frames arrive bit for bit
+        try:
+            cpus = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cpus = os.cpu_count() or 1
+        assert 1 <= workers <= max(1, cpus // 2)

@@ -127,7 +127,7 @@ def oracle_b8():
     return dict(wf=wf, wm=wm, frames=fr, logits=logits, disp=np.stack(disp))
 
 
-@pytest.mark.parametrize("precision", ["f32", "plan"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "plan"])
 def test_nets_b8_full_size_match_oracle(precision, oracle_b8):
     """configs[1] (FCN-8s forward, B = 8) and configs[2] (monodepth-resnet50 forward on frame + flip, B = 8) in one network pass
     each, every frame against the oracle: logits, masks, raw disparity pair, post-processed disparity"""
@@ -311,6 +311,45 @@ def test_split_engine_records_track_the_exact_f32_engine(prec, flip_tol, disp_to
 
 
 # ------------------------------------------------------------------------------------------------ the reference-shaped boundary
+@pytest.mark.parametrize("precision", ["bf16x3"])
+def test_process_frame_full_size_against_the_oracle(precision):
+    """BASELINE configs[0]'s substitute at the size it names: ONE 512 x 1024 frame through api.FrameProcessor.process_frame (the
+    reference's per-frame operator, semantic_depth.py:98-334) on the headline engine.  Networks against the CPU oracle (logits -> masks
+    as a mismatch fraction, disparity within 1e-3 and the strict bound); the exact tail -- back-projection, mask gather, road chain,
+    width -- bit for bit against oracle.pipeline.frame_tail fed the engine's own raw disparity pair and masks."""
+    from semantic_depth_amd import api
+    wf = Wt.make_fcn8s_weights(11, decoder_std=0.05, bias_std=0.1)
+    wm = Wt.make_monodepth_weights("resnet50", 12, bias_std=0.05)
+    depther = api.DepthFrame(False, "resnet50", H, W, wm, None, precision=precision)
+    segmenter = api.SegmentFrame((H, W), wf, True, False, "0", precision=precision)
+    assert segmenter.engine is depther.engine and depther.engine.precision == precision
+    frame = _smooth_frames(1, seed=77)[0]
+    road, fence, _ = segmenter.segment_frame(frame)
+    lg = nets.fcn8s_forward(frame[None], wf)
+    _, road_r, fence_r, _ = nets.softmax_masks(lg[0])
+    assert float((road[..., 0] != road_r).mean()) < 2e-3 and float((fence[..., 0] != fence_r).mean()) < 2e-3
+    disp = depther.compute_disparity(frame)
+    ref_disp = nets.compute_disparity(frame, wm, "resnet50")
+    assert_close(disp, ref_disp, precision, TOL, "disparity of the frame", kind="disp")
+    depther.f = 10.0 * float(np.median(disp)) * W                                   # the driver reassigns .f (:859): points at the measuring depth
+    fp = api.FrameProcessor(segmenter, depther, depth=10.0, approach="rw")
+    res = fp.process_frame(frame, want_clouds=True)
+    assert np.array_equal(res["road_mask"], road[..., 0]) and np.array_equal(res["disparity"], disp * np.float32(W))
+    cam_d = dict(cx=depther.cx, cy=depther.cy, f=depther.f, b=depther.b, disp_mult=float(W))
+    _, raw = depther.engine.monodepth_forward(dev(frame[None]), want_raw=True)
+    ref = pipeline.frame_tail(raw[0].cpu().numpy(), road[..., 0], fence[..., 0], frame, cam_d, pipeline.RoadWidthParams())
+    assert np.array_equal(res["road3D"], ref["road3d"]) and np.array_equal(res["road_colors"], ref["road_rgb"])
+    rec = res["record"]
+    assert int(rec["n_road"]) == ref["road3d"].shape[0]
+    for k in ("n_zcut", "n_mad_y", "n_mad_x", "n_plane", "n_sor", "n_ror"):
+        assert int(rec[k]) == int(ref["rw"][k]), k
+    assert bool(rec["found"]) == ref["rw"]["found"]
+    if ref["rw"]["found"]:
+        assert res["dist_rw"] == ref["rw"]["width"]
+    assert np.array_equal(res["road3D_final"].astype(np.float64), ref["rw"]["points"])
+    print("512x1024 process_frame", precision, "road points", int(rec["n_road"]), "after the chain", int(rec["n_ror"]), "width", res.get("dist_rw"))
+
+
 def test_api_classes_built_like_the_reference_main(tmp_path):
     """semantic_depth.py:773-789: DepthFrame and SegmentFrame are constructed independently (no shared-engine argument), then
     handed to FrameProcessor; process_frame on a frame that is NOT the network size (cubic resize on the GPU, :111)."""
