@@ -574,6 +574,21 @@ def peak_of(kernel: str, precision: str) -> float:
     return PEAK_2P if "f16w" in kernel else PEAK_3P
 
 
+def sustained_mfma_tflops():
+    """MFMA products per second the chip sustains under its power limit with operands that have the toggle statistics of the engine's planes
+    (scripts/probe_mfma_planes.hip, mode 2: hi / mid / lo planes of dense values in the six-product mix) -- read from the committed probe
+    output, profiles/r04_mfma_sustained_planes_probe.txt; (value, source)"""
+    import re
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_mfma_sustained_planes_probe.txt")
+    try:
+        vals = [float(m.group(1)) for m in re.finditer(r"mode 2 .*?: [0-9.]+ ms\s+([0-9.]+) TFLOP/s of MFMA products", open(path).read())]
+        if vals:
+            return sum(vals) / len(vals), "profiles/r04_mfma_sustained_planes_probe.txt (mode 2, mean of %d runs)" % len(vals)
+    except OSError:
+        pass
+    return 1812.0, "profiles/r01_mfma_sustained_probe.txt (random mantissas)"
+
+
 def conv_roofline(buckets, precision, dt):
     """`roofline` of the contract for the DOMINANT conv kernel (most time in this run) + the whole conv engine under `engine`.
     Durations are HIP events recorded by the library around every conv launch on the launch stream (sd_profile).  ``dt``: seconds of
@@ -593,9 +608,16 @@ def conv_roofline(buckets, precision, dt):
     if traffic_src is None:
         traffic, traffic_src = pmc_traffic(dom["kernel"], "*pmc_conv_traffic.json")
     dpk = peak_of(dom["kernel"], precision)
+    sus, sus_src = sustained_mfma_tflops()
+    prod = lambda k: 2500.0 / peak_of(k, precision) if "igemm" not in k else None       # MFMA products per algorithmic product
     return {
         "bound": "mfma", "kernel": dom["kernel"], "achieved": round(ach(dom), 2), "peak": round(dpk, 1), "unit": "TFLOP/s",
-        "frac": round(ach(dom) / dpk, 4), "traffic": traffic, "traffic_source": traffic_src,
+        "frac": round(ach(dom) / dpk, 4),
+        # the same against what the chip SUSTAINS under its power limit with plane-like operands (the nominal 2500 is reached with
+        # constant operands only): says whether the kernel's MFMA stream has anything left to tune
+        "frac_of_sustained": (round(ach(dom) * prod(dom["kernel"]) / sus, 4) if prod(dom["kernel"]) else None),
+        "sustained_mfma_tflops": round(sus, 1), "sustained_source": sus_src,
+        "traffic": traffic, "traffic_source": traffic_src,
         "launches": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
         "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
         "algorithmic_bytes_per_launch": round(dom.get("bytes", 0.0) / dom["launches"]),
@@ -608,7 +630,9 @@ def conv_roofline(buckets, precision, dt):
                    "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / eff_peak, 4), "launches": tot_n,
                    "conv_time_share_of_step": round(tot_ms * 1e-3 / dt, 4)},
         "by_kernel": [{"kernel": b["kernel"], "launches": b["launches"], "ms": round(b["ms"], 3), "tflops": round(ach(b), 2),
-                       "frac": round(ach(b) / peak_of(b["kernel"], precision), 4)} for b in sorted(buckets, key=lambda b: -b["ms"])],
+                       "frac": round(ach(b) / peak_of(b["kernel"], precision), 4),
+                       **({"frac_of_sustained": round(ach(b) * prod(b["kernel"]) / sus, 4)} if prod(b["kernel"]) else {})}
+                      for b in sorted(buckets, key=lambda b: -b["ms"])],
     }
 
 

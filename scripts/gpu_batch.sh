@@ -1,11 +1,10 @@
 #!/bin/bash
-tag=${1:-r04n}
+tag=${1:-r04o}
 mkdir -p gpurun_out/$tag
 o=gpurun_out/$tag
-timeout 900 python bench.py --legs none --steps 20 --warmup 5 --repeats 3 --no-cpu-baseline > $o/bench.json 2> $o/bench.log
-grep 'frames/s' $o/bench.log | cut -c1-220
-timeout 900 python -m pytest tests/test_gpu_pipeline.py -x -q -m gpu -s -k "process_frame_full_size or b8_full_size" > $o/pytest.txt 2>&1; tail -6 $o/pytest.txt
-for fd in "" "--from-disk"; do
-timeout 900 python bench.py --config 5 $fd --legs none --steps 10 --warmup 2 --repeats 2 --no-cpu-baseline > $o/bench5$fd.json 2> $o/bench5$fd.log
-echo "config 5 $fd: $(grep 'frames/s' $o/bench5$fd.log | cut -c1-160)"; tail -2 $o/bench5$fd.log | cut -c1-300
+for rep in 1 2; do
+for v in "" "SEMDEPTH_NO_FOLD=1" "SEMDEPTH_NO_ROWSKIP=1" "SEMDEPTH_NO_TAIL1=1"; do
+  env $v timeout 600 python bench.py --legs none --steps 12 --warmup 4 --repeats 2 --no-cpu-baseline > $o/bench_${v}_$rep.json 2> $o/bench_${v}_$rep.log
+  echo "[$v] $(grep 'frames/s' $o/bench_${v}_$rep.log | cut -c1-200)"
+done
 done

@@ -530,18 +530,20 @@ hipError_t launch_conv_direct3(const ConvDirectParams& p, hipStream_t s) {
     const bool up = p.all_up && !(p.H & 1) && !(p.W & 1) && !(p.sw & SW_NO_UPTILE);
     const int tiles = (p.W / T3_TW) * ((p.H + T3_TH - 1) / T3_TH) * p.N * p.nsplit;
     const dim3 grid((unsigned)(tiles < cus ? tiles : cus));        // persistent: one workgroup per CU (158 KB of LDS)
-    // A/B switches of the handle (plan.cpp latch_switches): the X fragments of the hi / mid planes kept in registers or re-read; the
-    // three-slot weight ring of the NB = 1 layers (measured equal or 3-6 % slower than the two-slot form on upconv1 / iconv1 / upconv2 /
-    // iconv2 -- profiles/r03g_conv_direct3_ring3_ab.txt -- so it is off by default)
     if (p.fold) {             // upsample-folded upconv layers: source-resolution tiles, two-slot ring, kept fragments
         if (!up || p.pool) return hipErrorInvalidValue;
         if (p.Cout <= 32) hipLaunchKernelGGL((conv_direct3_kernel<1, true, 2, 2, true>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv_direct3_kernel<2, true, 2, 2, true>), grid, dim3(512), 0, s, p);
         return hipGetLastError();
     }
+    // Production: X fragments of the hi / mid planes kept in registers (KEEP = 2), two-slot weight ring.  The variants measured and not
+    // adopted -- KEEP = 0 (re-read fragments: -1 %, profiles/r03d_conv_direct3_keep_ab.txt), the three-slot ring of the NB = 1 layers (equal
+    // or 3-6 % slower, profiles/r03g_conv_direct3_ring3_ab.txt) -- are compiled only with -DSD_DEV_VARIANTS (SEMDEPTH_X3_KEEP=0,
+    // SEMDEPTH_X3_RING3 then select them); the default build carries six instantiations of this kernel instead of sixteen.
+    const ConvDirectParams& pd = p;
+#ifdef SD_DEV_VARIANTS
     const int keep = (p.sw & SW_X3_NOKEEP) ? 0 : 2;
     const bool ring3 = (p.sw & SW_X3_RING3) != 0;
-    const ConvDirectParams& pd = p;
 #define SD_D3(NB_, UP_, WS_) do { if (keep >= 2) hipLaunchKernelGGL((conv_direct3_kernel<NB_, UP_, 2, WS_>), grid, dim3(512), 0, s, pd); \
                                   else hipLaunchKernelGGL((conv_direct3_kernel<NB_, UP_, 0, WS_>), grid, dim3(512), 0, s, pd); } while (0)
     if (p.Cout <= 32) {
@@ -550,6 +552,11 @@ hipError_t launch_conv_direct3(const ConvDirectParams& p, hipStream_t s) {
     } else {
         if (up) SD_D3(2, true, 2); else SD_D3(2, false, 2);
     }
+#else
+#define SD_D3(NB_, UP_, WS_) hipLaunchKernelGGL((conv_direct3_kernel<NB_, UP_, 2, WS_>), grid, dim3(512), 0, s, pd)
+    if (p.Cout <= 32) { if (up) SD_D3(1, true, 2); else SD_D3(1, false, 2); }
+    else { if (up) SD_D3(2, true, 2); else SD_D3(2, false, 2); }
+#endif
 #undef SD_D3
     return hipGetLastError();
 }
