@@ -39,7 +39,9 @@ def label(k):
         m2 = re.search(r"sd::(\w+_kernel)", k)
         return m2.group(1) if m2 else None
     fam, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
-    if fam == "conv_direct3":      # <NB, UP, KEEP>  (bf16 x 3)
+    if fam == "conv_direct3":      # <NB, UP, KEEP, WSLOTS, FOLD>  (bf16 x 3)
+        if len(args) > 4 and args[4] == "true":
+            return f"conv_direct_x3_fold_kernel<{args[0]}>"
         return f"conv_direct_x3_kernel<{args[0]},2>"
     if fam == "conv_direct":       # <NB, MT, F16, N16, UP, W1, X2>
         prec = "_f16w_x2" if (len(args) > 6 and args[6] == "true") else "_f16x1" if (len(args) > 5 and args[5] == "true") else ("_f16w" if args[2] == "true" else "")
