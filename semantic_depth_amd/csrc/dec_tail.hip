@@ -44,7 +44,7 @@ constexpr int DT_NPIX = DT_TH * DT_TW;
 
 __global__ __launch_bounds__(512, 1) void dec_tail1_x3_kernel(const DecTailParams p) {
     static_assert((2 * DT_UE + 3 * DT_APL) * 16 + DT_IR * DT_IC * DT_IPIX + 3 * DT_DPL * 4 <= 160 * 1024, "tiles fit the LDS of a CU");
-    static_assert(DT_IR % 2 == 0 && DT_NPIX % 2 == 0 && DT_NPIX / 2 <= DT_NG, "work split of stages 2 and 3");
+    static_assert(DT_IR % 2 == 0 && DT_NPIX % 4 == 0 && DT_NPIX / 4 <= 64, "work split of stages 2 and 3");
     __shared__ __attribute__((aligned(16))) u32x4 UE[2 * DT_UE];
     __shared__ __attribute__((aligned(16))) u32x4 A[3 * DT_APL];
     __shared__ __attribute__((aligned(16))) unsigned char I[DT_IR * DT_IC * DT_IPIX];
@@ -83,20 +83,37 @@ __global__ __launch_bounds__(512, 1) void dec_tail1_x3_kernel(const DecTailParam
     auto wd_at = [&](int i) {           // i: compile-time constant after unrolling
         return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, i < 64 ? wdr0 : i < 128 ? wdr1 : wdr2), i & 63));
     };
-    // stage 3 for pixel pi of the tile whose i tile is in LDS
+    // stage 3 for pixel pi of the tile whose i tile is in LDS.  The reads of a tap of the 3 x 3 x 16 window go out two taps ahead of its FMAs (one
+    // wave per SIMD runs this phase: nothing else hides an LDS round trip), the 16 weights of a tap are broadcast into 16 scalar registers before its FMAs (a
+    // v_readlane directly in front of the FMA that uses it costs two wait states each) and two accumulators halve the dependent chain
     auto head = [&](const Tile& tl, int pi) {
         const int ry = pi / DT_TW, cx = pi - ry * DT_TW;
-        float acc = p.bd[0];
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        f32x4 v[3][4];                                        // the 16 channels of a tap, two taps ahead of the FMAs
+        auto tapload = [&](int slot, int tap) {
             const unsigned char* ip = I + ((ry + tap / 3) * DT_IC + cx + tap % 3) * DT_IPIX;
 #pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(ip + 16 * c4);
+            for (int c4 = 0; c4 < 4; ++c4) v[slot][c4] = *reinterpret_cast<const f32x4*>(ip + 16 * c4);
+        };
+        tapload(0, 0); tapload(1, 1);
+        float acc0 = p.bd[0], acc1 = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc += v[e] * wd_at(tap * 16 + 4 * c4 + e);
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 2 < 9) tapload((tap + 2) % 3, tap + 2);
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {                     // eight weights at a time (scalar registers are scarce too)
+                float w[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[e] = wd_at(tap * 16 + 8 * hf + e);
+
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    acc0 += v[tap % 3][2 * hf + (e >> 2)][e & 3] * w[e];
+                    acc1 += v[tap % 3][2 * hf + ((e + 1) >> 2)][(e + 1) & 3] * w[e + 1];
+                }
+
             }
         }
+        const float acc = acc0 + acc1;
         p.out[((size_t)tl.img * H + tl.y0 + ry) * W + tl.x0 + cx] = 0.3f * (1.0f / (1.0f + expf(-acc)));
     };
 
@@ -172,15 +189,13 @@ __global__ __launch_bounds__(512, 1) void dec_tail1_x3_kernel(const DecTailParam
             for (int pl = 0; pl < 3; ++pl) w1[tp][pl] = p.w1[((q * 4 + tp) * 3 + pl) * 64 + lane];
         const f32x4 bias1 = *reinterpret_cast<const f32x4*>(p.b1 + 4 * lg);
 
-        Tile nxt = tile_of(K > 0 ? first : 0), prev = nxt;                    // (one tile decode per iteration: the divisions are VALU work)
+        Tile nxt = tile_of(K > 0 ? first : 0);                                // (one tile decode per iteration: the divisions are VALU work)
         if (K > 0) { prefetch(nxt); stash(); }
         __syncthreads();
         for (int k = 0; k <= K; ++k) {
-            const Tile done = prev;                                            // tile k - 1
             // ---------------- phase A: e and stage 1 of tile k (the other group: stage 2 of tile k - 1)
             if (k < K) {
                 const Tile cur = nxt;
-                prev = cur;
                 const int y0 = cur.y0, x0 = cur.x0;
                 u32x4* const Ub = UE + (k & 1) * DT_UE;
                 if (k + 1 < K) { nxt = tile_of(first + (k + 1) * stride); prefetch(nxt); }
@@ -238,9 +253,8 @@ __global__ __launch_bounds__(512, 1) void dec_tail1_x3_kernel(const DecTailParam
                 }
             }
             __syncthreads();
-            // ---------------- phase B: the source pixels of tile k + 1 into LDS, then this group's half of stage 3 of tile k - 1
+            // ---------------- phase B: the source pixels of tile k + 1 into LDS (the other group: stage 3 of tile k - 1)
             if (k + 1 < K) stash();
-            if (k >= 1 && diag != 3 && tg < DT_NPIX / 2) head(done, DT_NPIX / 2 + tg);
             __syncthreads();
         }
     } else {
@@ -294,8 +308,9 @@ __global__ __launch_bounds__(512, 1) void dec_tail1_x3_kernel(const DecTailParam
                 }
             }
             __syncthreads();
-            // ---------------- phase B: this group's half of stage 3 of tile k - 1
-            if (k >= 1 && diag != 3 && tg < DT_NPIX / 2) head(cur, tg);
+            // ---------------- phase B: stage 3 of tile k - 1, a quarter of the tile's pixels per wave: VALU time is per wave instruction, so
+            //                  one pass on each SIMD (56 of 64 lanes) instead of two passes on two of them
+            if (k >= 1 && diag != 3 && lane < DT_NPIX / 4) head(cur, wv * (DT_NPIX / 4) + lane);
             __syncthreads();
         }
     }
