@@ -189,6 +189,12 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 if (p.x3 && !op.fold && op.nsrc == 1 && op.vec && op.Kvec == op.Kpad && op.k >= 3 && op.sstride[0] == 1 && !op.up[0] && !c.pool &&
                     op.Kpad == op.k * op.k * s0.C && c.Wout > 0 && 256 % c.Wout == 0 && N % (256 / c.Wout) == 0 && !(h->sw & SW_NO_ROWSKIP))
                     c.rowgrp = 256 / c.Wout;
+                c.flat = (p.x3 && op.k == 1 && !op.fold && !op.up[0] && !(op.nsrc > 1 && op.up[1]) && op.nsrc <= 2 && !(h->sw & SW_NO_FLAT)) ? 1 : 0;
+                c.noup = (p.x3 && op.nsrc <= 2 && !(h->sw & SW_NO_FLAT)) ? 1 : 0;
+                for (int j = 0; j < op.nsrc; ++j) {      // (32-bit byte offsets inside a plane of every source; strides 1 or 2)
+                    if (PL(op.src[j]) * 2 >= ((size_t)1 << 32)) c.flat = c.noup = 0;
+                    if (op.up[j] || op.sstride[j] < 1 || op.sstride[j] > 2) c.noup = 0;
+                }
                 if (op.fold) {          // (conv_dma3.hip: the GEMM's pixel space is the source itself)
                     c.fold = 1; c.simple = 0; c.Hin = s0.H; c.Win = s0.W; c.Hout = s0.H; c.Wout = s0.W; c.kh = c.kw = 2;
                 }

@@ -56,6 +56,15 @@ constexpr int G3_PAIR = G3_XPL + G3_WPL;
 constexpr int G3_LDS = G3_RING * G3_PAIR;    // units (128 KB)
 constexpr int G3_ROW = G3_NT * 64 + 16;
 
+// FLAT (ConvParams::flat): every k-tile reads its source at tap (0, 0) without an upsample -- the 1x1 layers: the ResNet block tails (conv3 +
+// projection over the concatenated K axis, the shortcut source at the block's stride), conv1 of res4 / res5, fc7.  The pixel this lane
+// fetches is then the same for every k-tile of a source: its byte offset is computed ONCE per source geometry (at most two) and a piece
+// of the X DMA is a scalar base + that 32-bit offset, instead of ~20 VALU instructions with four quarter-rate multiplies per piece and
+// phase (274 VALU per k-tile beside 96 MFMAs, and the two pipes of a SIMD do not overlap: profiles/r04_mfma_valu_overlap_probe.txt).
+// Rows past M fetch pixel 0 (finite values; their outputs are never stored).
+// MODE 2 (ConvParams::noup, not flat): any taps, no upsample, at most two source geometries -- the same precomputed pixel offset plus a
+// SCALAR tap offset and the in-image test (fc6, the folded upconvs, the strided 3x3 layers): ~10 VALU per piece, no multiplies.
+template <int MODE>
 __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
     static_assert(G3_NW * 3 * 32 * G3_ROW <= G3_LDS * 16, "epilogue slabs fit in the ring");
     __shared__ __attribute__((aligned(16))) u32x4 lds[G3_LDS];
@@ -127,11 +136,44 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
     auto knext = [&](KCur c) { ++c.idx; if (++c.tt == nt) { c.tt = 0; c.idx += taps - nt; } return c; };
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds;
 
+    // FLAT: byte offsets of this lane's two pixels (+ its octet) in the source geometry of the first k-tile (A) and of the last one (B; the
+    // same as A for a single source); a k-tile takes B when its geometry differs from A's
+    unsigned offA0 = 0u, offA1 = 0u, offB0 = 0u, offB1 = 0u;
+    int geoA_W = 0, geoA_C = 0, geoA_st = 0;
+    constexpr bool FLAT = MODE == 1, PRE = MODE == 2;
+    if constexpr (FLAT || PRE) {
+        const KEntry ea = g3load_kentry(ktab), eb = g3load_kentry(ktab + p.Kpad / 32 - 1);
+        geoA_W = ea.W; geoA_C = ea.C; geoA_st = (ea.flags >> 4) & 3;
+        const int sa = geoA_st, sb = (eb.flags >> 4) & 3;
+        auto off_of = [&](int yx, int ik, int H_, int W_, int C_, int st_) {
+            const int oy = yx & 0xffff, ox = yx >> 16, img = ik & 0x3ffffff, oct = (ik >> 26) & 3;
+            return ((ik >> 30) & 1) ? (unsigned)((((img * H_ + oy * st_) * W_ + ox * st_) * C_ + oct * 8) * 2) : (unsigned)(oct * 16);
+        };
+        offA0 = off_of(pyx[0], pik[0], ea.H, ea.W, ea.C, sa); offA1 = off_of(pyx[1], pik[1], ea.H, ea.W, ea.C, sa);
+        offB0 = off_of(pyx[0], pik[0], eb.H, eb.W, eb.C, sb); offB1 = off_of(pyx[1], pik[1], eb.H, eb.W, eb.C, sb);
+    }
     // one DMA instruction of a pair: piece 0, 1 = the weight plane's two instructions of this wave, 2, 3 = the X plane's
     auto issue_x1 = [&](const KEntry& e, int pl, int slot, int i) {     // X plane pl of the k-tile of entry e -> ring slot
         const int st = (e.flags >> 4) & 3, up = e.flags & 1;
         const size_t plane = (size_t)Nmax * e.H * e.W * e.C;
         const unsigned dst = lds0 + (unsigned)(slot * G3_PAIR * 16);
+        if constexpr (FLAT) {
+            const bool isA = e.W == geoA_W && e.C == geoA_C && st == geoA_st;          // (wave-uniform)
+            const uint16_t* sbase = reinterpret_cast<const uint16_t*>(e.base) + (size_t)pl * plane;
+            g3dma16s(sbase, isA ? (i == 0 ? offA0 : offA1) : (i == 0 ? offB0 : offB1), dst + (unsigned)((wave + G3_NW * i) * 1024));
+            return;
+        }
+        if constexpr (PRE) {
+            const bool isA = e.W == geoA_W && e.C == geoA_C && st == geoA_st;          // (wave-uniform)
+            // scalar: plane base + the tap's offset; per lane: the pixel offset of tap (0, 0) and the in-image test
+            const uint16_t* sbase = reinterpret_cast<const uint16_t*>(e.base) + (ptrdiff_t)pl * (ptrdiff_t)plane + ((ptrdiff_t)e.dy * e.W + e.dx) * e.C;
+            const int iy = ((pyx[i] & 0xffff) << (st - 1)) + e.dy, ix = ((pyx[i] >> 16) << (st - 1)) + e.dx;      // (stride 1 or 2)
+            const bool ok = ((pik[i] >> 30) & 1) && (unsigned)iy < (unsigned)e.H && (unsigned)ix < (unsigned)e.W;
+            const unsigned voff = isA ? (i == 0 ? offA0 : offA1) : (i == 0 ? offB0 : offB1);
+            const unsigned char* px = reinterpret_cast<const unsigned char*>(sbase) + voff;
+            g3dma16(ok ? reinterpret_cast<const u32x4*>(px) : zero, dst + (unsigned)((wave + G3_NW * i) * 1024));
+            return;
+        }
         int iy = (pyx[i] & 0xffff) * st + e.dy, ix = (pyx[i] >> 16) * st + e.dx;
         const bool ok = ((pik[i] >> 30) & 1) && iy >= 0 && ix >= 0 && iy < (e.H << up) && ix < (e.W << up);
         iy >>= up; ix >>= up;
@@ -371,7 +413,10 @@ hipError_t launch_conv_dma3(const ConvParams& p, hipStream_t s) {
     if (!conv_dma3_eligible(p)) return hipErrorInvalidValue;
     const long M = (long)p.N * p.Hout * p.Wout;
     const int tilesM = (int)((M + G3_BM - 1) / G3_BM), tilesN = p.Cout / G3_BN;
-    hipLaunchKernelGGL(conv_dma3_kernel, dim3((unsigned)(tilesM * tilesN * (p.fold ? 4 : 1))), dim3(512), 0, s, p, (int)M, tilesM, tilesN);
+    const dim3 grid((unsigned)(tilesM * tilesN * (p.fold ? 4 : 1)));
+    if (p.flat && !p.fold && !p.rowgrp) hipLaunchKernelGGL(conv_dma3_kernel<1>, grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
+    else if (p.noup) hipLaunchKernelGGL(conv_dma3_kernel<2>, grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
+    else hipLaunchKernelGGL(conv_dma3_kernel<0>, grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
     return hipGetLastError();
 }
 

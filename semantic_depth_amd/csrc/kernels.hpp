@@ -19,7 +19,8 @@ enum Switch : unsigned {
     SW_X3_NOKEEP = 1u << 12, SW_X3_RING3 = 1u << 13, SW_NO_DMA3 = 1u << 14, SW_X3_DIAG_NOSTORE = 1u << 15, SW_X3_DIAG_NOMFMA = 1u << 16,
     SW_NO_FOLD = 1u << 17,       // SEMDEPTH_NO_FOLD: the upconv layers as 3x3 convs on the upsampled source (plan-time switch)
     SW_NO_TAIL1 = 1u << 18,      // SEMDEPTH_NO_TAIL1: upconv1 / iconv1 / disp1 of the bf16 x 3 monodepth as three launches (plan-time switch)
-    SW_NO_ROWSKIP = 1u << 19     // SEMDEPTH_NO_ROWSKIP: conv_dma3 without the row-grouped pixel order (ConvParams::rowgrp)
+    SW_NO_ROWSKIP = 1u << 19,    // SEMDEPTH_NO_ROWSKIP: conv_dma3 without the row-grouped pixel order (ConvParams::rowgrp)
+    SW_NO_FLAT = 1u << 20        // SEMDEPTH_NO_FLAT: conv_dma3's 1x1 layers through the general gather
 };
 unsigned latch_switches();      // plan.cpp
 
@@ -74,6 +75,10 @@ struct ConvParams {
     unsigned sw;       // Switch bits of the handle
     unsigned long long* sat;   // DEVICE counter of fp16-saturated output values (split_fmt.hpp sat_report; sd_saturation_count)
     int x3;            // 1: bf16 x 3 planes in, out and in the weights (SD_PREC_BF16X3: six MFMA products per product, split_fmt.hpp)
+    int flat;          // 1 (conv_dma3.hip): a 1x1 conv without upsample (every source read at tap (0, 0), per-source strides allowed): the gather
+                       // offset of a lane is computed once per source geometry (conv_dma3_kernel<FLAT>); SEMDEPTH_NO_FLAT switches it off
+    int noup;          // 1 (conv_dma3.hip): no source is read through an upsample, <= 2 sources, strides 1 or 2, planes below 4 GB: the gather of a
+                       // k-tile is a precomputed per-lane pixel offset + a scalar tap offset + the in-image test (conv_dma3_kernel<2>)
     int rowgrp;        // > 0 (conv_dma3.hip): the GEMM's pixels are ordered (image group of rowgrp images, row, image, column) with rowgrp * Wout = 256,
                        // so that a 256-pixel tile is ONE output row of rowgrp images and skips the k-tiles of the taps whose input row is zero
                        // padding (fc6: 7x7 on 16 rows, 10.7 % of the k-tiles).  Results are bit-identical to the plain order.
