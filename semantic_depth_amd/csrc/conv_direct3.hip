@@ -106,17 +106,27 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
         return r;
     };
 
-    // halo geometry of this lane's X-DMA slots (instruction j = wave + 8 i of a plane): constant over tiles and chunks.
-    // packed: ry | rx << 8 | octet << 19 | inside-halo << 20
-    int geo[XS];
+    // halo geometry of this lane's X-DMA slots (instruction j = wave + 8 i of a plane): constant over tiles and chunks.  The element offset
+    // of slot i inside a source is ((gy0 + ry) W + gx0 + rx) C + octet: the lane's pixel share ry W + rx is the same for every tile and every
+    // source that is not read through an upsample of its own (they all have the layer's width) -- kept in a register per slot; the tile's
+    // share is scalar arithmetic and the product with C one full-rate 24-bit multiply-add.  (Recomputing row and column per slot cost two
+    // quarter-rate multiplies + ten VALU per DMA instruction, and the MFMA and VALU pipes of a SIMD do not overlap.)
+    auto slot_geo = [&](int i, int& ry, int& rx, int& oct) {    // halo row / column / channel octet of slot i; false: beyond the halo
+        const int u = (wave + T3_WAVES * i) * 64 + lane;
+        const int pix = u >> 1;
+        oct = (u & 1) ^ ((pix >> 3) & 1);
+        ry = pix / S_HW; rx = pix - ry * S_HW;
+        return pix < S_HH * S_HW;
+    };
+    const int Wsrc = UP ? p.W >> 1 : p.W;                      // width of the sources read at the layer's own resolution
+    unsigned pshare[XS];                                       // ry W + rx
+    unsigned octb = 0;                                         // bit i: octet of slot i
 #pragma unroll
     for (int i = 0; i < XS; ++i) {
-        const int j = wave + T3_WAVES * i;
-        const int u = j * 64 + lane;
-        const int pix = u >> 1;
-        const int oct = (u & 1) ^ ((pix >> 3) & 1);
-        const int ry = pix / S_HW, rx = pix - ry * S_HW;
-        geo[i] = ry | (rx << 8) | (oct << 19) | ((pix < S_HH * S_HW ? 1 : 0) << 20);
+        int ry, rx, oct;
+        slot_geo(i, ry, rx, oct);
+        pshare[i] = (unsigned)(ry * Wsrc + rx);
+        octb |= (unsigned)oct << i;
     }
     unsigned okA = 0, okB = 0;            // bit i: slot i reads an existing pixel (okB: ... and the first channel octet of a chunk)
     int tgy = 0, tgx = 0;                 // source coordinates of halo pixel (0, 0) of the cursor tile (wave-uniform)
@@ -125,11 +135,12 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
         tgy = (UP ? (tl.ty0 >> 1) : tl.ty0) - 1; tgx = (UP ? (tl.tx0 >> 1) : tl.tx0) - 1;
 #pragma unroll
         for (int i = 0; i < XS; ++i) {
-            const int ry = geo[i] & 0xff, rx = (geo[i] >> 8) & 0xff;
+            int ry, rx, oct;
+            const bool halo = slot_geo(i, ry, rx, oct);
             const int gy = tgy + ry, gx = tgx + rx;
-            const bool in = ((geo[i] >> 20) & 1) && (unsigned)gy < (unsigned)(UP ? p.H >> 1 : p.H) && (unsigned)gx < (unsigned)(UP ? p.W >> 1 : p.W);
+            const bool in = halo && (unsigned)gy < (unsigned)(UP ? p.H >> 1 : p.H) && (unsigned)gx < (unsigned)(UP ? p.W >> 1 : p.W);
             okA |= (in ? 1u : 0u) << i;
-            okB |= ((in && !((geo[i] >> 19) & 1)) ? 1u : 0u) << i;
+            okB |= ((in && !oct) ? 1u : 0u) << i;
         }
     };
     // a chunk in flight: source image + plane stride, its X buffer, its weight block (hi plane; plane stride = nchunks * WUNITS)
@@ -148,9 +159,17 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
     auto xslot = [&](const ChunkCtx& k, int pl, int i) {       // X-DMA instruction wave + 8 i of plane pl
         const int j = wave + T3_WAVES * i;
         if (j >= XI) return;
-        const int gy = k.gy0 + (geo[i] & 0xff), gx = k.gx0 + ((geo[i] >> 8) & 0xff);      // (recomputed per slot: two VALU operations, no registers held)
-        const unsigned off = (unsigned)(gy >> k.up) * k.rowel + ((unsigned)(gx >> k.up) * k.C + ((unsigned)(geo[i] >> 16) & 8u));
-        const uint16_t* src = k.img + (size_t)pl * k.plane + off;
+        const uint16_t* src;
+        if (k.up == 0) {        // (wave-uniform) scalar tile share + the lane's pixel share x C
+            const unsigned off = __umul24(pshare[i], k.C) + (((octb >> i) & 1u) << 3);
+            src = k.img + (ptrdiff_t)pl * (ptrdiff_t)k.plane + ((ptrdiff_t)k.gy0 * (ptrdiff_t)k.rowel + (ptrdiff_t)k.gx0 * (ptrdiff_t)k.C) + off;
+        } else {                // a x2-upsampled source of a mixed layer (up2(disp) of the iconv layers): halo coordinates halved per pixel
+            int ry, rx, oct;
+            slot_geo(i, ry, rx, oct);
+            const int gy = k.gy0 + ry, gx = k.gx0 + rx;
+            const unsigned off = (unsigned)(gy >> 1) * k.rowel + ((unsigned)(gx >> 1) * k.C + (unsigned)(oct << 3));
+            src = k.img + (size_t)pl * k.plane + off;
+        }
         d3dma16(((k.okm >> i) & 1u) ? reinterpret_cast<const u32x4*>(src) : zero, k.xbyte + (unsigned)((pl * XUNITS + j * 64) * 16));
     };
     auto wslot = [&](const u32x4* wbase, int pl, int i, int slot) {     // weight-DMA instruction wave + 8 i of plane pl into ring slot
