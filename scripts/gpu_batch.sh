@@ -1,22 +1,13 @@
 #!/bin/bash
-# round-4 evidence run: all -m gpu tests, kernel stats, HBM traffic (separate FETCH / WRITE passes), SQ counters, layer times, the default bench line
-tag=${1:-r04v}
+tag=${1:-r04w}
 mkdir -p gpurun_out/$tag
 o=gpurun_out/$tag
-timeout 1500 python -m pytest tests -x -q -m gpu > $o/pytest.txt 2>&1; tail -3 $o/pytest.txt
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="bench.py --no-overlap --legs none --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -d $o/stats -o t --output-format csv -- python3 $B --steps 5 --warmup 2 --repeats 1 > $o/bench_stats.json 2> $o/bench_stats.log
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $o/fetch -o t --output-format csv -- python3 $B --steps 1 --warmup 1 --repeats 1 > /dev/null 2> $o/fetch.log
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $o/write -o t --output-format csv -- python3 $B --steps 1 --warmup 1 --repeats 1 > /dev/null 2> $o/write.log
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS -d $o/sq -o t --output-format csv -- python3 $B --steps 3 --warmup 2 --repeats 1 > /dev/null 2> $o/sq.log
-python3 scripts/pmc_conv_traffic.py $o/fetch/t_counter_collection.csv $o/write/t_counter_collection.csv $o/pmc_conv_traffic_bf16x3.json conv_ "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 $B --steps 1 --warmup 1 --repeats 1"
-python3 scripts/pmc_conv_traffic.py $o/fetch/t_counter_collection.csv $o/write/t_counter_collection.csv $o/pmc_tail_traffic.json dec_tail "same passes, dec_tail1_x3_kernel"
-python3 scripts/pmc_conv_traffic.py $o/fetch/t_counter_collection.csv $o/write/t_counter_collection.csv $o/pmc_fuse_traffic.json fuse_onepass "same passes, fuse_onepass_kernel"
-python3 scripts/pmc_sq_summary.py $o/sq/t_counter_collection.csv $o/sq/t_kernel_trace.csv $o/pmc_sq_bf16x3.json "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS -- python3 $B --steps 3 --warmup 2 --repeats 1" > $o/sq_summary.txt
-cp $o/stats/t_kernel_stats.csv $o/kernel_stats.csv
-rm -rf $o/fetch $o/write $o/sq $o/stats
-timeout 300 python scripts/layer_times.py 32 resnet50 bf16x3 2> $o/layer_times_bf16x3.txt >/dev/null
-timeout 1200 python bench.py > $o/bench_default.json 2> $o/bench_default.log
-grep 'frames/s' $o/bench_default.log | cut -c1-200
-head -3 $o/kernel_stats.csv | cut -c1-160
+timeout 900 python -m pytest tests/test_gpu_nets.py tests/test_gpu_geometries.py -x -q -m gpu > $o/pytest.txt 2>&1; tail -3 $o/pytest.txt
+for r in 1 2; do
+timeout 300 python scripts/layer_times.py 32 resnet50 bf16x3 2> $o/layers_new$r.txt >/dev/null; grep -h "conv1_1 \|enc/conv1 " $o/layers_new$r.txt | awk '{print $2, $6}' | tr '\n' ' '; tail -2 $o/layers_new$r.txt | tr '\n' ' '; echo
+done
+cp scripts/ab/conv_stem_old.hip semantic_depth_amd/csrc/conv_stem.hip
+python -m semantic_depth_amd.build > $o/build_old.log 2>&1
+for r in 1 2; do
+timeout 300 python scripts/layer_times.py 32 resnet50 bf16x3 2> $o/layers_old$r.txt >/dev/null; grep -h "conv1_1 \|enc/conv1 " $o/layers_old$r.txt | awk '{print $2, $6}' | tr '\n' ' '; tail -2 $o/layers_old$r.txt | tr '\n' ' '; echo
+done

@@ -38,6 +38,13 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int frow = lane & 31, fk = lane >> 5;
+    // halo offsets of the two taps of (k-step, k half), -1 = past the kernel (zero weights there): computed once, not with two runtime
+    // divisions per k-step and tile (the VALU work beside the MFMAs is paid in full: profiles/r04_mfma_valu_overlap_probe.txt)
+    __shared__ int2 otab[64];
+    if (t < 64) {
+        const int t0 = 4 * (t >> 1) + 2 * (t & 1), t1 = t0 + 1;
+        otab[t] = int2{t0 < taps ? (t0 / k) * IW + (t0 % k) : -1, t1 < taps ? (t1 / k) * IW + (t1 % k) : -1};
+    }
     {   // weights: the LDS image is the global image
         const u32x4* g = reinterpret_cast<const u32x4*>(p.wt);
         const size_t wplane = (size_t)(p.Kpad / 8) * p.CoutPad;
@@ -63,17 +70,24 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
         return r;
     };
     uint2 pf[ST_PF];
+    int pgeo[ST_PF];            // halo units of this thread (the same for every tile): ry | rx << 8 | plane << 16 | valid << 20
+#pragma unroll
+    for (int i = 0; i < ST_PF; ++i) {
+        const int u = t + 512 * i;
+        const int pl = u >= 2 * npix ? 2 : u >= npix ? 1 : 0;
+        const int px = u - pl * npix;
+        const int ry = px / IW, rx = px - ry * IW;
+        pgeo[i] = ry | (rx << 8) | (pl << 16) | ((u < (F16 ? 1 : NPL) * npix ? 1 : 0) << 20);      // fp16 input: ONE plane
+    }
     auto prefetch = [&](const Tile& tl) {                    // halo unit u = plane * npix + pixel
+        const int gy0 = tl.ty0 * s - p.pad, gx0 = tl.tx0 * s - p.pad;
+        const uint2* const isrc = src + (size_t)tl.img * p.Hin * p.Win;
 #pragma unroll
         for (int i = 0; i < ST_PF; ++i) {
-            const int u = t + 512 * i;
-            const int pl = u >= 2 * npix ? 2 : u >= npix ? 1 : 0;
-            const int px = u - pl * npix;
-            const int ry = px / IW, rx = px - ry * IW;
-            const int gy = tl.ty0 * s - p.pad + ry, gx = tl.tx0 * s - p.pad + rx;
+            const int gy = gy0 + (pgeo[i] & 0xff), gx = gx0 + ((pgeo[i] >> 8) & 0xff), pl = (pgeo[i] >> 16) & 3;
             uint2 v = {0u, 0u};
-            if (u < (F16 ? 1 : NPL) * npix && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win)      // fp16 input: ONE plane
-                v = src[(size_t)pl * splane + ((size_t)tl.img * p.Hin + gy) * p.Win + gx];
+            if (((pgeo[i] >> 20) & 1) && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win)
+                v = isrc[(size_t)pl * splane + (size_t)(gy * p.Win + gx)];
             pf[i] = v;
         }
     };
@@ -109,20 +123,21 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
                 for (int r = 0; r < 16; ++r) acc[a][nb][r] = 0.f;
         for (int ks = 0; ks < ksteps; ++ks) {
             // this lane's two taps (k = 16 ks + 8 fk .. + 7 = taps 4 ks + 2 fk, + 1); taps past the kernel meet zero weights
-            const int t0 = 4 * ks + 2 * fk, t1 = t0 + 1;
-            const int o0 = t0 < taps ? (t0 / k) * IW + (t0 % k) : 0, o1 = t1 < taps ? (t1 / k) * IW + (t1 % k) : 0;
+            const int2 ot = otab[2 * ks + fk];
+            const bool has0 = ot.x >= 0, has1 = ot.y >= 0;
+            const int o0 = has0 ? ot.x : 0, o1 = has1 ? ot.y : 0;
             u32x4 xh[RW], xl[RW], xm[RW];        // (X3: xl = the mid plane, xm = the lo plane -- named by their position in memory)
 #pragma unroll
             for (int a = 0; a < RW; ++a) {
                 const int base = ((RW * wave + a) * s) * IW + frow * s;
                 const uint2 h0 = Xh[base + o0], h1 = Xh[base + o1], l0 = Xl[base + o0], l1 = Xl[base + o1];
-                xh[a] = u32x4{h0.x, h0.y, t1 < taps ? h1.x : 0u, t1 < taps ? h1.y : 0u};
-                xl[a] = u32x4{l0.x, l0.y, t1 < taps ? l1.x : 0u, t1 < taps ? l1.y : 0u};
+                xh[a] = u32x4{h0.x, h0.y, has1 ? h1.x : 0u, has1 ? h1.y : 0u};
+                xl[a] = u32x4{l0.x, l0.y, has1 ? l1.x : 0u, has1 ? l1.y : 0u};
                 if constexpr (X3) {
                     const uint2 m0 = Xh[2 * ST_MAXPIX + base + o0], m1 = Xh[2 * ST_MAXPIX + base + o1];
-                    xm[a] = u32x4{m0.x, m0.y, t1 < taps ? m1.x : 0u, t1 < taps ? m1.y : 0u};
+                    xm[a] = u32x4{m0.x, m0.y, has1 ? m1.x : 0u, has1 ? m1.y : 0u};
                 } else xm[a] = xl[a];
-                if (t0 >= taps) { xh[a] = u32x4{0u, 0u, 0u, 0u}; xl[a] = xh[a]; xm[a] = xh[a]; }
+                if (!has0) { xh[a] = u32x4{0u, 0u, 0u, 0u}; xl[a] = xh[a]; xm[a] = xh[a]; }
             }
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
@@ -220,7 +235,7 @@ bool conv_stem_eligible(const ConvParams& p) {
     const int ih = (th - 1) * p.stride + p.kh, iw = (ST_TW - 1) * p.stride + p.kh;
     const int npl = p.x3 ? 3 : 2, nb = p.Cout / 32;
     const size_t lds = (size_t)npl * ST_MAXPIX * 8 + (size_t)(p.Kpad / 8) * p.Cout * 16 * npl + (size_t)8 * 32 * (64 * nb + 16);
-    return ih * iw <= ST_MAXPIX && lds <= 160 * 1024 && !(p.sw & SW_NO_STEM);
+    return ih * iw <= ST_MAXPIX && lds + 512 <= 160 * 1024 && (p.kh * p.kw * 4 + 15) / 16 <= 32 && !(p.sw & SW_NO_STEM);      // (+ the tap table)
 }
 
 hipError_t launch_conv_stem(const ConvParams& p, hipStream_t s) {
@@ -237,12 +252,12 @@ hipError_t launch_conv_stem(const ConvParams& p, hipStream_t s) {
     const int npl = p.x3 ? 3 : 2;
     const size_t wbytes = (size_t)(p.Kpad / 8) * p.Cout * 16 * npl;
     const size_t lds = (size_t)npl * ST_MAXPIX * 8 + wbytes + (size_t)8 * 32 * (64 * nb + 16);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds + 512 > 160 * 1024) return hipErrorInvalidValue;
     const dim3 grid((unsigned)(tiles < cus ? tiles : cus));
 #define SD_STEM(NB_, RW_, F_, ...)                                                                                     \
     do {                                                                                                               \
         static bool attr = false;                                                                                      \
-        if (!attr) { hipFuncSetAttribute((const void*)conv_stem_kernel<NB_, RW_, F_, ##__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        if (!attr) { hipFuncSetAttribute((const void*)conv_stem_kernel<NB_, RW_, F_, ##__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); attr = true; } \
         hipLaunchKernelGGL((conv_stem_kernel<NB_, RW_, F_, ##__VA_ARGS__>), grid, dim3(512), lds, s, p);                \
     } while (0)
     if (p.x3) {
