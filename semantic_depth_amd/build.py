@@ -20,6 +20,11 @@ SOURCES = [
     ("conv_igemm.hip", []),
     ("conv_split.hip", []),
     ("conv_dma.hip", []),
+    ("conv_dma_v1.hip", []),
+    ("conv_dma_v2.hip", []),
+    ("conv_dma_v3.hip", []),
+    ("conv_dma_v4.hip", []),
+    ("conv_dma_v5.hip", []),
     ("conv_dma3.hip", []),
     ("conv_direct.hip", []),
     ("conv_direct3.hip", []),
@@ -125,7 +130,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return r
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(max(4, min(os.cpu_count() or 4, 8)), len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or _stale(LIB, objs) or hash_changed:
         tmp = LIB + f".tmp{os.getpid()}"          # link aside, then rename: no process ever maps a half-written library
