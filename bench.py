@@ -269,6 +269,10 @@ def main():
         assert len(files) == world * B, (len(files), world, B)
         # K steps = K batches per rank: every file K times, adjacent in the sorted list, so that rank r's shard is its own B files x K
         disk_paths = [f for f in files for _ in range(args.steps)]
+        import atexit
+        import shutil
+        if rank == 0:
+            atexit.register(shutil.rmtree, ddir, True)             # (rank 0 outlives the last collective of the others' timed regions)
 
     def make_engine(precision):
         eng = Engine(H, W, B, args.encoder, local_rank, precision=precision, plan=custom_plan if precision == "plan" else None)
