@@ -1,8 +1,9 @@
 #!/bin/bash
-tag=${1:-r04x}
+tag=${1:-r04y}
 mkdir -p gpurun_out/$tag
 o=gpurun_out/$tag
-timeout 1500 python -m pytest tests -x -q -m gpu > $o/pytest.txt 2>&1; tail -3 $o/pytest.txt
-timeout 1200 python bench.py > $o/bench_default.json 2> $o/bench_default.log
-grep 'frames/s' $o/bench_default.log | cut -c1-200
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
+for r in 1 2; do
+timeout 300 python scripts/layer_times.py 32 resnet50 bf16x3 2> $o/layers_m$r.txt >/dev/null; tail -2 $o/layers_m$r.txt | tr '\n' ' '; echo
+SEMDEPTH_DMA3_NFAST=1 timeout 300 python scripts/layer_times.py 32 resnet50 bf16x3 2> $o/layers_n$r.txt >/dev/null; tail -2 $o/layers_n$r.txt | tr '\n' ' '; echo
+done
+paste <(grep "conv_dma3" $o/layers_m1.txt | awk '{printf "%-24s %8s\n", $2, $6}') <(grep "conv_dma3" $o/layers_n1.txt | awk '{print $6}')

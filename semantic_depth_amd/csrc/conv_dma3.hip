@@ -80,6 +80,7 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
     const int par = tid_ / (tilesM * tilesN);
     tid_ -= par * (tilesM * tilesN);
     int tm = tid_ % tilesM, tn = tid_ / tilesM;
+    if (p.m_fastest == 0) { tn = tid_ % tilesN; tm = tid_ / tilesN; }      // (walk N first: the tiles that share an X panel run side by side)
     if (p.rowgrp && p.Hout >= 2 * p.pad) {
         // row-grouped tiles differ in length (border rows skip taps): dispatch the longest first -- rows by decreasing distance from the
         // border -- so that the CUs that finish early pick up the short ones (the workgroups start in blockIdx order)
