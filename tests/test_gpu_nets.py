@@ -207,6 +207,34 @@ def test_row_grouped_fc6_tiles_skip_padding_taps_bit_identically():
     assert float(outs[0][0].abs().max()) > 0
 
 
+def test_precomputed_gather_offsets_of_conv_dma3_are_bit_identical_to_the_general_gather():
+    """conv_dma3 computes a lane's gather offset once per source geometry (kernel<1>: the 1x1 layers -- block tails with their strided
+    shortcut source, conv1 of res4 / res5, fc7; kernel<2>: tap layers without upsample -- fc6, the folded upconvs, strided 3x3) instead of
+    per DMA piece and phase (kernel<0>, SEMDEPTH_NO_FLAT).  Same k order, same products: raw disparities and logits must not change by a
+    bit.  256 x 512 frames, 8 of them (the block tails have >= 128 tiles of 256 x 256 there)."""
+    from semantic_depth_amd.engine import Engine
+    from semantic_depth_amd import weights as Wt
+    H, W, B = 256, 512, 8
+    wf = Wt.make_fcn8s_weights(6, decoder_std=0.05, bias_std=0.1)
+    wm = Wt.make_monodepth_weights("resnet50", 7, bias_std=0.05)
+    fr = dev(_frames(B, H, W, seed=31))
+    outs = []
+    for off in (False, True):
+        if off:
+            os.environ["SEMDEPTH_NO_FLAT"] = "1"
+        try:
+            eng = Engine(H, W, B, "resnet50", precision="bf16x3")
+            eng.load_weights(L.SD_NET_FCN8S, wf)
+            eng.load_weights(L.SD_NET_MONODEPTH, wm)
+            lg = eng.fcn8s_forward(fr, want_logits=True)["logits"].clone()
+            _, raw = eng.monodepth_forward(fr, want_raw=True)
+            outs.append((lg, raw.clone()))
+        finally:
+            os.environ.pop("SEMDEPTH_NO_FLAT", None)
+        del eng
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("H,W,B,enc", [(512, 1024, 2, "resnet50"), (128, 256, 3, "resnet50"), (256, 512, 1, "vgg")])
 def test_folded_upconvs_and_fused_decoder_tail_against_the_layer_by_layer_form(H, W, B, enc):
     """bf16x3 runs the wide upconv layers upsample-FOLDED (four 2x2 convs on the source instead of a 3x3 conv on the upsampled source:
