@@ -88,6 +88,9 @@ def parse_args():
                     help="--config 5 only: the frames are PNG files on disk and the input stage (native decode on this rank's share of the "
                          "CPUs -> pinned staging -> upload) runs INSIDE the timed region, one batch ahead of the GPU "
                          "(distributed.run_sequence_files: every rank decodes only its shard)")
+    ap.add_argument("--side-priority", type=int, default=-1,
+                    help="priority of the side stream the per-frame tail runs on under --overlap (-1 = high, the default: the tail's small "
+                         "launches win the CUs each persistent conv workgroup frees; 0 = the default priority of rounds 1-4)")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--repeats", type=int, default=3, help="back-to-back timed regions of --steps steps each; value = mean over them")
@@ -313,12 +316,12 @@ def main():
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
         # The two networks run on the main stream; with --overlap the per-frame tail of step i (back-projection, road chain, record
         # gather) runs on a side stream underneath the convolutions of step i+1; the default keeps everything on one stream.
-        side_stream = torch.cuda.Stream() if args.overlap else None
+        side_stream = torch.cuda.Stream(priority=args.side_priority) if args.overlap else None
         st = {"fused_once": False, "side": side_stream}
 
         def instrumented_step():
-            side = st["side"]
             """one step, stage by stage with stream events (the same launches as Engine.process_batch / make_engine_step)"""
+            side = st["side"]
             ev[0].record()
             fr = eng.resize_cubic(src_frames) if args.config == 5 else frames
             ev[1].record()
@@ -443,7 +446,9 @@ def main():
                 "stage_ms_last_step": {"resize": round(res["stage_ms"][0], 2), "seg": round(res["stage_ms"][1], 2), "disp": round(res["stage_ms"][2], 2),
                                        "to3D": round(res["stage_ms"][3], 2), "road": round(res["stage_ms"][4], 2),
                                        **({"fence": round(res["stage_ms"][5], 2)} if args.approach == "both" else {})},
-                **({"tail_overlap": {"on": True, "ms_per_step_one_stream": round(res["prof_ms_per_step"], 3),
+                **({"tail_overlap": {"on": True, "side_stream_priority": args.side_priority,
+                                     "ms_per_step_one_stream": round(res["prof_ms_per_step"], 3),
+                                     "frames_per_s_one_stream": round(world * B * 1e3 / res["prof_ms_per_step"], 3),
                                      "tail_ms_exposed": round(res["dt_mean"] / args.steps * 1e3 - sum(res["stage_ms"][:3]), 3),
                                      "note": "timed regions: the tail of step i (back-projection, road chain, record gather) runs on a side stream under "
                                              "the convolutions of step i+1; stage_ms_last_step and the roofline durations come from the extra "
@@ -527,8 +532,8 @@ def main():
 
     flops_frame = eng.flops_per_image(L.SD_NET_FCN8S) + 2 * eng.flops_per_image(L.SD_NET_MONODEPTH)
     workload = ("BASELINE.json configs[3]: full fused pipeline (seg + depth + pcl back-projection + road width), " if args.config == 4 else
-                "BASELINE.json configs[4]: batch-sharded sequence driver (1024x2048 frames -> GPU cubic resize -> full fused pipeline -> "
-                "RCCL all_gather of the records), ")
+                "BASELINE.json configs[4]: batch-sharded sequence driver (1024x2048 frames -> GPU cubic resize -> full fused pipeline -> " +
+                ("gloo all_gather of the records; both ranks on ONE GPU: plumbing only), " if share else "RCCL all_gather of the records), "))
     line = {
         "metric": "fused frames/sec (FCN-8s+monodepth+pcl fusion) at 512x1024", "value": head_rec["value"], "unit": "frames/s",
         "n_gpus": world, "ranks_seen": ranks_seen, **({"shared_gpu_plumbing_test": True} if share else {}), "steps": args.steps, "warmup": args.warmup,

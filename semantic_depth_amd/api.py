@@ -24,9 +24,13 @@ from .engine import Camera, Engine, FenceParams, RoadWidthParams
 # live in one process / on one GPU; here they share the handle, the activation workspace and the stream
 # ---------------------------------------------------------------------------------------------------------------------
 _engines: dict = {}
+# The reference computes in float32 (semantic_depth.py:550-552, 675).  Two engines here do, to the same measured error against a float64
+# oracle: "bf16x3" (every f32 operand carried exactly as three bf16 planes, six MFMA products, f32 accumulation: the engine bench.py
+# headlines) and "f32" (the f32 MFMA, about half the speed).  The classes below default to the faster one; precision="f32" selects the other.
+DEFAULT_PRECISION = "bf16x3"
 
 
-def shared_engine(H: int, W: int, device: int = 0, precision: str = "f32", encoder: str | None = None, max_batch: int = 1) -> Engine:
+def shared_engine(H: int, W: int, device: int = 0, precision: str = DEFAULT_PRECISION, encoder: str | None = None, max_batch: int = 1) -> Engine:
     """the registered Engine for this geometry; created on first use.  ``encoder`` None = whatever is registered (or 'vgg',
     the reference's default --monodepth_encoder, semantic_depth.py:721-722)."""
     key = (int(H), int(W), int(device), precision)
@@ -93,7 +97,7 @@ class SegmentFrame:
     and ignored (TF graph details)."""
 
     def __init__(self, input_shape, model_var_dir, use_frozen=True, use_xla=False, CUDA_DEVICE_NUMBER="0", engine: Engine | None = None,
-                 precision: str = "f32"):
+                 precision: str = DEFAULT_PRECISION):
         self.input_shape = tuple(input_shape)
         self.model_var_dir = model_var_dir
         self.CUDA_DEVICE_NUMBER = CUDA_DEVICE_NUMBER
@@ -134,7 +138,7 @@ class DepthFrame:
     ``checkpoint_path``: dict / .npz of monodepth weights."""
 
     def __init__(self, is_city=False, encoder="vgg", input_height=256, input_width=512, checkpoint_path=None, f=None,
-                 engine: Engine | None = None, precision: str = "f32", device: int = 0):
+                 engine: Engine | None = None, precision: str = DEFAULT_PRECISION, device: int = 0):
         self.is_city, self.encoder = is_city, encoder
         self.input_height, self.input_width = input_height, input_width
         self.f = float(f) if f is not None else None

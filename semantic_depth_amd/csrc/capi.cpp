@@ -193,7 +193,8 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.noup = (p.x3 && op.nsrc <= 2 && !(h->sw & SW_NO_FLAT)) ? 1 : 0;
                 for (int j = 0; j < op.nsrc; ++j) {      // (32-bit byte offsets inside a plane of every source; strides 1 or 2)
                     if (PL(op.src[j]) * 2 >= ((size_t)1 << 32)) c.flat = c.noup = 0;
-                    if (op.up[j] || op.sstride[j] < 1 || op.sstride[j] > 2) c.noup = 0;
+                    // (a folded op keeps up[0] = 1 from the plan, but its table reads the source at its own resolution: tap layers without upsample)
+                    if ((op.up[j] && !op.fold) || op.sstride[j] < 1 || op.sstride[j] > 2) c.noup = 0;
                 }
                 if (op.fold) {          // (conv_dma3.hip: the GEMM's pixel space is the source itself)
                     c.fold = 1; c.simple = 0; c.Hin = s0.H; c.Win = s0.W; c.Hout = s0.H; c.Wout = s0.W; c.kh = c.kw = 2;
@@ -214,7 +215,10 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 if (h->prof) {
                     hipEventRecord(eb, s);
                     h->prof_last = eb; conv_op = true;
-                    h->prof_recs.push_back({dma3 ? "conv_dma3_kernel" : dma ? conv_dma_kernel_name(c) : stem ? (c.x3 ? "conv_stem_x3_kernel" : c.f16 ? "conv_stem_f16w_kernel" : "conv_stem_kernel") : split ? conv_split_kernel_name(c) : conv_igemm_kernel_name(c), op.flops * N / p.images, ea, eb,
+                    static const char* const dma3_names[3] = {"conv_dma3_kernel<0>", "conv_dma3_kernel<1>", "conv_dma3_kernel<2>"};
+                    // (one bucket for the bench line; the per-layer listing of SEMDEPTH_PROFILE_VERBOSE names the gather variant)
+                    const char* const dma3_name = (h->sw & SW_PROFILE_VERBOSE) ? dma3_names[conv_dma3_mode(c)] : "conv_dma3_kernel";
+                    h->prof_recs.push_back({dma3 ? dma3_name : dma ? conv_dma_kernel_name(c) : stem ? (c.x3 ? "conv_stem_x3_kernel" : c.f16 ? "conv_stem_f16w_kernel" : "conv_stem_kernel") : split ? conv_split_kernel_name(c) : conv_igemm_kernel_name(c), op.flops * N / p.images, ea, eb,
                                             op.name.c_str(), N * c.Hout * c.Wout * (c.fold ? 4 : 1), d.C, op.K, op_bytes(op)});
                 }
                 break;

@@ -410,13 +410,18 @@ bool conv_dma3_eligible(const ConvParams& p) {
     return ((M + G3_BM - 1) / G3_BM) * (p.Cout / G3_BN) >= 128;
 }
 
+// gather variant a layer runs: 1 = 1x1 layers (one offset per source geometry), 2 = tap layers without upsample (fc6, the folded upconvs, strided
+// 3x3: precomputed pixel offset + scalar tap offset), 0 = the general gather
+int conv_dma3_mode(const ConvParams& p) { return (p.flat && !p.fold && !p.rowgrp) ? 1 : p.noup ? 2 : 0; }
+
 hipError_t launch_conv_dma3(const ConvParams& p, hipStream_t s) {
     if (!conv_dma3_eligible(p)) return hipErrorInvalidValue;
     const long M = (long)p.N * p.Hout * p.Wout;
     const int tilesM = (int)((M + G3_BM - 1) / G3_BM), tilesN = p.Cout / G3_BN;
     const dim3 grid((unsigned)(tilesM * tilesN * (p.fold ? 4 : 1)));
-    if (p.flat && !p.fold && !p.rowgrp) hipLaunchKernelGGL(conv_dma3_kernel<1>, grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
-    else if (p.noup) hipLaunchKernelGGL(conv_dma3_kernel<2>, grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
+    const int mode = conv_dma3_mode(p);
+    if (mode == 1) hipLaunchKernelGGL(conv_dma3_kernel<1>, grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
+    else if (mode == 2) hipLaunchKernelGGL(conv_dma3_kernel<2>, grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
     else hipLaunchKernelGGL(conv_dma3_kernel<0>, grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
     return hipGetLastError();
 }

@@ -100,6 +100,7 @@ hipError_t launch_conv_stem(const ConvParams& p, hipStream_t s);
 const char* conv_dma_kernel_name(const ConvParams& p);
 bool conv_dma3_eligible(const ConvParams& p);                        // conv_dma3.hip: bf16 x 3, 256 x 256 block with phased weight planes
 hipError_t launch_conv_dma3(const ConvParams& p, hipStream_t s);
+int conv_dma3_mode(const ConvParams& p);                             // gather variant (conv_dma3_kernel<MODE>) the layer runs
 
 #ifdef __HIPCC__
 // ELU for the conv epilogues.  expm1f() is a ~60-instruction library routine and the monodepth layers apply it to every

@@ -118,7 +118,7 @@ struct Builder {
         // bf16 x 3: an upconv layer (3x3 on a x2 nearest-neighbour upsampled source) with a wide output runs as four 2x2 convs on the source
         // itself, one per output parity, on the 256 x 256 GEMM block (OpDesc::fold).  The choice depends on the layer alone, never on the batch.
         if (p.x3 && k == 3 && stride == 1 && op.nsrc == 1 && op.up[0] && Cout % 256 == 0 && p.tensors[op.src[0]].C % 32 == 0 && residual < 0 &&
-            !(latch_switches() & SW_NO_FOLD)) {
+            !(latch_switches() & (SW_NO_FOLD | SW_NO_DMA))) {        // (the folded GEMM form exists on conv_dma3 only: SEMDEPTH_NO_DMA implies no fold)
             const TensorDesc& t = p.tensors[op.src[0]];
             op.fold = 1; op.vec = 1;
             op.Ctot = t.C; op.K = 4 * t.C; op.Kpad = op.Kvec = 4 * t.C; op.CqPad = 0;

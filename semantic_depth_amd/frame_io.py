@@ -81,23 +81,52 @@ def imread(path: str) -> np.ndarray:
     return decode_png(buf) if buf[:8] == _SIG else decode_image(buf)
 
 
+def _cgroup_cpu_quota():
+    """CPUs the cgroup quota allows (v2: cpu.max "<quota> <period>" | "max <period>"; v1: cpu.cfs_quota_us / cpu.cfs_period_us), or None"""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        return None if q == "max" else max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = int(f.read())
+        return None if q <= 0 or per <= 0 else max(1, q // per)
+    except (OSError, ValueError):
+        return None
+
+
+def _local_ranks() -> int:
+    """ranks that share this node: LOCAL_WORLD_SIZE (torch.distributed.run, bench.py's launcher), Open MPI's / Slurm's per-node counts,
+    else WORLD_SIZE (a single-node job started by hand with RANK / WORLD_SIZE), else 1"""
+    import os
+    for k in ("LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "SLURM_NTASKS_PER_NODE", "WORLD_SIZE"):
+        v = os.environ.get(k, "")
+        try:
+            n = int(v.split("(")[0])           # (Slurm writes "8(x2)" for heterogeneous jobs)
+        except ValueError:
+            continue
+        if n >= 1:
+            return n
+    return 1
+
+
 def default_decode_workers() -> int:
     """decode threads of ONE rank: the CPUs this process may run on (its affinity mask, capped by the cgroup CPU quota -- os.cpu_count()
-    reports the host's 256 whatever the container may use) divided by the ranks of the node (LOCAL_WORLD_SIZE, set by torch.distributed.run
-    and by bench.py's launcher), at least 1, at most 128.  Eight ranks on a 256-CPU node get 32 threads each instead of 8 x 128."""
+    reports the host's 256 whatever the container may use) divided by the ranks of the node (_local_ranks), at least 1, at most 128.
+    Eight ranks on a 256-CPU node get 32 threads each instead of 8 x 128."""
     import os
     try:
         n = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         n = os.cpu_count() or 8
-    try:                                                   # cgroup v2: "max 100000" or "<quota> <period>"
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if q != "max":
-            n = min(n, max(1, int(int(q) / int(per))))
-    except (OSError, ValueError):
-        pass
-    local = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
-    return max(1, min(n // local, 128))
+    q = _cgroup_cpu_quota()
+    if q is not None:
+        n = min(n, q)
+    return max(1, min(n // _local_ranks(), 128))
 
 
 class FrameFeeder:

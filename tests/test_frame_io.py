@@ -377,3 +377,25 @@ def test_jpeg_reader_refuses_structurally_hostile_files():
             assert st_d != L.SD_OK, name
             if name.startswith("dht"):
                 assert st_q != L.SD_OK, name
+
+
+def test_default_decode_workers_divides_by_the_ranks_of_the_node(monkeypatch):
+    """launchers that do not set LOCAL_WORLD_SIZE (mpirun, srun, RANK / WORLD_SIZE by hand) must not give every rank the whole
+    affinity mask; cgroup v1 quotas count like v2 ones"""
+    from semantic_depth_amd import frame_io
+    for k in ("LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "SLURM_NTASKS_PER_NODE", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(frame_io, "_cgroup_cpu_quota", lambda: None)
+    monkeypatch.setattr("os.sched_getaffinity", lambda pid: set(range(64)), raising=False)
+    assert frame_io.default_decode_workers() == 64
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    assert frame_io.default_decode_workers() == 8
+    monkeypatch.setenv("SLURM_NTASKS_PER_NODE", "4(x2)")
+    assert frame_io.default_decode_workers() == 16
+    monkeypatch.setenv("OMPI_COMM_WORLD_LOCAL_SIZE", "2")
+    assert frame_io.default_decode_workers() == 32
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "64")
+    assert frame_io.default_decode_workers() == 1
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+    monkeypatch.setattr(frame_io, "_cgroup_cpu_quota", lambda: 16)
+    assert frame_io.default_decode_workers() == 16

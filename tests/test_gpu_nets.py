@@ -129,7 +129,7 @@ def test_flipped_frame_symmetry_of_post_processing():
 @pytest.mark.parametrize("switch", ["SEMDEPTH_NO_DMA", "SEMDEPTH_NO_DIRECT", "SEMDEPTH_NO_STEM", "SEMDEPTH_NO_POOL_FUSE", "SEMDEPTH_NO_PLANAR",
                                     "SEMDEPTH_NO_N16", "SEMDEPTH_NO_SMALLN_TILE", "SEMDEPTH_NO_DIRECT128", "SEMDEPTH_NO_N16_MT1",
                                     "SEMDEPTH_NO_PLANAR_WIDE", "SEMDEPTH_NO_UPTILE", "SEMDEPTH_DIRECT_MINPIX=1000000000"])
-def test_generic_kernels_behind_each_specialised_one(switch):
+def test_generic_kernels_behind_each_specialised_one(switch, precision="bf16x2"):
     """every specialised kernel (LDS-DMA pipeline, direct conv and its multi-pass form for 128..512 output channels, stem
     conv, fused pools, sub-plane hand-off, 16-wide MFMA and its 8-row tiles, tiled heads) has a generic one behind it; with
     the specialised one switched off the networks still meet the budget."""
@@ -139,7 +139,7 @@ def test_generic_kernels_behind_each_specialised_one(switch):
     switch, _, val = switch.partition("=")
     os.environ[switch] = val or "1"
     try:
-        eng = Engine(H, W, B, "resnet50", precision="bf16x2")       # the switches are read when the plan is built / at launch
+        eng = Engine(H, W, B, "resnet50", precision=precision)      # the switches are read when the plan is built / at launch
         wf = Wt.make_fcn8s_weights(1, decoder_std=0.05, bias_std=0.1)
         wm = Wt.make_monodepth_weights("resnet50", 2, bias_std=0.05)
         eng.load_weights(L.SD_NET_FCN8S, wf)
@@ -153,6 +153,13 @@ def test_generic_kernels_behind_each_specialised_one(switch):
     f = fr[1].astype(np.float32) / 255
     ref = nets.monodepth_forward(np.stack((f, np.fliplr(f)), 0), wm, "resnet50")[..., 0]
     assert relerr(raw[1].cpu().numpy(), ref) < TOL
+
+
+@pytest.mark.parametrize("switch", ["SEMDEPTH_NO_DMA", "SEMDEPTH_NO_DMA3", "SEMDEPTH_NO_FOLD", "SEMDEPTH_NO_TAIL1", "SEMDEPTH_NO_STEM"])
+def test_generic_kernels_behind_the_specialised_ones_of_the_fp32_grade_engine(switch):
+    """the same on bf16x3 (SEMDEPTH_NO_DMA made the folded upconvs fail with SD_ERR_STATE -- the folded GEMM form exists on
+    conv_dma3 only, so the switch now also keeps the plan from folding)"""
+    test_generic_kernels_behind_each_specialised_one(switch, precision="bf16x3")
 
 
 def test_256x256_block_of_the_dma_pipeline_is_bit_identical_to_the_128x256_one():
@@ -211,31 +218,46 @@ def test_precomputed_gather_offsets_of_conv_dma3_are_bit_identical_to_the_genera
     """conv_dma3 computes a lane's gather offset once per source geometry (kernel<1>: the 1x1 layers -- block tails with their strided
     shortcut source, conv1 of res4 / res5, fc7; kernel<2>: tap layers without upsample -- fc6, the folded upconvs, strided 3x3) instead of
     per DMA piece and phase (kernel<0>, SEMDEPTH_NO_FLAT).  Same k order, same products: raw disparities and logits must not change by a
-    bit.  256 x 512 frames, 8 of them (the block tails have >= 128 tiles of 256 x 256 there)."""
+    bit.  256 x 512 frames, 8 of them (the block tails have >= 128 tiles of 256 x 256 there).  The per-layer profile labels
+    (SEMDEPTH_PROFILE_VERBOSE) name the variant that ran: no layer of either network is left on the general gather -- the folded
+    upconv6 / upconv5 included -- and with the switch every one of them is."""
     from semantic_depth_amd.engine import Engine
     from semantic_depth_amd import weights as Wt
     H, W, B = 256, 512, 8
     wf = Wt.make_fcn8s_weights(6, decoder_std=0.05, bias_std=0.1)
     wm = Wt.make_monodepth_weights("resnet50", 7, bias_std=0.05)
     fr = dev(_frames(B, H, W, seed=31))
-    outs = []
-    for off in (False, True):
-        if off:
-            os.environ["SEMDEPTH_NO_FLAT"] = "1"
-        try:
-            eng = Engine(H, W, B, "resnet50", precision="bf16x3")
-            eng.load_weights(L.SD_NET_FCN8S, wf)
-            eng.load_weights(L.SD_NET_MONODEPTH, wm)
-            lg = eng.fcn8s_forward(fr, want_logits=True)["logits"].clone()
-            _, raw = eng.monodepth_forward(fr, want_raw=True)
-            outs.append((lg, raw.clone()))
-        finally:
-            os.environ.pop("SEMDEPTH_NO_FLAT", None)
-        del eng
+    outs, variants = [], []
+    os.environ["SEMDEPTH_PROFILE_VERBOSE"] = "1"
+    try:
+        for off in (False, True):
+            if off:
+                os.environ["SEMDEPTH_NO_FLAT"] = "1"
+            try:
+                eng = Engine(H, W, B, "resnet50", precision="bf16x3")
+                eng.load_weights(L.SD_NET_FCN8S, wf)
+                eng.load_weights(L.SD_NET_MONODEPTH, wm)
+                eng.profile(True)
+                lg = eng.fcn8s_forward(fr, want_logits=True)["logits"].clone()
+                _, raw = eng.monodepth_forward(fr, want_raw=True)
+                variants.append({b["kernel"]: b["launches"] for b in eng.profile_read() if b["kernel"].startswith("conv_dma3")})
+                eng.profile(False)
+                outs.append((lg, raw.clone()))
+            finally:
+                os.environ.pop("SEMDEPTH_NO_FLAT", None)
+            del eng
+    finally:
+        os.environ.pop("SEMDEPTH_PROFILE_VERBOSE", None)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # fc6 + upconv6 + upconv5 (+ the strided 3x3 layers that qualify) on <2>, the 1x1 layers on <1>, nothing on <0>; all on <0> with the switch
+    assert "conv_dma3_kernel<0>" not in variants[0] and variants[0].get("conv_dma3_kernel<2>", 0) >= 3 and variants[0].get("conv_dma3_kernel<1>", 0) >= 10, variants
+    assert set(variants[1]) == {"conv_dma3_kernel<0>"} and sum(variants[1].values()) == sum(variants[0].values()), variants
 
 
-@pytest.mark.parametrize("H,W,B,enc", [(512, 1024, 2, "resnet50"), (128, 256, 3, "resnet50"), (256, 512, 1, "vgg")])
+# (the small shapes, ADVICE r4: W % 28 == 0 -- no inward-shifted last tile column --, the narrowest width the networks take -- three tile columns
+# that overlap almost entirely --, and grids with fewer tiles than CUs -- one tile per workgroup, the u / e double buffer never swaps)
+@pytest.mark.parametrize("H,W,B,enc", [(512, 1024, 2, "resnet50"), (128, 256, 3, "resnet50"), (256, 512, 1, "vgg"),
+                                       (64, 448, 1, "resnet50"), (64, 64, 1, "resnet50"), (64, 128, 2, "resnet50"), (128, 64, 1, "vgg")])
 def test_folded_upconvs_and_fused_decoder_tail_against_the_layer_by_layer_form(H, W, B, enc):
     """bf16x3 runs the wide upconv layers upsample-FOLDED (four 2x2 convs on the source instead of a 3x3 conv on the upsampled source:
     the taps that read the same source pixel are added, 4/9 of the multiplications) and upconv1 -> iconv1 -> disp1 as ONE kernel
