@@ -249,8 +249,8 @@ def test_precomputed_gather_offsets_of_conv_dma3_are_bit_identical_to_the_genera
     finally:
         os.environ.pop("SEMDEPTH_PROFILE_VERBOSE", None)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    # fc6 + upconv6 + upconv5 (+ the strided 3x3 layers that qualify) on <2>, the 1x1 layers on <1>, nothing on <0>; all on <0> with the switch
-    assert "conv_dma3_kernel<0>" not in variants[0] and variants[0].get("conv_dma3_kernel<2>", 0) >= 3 and variants[0].get("conv_dma3_kernel<1>", 0) >= 10, variants
+    # upconv6 + upconv5 (at this size fc6 has too few tiles for conv_dma3) on <2>, the 1x1 layers on <1>, nothing on <0>; all on <0> with the switch
+    assert "conv_dma3_kernel<0>" not in variants[0] and variants[0].get("conv_dma3_kernel<2>", 0) >= 2 and variants[0].get("conv_dma3_kernel<1>", 0) >= 10, variants
     assert set(variants[1]) == {"conv_dma3_kernel<0>"} and sum(variants[1].values()) == sum(variants[0].values()), variants
 
 
