@@ -62,6 +62,8 @@ DTYPE = {
     "f32": "f32 (exact: v_mfma_f32_16x16x4_f32)",
     "bf16x3": "f32 operands carried EXACTLY as three bf16 planes each (v = hi + mid + lo, 8+8+8 significand bits), 6 bf16 MFMA products per "
               "product (the three dropped cross terms are below 2^-23 of the product), f32 accumulate",
+    "f16x2": "f32 operands carried to 22 significand bits as two fp16 planes each (activations: hi + 2^11-scaled lo, no calibration; weights: hi + lo of "
+             "w * 2^12), 3 fp16 MFMA products per product (x_hi*w_hi + x_hi*w_lo + x_lo*w_hi; dropped terms 2^-23 .. 2^-24 of the product), f32 accumulate",
     "bf16x2": "bf16x2 split operands (hi+lo, 16 mantissa bits), 3 bf16 MFMA products per product, f32 accumulate",
     "mixed": "FCN-8s: bf16x2 split operands, 3 bf16 MFMA products; monodepth: fp16 activations x fp16x2 split weights (22 bits), "
              "2 fp16 MFMA products; f32 accumulate",
@@ -224,7 +226,7 @@ def main():
     if custom_plan is not None and len(custom_plan) != 2:
         raise SystemExit("--plan needs the form 'fcn layers|monodepth layers'")
     if args.legs is None:
-        legs = [] if args.no_f32_leg else [p_ for p_ in ("f32", "plan") if p_ != args.precision]
+        legs = [] if args.no_f32_leg else [p_ for p_ in ("f32", "f16x2", "plan") if p_ != args.precision]
     else:
         legs = [] if args.legs in ("", "none") else [p_ for p_ in args.legs.split(",") if p_ != args.precision]
     for p_ in legs:

@@ -52,8 +52,15 @@ typedef enum { SD_NET_FCN8S = 0, SD_NET_MONODEPTH = 1 } sd_net;
  *                  the f32 value EXACTLY (8 + 8 + 8 significand bits, f32's exponent range); a product is SIX bf16 MFMA products
  *                  (hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi, each exact in the f32 accumulator); the dropped terms are below
  *                  2^-23 of the product, the size of the rounding an f32 FMA chain commits per accumulation.  Ceiling 2500 / 6 = 417
- *                  TFLOP/s of algorithmic work against 157.3 for the f32 MFMA. */
-typedef enum { SD_PREC_F32 = 0, SD_PREC_BF16X2 = 1, SD_PREC_MIXED = 2, SD_PREC_PLAN = 3, SD_PREC_BF16X3 = 4 } sd_precision;
+ *                  TFLOP/s of algorithmic work against 157.3 for the f32 MFMA;
+ *   SD_PREC_F16X2  fp32-grade on THREE fp16 MFMA products (round 5): an activation is two fp16 planes, hi = RNE(v) and lo = RNE((v - hi) * 2^11)
+ *                  -- the scaled residual stays in fp16's normal range wherever hi does, so v is carried to 22 significand bits for every
+ *                  |v| in [1.2e-4, 65504] without any calibration (4 bytes per element); a weight is two fp16 planes of w * 2^12 (|w| < 16);
+ *                  a product is x_hi*w_hi + x_hi*w_lo + x_lo*(w_hi * 2^-11) (the third weight operand formed in registers), f32 accumulate,
+ *                  the accumulator times 2^-12 in the epilogue.  Dropped: x_lo*w_lo and the representation error of each operand, 2^-23 ..
+ *                  2^-24 of the product (an f32 FMA chain commits 2^-24 of the ACCUMULATOR per step).  Activations beyond +-65504 are clamped
+ *                  and counted (sd_saturation_count).  Ceiling 2500 / 3 = 833 TFLOP/s of algorithmic work. */
+typedef enum { SD_PREC_F32 = 0, SD_PREC_BF16X2 = 1, SD_PREC_MIXED = 2, SD_PREC_PLAN = 3, SD_PREC_BF16X3 = 4, SD_PREC_F16X2 = 5 } sd_precision;
 
 typedef struct sd_handle sd_handle;
 

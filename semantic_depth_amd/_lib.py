@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libsemdepth.so")
 SD_OK = 0
 SD_ENC_VGG, SD_ENC_RESNET50 = 0, 1
 SD_NET_FCN8S, SD_NET_MONODEPTH = 0, 1
-SD_PREC_F32, SD_PREC_BF16X2, SD_PREC_MIXED, SD_PREC_PLAN, SD_PREC_BF16X3 = 0, 1, 2, 3, 4
+SD_PREC_F32, SD_PREC_BF16X2, SD_PREC_MIXED, SD_PREC_PLAN, SD_PREC_BF16X3, SD_PREC_F16X2 = 0, 1, 2, 3, 4, 5
 
 
 class sd_camera(C.Structure):

@@ -141,7 +141,8 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
         if (op.w >= 0) b += (double)p.weights[op.w].bytes;
         return b;
     };
-    auto FMT = [&](int t) -> int { return p.tensors[t].fmt ? (p.tensors[t].x3 ? 4 : p.tensors[t].f16 ? 2 : 1) : 0; };     // (fp16 hi+lo tensors never reach the ops that take this)     // 0 f32, 1 split bf16, 2 split fp16
+    // 0 f32, 1 split bf16, 2 ONE fp16 plane, 4 bf16 x 3, 5 fp16 hi + scaled lo (fp16 hi + lo tensors never reach the ops that take this)
+    auto FMT = [&](int t) -> int { return p.tensors[t].fmt ? (p.tensors[t].x3 ? 4 : p.tensors[t].f16 == 3 ? 5 : p.tensors[t].f16 ? 2 : 1) : 0; };
     for (const WeightSlot& wsl : p.weights)
         if (!wsl.loaded) return fail(h, SD_ERR_STATE, "weight not loaded: " + wsl.name);
     h->prof_last = nullptr;                 // (other work may have been put on the stream since the previous call)
@@ -179,7 +180,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.out_plane = PL(op.dst); c.Nmax = p.images;
                 c.zero16 = h->ws + h->o_misc + 256;        // the arena is zero-filled and nothing writes here
                 const bool split = p.prec != 0;
-                c.f16 = op.f16; c.out_f16 = d.f16;
+                c.f16 = op.f16; c.out_f16 = d.f16; c.alpha = op.f16 == 4 ? HS_ALPHA : 1.f;
                 c.src0 = T(op.src[0]); c.src0_plane = PL(op.src[0]);
                 c.out_planar16 = d.planar16;
                 c.sw = h->sw;
@@ -239,7 +240,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.out = T(op.dst); c.out_plane = PL(op.dst); c.act = op.act; c.Nmax = p.images;
                 c.zero16 = h->ws + h->o_misc + 256;
                 c.rows_per_wave = 2;
-                c.f16 = op.f16; c.out_f16 = d.f16;
+                c.f16 = op.f16; c.out_f16 = d.f16; c.alpha = op.f16 == 4 ? HS_ALPHA : 1.f;
                 c.sw = h->sw;
                 c.sat = reinterpret_cast<unsigned long long*>(h->ws + h->o_misc + SAT_OFF);
                 hipEvent_t ea = nullptr, eb = nullptr;
@@ -373,7 +374,8 @@ static sd_status create_impl(sd_handle** out, int device, int H, int W, int max_
                              const char* fcn_f16, const char* mono_f16);
 
 sd_status sd_create(sd_handle** out, int device, int H, int W, int max_batch, sd_encoder enc, sd_precision prec) {
-    if (prec != SD_PREC_F32 && prec != SD_PREC_BF16X2 && prec != SD_PREC_MIXED && prec != SD_PREC_PLAN && prec != SD_PREC_BF16X3) return SD_ERR_INVALID;
+    if (prec != SD_PREC_F32 && prec != SD_PREC_BF16X2 && prec != SD_PREC_MIXED && prec != SD_PREC_PLAN && prec != SD_PREC_BF16X3 && prec != SD_PREC_F16X2)
+        return SD_ERR_INVALID;
     const char* fcn = prec == SD_PREC_PLAN ? kDefaultPlanFcn : "";
     // (the calibrated monodepth plan names ResNet-50 layers; the vgg encoder -- the ill-conditioned one of the two in the tests --
     //  stays on three products under SD_PREC_PLAN)
@@ -407,7 +409,8 @@ static sd_status create_impl(sd_handle** out, int device, int H, int W, int max_
     if (const char* e = std::getenv("SEMDEPTH_CHUNK")) chunk = std::max(1, atoi(e));
     h->chunk = std::min(max_batch, chunk);
     try {
-        const int eng = h->prec == SD_PREC_F32 ? 0 : h->prec == SD_PREC_BF16X3 ? 2 : 1;      // exact f32 MFMA | split, three bf16 planes | split
+        // exact f32 MFMA | split, three bf16 planes | split, fp16 hi + scaled lo planes | split (bf16 x 2 + the fp16 forms of the plan)
+        const int eng = h->prec == SD_PREC_F32 ? 0 : h->prec == SD_PREC_BF16X3 ? 2 : h->prec == SD_PREC_F16X2 ? 3 : 1;
         h->fcn = build_fcn8s(h->chunk, H, W, eng, fcn_f16);
         h->mono = build_monodepth(enc == SD_ENC_VGG ? 0 : 1, h->chunk, H, W, eng, mono_f16);
     } catch (const std::exception& ex) {
@@ -472,6 +475,14 @@ sd_status sd_load_weight(sd_handle* h, sd_net net, const char* name, const float
     for (int i = 0; i < rank; ++i)
         if (shape[i] != s.shape[i]) return fail(h, SD_ERR_INVALID, std::string("shape mismatch for ") + name);
     std::vector<float> buf, scaled;
+    if (s.hs) {                         // SD_PREC_F16X2: the planes hold w * 2^12 in fp16
+        size_t n = 1;
+        for (int i = 0; i < rank; ++i) n *= (size_t)shape[i];
+        float mx = 0.f;
+        for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(data[i] * s.scale));
+        if (!(mx * HS_WSCALE * (s.fold ? 4.f : 1.f) <= 65504.f))
+            return fail(h, SD_ERR_INVALID, std::string("weight ") + name + ": |w| beyond the range of the fp16 weight planes of SD_PREC_F16X2 (max 15.99)");
+    }
     if (s.scale != 1.f) {               // (monodepth stem with integer input: the weights carry the 1/255)
         size_t n = 1;
         for (int i = 0; i < rank; ++i) n *= (size_t)shape[i];

@@ -69,9 +69,13 @@ __device__ __forceinline__ DirectChunk load_chunk(const DirectChunk* ptr) {
 // v_mfma_f32_16x16x32 instead: K = 32 is one PAIR of taps x 16 channels, a wave's 2 x 32 pixels are four 16-pixel blocks.
 // W1 (with F16): ONE MFMA product per product -- the w_lo plane is neither fetched nor multiplied (plain fp16 x fp16, f32 accumulate)
 // X2 (with F16): the input is fp16 hi + lo planes and only w_hi is used: TWO products x_hi*w_hi + x_lo*w_hi (split_fmt.hpp)
-template <int NB, int MT, bool F16, bool N16 = false, bool UP = false, bool W1 = false, bool X2 = false>
+// H2 (with F16 and X2; SD_PREC_F16X2): fp16 hi + SCALED lo input planes x fp16 hi + lo weight planes, THREE products
+// x_hi*w_hi + x_hi*w_lo + x_lo*(w_hi * 2^-11), the accumulator times ConvDirectParams::alpha, HS output planes (split_fmt.hpp "HS")
+template <int NB, int MT, bool F16, bool N16 = false, bool UP = false, bool W1 = false, bool X2 = false, bool H2 = false>
 __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_kernel(const ConvDirectParams p) {
     static_assert(!N16 || NB == 1, "N16 is a variant of the 32-channel kernel");
+    static_assert(!H2 || (F16 && X2 && !W1), "H2 is the fp16 form with both planes of both operands");
+    constexpr bool ONEW = W1 || (X2 && !H2);           // only the w_hi plane is fetched and multiplied
     using Cfg = DirectCfg<NB, MT, UP>;
     constexpr int S_HH = Cfg::SH, S_HW = Cfg::SW;
     // LDS pixel slot of halo pixel (hy, hx)
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
     // a stage holds the planes the form reads -- X hi [+ lo] | W hi [+ lo] -- and is at least as large as the epilogue's transposition
     // slabs, which live in a consumed stage.  (The fp16 forms of the 16-channel kernels thereby fit THREE workgroups per CU instead of
     // two: these layers -- two chunks of little arithmetic per tile -- are bound by the latency of the two-stage ring.)
-    constexpr int XPL = (F16 && !X2) ? 1 : 2, WPL = (W1 || X2) ? 1 : 2;
+    constexpr int XPL = (F16 && !X2) ? 1 : 2, WPL = ONEW ? 1 : 2;
     constexpr int SLAB = N16 ? D_WAVES * 2 * 32 * 48 / 16 : D_WAVES * 32 * (64 * NB + 16) / 16;
     constexpr int STAGE_MIN = XPL * Cfg::XUNITS + WPL * D_WUNITS;
     constexpr int D_STAGE = STAGE_MIN < SLAB ? SLAB : STAGE_MIN;
@@ -249,7 +253,8 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                     const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;         // tap / 3, tap % 3 for tap < 10
                     const int wi = (tap * 2 + oct) * 16 + c16;
                     const u32x4 wh = live ? Wh[wi] : z4;
-                    const u32x4 wl = (W1 || X2) ? wh : (live ? Wl[wi] : z4);
+                    const u32x4 wl = ONEW ? wh : (live ? Wl[wi] : z4);
+                    const u32x4 whs = H2 ? hs_wscaled(wh) : wh;          // the weight operand of the x_lo product
 #pragma unroll
                     for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -260,8 +265,8 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                             const u32x4 xl = (F16 && !X2) ? xh : (live ? Xl[idx] : z4);
 #pragma unroll
                             for (int pr = 0; pr < 3; ++pr) {      // x_hi*w_lo, x_lo*w_hi, x_hi*w_hi; fp16 activations have no lo plane
-                                if ((F16 && !X2 && pr == 1) || ((W1 || X2) && pr == 0)) continue;
-                                acc16[a][pb] = mfma_frag16<F16>(pr == 0 ? wl : wh, pr == 1 ? xl : xh, acc16[a][pb]);
+                                if ((F16 && !X2 && pr == 1) || (ONEW && pr == 0)) continue;
+                                acc16[a][pb] = mfma_frag16<F16>(pr == 0 ? wl : pr == 1 ? whs : wh, pr == 1 ? xl : xh, acc16[a][pb]);
                             }
                         }
                 }
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
             // fragment's ds_read + s_waitcnt directly in front of its 1-3 products x MT MFMAs, and the two waves of a SIMD then do not have
             // enough MFMAs per group to cover an LDS round trip -- the one-product layers least of all): the weight fragment(s) of group
             // g + 2 and the next X row(s) (row dy + 2 / the first two rows of the next dx) are issued before group g's MFMAs.
-            constexpr bool HASWL = !(W1 || X2), HASXL = !(F16 && !X2);
+            constexpr bool HASWL = !ONEW, HASXL = !(F16 && !X2);
             u32x4 xh[MT + 2], xl[HASXL ? MT + 2 : 1];
             u32x4 wqh[3], wql[HASWL ? 3 : 1];
             auto wload = [&](int grp) {
@@ -306,12 +311,13 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                 {
                     const u32x4 wh = wqh[grp % 3];
                     const u32x4 wl = HASWL ? wql[HASWL ? grp % 3 : 0] : wh;
+                    const u32x4 whs = H2 ? hs_wscaled(wh) : wh;          // the weight operand of the x_lo product (4 v_pk_mul_f16 beside 3 MT MFMAs)
 #pragma unroll
                     for (int pr = 0; pr < 3; ++pr) {          // x_hi*w_lo, x_lo*w_hi, x_hi*w_hi; fp16 activations have no lo plane
-                        if ((F16 && !X2 && pr == 1) || ((W1 || X2) && pr == 0)) continue;
+                        if ((F16 && !X2 && pr == 1) || (ONEW && pr == 0)) continue;
 #pragma unroll
                         for (int a = 0; a < MT; ++a)
-                            acc[a][nb] = mfma_frag<F16>(pr == 0 ? wl : wh, pr == 1 ? xl[HASXL ? a + dy : 0] : xh[a + dy], acc[a][nb]);
+                            acc[a][nb] = mfma_frag<F16>(pr == 0 ? wl : pr == 1 ? whs : wh, pr == 1 ? xl[HASXL ? a + dy : 0] : xh[a + dy], acc[a][nb]);
                     }
                 }
                 if (grp == 0 && more) {
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                     const int y = cur.ty0 + MT * wave + a;
 #pragma unroll
                     for (int pb = 0; pb < 2; ++pb) {
-                        f32x4 v = acc16[a][pb] + bias16;
+                        f32x4 v = H2 ? acc16[a][pb] * p.alpha + bias16 : acc16[a][pb] + bias16;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
                         if (p.nreal) {
@@ -409,7 +415,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                         const float m = fmaxf(acc[0][nb][4 * q + r], acc[MT - 1][nb][4 * q + r]);
                         v[r] = fmaxf(m, __shfl_xor(m, 1));
                     }
-                    v += bias[r4];
+                    if constexpr (H2) v = v * p.alpha + bias[r4]; else v += bias[r4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
                     split4_fmt<OF>(v, hh[r4], ll[r4], p.sat);
@@ -462,7 +468,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                     if (8 * r4 >= p.Cout) continue;         // rows past Cout are padding, never stored
                     const int nb = r4 >> 2, q = r4 & 3;
                     f32x4 v = {acc[a][nb][4 * q], acc[a][nb][4 * q + 1], acc[a][nb][4 * q + 2], acc[a][nb][4 * q + 3]};
-                    v += bias[r4];
+                    if constexpr (H2) v = v * p.alpha + bias[r4]; else v += bias[r4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
                     split4_fmt<OF>(v, hh[r4], ll[r4], p.sat);
@@ -505,8 +511,11 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
             }
         };
         auto ep = [&](auto tag) {
-            if constexpr (!N16) { if (p.out_f16 == 2) { epilogue(tag, IntTag<2>{}); return; } }
-            if (p.out_f16) epilogue(tag, IntTag<1>{}); else epilogue(tag, IntTag<0>{});
+            if constexpr (H2) { epilogue(tag, IntTag<3>{}); return; }           // (an HS layer writes HS planes, nothing else)
+            else {
+                if constexpr (!N16) { if (p.out_f16 == 2) { epilogue(tag, IntTag<2>{}); return; } }
+                if (p.out_f16) epilogue(tag, IntTag<1>{}); else epilogue(tag, IntTag<0>{});
+            }
         };
         if (p.act == ACT_RELU) ep(ActTag<ACT_RELU>{});
         else if (p.act == ACT_ELU) ep(ActTag<ACT_ELU>{});
@@ -540,14 +549,21 @@ hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
     const int th = mt1 ? 8 : 16;
     const int tiles = (p.W / D_TW) * ((p.H + th - 1) / th) * p.N * p.nsplit;
     // persistent grid: as many workgroups as the instantiation keeps resident (1-3 per CU, by LDS and registers)
-#define SD_DIRECT_(NB_, MT_, F16_, N16_, UP_, W1_, X2_) \
+#define SD_DIRECT_(NB_, MT_, F16_, N16_, UP_, W1_, X2_, ...) \
     do { static int per_cu = 0; \
-         if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_direct_kernel<NB_, MT_, F16_, N16_, UP_, W1_, X2_>, 512, 0) != hipSuccess || per_cu < 1)) per_cu = 1; \
+         if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_direct_kernel<NB_, MT_, F16_, N16_, UP_, W1_, X2_, ##__VA_ARGS__>, 512, 0) != hipSuccess || per_cu < 1)) per_cu = 1; \
          const int slots = cus * per_cu; \
          const dim3 grid((unsigned)(tiles < slots ? tiles : slots)); \
-         hipLaunchKernelGGL((conv_direct_kernel<NB_, MT_, F16_, N16_, UP_, W1_, X2_>), grid, dim3(512), 0, s, q); } while (0)
+         hipLaunchKernelGGL((conv_direct_kernel<NB_, MT_, F16_, N16_, UP_, W1_, X2_, ##__VA_ARGS__>), grid, dim3(512), 0, s, q); } while (0)
+#define SD_DIRECT_H2(NB_, MT_, N16_) do { if (up) SD_DIRECT_(NB_, MT_, true, N16_, true, false, true, true); else SD_DIRECT_(NB_, MT_, true, N16_, false, false, true, true); } while (0)
 #define SD_DIRECT(NB_, MT_, F16_, N16_, W1_) do { if (up) SD_DIRECT_(NB_, MT_, F16_, N16_, true, W1_, false); else SD_DIRECT_(NB_, MT_, F16_, N16_, false, W1_, false); } while (0)
-    if (p.f16 == 3) {           // fp16 hi + lo input x w_hi: the 64-channel-pass form only (the planner asks for nothing else)
+    if (p.f16 == 4) {           // SD_PREC_F16X2: fp16 hi + scaled lo x fp16 hi + lo weights, three products (every tile shape of the bf16 form)
+        if (p.out_f16 != 3) return hipErrorInvalidValue;
+        if (mt1) SD_DIRECT_H2(1, 1, true);
+        else if (n16) SD_DIRECT_H2(1, 2, true);
+        else if (nb == 1) SD_DIRECT_H2(1, 2, false);
+        else SD_DIRECT_H2(2, 2, false);
+    } else if (p.f16 == 3) {           // fp16 hi + lo input x w_hi: the 64-channel-pass form only (the planner asks for nothing else)
         if (mt1 || n16 || nb == 1 || up) return hipErrorInvalidValue;
         SD_DIRECT_(2, 2, true, false, false, false, true);
     } else if (p.f16 == 2) {           // fp16, ONE product
@@ -566,6 +582,7 @@ hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
         else if (nb == 1) SD_DIRECT(1, 2, false, false, false);
         else SD_DIRECT(2, 2, false, false, false);
     }
+#undef SD_DIRECT_H2
 #undef SD_DIRECT_
 #undef SD_DIRECT
     return hipGetLastError();
@@ -576,6 +593,7 @@ hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
 const char* conv_direct_kernel_name(const ConvDirectParams& p) {
     const bool n16 = p.Cout <= 16 && p.nsplit == 1 && !p.pool && !(p.sw & SW_NO_N16);
     // f16w: fp16 activations x two fp16 weight planes (2 products); f16x1: fp16 x fp16 (1 product); f16w_x2: fp16 hi+lo x w_hi (2 products)
+    if (p.f16 == 4) return n16 ? "conv_direct_hs_kernel<1,n16>" : p.Cout <= 32 ? "conv_direct_hs_kernel<1,2>" : "conv_direct_hs_kernel<2,2>";
     if (p.f16 == 3) return "conv_direct_f16w_x2_kernel<2,2>";
     if (n16) return p.f16 == 2 ? "conv_direct_f16x1_kernel<1,n16>" : p.f16 ? "conv_direct_f16w_kernel<1,n16>" : "conv_direct_kernel<1,n16>";
     if (p.Cout <= 32) return p.f16 == 2 ? "conv_direct_f16x1_kernel<1,2>" : p.f16 ? "conv_direct_f16w_kernel<1,2>" : "conv_direct_kernel<1,2>";

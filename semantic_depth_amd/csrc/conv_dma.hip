@@ -56,6 +56,9 @@ const char* conv_dma_kernel_name(const ConvParams& p) {
         {"conv_dma_f16x1_kernel<2,4,2,2>", "conv_dma_f16x1_kernel<4,2,2,2>", "conv_dma_f16x1_kernel<4,2,2,1>", "conv_dma_f16x1_kernel<8,1,1,1>",
          "conv_dma_f16x1_kernel<2,4,4,2>"}};
     const int v = conv_dma_variant(p);
+    static const char* const namesh[5] = {"conv_dma_hs_kernel<2,4,2,2>", "conv_dma_hs_kernel<4,2,2,2>", "conv_dma_hs_kernel<4,2,2,1>", "conv_dma_hs_kernel<8,1,1,1>",
+                                          "conv_dma_hs_kernel<2,4,4,2>"};
+    if (p.f16 == 4) return namesh[v >= 1 && v <= 5 ? v - 1 : 2];
     return names[p.f16 == 2 ? 2 : (p.f16 ? 1 : 0)][v >= 1 && v <= 5 ? v - 1 : 2];
 }
 

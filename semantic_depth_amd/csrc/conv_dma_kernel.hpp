@@ -70,9 +70,13 @@ __device__ __forceinline__ KEntry load_kentry(const KEntry* ptr) {
 // W1 (with F16): ONE MFMA product per product -- the w_lo plane is neither fetched nor multiplied (plain fp16 x fp16, f32 accumulate)
 // X3 (SD_PREC_BF16X3): three bf16 planes per operand, six MFMA products per product, three output planes; two 72-KiB stages for the
 // 128 x 256 / 256 x 128 blocks (a k-tile moves 72 KB through the 16 B/clk L2 -> LDS path against 48 MFMAs per wave: the DMA bounds it)
-template <int WAVES_M, int WAVES_N, int MT, int NT, int SIMPLE, int STAGES, bool F16 = false, bool W1 = false, bool X3 = false>
+// H2 (SD_PREC_F16X2): the stage of the bf16 x 2 form (two planes per operand, three products), but the planes are fp16 hi + SCALED lo
+// activations and fp16 hi + lo weights (split_fmt.hpp "HS"): fp16 MFMAs, the x_lo product against w_hi * 2^-11 formed in registers, the
+// accumulator times ConvParams::alpha, HS output planes
+template <int WAVES_M, int WAVES_N, int MT, int NT, int SIMPLE, int STAGES, bool F16 = false, bool W1 = false, bool X3 = false, bool H2 = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 : 1) void conv_dma_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
     static_assert(!X3 || (!F16 && !W1), "bf16 x 3 is a form of its own");
+    static_assert(!H2 || (!F16 && !W1 && !X3), "H2 stages like the bf16 x 2 form");
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
     constexpr int NPX = F16 ? 1 : X3 ? 3 : 2, NPW = W1 ? 1 : X3 ? 3 : 2;      // planes of a stage per operand
@@ -366,9 +370,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
                         fragments_of((kt + 1) % STAGES, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    const u32x4 wv = (H2 && pr == 1) ? hs_wscaled(w[0][s][b]) : w[wi][s][b];      // (H2: x_lo multiplies w_hi * 2^-11)
 #pragma unroll
                     for (int a = 0; a < MT; ++a)
-                        acc[a][b] = mfma_frag<F16>(w[wi][s][b], x[xi][s][a], acc[a][b]);
+                        acc[a][b] = mfma_frag<F16 || H2>(wv, x[xi][s][a], acc[a][b]);
                     if (gidx * PPG < NDMA) {
                         __builtin_amdgcn_sched_barrier(0);
                         if (doissue) {
@@ -436,7 +441,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
     }
     auto epilogue = [&](auto tag, auto otag) {
         constexpr int ACT = decltype(tag)::value;
-        constexpr bool O16 = decltype(otag)::value;            // output planes: fp16 or bf16 (the consumers' format)
+        constexpr int OF = decltype(otag)::value;              // output planes (the consumers' format): 0 bf16 hi + lo, 1 ONE fp16, 3 fp16 hi + scaled lo
+        constexpr bool O16 = OF == 1;
         constexpr int ROW = EPI_ROW;
         unsigned char* sh = reinterpret_cast<unsigned char*>(ring) + wave * (2 * 32 * ROW);
         unsigned char* sl = sh + 32 * ROW;
@@ -467,11 +473,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
                             mx = fmaxf(mx, __shfl_xor(mx, 2));
                             v[r] = mx;
                         }
-                        v += *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+                        if constexpr (H2) v = v * p.alpha + *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+                        else v += *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
                         uint2 h, l;
-                        split4_t<O16>(v, h, l, p.sat);
+                        split4_fmt<OF>(v, h, l, p.sat);
                         if ((lane & 3) == 0) {
                             *reinterpret_cast<uint2*>(sh + ((lane & 31) >> 2) * ROW + nl * 2) = h;
                             if constexpr (!O16) *reinterpret_cast<uint2*>(sl + ((lane & 31) >> 2) * ROW + nl * 2) = l;
@@ -503,11 +510,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int nl = b * 32 + 8 * r4 + 4 * (lane >> 5);
                     f32x4 v = {acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
-                    v += *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+                    if constexpr (H2) v = v * p.alpha + *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+                    else v += *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
                     uint2 h, l;
-                    split4_t<O16>(v, h, l, p.sat);
+                    split4_fmt<OF>(v, h, l, p.sat);
                     *reinterpret_cast<uint2*>(sh + (lane & 31) * ROW + nl * 2) = h;
                     if constexpr (!O16) *reinterpret_cast<uint2*>(sl + (lane & 31) * ROW + nl * 2) = l;
                 }
@@ -528,7 +536,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     };
-    auto ep = [&](auto tag) { if (p.out_f16) epilogue(tag, BoolTag<true>{}); else epilogue(tag, BoolTag<false>{}); };
+    auto ep = [&](auto tag) {
+        if constexpr (H2) epilogue(tag, IntTag<3>{});          // (an HS layer writes HS planes, nothing else)
+        else { if (p.out_f16) epilogue(tag, IntTag<1>{}); else epilogue(tag, IntTag<0>{}); }
+    };
     if (p.act == ACT_RELU) ep(ActTag<ACT_RELU>{});
     else if (p.act == ACT_ELU) ep(ActTag<ACT_ELU>{});
     else ep(ActTag<ACT_NONE>{});
@@ -546,6 +557,12 @@ void launch_dma_variant(const ConvParams& p, long M, hipStream_t s) {
         if (mode == 2) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 2, 2, false, false, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
         else if (mode == 1) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 1, 2, false, false, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
         else hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 0, 2, false, false, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+        return;
+    }
+    if (p.f16 == 4) {                     // SD_PREC_F16X2: the three-product stage, fp16 HS planes
+        if (mode == 2) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 2, S3, false, false, false, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+        else if (mode == 1) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 1, S3, false, false, false, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
+        else hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 0, S3, false, false, false, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
         return;
     }
     if (p.f16 == 2) {

@@ -31,8 +31,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // Output path shared by the split kernels.  A wave owns a (MT*32) x (NT*32) tile; per 32-pixel slab it applies bias +
 // activation, splits ONCE into hi/lo, transposes through a wave-private LDS slab and writes 16-byte runs of 8 channels,
 // so every pixel's NT*64 bytes per plane leave as one contiguous segment (the MFMA layout alone gives 8-byte fragments).
-template <int ACT, int MT, int NT, bool F16>
+// OF = OUTPUT format: 0 bf16 hi + lo, 1 ONE fp16 plane, 3 fp16 hi + scaled lo (an H2 layer: the accumulator times ConvParams::alpha)
+template <int ACT, int MT, int NT, int OF>
 __device__ __forceinline__ void split_epilogue_act(f32x16 (&acc)[MT][NT], unsigned char* slab, const ConvParams& p, int m0, int n0, int M, int lane) {
+    constexpr bool F16 = OF == 1;
     constexpr int ROW = NT * 64 + 16;
     unsigned char* sh = slab;
     unsigned char* sl = slab + 32 * ROW;
@@ -49,11 +51,12 @@ __device__ __forceinline__ void split_epilogue_act(f32x16 (&acc)[MT][NT], unsign
                 const int nl = b * 32 + 8 * r4 + 4 * (lane >> 5);
                 const int n = n0 + nl;
                 f32x4 v = {acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
+                if constexpr (OF == 3) v *= p.alpha;
                 if (n < p.Cout) v += *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
                 uint2 h, l;
-                split4_t<F16>(v, h, l, p.sat);
+                split4_fmt<OF>(v, h, l, p.sat);
                 *reinterpret_cast<uint2*>(sh + (lane & 31) * ROW + nl * 2) = h;
                 *reinterpret_cast<uint2*>(sl + (lane & 31) * ROW + nl * 2) = l;
             }
@@ -119,18 +122,24 @@ __device__ __forceinline__ void split_epilogue_x3(f32x16 (&acc)[MT][NT], unsigne
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
-template <int MT, int NT, bool F16>
+template <int MT, int NT, bool F16, bool H2 = false>
 __device__ __forceinline__ void split_epilogue(f32x16 (&acc)[MT][NT], unsigned char* slab, const ConvParams& p, int m0, int n0, int M, int lane) {
     // the template's F16 is the INPUT format of the kernel; the output planes follow p.out_f16 (the consumers' format)
-    if (p.out_f16) {
-        if (p.act == ACT_RELU) split_epilogue_act<ACT_RELU, MT, NT, true>(acc, slab, p, m0, n0, M, lane);
-        else if (p.act == ACT_ELU) split_epilogue_act<ACT_ELU, MT, NT, true>(acc, slab, p, m0, n0, M, lane);
-        else split_epilogue_act<ACT_NONE, MT, NT, true>(acc, slab, p, m0, n0, M, lane);
+    if constexpr (H2) {
+        if (p.act == ACT_RELU) split_epilogue_act<ACT_RELU, MT, NT, 3>(acc, slab, p, m0, n0, M, lane);
+        else if (p.act == ACT_ELU) split_epilogue_act<ACT_ELU, MT, NT, 3>(acc, slab, p, m0, n0, M, lane);
+        else split_epilogue_act<ACT_NONE, MT, NT, 3>(acc, slab, p, m0, n0, M, lane);
         return;
     }
-    if (p.act == ACT_RELU) split_epilogue_act<ACT_RELU, MT, NT, false>(acc, slab, p, m0, n0, M, lane);
-    else if (p.act == ACT_ELU) split_epilogue_act<ACT_ELU, MT, NT, false>(acc, slab, p, m0, n0, M, lane);
-    else split_epilogue_act<ACT_NONE, MT, NT, false>(acc, slab, p, m0, n0, M, lane);
+    if (p.out_f16) {
+        if (p.act == ACT_RELU) split_epilogue_act<ACT_RELU, MT, NT, 1>(acc, slab, p, m0, n0, M, lane);
+        else if (p.act == ACT_ELU) split_epilogue_act<ACT_ELU, MT, NT, 1>(acc, slab, p, m0, n0, M, lane);
+        else split_epilogue_act<ACT_NONE, MT, NT, 1>(acc, slab, p, m0, n0, M, lane);
+        return;
+    }
+    if (p.act == ACT_RELU) split_epilogue_act<ACT_RELU, MT, NT, 0>(acc, slab, p, m0, n0, M, lane);
+    else if (p.act == ACT_ELU) split_epilogue_act<ACT_ELU, MT, NT, 0>(acc, slab, p, m0, n0, M, lane);
+    else split_epilogue_act<ACT_NONE, MT, NT, 0>(acc, slab, p, m0, n0, M, lane);
 }
 
 template <int WAVES_M, int WAVES_N, int MT, int NT, int NPL = 2>
@@ -148,8 +157,11 @@ struct STile {
 
 // F16: ONE fp16 activation plane (the lo-plane reads below fetch unused bytes), two fp16 weight planes, two MFMA products per
 // product (split_fmt.hpp).  X3: three bf16 planes per operand, six MFMA products per product (SD_PREC_BF16X3).
-template <int WAVES_M, int WAVES_N, int MT, int NT, bool VEC, bool F16 = false, bool X3 = false>
+// H2 (SD_PREC_F16X2): the bf16 x 2 staging with fp16 hi + scaled lo activations and fp16 hi + lo weights: three fp16 products, the x_lo one
+// against w_hi * 2^-11 formed in registers (split_fmt.hpp "HS")
+template <int WAVES_M, int WAVES_N, int MT, int NT, bool VEC, bool F16 = false, bool X3 = false, bool H2 = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_split_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
+    static_assert(!H2 || (!F16 && !X3), "H2 stages like the bf16 x 2 form");
     constexpr int NPL = X3 ? 3 : 2;
     using T = STile<WAVES_M, WAVES_N, MT, NT, NPL>;
     constexpr int BM = T::BM, BN = T::BN, NTHR = T::NTHR;
@@ -323,10 +335,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_split_kernel(cons
                 if (!X3 && F16 && pr == 0 && p.f16 == 2) continue;        // one-product layer (':1'): x*w_hi only, as conv_dma / conv_direct W1
                 const int xi = X3 ? xp3[pr] : xp2[pr], wi = X3 ? wp3[pr] : wp2[pr];
 #pragma unroll
-                for (int b = 0; b < NT; ++b)
+                for (int b = 0; b < NT; ++b) {
+                    const u32x4 wv = (H2 && pr == 1) ? hs_wscaled(w[0][b]) : w[wi][b];      // (H2: x_lo multiplies w_hi * 2^-11)
 #pragma unroll
                     for (int a = 0; a < MT; ++a)
-                        acc[a][b] = mfma_frag<F16>(w[wi][b], x[xi][a], acc[a][b]);
+                        acc[a][b] = mfma_frag<F16 || H2>(wv, x[xi][a], acc[a][b]);
+                }
             }
         }
     }
@@ -339,7 +353,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_split_kernel(cons
         else if (p.act == ACT_ELU) split_epilogue_x3<ACT_ELU, MT, NT>(acc, slab, p, bm0 + wm0, bn0 + wn0, M, lane);
         else split_epilogue_x3<ACT_NONE, MT, NT>(acc, slab, p, bm0 + wm0, bn0 + wn0, M, lane);
     } else {
-        split_epilogue<MT, NT, F16>(acc, lds + wave * (2 * 32 * T::EPI_ROW), p, bm0 + wm0, bn0 + wn0, M, lane);
+        split_epilogue<MT, NT, F16, H2>(acc, lds + wave * (2 * 32 * T::EPI_ROW), p, bm0 + wm0, bn0 + wn0, M, lane);
     }
 }
 
@@ -355,6 +369,11 @@ static hipError_t launch_scfg(const ConvParams& p, hipStream_t s) {
             hipLaunchKernelGGL((conv_split_kernel<WAVES_M, WAVES_N, MT, NT, true, false, true>), grid, dim3(T::NTHR), 0, s, p, (int)M, tilesM, tilesN);
         else
             hipLaunchKernelGGL((conv_split_kernel<WAVES_M, WAVES_N, MT, NT, false, false, true>), grid, dim3(T::NTHR), 0, s, p, (int)M, tilesM, tilesN);
+    } else if (p.f16 == 4) {
+        if (p.vec)
+            hipLaunchKernelGGL((conv_split_kernel<WAVES_M, WAVES_N, MT, NT, true, false, false, true>), grid, dim3(T::NTHR), 0, s, p, (int)M, tilesM, tilesN);
+        else
+            hipLaunchKernelGGL((conv_split_kernel<WAVES_M, WAVES_N, MT, NT, false, false, false, true>), grid, dim3(T::NTHR), 0, s, p, (int)M, tilesM, tilesN);
     } else if (p.f16) {
         if (p.vec)
             hipLaunchKernelGGL((conv_split_kernel<WAVES_M, WAVES_N, MT, NT, true, true>), grid, dim3(T::NTHR), 0, s, p, (int)M, tilesM, tilesN);
@@ -405,6 +424,7 @@ const char* conv_split_kernel_name(const ConvParams& p) {
             default: return "conv_split_x3_kernel<4,1,2,1>";
         }
     }
+    if (p.f16 == 4) return "conv_split_hs_kernel";
     if (p.f16) {
         switch (split_variant(p)) {
             case 0:  return "conv_split_f16w_kernel<2,4,2,2>";

@@ -19,8 +19,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ST_TW = 32;              // output tile width
 constexpr int ST_MAXPIX = 1536;        // halo pixels: 21 x 69 (7x7 stride 2, 8 rows) = 1449, 22 x 38 (7x7 stride 1, 16 rows) = 836
-template <int NB, int RW, bool F16, bool X3 = false>
+// H2 (SD_PREC_F16X2): fp16 hi + scaled lo input planes x fp16 hi + lo weights, three fp16 products (the x_lo one against w_hi * 2^-11), the
+// accumulator times ConvParams::alpha, HS output planes (split_fmt.hpp "HS")
+template <int NB, int RW, bool F16, bool X3 = false, bool H2 = false>
 __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
+    static_assert(!H2 || (!F16 && !X3), "H2 stages like the bf16 x 2 form");
     constexpr int NPL = X3 ? 3 : 2;              // planes per operand (X3: bf16 hi, mid, lo -- SD_PREC_BF16X3, six products per product)
     constexpr int ST_PF = NPL * ST_MAXPIX / 512; // halo units (pixel, plane) prefetched per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -156,12 +159,13 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
                         }
                     }
                 } else {
+                const u32x4 whs = H2 ? hs_wscaled(wh) : wh;   // the weight operand of the x_lo product
 #pragma unroll
                 for (int pr = 0; pr < 3; ++pr) {              // x_hi*w_lo, x_lo*w_hi, x_hi*w_hi; an fp16 input has no lo plane
                     if (F16 && pr == 1) continue;
 #pragma unroll
                     for (int a = 0; a < RW; ++a)
-                        acc[a][nb] = mfma_frag<F16>(pr == 0 ? wl : wh, pr == 1 ? xl[a] : xh[a], acc[a][nb]);
+                        acc[a][nb] = mfma_frag<F16 || H2>(pr == 0 ? wl : pr == 1 ? whs : wh, pr == 1 ? xl[a] : xh[a], acc[a][nb]);
                 }
                 }
             }
@@ -170,7 +174,8 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
         // ---- epilogue: bias + activation, split once, LDS transpose one plane at a time, 16-byte runs per pixel ----
         auto epilogue = [&](auto tag, auto otag) {
             constexpr int ACT = decltype(tag)::value;
-            constexpr bool O16 = decltype(otag)::value;
+            constexpr int OF = decltype(otag)::value;          // 0 bf16 hi + lo, 1 ONE fp16 plane, 3 fp16 hi + scaled lo
+            constexpr bool O16 = OF == 1;
             constexpr int SEGS = 4 * NB, PPP = 64 / SEGS;
             unsigned char* sh = slab + wave * (32 * ROW);
             const int seg = lane % SEGS, prow = lane / SEGS;
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
                 for (int r4 = 0; r4 < 4 * NB; ++r4) {
                     const int nb = r4 >> 2, q = r4 & 3;
                     f32x4 v = {acc[a][nb][4 * q], acc[a][nb][4 * q + 1], acc[a][nb][4 * q + 2], acc[a][nb][4 * q + 3]};
-                    v += bias[r4];
+                    if constexpr (H2) v = v * p.alpha + bias[r4]; else v += bias[r4];
                     if constexpr (X3) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = act_f32<ACT>(v[r]);
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
-                        split4_t<O16>(v, hh[r4], ll[r4], p.sat);
+                        split4_fmt<OF>(v, hh[r4], ll[r4], p.sat);
                         mm[r4] = ll[r4];
                     }
                 }
@@ -218,7 +223,10 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
                 }
             }
         };
-        auto ep = [&](auto tag) { if (p.out_f16) epilogue(tag, BoolTag<true>{}); else epilogue(tag, BoolTag<false>{}); };
+        auto ep = [&](auto tag) {
+            if constexpr (H2) epilogue(tag, IntTag<3>{});
+            else { if (p.out_f16) epilogue(tag, IntTag<1>{}); else epilogue(tag, IntTag<0>{}); }
+        };
         if (p.act == ACT_RELU) ep(ActTag<ACT_RELU>{});
         else if (p.act == ACT_ELU) ep(ActTag<ACT_ELU>{});
         else ep(ActTag<ACT_NONE>{});
@@ -263,6 +271,9 @@ hipError_t launch_conv_stem(const ConvParams& p, hipStream_t s) {
     if (p.x3) {
         if (nb == 1 && rw == 1) SD_STEM(1, 1, false, true); else if (nb == 1) SD_STEM(1, 2, false, true);
         else if (rw == 1) SD_STEM(2, 1, false, true); else SD_STEM(2, 2, false, true);
+    } else if (p.f16 == 4) {
+        if (nb == 1 && rw == 1) SD_STEM(1, 1, false, false, true); else if (nb == 1) SD_STEM(1, 2, false, false, true);
+        else if (rw == 1) SD_STEM(2, 1, false, false, true); else SD_STEM(2, 2, false, false, true);
     } else if (p.f16) {
         if (nb == 1 && rw == 1) SD_STEM(1, 1, true); else if (nb == 1) SD_STEM(1, 2, true);
         else if (rw == 1) SD_STEM(2, 1, true); else SD_STEM(2, 2, true);

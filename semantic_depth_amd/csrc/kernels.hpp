@@ -64,7 +64,9 @@ struct ConvParams {
     size_t src0_plane;
     int f16;           // 1: the INPUT is ONE fp16 plane and the weights two fp16 planes (2 MFMA products, split_fmt.hpp); 2: the same
                        // input and w_hi only (1 MFMA product: plain fp16 x fp16; conv_dma / conv_direct, the others run the 2-product form)
-    int out_f16;       // OUTPUT split planes are fp16 (the format the consumers of the output tensor compute in)
+                       // 4 (SD_PREC_F16X2): fp16 hi + SCALED lo input planes x fp16 hi + lo weights, THREE products, `alpha` applied (split_fmt.hpp "HS")
+    int out_f16;       // OUTPUT split planes are fp16 (the format the consumers of the output tensor compute in); 3 = fp16 hi + scaled lo (HS)
+    float alpha;       // f16 == 4: 2^-k of the layer's weight scale (WeightSlot::wscale): out = act(acc * alpha + bias)
     int out_planar16;  // conv_stem.hip: write the output as Cout/16 sub-planes of 16 channels (TensorDesc::planar16)
     int pool;          // conv_dma.hip: output pixels are walked in 2x2-window-major order and the epilogue max-pools each
                        // window: out is [N,Hout/2,Wout/2,Cout]
@@ -164,7 +166,9 @@ struct ConvDirectParams {
     int rows_per_wave;           // 1: 8 x 32 tiles, 2: 16 x 32 tiles (see conv_direct.hip)
     int f16;                     // 1: ONE fp16 input plane x two fp16 weight planes (2 MFMA products); 2: x w_hi only (1 product);
                                  // 3: fp16 hi + lo input planes x w_hi (2 products: x_hi*w_hi + x_lo*w_hi)
-    int out_f16;                 // OUTPUT planes: 0 bf16 hi + lo, 1 ONE fp16 plane, 2 fp16 hi + lo
+                                 // 4 (SD_PREC_F16X2): fp16 hi + scaled lo input planes x fp16 hi + lo weights, THREE products, `alpha` applied
+    int out_f16;                 // OUTPUT planes: 0 bf16 hi + lo, 1 ONE fp16 plane, 2 fp16 hi + lo, 3 fp16 hi + scaled lo (HS)
+    float alpha;                 // f16 == 4: 2^-k of the layer's weight scale: out = act(acc * alpha + bias)
     int pool;                    // 1: fused 2x2 stride-2 max pool, out is [N,H/2,W/2,Cout] (needs rows_per_wave == 2)
     unsigned sw;                 // Switch bits of the handle
     unsigned long long* sat;     // DEVICE counter of fp16-saturated output values (split_fmt.hpp sat_report; sd_saturation_count)
@@ -209,9 +213,9 @@ struct SmallNParams {
     float* out;         // [N,H,W,nout]
     int act;
     const void* zero16; // 16 zero bytes (padding source of the LDS-DMA halo loads of the tiled kernel)
-    int f16;            // INPUT planes: 0 bf16 hi + lo, 1 ONE fp16 plane, 2 fp16 hi + lo (per-thread / per-wave kernels)
+    int f16;            // INPUT planes: 0 bf16 hi + lo, 1 ONE fp16 plane, 2 fp16 hi + lo (per-thread / per-wave kernels), 3 fp16 hi + scaled lo (HS)
     int x3;             // split planes (in and out) are bf16 x 3 (per-thread / per-wave kernels)
-    int out_f16;        // OUTPUT split planes (out_split) are fp16
+    int out_f16;        // OUTPUT split planes (out_split) are fp16 (3: fp16 hi + scaled lo)
     unsigned sw;        // Switch bits of the handle
 };
 hipError_t launch_conv_smalln(const SmallNParams& p, hipStream_t s);
@@ -220,12 +224,12 @@ bool conv_smalln_tiled(int in_split, int k, int W, int C, int nout, unsigned sw)
 // ---------------------------------------------------------------------------------------------
 // misc network ops (ops_misc.hip)
 // ---------------------------------------------------------------------------------------------
-// `split`: 0 f32, 1 split-bf16 planes (split_fmt.hpp), 2 ONE fp16 plane, 4 bf16 x 3 planes; `plane*` = element offset of the lo plane
+// `split`: 0 f32, 1 split-bf16 planes (split_fmt.hpp), 2 ONE fp16 plane, 4 bf16 x 3 planes, 5 fp16 hi + scaled lo (HS); `plane*` = element offset of the lo plane
 hipError_t launch_pre_vgg(const uint8_t* frames, float* out, long npix, int split, size_t plane, hipStream_t s);                 // K1
 hipError_t launch_pre_mono(const uint8_t* frames, float* out, int B, int H, int W, int split, size_t plane, int raw, hipStream_t s);      // /255 (raw: not) + fliplr pair
 hipError_t launch_maxpool2(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s);
 hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s);
-hipError_t launch_unsplit(const float* x, float* y, long npix, int C, int Ctf, size_t plane, size_t sub, int f16, hipStream_t s);  // split planes -> f32 [npix][Ctf]; f16 = -1: bf16 x 3
+hipError_t launch_unsplit(const float* x, float* y, long npix, int C, int Ctf, size_t plane, size_t sub, int f16, hipStream_t s);  // split planes -> f32 [npix][Ctf]; f16 = TensorDesc::f16, or -1: bf16 x 3
 // y[n,2i+ky-1,2j+kx-1,o] += x[n,i,j,c]*w[ky,kx,o,c]; y += bias + skip   (3->3 channels; fcn8s/fcn.py:186-204)
 hipError_t launch_deconv4s2_add(const float* x, const float* w, const float* bias, const float* skip, float* y,
                                 int N, int H, int W, hipStream_t s);

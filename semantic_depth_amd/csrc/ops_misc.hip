@@ -10,14 +10,19 @@ namespace sd {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Every op below exists for the activation formats f32 NHWC (0), split-bf16 planes (1), ONE fp16 plane (2), [read side: fp16 hi + lo (3)]
-// and bf16 x 3 planes (4) of split_fmt.hpp (template parameter SPLIT; `plane` = element offset between planes).
+// , bf16 x 3 planes (4) and fp16 hi + scaled lo (5, "HS": SD_PREC_F16X2) of split_fmt.hpp (template parameter SPLIT; `plane` = element offset between planes).
 // ---------------------------------------------------------------------------------------------
 // K1: VGG 'Processing' block [UPSTREAM Udacity vgg]: split (c0,c1,c2), subtract means, concat reversed.
 // 4 stored channels (the 4th is zero and meets zero weight rows): conv1_1 gathers whole channel quads.
 // ---------------------------------------------------------------------------------------------
 template <int SPLIT>
 __device__ __forceinline__ void store4(float* base, size_t plane, long quad_index, f32x4 v) {
-    if (SPLIT == 4) {              // bf16 x 3: exact
+    if (SPLIT == 5) {              // fp16 hi + scaled lo
+        uint2 h, l;
+        split4_hs(v, h, l, (sat_ptr_t) nullptr);
+        reinterpret_cast<uint2*>(base)[quad_index] = h;
+        reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + plane)[quad_index] = l;
+    } else if (SPLIT == 4) {              // bf16 x 3: exact
         uint2 h, m, l;
         split4_x3(v, h, m, l);
         uint16_t* b16 = reinterpret_cast<uint16_t*>(base);
@@ -36,6 +41,8 @@ __device__ __forceinline__ void store4(float* base, size_t plane, long quad_inde
 }
 template <int SPLIT>
 __device__ __forceinline__ f32x4 load4(const float* base, size_t plane, long quad_index) {
+    if (SPLIT == 5)
+        return recon4_hs(reinterpret_cast<const uint2*>(base)[quad_index], reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + plane)[quad_index]);
     if (SPLIT == 4) {
         const uint16_t* b16 = reinterpret_cast<const uint16_t*>(base);
         return recon4_x3(reinterpret_cast<const uint2*>(b16)[quad_index], reinterpret_cast<const uint2*>(b16 + plane)[quad_index],
@@ -63,7 +70,8 @@ __global__ __launch_bounds__(256) void pre_vgg_kernel(const uint8_t* __restrict_
 }
 hipError_t launch_pre_vgg(const uint8_t* frames, float* out, long npix, int split, size_t plane, hipStream_t s) {
     const dim3 grid((unsigned)((npix + 255) / 256));
-    if (split == 4) hipLaunchKernelGGL(pre_vgg_kernel<4>, grid, dim3(256), 0, s, frames, out, npix, plane);
+    if (split == 5) hipLaunchKernelGGL(pre_vgg_kernel<5>, grid, dim3(256), 0, s, frames, out, npix, plane);
+    else if (split == 4) hipLaunchKernelGGL(pre_vgg_kernel<4>, grid, dim3(256), 0, s, frames, out, npix, plane);
     else if (split == 2) hipLaunchKernelGGL(pre_vgg_kernel<2>, grid, dim3(256), 0, s, frames, out, npix, plane);
     else if (split) hipLaunchKernelGGL(pre_vgg_kernel<1>, grid, dim3(256), 0, s, frames, out, npix, plane);
     else hipLaunchKernelGGL(pre_vgg_kernel<0>, grid, dim3(256), 0, s, frames, out, npix, plane);
@@ -89,7 +97,8 @@ __global__ __launch_bounds__(256) void pre_mono_kernel(const uint8_t* __restrict
 hipError_t launch_pre_mono(const uint8_t* frames, float* out, int B, int H, int W, int split, size_t plane, int raw, hipStream_t s) {
     long npix = (long)B * H * W;
     const dim3 grid((unsigned)((npix + 255) / 256));
-    if (split == 4) hipLaunchKernelGGL(pre_mono_kernel<4>, grid, dim3(256), 0, s, frames, out, B, H, W, plane, raw);
+    if (split == 5) hipLaunchKernelGGL(pre_mono_kernel<5>, grid, dim3(256), 0, s, frames, out, B, H, W, plane, raw);
+    else if (split == 4) hipLaunchKernelGGL(pre_mono_kernel<4>, grid, dim3(256), 0, s, frames, out, B, H, W, plane, raw);
     else if (split == 2) hipLaunchKernelGGL(pre_mono_kernel<2>, grid, dim3(256), 0, s, frames, out, B, H, W, plane, raw);
     else if (split) hipLaunchKernelGGL(pre_mono_kernel<1>, grid, dim3(256), 0, s, frames, out, B, H, W, plane, raw);
     else hipLaunchKernelGGL(pre_mono_kernel<0>, grid, dim3(256), 0, s, frames, out, B, H, W, plane, raw);
@@ -122,7 +131,8 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__
 hipError_t launch_maxpool2(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s) {
     long total = (long)N * (H / 2) * (W / 2) * (C / 4);
     const dim3 grid((unsigned)((total + 255) / 256));
-    if (split == 4) hipLaunchKernelGGL(maxpool2_kernel<4>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
+    if (split == 5) hipLaunchKernelGGL(maxpool2_kernel<5>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
+    else if (split == 4) hipLaunchKernelGGL(maxpool2_kernel<4>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
     else if (split == 2) hipLaunchKernelGGL(maxpool2_kernel<2>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
     else if (split) hipLaunchKernelGGL(maxpool2_kernel<1>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
     else hipLaunchKernelGGL(maxpool2_kernel<0>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
@@ -156,7 +166,8 @@ __global__ __launch_bounds__(256) void maxpool3z_kernel(const float* __restrict_
 }
 // split planes with C % 8 == 0: one thread per (output pixel, channel octet), 16-byte loads per plane and tap.
 // NPL = planes: 1 ONE fp16 plane, 2 bf16 hi + lo, 3 bf16 hi + mid + lo (exact: the max of exact values, split exactly again)
-template <int NPL>
+// HS (NPL = 2): the planes are fp16 hi + scaled lo (the max of 22-bit values, split again without loss)
+template <int NPL, bool HS = false>
 __global__ __launch_bounds__(256) void maxpool3z_oct_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C8,
                                                             size_t plane_in, size_t plane_out) {
     constexpr bool F16 = NPL == 1;
@@ -186,6 +197,9 @@ __global__ __launch_bounds__(256) void maxpool3z_oct_kernel(const float* __restr
                     const u32x4_t t = x3[q];
                     v0 = recon4_x3(uint2{h[0], h[1]}, uint2{l[0], l[1]}, uint2{t[0], t[1]});
                     v1 = recon4_x3(uint2{h[2], h[3]}, uint2{l[2], l[3]}, uint2{t[2], t[3]});
+                } else if constexpr (HS) {
+                    v0 = recon4_hs(uint2{h[0], h[1]}, uint2{l[0], l[1]});
+                    v1 = recon4_hs(uint2{h[2], h[3]}, uint2{l[2], l[3]});
                 } else {
                     v0 = recon4_t<F16>(uint2{h[0], h[1]}, uint2{l[0], l[1]});
                     v1 = recon4_t<F16>(uint2{h[2], h[3]}, uint2{l[2], l[3]});
@@ -200,6 +214,9 @@ __global__ __launch_bounds__(256) void maxpool3z_oct_kernel(const float* __restr
         split4_x3(m0, h0, l0, t0);
         split4_x3(m1, h1, l1, t1);
         reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(y) + 2 * plane_out)[i] = (u32x4_t){t0.x, t0.y, t1.x, t1.y};
+    } else if constexpr (HS) {
+        split4_hs(m0, h0, l0, (sat_ptr_t) nullptr);
+        split4_hs(m1, h1, l1, (sat_ptr_t) nullptr);
     } else {
         split4_t<F16>(m0, h0, l0);
         split4_t<F16>(m1, h1, l1);
@@ -212,14 +229,16 @@ hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C
     if (split && C % 8 == 0) {
         const long tot8 = (long)N * Ho * Wo * (C / 8);
         const dim3 g8((unsigned)((tot8 + 255) / 256));
-        if (split == 4) hipLaunchKernelGGL(maxpool3z_oct_kernel<3>, g8, dim3(256), 0, s, x, y, N, H, W, C / 8, plane_in, plane_out);
+        if (split == 5) hipLaunchKernelGGL((maxpool3z_oct_kernel<2, true>), g8, dim3(256), 0, s, x, y, N, H, W, C / 8, plane_in, plane_out);
+        else if (split == 4) hipLaunchKernelGGL(maxpool3z_oct_kernel<3>, g8, dim3(256), 0, s, x, y, N, H, W, C / 8, plane_in, plane_out);
         else if (split == 2) hipLaunchKernelGGL(maxpool3z_oct_kernel<1>, g8, dim3(256), 0, s, x, y, N, H, W, C / 8, plane_in, plane_out);
         else hipLaunchKernelGGL(maxpool3z_oct_kernel<2>, g8, dim3(256), 0, s, x, y, N, H, W, C / 8, plane_in, plane_out);
         return hipGetLastError();
     }
     long total = (long)N * Ho * Wo * (C / 4);
     const dim3 grid((unsigned)((total + 255) / 256));
-    if (split == 4) hipLaunchKernelGGL(maxpool3z_kernel<4>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
+    if (split == 5) hipLaunchKernelGGL(maxpool3z_kernel<5>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
+    else if (split == 4) hipLaunchKernelGGL(maxpool3z_kernel<4>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
     else if (split == 2) hipLaunchKernelGGL(maxpool3z_kernel<2>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
     else if (split) hipLaunchKernelGGL(maxpool3z_kernel<1>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
     else hipLaunchKernelGGL(maxpool3z_kernel<0>, grid, dim3(256), 0, s, x, y, N, H, W, C / 4, plane_in, plane_out);
@@ -281,21 +300,23 @@ __global__ __launch_bounds__(256) void conv_smalln_thread_kernel(const SmallNPar
         unsigned h, l, m = 0u;
         const f32x2_t v2 = {smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)};
         if (p.x3) split2_x3(v2, h, m, l);
+        else if (p.out_f16 == 3) split2_hs(v2, h, l, (sat_ptr_t) nullptr);
         else if (p.out_f16) split2_t<true>(v2, h, l);
         else split2_t<false>(v2, h, l);
+        const bool two = !p.out_f16 || p.out_f16 == 3;          // a second plane exists (bf16 hi + lo, fp16 hi + scaled lo)
         uint16_t* const o16 = reinterpret_cast<uint16_t*>(p.out);
         if (p.out_c == 8) {       // one zero-padded channel octet per pixel (source of the direct 3x3 kernel)
             reinterpret_cast<u32x4_t*>(o16)[pix] = (u32x4_t){h, 0u, 0u, 0u};
             if (p.x3) {
                 reinterpret_cast<u32x4_t*>(o16 + p.out_plane)[pix] = (u32x4_t){m, 0u, 0u, 0u};
                 reinterpret_cast<u32x4_t*>(o16 + 2 * p.out_plane)[pix] = (u32x4_t){l, 0u, 0u, 0u};
-            } else if (!p.out_f16) reinterpret_cast<u32x4_t*>(o16 + p.out_plane)[pix] = (u32x4_t){l, 0u, 0u, 0u};
+            } else if (two) reinterpret_cast<u32x4_t*>(o16 + p.out_plane)[pix] = (u32x4_t){l, 0u, 0u, 0u};
         } else {
             reinterpret_cast<unsigned*>(o16)[pix] = h;
             if (p.x3) {
                 reinterpret_cast<unsigned*>(o16 + p.out_plane)[pix] = m;
                 reinterpret_cast<unsigned*>(o16 + 2 * p.out_plane)[pix] = l;
-            } else if (!p.out_f16) reinterpret_cast<unsigned*>(o16 + p.out_plane)[pix] = l;
+            } else if (two) reinterpret_cast<unsigned*>(o16 + p.out_plane)[pix] = l;
         }
     } else {
         float* o = p.out + pix * NOUT;
@@ -360,7 +381,8 @@ constexpr int SN_TH = 8, SN_TW = 32, SN_HW = SN_TW + 2, SN_HH = SN_TH + 2;
 constexpr int SN_XI = (SN_HH * SN_HW * 2 + 63) / 64;        // 11 DMA instructions per plane
 constexpr int SN_XUNITS = SN_XI * 64;
 // NPL = planes of the input: 1 ONE fp16 plane, 2 bf16 hi + lo, 3 bf16 hi + mid + lo (SD_PREC_BF16X3: exact f32 values, f32 FMAs)
-template <int NOUT, int NPL>
+// HS (NPL = 2): fp16 hi + scaled lo planes (SD_PREC_F16X2)
+template <int NOUT, int NPL, bool HS = false>
 __global__ __launch_bounds__(256) void conv_smalln_tile_kernel(const SmallNParams p) {
     constexpr bool F16 = NPL == 1;
     __shared__ __attribute__((aligned(16))) u32x4_t X[NPL * SN_XUNITS];
@@ -409,6 +431,9 @@ __global__ __launch_bounds__(256) void conv_smalln_tile_kernel(const SmallNParam
                     const u32x4_t m3 = X[2 * SN_XUNITS + idx];            // (l = the mid plane, m3 = the lo plane: memory order)
                     v0 = recon4_x3(uint2{h[0], h[1]}, uint2{l[0], l[1]}, uint2{m3[0], m3[1]});
                     v1 = recon4_x3(uint2{h[2], h[3]}, uint2{l[2], l[3]}, uint2{m3[2], m3[3]});
+                } else if constexpr (HS) {
+                    v0 = recon4_hs(uint2{h[0], h[1]}, uint2{l[0], l[1]});
+                    v1 = recon4_hs(uint2{h[2], h[3]}, uint2{l[2], l[3]});
                 } else {
                     v0 = recon4_t<F16>(uint2{h[0], h[1]}, uint2{l[0], l[1]});
                     v1 = recon4_t<F16>(uint2{h[2], h[3]}, uint2{l[2], l[3]});
@@ -430,21 +455,23 @@ __global__ __launch_bounds__(256) void conv_smalln_tile_kernel(const SmallNParam
         unsigned h, l, m = 0u;
         const f32x2_t v2 = {smalln_act(acc[0], p.act), smalln_act(acc[NOUT > 1 ? 1 : 0], p.act)};
         if (NPL == 3) split2_x3(v2, h, m, l);
+        else if (HS) split2_hs(v2, h, l, (sat_ptr_t) nullptr);
         else if (p.out_f16) split2_t<true>(v2, h, l);
         else split2_t<false>(v2, h, l);
+        const bool two = HS || !p.out_f16;
         uint16_t* const o16 = reinterpret_cast<uint16_t*>(p.out);
         if (p.out_c == 8) {
             reinterpret_cast<u32x4_t*>(o16)[pix] = (u32x4_t){h, 0u, 0u, 0u};
             if (NPL == 3) {
                 reinterpret_cast<u32x4_t*>(o16 + p.out_plane)[pix] = (u32x4_t){m, 0u, 0u, 0u};
                 reinterpret_cast<u32x4_t*>(o16 + 2 * p.out_plane)[pix] = (u32x4_t){l, 0u, 0u, 0u};
-            } else if (!p.out_f16) reinterpret_cast<u32x4_t*>(o16 + p.out_plane)[pix] = (u32x4_t){l, 0u, 0u, 0u};
+            } else if (two) reinterpret_cast<u32x4_t*>(o16 + p.out_plane)[pix] = (u32x4_t){l, 0u, 0u, 0u};
         } else {
             reinterpret_cast<unsigned*>(o16)[pix] = h;
             if (NPL == 3) {
                 reinterpret_cast<unsigned*>(o16 + p.out_plane)[pix] = m;
                 reinterpret_cast<unsigned*>(o16 + 2 * p.out_plane)[pix] = l;
-            } else if (!p.out_f16) reinterpret_cast<unsigned*>(o16 + p.out_plane)[pix] = l;
+            } else if (two) reinterpret_cast<unsigned*>(o16 + p.out_plane)[pix] = l;
         }
     } else {
         float* o = p.out + pix * NOUT;
@@ -461,7 +488,10 @@ static void launch_smalln_t(const SmallNParams& p, hipStream_t s) {
         !(p.sw & SW_NO_SMALLN_TILE)) {
         const dim3 grid((unsigned)((p.W / SN_TW) * ((p.H + SN_TH - 1) / SN_TH) * p.N));
         const size_t lds = (size_t)K * 4 * p.nout;
-        if (IN_SPLIT == 4) {
+        if (IN_SPLIT == 5) {
+            if (p.nout == 1) hipLaunchKernelGGL((conv_smalln_tile_kernel<1, 2, true>), grid, dim3(256), lds, s, p);
+            else hipLaunchKernelGGL((conv_smalln_tile_kernel<2, 2, true>), grid, dim3(256), lds, s, p);
+        } else if (IN_SPLIT == 4) {
             if (p.nout == 1) hipLaunchKernelGGL((conv_smalln_tile_kernel<1, 3>), grid, dim3(256), lds, s, p);
             else hipLaunchKernelGGL((conv_smalln_tile_kernel<2, 3>), grid, dim3(256), lds, s, p);
         } else if (IN_SPLIT == 2) {
@@ -496,6 +526,8 @@ hipError_t launch_conv_smalln(const SmallNParams& p, hipStream_t s) {
     if (p.in_split && p.x3) {            // bf16 x 3 input: exact f32 arithmetic on the reconstructed values (tiled or per-thread / per-wave)
         if (p.in_sub) return hipErrorInvalidValue;
         launch_smalln_t<4>(p, s);
+    } else if (p.in_split && p.f16 == 3) {      // fp16 hi + scaled lo planes (SD_PREC_F16X2): f32 arithmetic on the reconstructed values
+        launch_smalln_t<5>(p, s);                // (sub-planar inputs: the tiled kernel, checked above)
     } else if (p.in_split && p.f16 == 2) {      // fp16 hi + lo input: the per-thread / per-wave kernels only
         if (p.in_sub || p.out_split) return hipErrorInvalidValue;
         SmallNParams q = p;
@@ -516,6 +548,7 @@ __global__ __launch_bounds__(256) void unsplit_kernel(const float* __restrict__ 
     const int c = (int)(i - pix * Ctf);
     const uint16_t* h = reinterpret_cast<const uint16_t*>(x) + (sub ? (size_t)(c >> 4) * sub + (size_t)pix * 16 + (c & 15) : (size_t)pix * C + c);
     if (f16 < 0) y[i] = (__uint_as_float((unsigned)h[0] << 16) + __uint_as_float((unsigned)h[plane] << 16)) + __uint_as_float((unsigned)h[2 * plane] << 16);   // bf16 x 3
+    else if (f16 == 3) y[i] = (float)__builtin_bit_cast(_Float16, h[0]) + (float)__builtin_bit_cast(_Float16, h[plane]) * (1.f / 2048.f);      // fp16 hi + scaled lo
     else if (f16 == 2) y[i] = (float)__builtin_bit_cast(_Float16, h[0]) + (float)__builtin_bit_cast(_Float16, h[plane]);      // fp16 hi + lo
     else if (f16) y[i] = (float)__builtin_bit_cast(_Float16, h[0]);                   // ONE fp16 plane
     else y[i] = __uint_as_float((unsigned)h[0] << 16) + __uint_as_float((unsigned)h[plane] << 16);

@@ -42,6 +42,7 @@ struct Builder {
         t.name = name; t.N = N; t.H = H; t.W = W; t.C = C; t.Ctf = C;
         t.fmt = p.prec ? 1 : 0;          // the split engine keeps its activations as split-bf16 planes
         t.x3 = p.x3;
+        if (p.h2) t.f16 = 3;             // fp16 hi + scaled lo planes (SD_PREC_F16X2)
         t.bytes = (size_t)N * H * W * C * (p.x3 ? 6 : sizeof(float));        // bf16 x 3: three 16-bit planes
         p.tensors.push_back(t);
         p.tensor_by_name[name] = (int)p.tensors.size() - 1;
@@ -66,6 +67,7 @@ struct Builder {
         }
         s.bytes = n * sizeof(float);
         if (p.x3 && (layout == WL_IGEMM_SPLIT || layout == WL_DIRECT_SPLIT)) { s.x3 = 1; s.bytes = n * 6; }      // three bf16 planes
+        if (p.h2 && (layout == WL_IGEMM_SPLIT || layout == WL_DIRECT_SPLIT)) { s.f16 = 1; s.hs = 1; }            // two fp16 planes of w * 2^12
         p.weights.push_back(s);
         p.weight_by_name[name] = (int)p.weights.size() - 1;
         return (int)p.weights.size() - 1;
@@ -332,6 +334,11 @@ struct Builder {
 
     // precision plan: mark the conv layers named in p.f16_spec, then close the choice under the one-format-per-tensor rule
     void apply_precision_plan() {
+        if (p.h2) {                      // SD_PREC_F16X2: every conv in the three-product HS form (the tensors and weight slots were marked when they were made)
+            for (OpDesc& op : p.ops)
+                if (op.kind == OP_CONV || op.kind == OP_CONV_DIRECT) op.f16 = 4;
+            return;
+        }
         if (!p.prec || p.x3 || p.f16_spec.empty()) return;
         std::vector<std::string> toks;
         {
@@ -494,7 +501,7 @@ struct Builder {
 NetPlan build_fcn8s(int frames, int H, int W, int prec, const char* f16_layers) {
     if (H % 32 || W % 32) throw std::runtime_error("FCN-8s needs H, W multiples of 32");
     Builder b;
-    b.p.prec = prec ? 1 : 0; b.p.x3 = prec == 2; b.p.f16_spec = (prec == 1 && f16_layers) ? f16_layers : "";
+    b.p.prec = prec ? 1 : 0; b.p.x3 = prec == 2; b.p.h2 = prec == 3; b.p.f16_spec = (prec == 1 && f16_layers) ? f16_layers : "";
     b.p.net = "fcn8s"; b.p.frames = frames; b.p.images = frames; b.p.H = H; b.p.W = W;
     int x = b.tensor("input_pre", frames, H, W, 4);      // 4th channel is zero: float4 gathers in conv1_1
     b.p.tensors[x].Ctf = 3;
@@ -556,7 +563,7 @@ NetPlan build_monodepth(int encoder, int frames, int H, int W, int prec, const c
     const int mult = encoder == 0 ? 128 : 64;
     if (H % mult || W % mult) throw std::runtime_error("monodepth needs H, W multiples of 128 (vgg) / 64 (resnet50)");
     Builder b;
-    b.p.prec = prec ? 1 : 0; b.p.x3 = prec == 2; b.p.f16_spec = (prec == 1 && f16_layers) ? f16_layers : "";
+    b.p.prec = prec ? 1 : 0; b.p.x3 = prec == 2; b.p.h2 = prec == 3; b.p.f16_spec = (prec == 1 && f16_layers) ? f16_layers : "";
     b.p.net = encoder == 0 ? "monodepth-vgg" : "monodepth-resnet50";
     b.p.frames = frames; b.p.images = 2 * frames; b.p.H = H; b.p.W = W;
     const int N = 2 * frames;
@@ -746,7 +753,7 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
                     } else {                          // two bf16 planes [k/8][n][8]
                         const size_t base = (size_t)(k / 8) * s.CoutPad * 8 + (k % 8);
                         for (int64_t n = 0; n < Cout; ++n) {
-                            if (f16) { f16_split(src[n], hi[base + n * 8], lo[base + n * 8]); continue; }
+                            if (f16) { f16_split(s.hs ? src[n] * HS_WSCALE : src[n], hi[base + n * 8], lo[base + n * 8]); continue; }      // (hs: planes of w * 2^12)
                             const uint16_t h = bf16(src[n]);
                             hi[base + n * 8] = h;
                             const float r1 = src[n] - bf16_to_f(h);
@@ -806,7 +813,7 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
                         const size_t base = (((size_t)chunk * 9 + tap) * 2 + oct) * s.CoutPad * 8 + e;
                         for (int64_t n = 0; n < Cout; ++n) {
                             uint16_t* hi = hi0 + (size_t)(n / s.CoutPad) * (s.x3 ? 3 : 2) * plane + base + (n % s.CoutPad) * 8;
-                            if (s.f16) { f16_split(src[n], *hi, hi[plane]); continue; }
+                            if (s.f16) { f16_split(s.hs ? src[n] * HS_WSCALE : src[n], *hi, hi[plane]); continue; }
                             const uint16_t h = bf16(src[n]);
                             *hi = h;
                             const float r1 = src[n] - bf16_to_f(h);

@@ -16,7 +16,8 @@ struct TensorDesc {
     int N = 0, H = 0, W = 0, C = 0;   // C = stored channels
     int Ctf = 0;                      // channels the TensorFlow graph sees (input_pre stores 4, TF sees 3)
     int fmt = 0;                      // 0: f32 NHWC; 1: split-bf16 planes (split_fmt.hpp)
-    int f16 = 0;                      // 1: ONE fp16 plane, 2: fp16 hi + lo planes, instead of two bf16 planes (split_fmt.hpp): every conv that reads it runs the
+    int f16 = 0;                      // 3: fp16 hi + SCALED lo planes ("HS": every tensor of SD_PREC_F16X2, NetPlan::h2);
+                                      // 1: ONE fp16 plane, 2: fp16 hi + lo planes, instead of two bf16 planes (split_fmt.hpp): every conv that reads it runs the
                                       // 2-product scheme x * (w_hi + w_lo) (precision plan, see NetPlan::f16_spec)
     int x3 = 0;                       // 1: bf16 x 3 planes (SD_PREC_BF16X3; 6 bytes per element, planes at 0, plane, 2 * plane)
     int planar16 = 0;                 // split planes stored as C/16 sub-planes of 16 channels ([C/16][N][H][W][16] per plane): the
@@ -43,6 +44,8 @@ struct WeightSlot {
     int vec = 0;           // 1: K axis is ordered (32-channel block, tap, channel) instead of (tap, channel)
     int f16 = 0;           // split layouts: two fp16 planes, hi = fp16(w), lo = fp16(w - hi) (the 2-product scheme of split_fmt.hpp)
     int x3 = 0;            // split layouts: THREE bf16 planes hi, mid, lo (exact: w = hi + mid + lo), SD_PREC_BF16X3
+    int hs = 0;            // split layouts (with f16): the two fp16 planes hold w * 2^12 (SD_PREC_F16X2: hi = fp16(w'), lo = fp16(w' - hi); the conv epilogues
+                           // multiply the accumulator by 2^-12 = HS_ALPHA); a weight beyond +-15.99 does not fit and sd_load_weight refuses it
     float scale = 1.f;     // the tensor is multiplied by this while it is loaded (monodepth stem with integer input: 1/255, see NetPlan::input_scale)
     // a slot may be a VIEW of rows [k_off, k_off+Kpad) of a larger device matrix of Ktotal rows owned by slot `owner`
     // (ResNet block: conv3 and the projection shortcut are one GEMM over the concatenated K axis); a bias view is ADDED
@@ -69,7 +72,8 @@ struct OpDesc {
     // conv engine
     int Ctot = 0;          // padded channels per tap (every source rounded up to a multiple of 4)
     int K = 0, Kpad = 0, vec = 0, m_fastest = 0;
-    int f16 = 0;                 // conv ops: 1 = sources are single fp16 planes, weights two fp16 planes, TWO MFMA products per product;
+    int f16 = 0;                 // conv ops: 4 = SD_PREC_F16X2: fp16 hi + scaled lo sources x fp16 hi + lo weights (times 2^12), THREE products;
+                                 // 1 = sources are single fp16 planes, weights two fp16 planes, TWO MFMA products per product;
                                  // 2 = the same sources, w_hi only, ONE product (plain fp16 x fp16)
     int fold = 0;                // OP_CONV: a 3x3 stride-1 conv on a x2 nearest-neighbour upsampled source, run as FOUR 2x2 convs on the source itself
                                  // (one per output parity (y & 1, x & 1)): out[2i+py, 2j+px] = sum_{a,b in 0..1} Wf[py][px][a][b] . src[i+a-1+py, j+b-1+px]
@@ -90,6 +94,8 @@ struct NetPlan {
     int H = 0, W = 0;
     int prec = 0;          // 0: exact f32 MFMA, 1: split engine (planes of split_fmt.hpp)
     int x3 = 0;            // split engine with bf16 x 3 planes everywhere (SD_PREC_BF16X3): fp32-grade, six MFMA products per product
+    int h2 = 0;            // split engine with fp16 hi + scaled lo planes everywhere (SD_PREC_F16X2, split_fmt.hpp "HS"): fp32-grade, THREE fp16 MFMA
+                           // products per product, 4 bytes per activation element; the kernels of the bf16 x 2 engine in their H2 form
     // precision plan of the split engine: which conv layers run the 2-product fp16 scheme (fp16x2 activations x fp16 weights)
     // instead of the 3-product bf16 one.  f16_spec = what was asked for (comma-separated op names, a trailing '*' matches a
     // prefix, "*" = every layer, empty = none); f16_ops = the layers that run it after the consistency closure (a tensor has ONE
@@ -110,7 +116,9 @@ struct NetPlan {
     float input_scale = 1.f / 255.f;
 };
 
-// prec: 0 exact f32 MFMA, 1 split engine (bf16 x 2 + the fp16 forms of f16_layers), 2 split engine with bf16 x 3 planes (f16_layers ignored)
+// prec: 0 exact f32 MFMA, 1 split engine (bf16 x 2 + the fp16 forms of f16_layers), 2 split engine with bf16 x 3 planes (f16_layers ignored),
+// 3 split engine with fp16 hi + scaled lo planes (f16_layers ignored)
+constexpr float HS_WSCALE = 4096.f, HS_ALPHA = 1.f / 4096.f;
 NetPlan build_fcn8s(int frames, int H, int W, int prec, const char* f16_layers = nullptr);
 NetPlan build_monodepth(int encoder /*0 vgg, 1 resnet50*/, int frames, int H, int W, int prec, const char* f16_layers = nullptr);
 

@@ -17,6 +17,17 @@
 //        x_hi*w_hi + x_hi*w_mid + x_mid*w_hi + x_mid*w_mid + x_hi*w_lo + x_lo*w_hi
 //     (every bf16 x bf16 product is exact in the f32 accumulator); the three dropped terms x_mid*w_lo, x_lo*w_mid, x_lo*w_lo are below
 //     2^-23 |x w| together, the size of ONE f32 rounding of the product, which an f32 FMA chain commits on every accumulation anyway.
+//   fp16 hi + SCALED lo ("HS"; SD_PREC_F16X2, round 5: an fp32-grade engine on THREE MFMA products): hi = RNE_fp16(clamp(v)),
+//     lo = RNE_fp16((v - hi) * 2^11) -- the residual is at most half an fp16 ulp of hi, so the scaled lo plane has the magnitude of hi / 2
+//     and stays in fp16's NORMAL range wherever hi does: v is carried to 22 significand bits for every |v| in [1.2e-4, 65504] (29 binades:
+//     no per-tensor calibration), 4 bytes per element.  Weights: w' = w * 2^k (k per layer, chosen at load time so that max |w'| lies in
+//     [2^12, 2^13); the epilogue multiplies the accumulator by 2^-k), planes w_hi = RNE(w'), w_lo = RNE(w' - w_hi) (unscaled: w' is large).
+//     A product is THREE fp16 MFMA products
+//        x_hi * w_hi  +  x_hi * w_lo  +  x_lo * (w_hi * 2^-11)
+//     the third weight operand being formed IN REGISTERS from the w_hi fragment (one v_pk_mul_f16 per register, exact: a power of two;
+//     VALU beside 8-pass MFMAs is free, profiles/r05_probe_mfma_valu_overlap2.txt).  Dropped: x_lo * w_lo < 2^-24 |x w| and the 2^-23
+//     representation error of each operand -- the size of ONE f32 rounding of the product; the accumulation is the same f32 chain as every
+//     other engine's.  The MFMA honours fp16 subnormals (scripts/probe_mfma_f16_denorm.hip).
 // The MFMA operands of the conv engine are read straight from the planes (16-byte runs of 8 channels), nothing is converted at
 // load time.  The F16 template argument of the helpers selects the format; their `l` argument is ignored / zero for fp16.
 #pragma once
@@ -133,10 +144,39 @@ template <bool F16> __device__ __forceinline__ void split4_t(f32x4_t v, uint2& h
 template <bool F16> __device__ __forceinline__ void split4_t(f32x4_t v, uint2& h, uint2& l) {
     split4_t<F16>(v, h, l, (sat_ptr_t) nullptr);
 }
-// output format of an epilogue: 0 = bf16 hi + lo, 1 = ONE fp16 plane, 2 = fp16 hi + lo (the hi plane is bit for bit the one of format
+// fp16 hi + SCALED lo (HS): split and its inverse
+__device__ __forceinline__ void split2_hs(f32x2_t v, unsigned& h, unsigned& l, sat_ptr_t sat) {
+    const f32x2_t c = {__builtin_amdgcn_fmed3f(v[0], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v[1], -65504.f, 65504.f)};
+    sat_check(c, v, sat);
+    const f16x2_t hb = __builtin_convertvector(c, f16x2_t);
+    const f32x2_t r = (c - __builtin_convertvector(hb, f32x2_t)) * 2048.f;        // exact residual, exact scaling
+    const f16x2_t lb = __builtin_convertvector(r, f16x2_t);
+    h = __builtin_bit_cast(unsigned, hb);
+    l = __builtin_bit_cast(unsigned, lb);
+}
+__device__ __forceinline__ void split4_hs(f32x4_t v, uint2& h, uint2& l, sat_ptr_t sat) {
+    split2_hs(f32x2_t{v[0], v[1]}, h.x, l.x, sat);
+    split2_hs(f32x2_t{v[2], v[3]}, h.y, l.y, sat);
+}
+__device__ __forceinline__ f32x2_t recon2_hs(unsigned h, unsigned l) {
+    return __builtin_convertvector(__builtin_bit_cast(f16x2_t, h), f32x2_t) + __builtin_convertvector(__builtin_bit_cast(f16x2_t, l), f32x2_t) * (1.f / 2048.f);
+}
+__device__ __forceinline__ f32x4_t recon4_hs(uint2 h, uint2 l) {
+    const f32x2_t a = recon2_hs(h.x, l.x), b = recon2_hs(h.y, l.y);
+    return f32x4_t{a[0], a[1], b[0], b[1]};
+}
+// the weight operand of the x_lo product: an fp16 w_hi fragment times 2^-11 (exact; w' >= 2^-3 stays normal, smaller weights are below
+// 2^-15 of the layer's largest)
+__device__ __forceinline__ u32x4s_t hs_wscaled(u32x4s_t w) {
+    const f16x8_t s = __builtin_bit_cast(f16x8_t, w) * (_Float16)(1.0 / 2048.0);
+    return __builtin_bit_cast(u32x4s_t, s);
+}
+// output format of an epilogue: 0 = bf16 hi + lo, 1 = ONE fp16 plane, 3 = fp16 hi + SCALED lo (HS), 2 = fp16 hi + lo (the hi plane is bit for bit the one of format
 // 1, so every fp16 layer can read such a tensor; the lo plane serves the layers that multiply x_hi and x_lo by ONE weight plane)
 template <int FMT> __device__ __forceinline__ void split2_fmt(f32x2_t v, unsigned& h, unsigned& l, sat_ptr_t sat) {
-    if constexpr (FMT == 2) {
+    if constexpr (FMT == 3) {          // fp16 hi + scaled lo (SD_PREC_F16X2)
+        split2_hs(v, h, l, sat);
+    } else if constexpr (FMT == 2) {
         const f32x2_t c = {__builtin_amdgcn_fmed3f(v[0], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v[1], -65504.f, 65504.f)};
         sat_check(c, v, sat);
         const f16x2_t hb = __builtin_convertvector(c, f16x2_t);

@@ -77,7 +77,8 @@ class Engine:
     def __init__(self, H: int, W: int, max_batch: int = 1, encoder: str = "resnet50", device: int = 0, precision: str = "f32",
                  plan: tuple[str, str] | None = None):
         """precision: 'f32' (exact f32 MFMA), 'bf16x3' (fp32-grade on the bf16 MFMA: every f32 operand as three bf16 planes that sum to it
-        exactly, 6 MFMA products), 'bf16x2' (3 bf16 MFMA products, ~1e-5), 'mixed' (monodepth on 2 fp16 products), 'plan' (per-layer
+        exactly, 6 MFMA products), 'f16x2' (fp32-grade on 3 fp16 MFMA products: activations as fp16 hi + 2^11-scaled lo planes, weights as fp16 hi + lo of
+        w * 2^12), 'bf16x2' (3 bf16 MFMA products, ~1e-5), 'mixed' (monodepth on 2 fp16 products), 'plan' (per-layer
         choice; ``plan`` = (fcn8s layers, monodepth layers) that run the 2-product scheme, default = the calibrated built-in)"""
         if not torch.cuda.is_available():
             raise RuntimeError("semantic_depth_amd.Engine needs a GPU (MI355X); there is no CPU fallback")
@@ -88,7 +89,8 @@ class Engine:
         h = C.c_void_p()
         enc = {"vgg": L.SD_ENC_VGG, "resnet50": L.SD_ENC_RESNET50}[encoder]
         self.precision = precision
-        prec = {"f32": L.SD_PREC_F32, "bf16x2": L.SD_PREC_BF16X2, "mixed": L.SD_PREC_MIXED, "plan": L.SD_PREC_PLAN, "bf16x3": L.SD_PREC_BF16X3}[precision]
+        prec = {"f32": L.SD_PREC_F32, "bf16x2": L.SD_PREC_BF16X2, "mixed": L.SD_PREC_MIXED, "plan": L.SD_PREC_PLAN, "bf16x3": L.SD_PREC_BF16X3,
+                "f16x2": L.SD_PREC_F16X2}[precision]
         if plan is not None:
             if precision != "plan":
                 raise ValueError("an explicit plan needs precision='plan'")

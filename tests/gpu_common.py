@@ -66,6 +66,13 @@ STRICT_MAX = {("f32", "logits"): 4e-4, ("bf16x3", "logits"): 4e-4, ("bf16x2", "l
               ("f32", "disp"): 1e-5, ("bf16x3", "disp"): 1e-5, ("bf16x2", "disp"): 3e-5, ("mixed", "disp"): 2e-3, ("plan", "disp"): 2e-3}
 
 
+# "f16x2" (round 5: fp32-grade on three fp16 MFMA products, split_fmt.hpp "HS") is held to the FROZEN bounds of the exact-f32 engine: it claims the
+# reference's own precision, so it gets no bound of its own
+for _k in ("logits", "disp"):
+    STRICT_P99[("f16x2", _k)] = STRICT_P99[("f32", _k)]
+    STRICT_MAX[("f16x2", _k)] = STRICT_MAX[("f32", _k)]
+
+
 def assert_close(got, ref, precision, tol=1e-3, what="", kind="logits"):
     """the parity bar: max-normalised error within north_star's 1e-3 AND the strict per-element figure within the engine's bound
     (``kind``: 'logits' or 'disp')"""

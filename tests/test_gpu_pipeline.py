@@ -53,7 +53,7 @@ def oracle_full():
     return dict(wf=wf, wm=wm, frames=fr, logits=logits, taps=taps, scales=scales)
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x2", "plan"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2", "bf16x2", "plan"])
 def test_fcn8s_full_size_matches_oracle(precision, oracle_full, keep_taps):
     o = oracle_full
     eng = Engine(H, W, 1, "resnet50", precision=precision)
@@ -74,7 +74,7 @@ def test_fcn8s_full_size_matches_oracle(precision, oracle_full, keep_taps):
     assert 0.02 < road_r.mean() < 0.98
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x2", "mixed", "plan"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2", "bf16x2", "mixed", "plan"])
 def test_monodepth_full_size_matches_oracle(precision, oracle_full, keep_taps):
     o = oracle_full
     eng = Engine(H, W, 1, "resnet50", precision=precision)
@@ -93,7 +93,7 @@ def test_monodepth_full_size_matches_oracle(precision, oracle_full, keep_taps):
     assert np.array_equal(pp.cpu().numpy()[0], fusion.post_processing(raw).astype(np.float32))
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x2", "plan"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2", "bf16x2", "plan"])
 def test_monodepth_vgg_full_size_matches_oracle(precision):
     """the reference's DEFAULT monodepth encoder (--monodepth_encoder vgg, semantic_depth.py:721-722) at BASELINE's frame size against
     the CPU oracle: raw disparity pair and the post-processed map (this encoder had only a 128 x 256 oracle test).
@@ -127,7 +127,7 @@ def oracle_b8():
     return dict(wf=wf, wm=wm, frames=fr, logits=logits, disp=np.stack(disp))
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "plan"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2", "plan"])
 def test_nets_b8_full_size_match_oracle(precision, oracle_b8):
     """configs[1] (FCN-8s forward, B = 8) and configs[2] (monodepth-resnet50 forward on frame + flip, B = 8) in one network pass
     each, every frame against the oracle: logits, masks, raw disparity pair, post-processed disparity"""
@@ -154,7 +154,7 @@ def test_nets_b8_full_size_match_oracle(precision, oracle_b8):
     assert worst_l < TOL and worst_d < TOL
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "plan"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2", "plan"])
 def test_nets_b32_as_benchmarked_match_oracle(precision, oracle_b8):
     """configs[3] as bench.py runs it: ONE pass of B = 32 frames per network on the benchmarked engines; frames 0, 9, 22 and 31 of the
     batch (= frames 0..3 of the oracle batch, placed there) against the CPU oracle: logits, masks, raw and post-processed disparity.
@@ -224,7 +224,7 @@ def _check_records_against_oracle(eng, frames_np, out, raw, cam, prm, colours=Tr
 
 # (the benchmarked batch of 32 on the headline engine and on the plan leg; the other engines on 8: the CPU oracle tail costs ~1 s per frame,
 #  and the tail kernels are the same whatever engine produced the masks and the disparity)
-@pytest.mark.parametrize("B,precision", [(8, "bf16x2"), (8, "f32"), (32, "plan"), (32, "bf16x3")])
+@pytest.mark.parametrize("B,precision", [(8, "bf16x2"), (8, "f32"), (32, "plan"), (32, "bf16x3"), (32, "f16x2")])
 def test_process_batch_records_equal_oracle_tail(B, precision):
     """configs[3] (B = 32: the benchmarked configuration, on the engines bench.py times -- f32 headline, plan leg) and the B = 8 batch
     of configs[1]/[2] through Engine.process_batch"""
