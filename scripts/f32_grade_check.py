@@ -1,6 +1,6 @@
 """Is the bf16 x 3 engine fp32-grade?  One frame through a float64 oracle (torch-CPU double = the check value) and through
   * the float32 CPU oracle (torch-CPU f32 convs: what "an fp32 implementation" gives),
-  * the exact-f32 MFMA engine, the bf16 x 3 engine, the bf16 x 2 engine and the built-in precision plan;
+  * the exact-f32 MFMA engine, the bf16 x 3 engine, the three-product fp16 engine (f16x2, round 5), the bf16 x 2 engine and the built-in precision plan;
 every one against the float64 result: max |delta| / max |ref| and the strict per-element figure |delta| / (|ref| + 1e-2 max|ref|).
 An engine is fp32-grade when its error against float64 is no larger than that of the fp32 implementations.
     python scripts/f32_grade_check.py [H W] > profiles/r03_f32_grade_check.txt"""
@@ -30,7 +30,7 @@ def stats(x, r):
     q = d / (np.abs(r) + 1e-2 * sc)
     return d.max() / sc, float(np.quantile(q, 0.99)), float(q.max()), float(np.sqrt((d * d).mean()) / sc)
 rows = [("float32 CPU oracle (torch f32)", nets.fcn8s_forward(fr, wf), nets.monodepth_forward(pair, wm, "resnet50")[..., 0])]
-for prec in ("f32", "bf16x3", "bf16x2", "plan"):
+for prec in ("f32", "bf16x3", "f16x2", "bf16x2", "plan"):
     e = Engine(H, W, 1, "resnet50", precision=prec)
     e.load_weights(L.SD_NET_FCN8S, wf); e.load_weights(L.SD_NET_MONODEPTH, wm)
     d = torch.from_numpy(fr).cuda()

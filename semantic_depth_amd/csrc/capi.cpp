@@ -211,7 +211,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 const bool stem = split && !dma && !dma3 && conv_stem_eligible(c);
                 if (c.out_planar16 && !stem && !dma) return fail(h, SD_ERR_STATE, "sub-planar output needs the LDS-DMA or the stem conv kernel");
                 if (c.pool && !dma) return fail(h, SD_ERR_STATE, "fused pool needs the LDS-DMA conv kernel");
-                if (c.fold && !dma3) return fail(h, SD_ERR_STATE, "an upsample-folded conv needs the conv_dma3 kernel");
+                if (c.fold && !dma3 && !(dma && c.f16 == 4)) return fail(h, SD_ERR_STATE, "an upsample-folded conv needs the conv_dma3 kernel (bf16 x 3) or the H2 form of conv_dma");
                 e = dma3 ? launch_conv_dma3(c, s) : dma ? launch_conv_dma(c, s) : stem ? launch_conv_stem(c, s) : split ? launch_conv_split(c, s) : launch_conv_igemm(c, s);
                 if (h->prof) {
                     hipEventRecord(eb, s);
@@ -219,7 +219,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                     static const char* const dma3_names[3] = {"conv_dma3_kernel<0>", "conv_dma3_kernel<1>", "conv_dma3_kernel<2>"};
                     // (one bucket for the bench line; the per-layer listing of SEMDEPTH_PROFILE_VERBOSE names the gather variant)
                     const char* const dma3_name = (h->sw & SW_PROFILE_VERBOSE) ? dma3_names[conv_dma3_mode(c)] : "conv_dma3_kernel";
-                    h->prof_recs.push_back({dma3 ? dma3_name : dma ? conv_dma_kernel_name(c) : stem ? (c.x3 ? "conv_stem_x3_kernel" : c.f16 ? "conv_stem_f16w_kernel" : "conv_stem_kernel") : split ? conv_split_kernel_name(c) : conv_igemm_kernel_name(c), op.flops * N / p.images, ea, eb,
+                    h->prof_recs.push_back({dma3 ? dma3_name : dma ? conv_dma_kernel_name(c) : stem ? (c.x3 ? "conv_stem_x3_kernel" : c.f16 == 4 ? "conv_stem_hs_kernel" : c.f16 ? "conv_stem_f16w_kernel" : "conv_stem_kernel") : split ? conv_split_kernel_name(c) : conv_igemm_kernel_name(c), op.flops * N / p.images, ea, eb,
                                             op.name.c_str(), N * c.Hout * c.Wout * (c.fold ? 4 : 1), d.C, op.K, op_bytes(op)});
                 }
                 break;

@@ -14,7 +14,7 @@ void launch_dma_v5(const ConvParams& p, long M, hipStream_t s);      // 256 x 25
 int conv_dma_variant(const ConvParams& p) {
     if (!p.vec || !p.zero16 || p.Cout % 32 || p.Kpad < 64) return 0;
     const long M = (long)p.N * p.Hout * p.Wout;
-    const long thr = (p.pool || p.out_planar16) ? 0 : 96;     // tiles needed: the DMA pipeline at half occupancy still beats the register-staged
+    const long thr = (p.pool || p.out_planar16 || p.fold) ? 0 : 96;     // (a folded layer runs here whatever the batch: its results must not depend on it) tiles needed: the DMA pipeline at half occupancy still beats the register-staged
                                           // kernel (a fused pool exists only here: such layers always take this kernel)
     const bool big = !(p.sw & SW_NO_DMA_BIG);
     // 256 x 256 (one workgroup per CU): 128 flop per byte of L2 -> LDS DMA, the resource the long-K GEMMs run against.  The one-product
@@ -22,7 +22,8 @@ int conv_dma_variant(const ConvParams& p) {
     // the other's k-loop, which wins below ~32 k-tiles (measured: K <= 640 +5..14 %, K = 768..1280 equal, K >= 1536 and fc6 -2..4 %)
     const bool shortk = p.f16 == 2 && p.Kpad < 1024;
     if (p.x3 && (p.pool || p.out_planar16)) return 0;         // (bf16 x 3: plain outputs only)
-    if (big && !p.x3 && !shortk && !p.pool && p.Cout % 256 == 0 && ((M + 255) / 256) * (p.Cout / 256) >= 512) return 5;
+    if (p.fold && p.f16 != 4) return 0;                       // (folded GEMMs: the H2 form only)
+    if (big && !p.x3 && !shortk && !p.pool && p.Cout % 256 == 0 && ((M + 255) / 256) * (p.Cout / 256) * (p.fold ? 4 : 1) >= 512) return 5;
     if (p.Cout % 256 == 0 && ((M + 127) / 128) * (p.Cout / 256) >= thr) return 1;     // 128 x 256
     if (p.Cout % 128 == 0 && ((M + 255) / 256) * (p.Cout / 128) >= thr) return 2;     // 256 x 128
     if (p.Cout % 64 == 0 && p.Cout % 128 != 0 && ((M + 255) / 256) * (p.Cout / 64) >= thr) return 3;      // 256 x 64

@@ -119,8 +119,9 @@ struct Builder {
             if (p.tensors[op.src[i]].C % 8 || op.sstride[i] != 1) direct = false;
         // bf16 x 3: an upconv layer (3x3 on a x2 nearest-neighbour upsampled source) with a wide output runs as four 2x2 convs on the source
         // itself, one per output parity, on the 256 x 256 GEMM block (OpDesc::fold).  The choice depends on the layer alone, never on the batch.
-        if (p.x3 && k == 3 && stride == 1 && op.nsrc == 1 && op.up[0] && Cout % 256 == 0 && p.tensors[op.src[0]].C % 32 == 0 && residual < 0 &&
-            !(latch_switches() & (SW_NO_FOLD | SW_NO_DMA))) {        // (the folded GEMM form exists on conv_dma3 only: SEMDEPTH_NO_DMA implies no fold)
+        // SD_PREC_F16X2: the same on the H2 form of conv_dma.hip, for outputs of 128 channels and more (upconv6 / 5 / 4)
+        if (((p.x3 && Cout % 256 == 0) || (p.h2 && Cout % 128 == 0)) && k == 3 && stride == 1 && op.nsrc == 1 && op.up[0] && p.tensors[op.src[0]].C % 32 == 0 &&
+            residual < 0 && !(latch_switches() & (SW_NO_FOLD | SW_NO_DMA))) {        // (the folded GEMM form exists on conv_dma3 only: SEMDEPTH_NO_DMA implies no fold)
             const TensorDesc& t = p.tensors[op.src[0]];
             op.fold = 1; op.vec = 1;
             op.Ctot = t.C; op.K = 4 * t.C; op.Kpad = op.Kvec = 4 * t.C; op.CqPad = 0;
@@ -720,11 +721,12 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
                             for (int iy = 0; iy < ny; ++iy)
                                 for (int ix = 0; ix < nx; ++ix) acc += (double)w[((int64_t)(dys[iy] * 3 + dxs[ix]) * C + c) * Cout + n];
                             const float wf = (float)acc;
+                            if (f16) { f16_split(s.hs ? wf * HS_WSCALE : wf, hi[base + n * 8], lo[base + n * 8]); continue; }      // (SD_PREC_F16X2: planes of w * 2^12)
                             const uint16_t h = bf16(wf);
                             hi[base + n * 8] = h;
                             const float r1 = wf - bf16_to_f(h);
                             lo[base + n * 8] = bf16(r1);
-                            lo3[base + n * 8] = bf16(r1 - bf16_to_f(lo[base + n * 8]));
+                            if (s.x3) lo3[base + n * 8] = bf16(r1 - bf16_to_f(lo[base + n * 8]));
                         }
                     }
                 }

@@ -300,6 +300,49 @@ def test_folded_upconvs_and_fused_decoder_tail_against_the_layer_by_layer_form(H
             assert ef < 1e-5 and ef < 2.0 * ep + 1e-6
 
 
+@pytest.mark.parametrize("H,W,B,enc", [(512, 1024, 2, "resnet50"), (128, 256, 3, "resnet50"), (256, 512, 1, "vgg"), (64, 128, 2, "resnet50")])
+def test_folded_upconvs_of_the_three_product_fp16_engine(H, W, B, enc):
+    """f16x2 runs the upconv layers with >= 128 output channels upsample-FOLDED as four parity GEMMs on the H2 form of conv_dma (the algebra of the
+    bf16x3 engine's fold: 4 / 9 of the multiplications; the folded weight summed in double, rounded once to f32, then split into its two fp16
+    planes of w * 2^12).  Against the layer-by-layer form (SEMDEPTH_NO_FOLD) the raw disparities agree to a few f32 roundings; at the small size
+    both are held against the CPU oracle."""
+    from semantic_depth_amd.engine import Engine
+    from semantic_depth_amd import weights as Wt
+    wm = Wt.make_monodepth_weights(enc, 5, bias_std=0.05)
+    frn = _frames(B, H, W, seed=H + 3)
+    fr = dev(frn)
+    outs, kern = {}, {}
+    for mode, env in (("fold", {}), ("plain", {"SEMDEPTH_NO_FOLD": "1"})):
+        os.environ.update(env)
+        os.environ["SEMDEPTH_PROFILE_VERBOSE"] = "1"
+        try:
+            eng = Engine(H, W, B, enc, precision="f16x2")
+            eng.load_weights(L.SD_NET_MONODEPTH, wm)
+            eng.profile(True)
+            _, raw = eng.monodepth_forward(fr, want_raw=True)
+            kern[mode] = {b["kernel"]: b["launches"] for b in eng.profile_read()}
+            eng.profile(False)
+            outs[mode] = raw.clone().cpu().numpy()
+            assert eng.saturation_count() == 0
+        finally:
+            os.environ.pop("SEMDEPTH_PROFILE_VERBOSE", None)
+            for k in env:
+                os.environ.pop(k, None)
+        del eng
+    n_direct = lambda d: sum(v for k, v in d.items() if k.startswith("conv_direct_hs"))
+    assert n_direct(kern["fold"]) <= n_direct(kern["plain"]) - 3, kern     # upconv6 / 5 / 4 (vgg: 7 / 6 / 5 / 4) left the direct 3x3 kernel for the GEMM one
+    e1 = relerr(outs["fold"], outs["plain"])
+    print(H, W, enc, "f16x2 folded vs layer by layer:", e1)
+    assert e1 < 5e-6
+    if H * W <= 128 * 256:
+        for i in range(B):
+            f = frn[i].astype(np.float32) / 255
+            ref = nets.monodepth_forward(np.stack((f, np.fliplr(f)), 0), wm, enc)[..., 0]
+            ef, ep = relerr(outs["fold"][i], ref), relerr(outs["plain"][i], ref)
+            print("  frame", i, "vs oracle: folded", ef, "layer by layer", ep)
+            assert ef < 1e-5 and ef < 2.0 * ep + 1e-6
+
+
 @pytest.mark.parametrize("H,W,B,enc", [(512, 1024, 2, "resnet50"), (384, 1280, 2, "resnet50"), (512, 1024, 1, "vgg")])
 def test_full_size_split_engine_matches_the_exact_f32_engine(H, W, B, enc):
     """BASELINE.json's frame size is out of the CPU oracle's reach, so the split-bf16 engine (direct conv passes,
