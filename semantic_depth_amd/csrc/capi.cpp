@@ -266,6 +266,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.w2 = reinterpret_cast<const u32x4_t*>(Wp(op.w2)); c.b2 = Wp(op.b2);
                 c.wd = Wp(op.w3); c.bd = Wp(op.b3);
                 c.out = T(op.dst); c.sw = h->sw;
+                c.hs = p.h2; c.alpha = p.h2 ? HS_ALPHA : 1.f;
                 hipEvent_t ea = nullptr, eb = nullptr;
                 if (h->prof) {
                     ea = h->prof_last;
@@ -276,7 +277,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 if (h->prof) {
                     hipEventRecord(eb, s);
                     h->prof_last = eb; conv_op = true;
-                    h->prof_recs.push_back({"dec_tail1_x3_kernel", op.flops * N / p.images, ea, eb, op.name.c_str(), N * d.H * d.W, 16, op.K, op_bytes(op)});
+                    h->prof_recs.push_back({p.h2 ? "dec_tail1_hs_kernel" : "dec_tail1_x3_kernel", op.flops * N / p.images, ea, eb, op.name.c_str(), N * d.H * d.W, 16, op.K, op_bytes(op)});
                 }
                 break;
             }

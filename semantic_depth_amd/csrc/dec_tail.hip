@@ -35,20 +35,26 @@ constexpr int DT_TH = 8, DT_TW = 28;
 constexpr int DT_AR = DT_TH / 2 + 4, DT_AC = 18, DT_APL = DT_AR * DT_AC * 4;   // source tile: rows, columns, 16-byte units per plane ([pixel][octet ^ swizzle])
 constexpr int DT_UR = DT_TH + 4, DT_UC = 34, DT_UPL = DT_UR * DT_UC * 2;       // u tile: [pixel][octet ^ swizzle] per plane
 constexpr int DT_ER = DT_UR / 2, DT_EPL = DT_ER * DT_UC;                        // e tile: one unit per (half-resolution row, full-resolution column) and plane
-constexpr int DT_UE = 3 * DT_UPL + 3 * DT_EPL;                                  // units of one (u, e) buffer
 constexpr int DT_IR = DT_TH + 2, DT_IC = 32, DT_IPIX = 80;                      // i tile (f32): bytes per pixel (64 + 16 of padding: conflict-free 16-byte reads)
 constexpr int DT_DPL = DT_AR * DT_AC;                                           // disp2 tile: one 32-bit word (2 channels) per pixel and plane
 constexpr int DT_NG = 256;                                                      // threads of a group
-constexpr int DT_NA = (3 * DT_APL + DT_NG - 1) / DT_NG, DT_ND = (3 * DT_DPL + DT_NG - 1) / DT_NG, DT_NE = (3 * DT_EPL + DT_NG - 1) / DT_NG;
 constexpr int DT_NPIX = DT_TH * DT_TW;
 
-__global__ __launch_bounds__(512, 1) void dec_tail1_x3_kernel(const DecTailParams p) {
-    static_assert((2 * DT_UE + 3 * DT_APL) * 16 + DT_IR * DT_IC * DT_IPIX + 3 * DT_DPL * 4 <= 160 * 1024, "tiles fit the LDS of a CU");
+// HS = false: SD_PREC_BF16X3 (three bf16 planes per operand, six products per product).  HS = true: SD_PREC_F16X2 -- two planes per operand (fp16 hi +
+// scaled lo activations, fp16 hi + lo of w * 2^12: split_fmt.hpp "HS"), THREE fp16 products per product, the x_lo one against w_hi * 2^-11, which is
+// formed ONCE per launch here (the weight fragments are resident: it sits in the register slot of the bf16 form's third plane), the accumulators
+// times DecTailParams::alpha; the same tiles, stages and wave groups.
+template <bool HS>
+__global__ __launch_bounds__(512, 1) void dec_tail1_kernel(const DecTailParams p) {
+    constexpr int NPL = HS ? 2 : 3;                                                 // planes per tensor
+    constexpr int DT_UE = NPL * DT_UPL + NPL * DT_EPL;                              // units of one (u, e) buffer
+    constexpr int DT_NA = (NPL * DT_APL + DT_NG - 1) / DT_NG, DT_ND = (NPL * DT_DPL + DT_NG - 1) / DT_NG, DT_NE = (NPL * DT_EPL + DT_NG - 1) / DT_NG;
+    static_assert((2 * DT_UE + NPL * DT_APL) * 16 + DT_IR * DT_IC * DT_IPIX + NPL * DT_DPL * 4 <= 160 * 1024, "tiles fit the LDS of a CU");
     static_assert(DT_IR % 2 == 0 && DT_NPIX % 4 == 0 && DT_NPIX / 4 <= 64, "work split of stages 2 and 3");
     __shared__ __attribute__((aligned(16))) u32x4 UE[2 * DT_UE];
-    __shared__ __attribute__((aligned(16))) u32x4 A[3 * DT_APL];
+    __shared__ __attribute__((aligned(16))) u32x4 A[NPL * DT_APL];
     __shared__ __attribute__((aligned(16))) unsigned char I[DT_IR * DT_IC * DT_IPIX];
-    __shared__ unsigned Dt[3 * DT_DPL];
+    __shared__ unsigned Dt[NPL * DT_DPL];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const bool s1 = wave < 4;                            // group 1: stage 1 (and the tile loads); group 2: stages 2 and 3
@@ -69,7 +75,14 @@ __global__ __launch_bounds__(512, 1) void dec_tail1_x3_kernel(const DecTailParam
         return r;
     };
     // six MFMA products of one (weight fragment, source fragment) pair, the smaller terms first
+    // (HS: w = {hi, lo, hi * 2^-11}, x = {hi, scaled lo}: x_hi * w_lo, x_lo * w_hs, x_hi * w_hi; the xl argument is not read)
     auto mac6 = [](const u32x4 (&w)[3], const u32x4& xh, const u32x4& xm, const u32x4& xl, f32x4 acc) {
+        if constexpr (HS) {
+            acc = mfma_frag16<true>(w[1], xh, acc);
+            acc = mfma_frag16<true>(w[2], xm, acc);
+            acc = mfma_frag16<true>(w[0], xh, acc);
+            return acc;
+        }
         acc = mfma_frag16<false>(w[2], xh, acc);
         acc = mfma_frag16<false>(w[1], xm, acc);
         acc = mfma_frag16<false>(w[0], xl, acc);
@@ -131,7 +144,7 @@ __global__ __launch_bounds__(512, 1) void dec_tail1_x3_kernel(const DecTailParam
             const int u = tg + DT_NG * k;
             const int pl = u / DT_APL, rem = u - pl * DT_APL, pix = rem >> 2, slot = rem & 3;
             const int arow = pix / DT_AC, acol = pix - arow * DT_AC;
-            ga[k] = arow | (acol << 8) | ((slot ^ ((acol >> 1) & 3)) << 16) | (pl << 20) | ((u < 3 * DT_APL ? 1 : 0) << 24);
+            ga[k] = arow | (acol << 8) | ((slot ^ ((acol >> 1) & 3)) << 16) | (pl << 20) | ((u < NPL * DT_APL ? 1 : 0) << 24);
         }
         int gd[DT_ND];          // arow | acol << 8 | plane << 20 | valid << 24
 #pragma unroll
@@ -139,7 +152,7 @@ __global__ __launch_bounds__(512, 1) void dec_tail1_x3_kernel(const DecTailParam
             const int d = tg + DT_NG * k;
             const int pl = d / DT_DPL, pix = d - pl * DT_DPL;
             const int arow = pix / DT_AC, acol = pix - arow * DT_AC;
-            gd[k] = arow | (acol << 8) | (pl << 20) | ((d < 3 * DT_DPL ? 1 : 0) << 24);
+            gd[k] = arow | (acol << 8) | (pl << 20) | ((d < NPL * DT_DPL ? 1 : 0) << 24);
         }
         int ge[DT_NE];          // er | uc << 8 | plane << 16 | valid << 24
         int gew[DT_NE];         // word of (drow, dcol(-1)) in Dt | step to dcol(0) << 16 | step from dcol(0) to dcol(+1) << 17
@@ -149,7 +162,7 @@ __global__ __launch_bounds__(512, 1) void dec_tail1_x3_kernel(const DecTailParam
             const int pl = e / DT_EPL, pix = e - pl * DT_EPL;
             const int er = pix / DT_UC, uc = pix - er * DT_UC;
             auto dcol = [&](int dx) { int c = ((uc + dx) >> 1) + 1; return c < 0 ? 0 : c > DT_AC - 1 ? DT_AC - 1 : c; };
-            ge[k] = er | (uc << 8) | (pl << 16) | ((e < 3 * DT_EPL ? 1 : 0) << 24);
+            ge[k] = er | (uc << 8) | (pl << 16) | ((e < NPL * DT_EPL ? 1 : 0) << 24);
             gew[k] = (pl * DT_DPL + (er + 1) * DT_AC + dcol(-1)) | ((dcol(0) - dcol(-1)) << 16) | ((dcol(1) - dcol(0)) << 17);
         }
         u32x4 pa[DT_NA];
@@ -184,9 +197,11 @@ __global__ __launch_bounds__(512, 1) void dec_tail1_x3_kernel(const DecTailParam
         const int q = wv, py = q >> 1, px = q & 1;                             // this wave's output parity
         u32x4 w1[4][3];                                                        // [2x2 tap][plane], resident for the whole launch
 #pragma unroll
-        for (int tp = 0; tp < 4; ++tp)
+        for (int tp = 0; tp < 4; ++tp) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) w1[tp][pl] = p.w1[((q * 4 + tp) * 3 + pl) * 64 + lane];
+            for (int pl = 0; pl < NPL; ++pl) w1[tp][pl] = p.w1[((q * 4 + tp) * 3 + pl) * 64 + lane];
+            if constexpr (HS) w1[tp][2] = hs_wscaled(w1[tp][0]);
+        }
         const f32x4 bias1 = *reinterpret_cast<const f32x4*>(p.b1 + 4 * lg);
 
         Tile nxt = tile_of(K > 0 ? first : 0);                                // (one tile decode per iteration: the divisions are VALU work)
@@ -212,7 +227,7 @@ __global__ __launch_bounds__(512, 1) void dec_tail1_x3_kernel(const DecTailParam
                     ev[1] = oky && (unsigned)x < (unsigned)W ? b0 : 0u;
                     ev[2] = oky && (unsigned)(x + 1) < (unsigned)W ? c : 0u;
                     ev[3] = 0u;
-                    if ((ge[j] >> 24) & 1) Ub[3 * DT_UPL + pl * DT_EPL + er * DT_UC + uc] = ev;
+                    if ((ge[j] >> 24) & 1) Ub[NPL * DT_UPL + pl * DT_EPL + er * DT_UC + uc] = ev;
                 }
                 // stage 1: u rows 2 n + py, n = 0 .. UR / 2 - 1, columns 2 m + px (m = lane & 15)
                 if (diag != 1) {
@@ -225,30 +240,35 @@ __global__ __launch_bounds__(512, 1) void dec_tail1_x3_kernel(const DecTailParam
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
 #pragma unroll
-                        for (int pl = 0; pl < 3; ++pl) F[0][b][pl] = frag(py, b, pl);
+                        for (int pl = 0; pl < NPL; ++pl) F[0][b][pl] = frag(py, b, pl);
 #pragma unroll
                     for (int n = 0; n < DT_UR / 2; ++n) {
                         const int s0 = n & 1, s1_ = s0 ^ 1;                       // slots of source rows n + py (a = 0) and n + py + 1 (a = 1)
 #pragma unroll
                         for (int b = 0; b < 2; ++b)
 #pragma unroll
-                            for (int pl = 0; pl < 3; ++pl) F[s1_][b][pl] = frag(n + py + 1, b, pl);
+                            for (int pl = 0; pl < NPL; ++pl) F[s1_][b][pl] = frag(n + py + 1, b, pl);
                         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int b = 0; b < 2; ++b) {
-                            acc0 = mac6(w1[b], F[s0][b][0], F[s0][b][1], F[s0][b][2], acc0);
-                            acc1 = mac6(w1[2 + b], F[s1_][b][0], F[s1_][b][1], F[s1_][b][2], acc1);
+                            acc0 = mac6(w1[b], F[s0][b][0], F[s0][b][1], F[s0][b][HS ? 1 : 2], acc0);
+                            acc1 = mac6(w1[2 + b], F[s1_][b][0], F[s1_][b][1], F[s1_][b][HS ? 1 : 2], acc1);
                         }
-                        f32x4 v = acc0 + acc1 + bias1;
+                        f32x4 v = HS ? (acc0 + acc1) * p.alpha + bias1 : acc0 + acc1 + bias1;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = act_f32<ACT_ELU>(v[r]);
+                        for (int r = 0; r < 4; ++r) v[r] = HS ? act_split<ACT_ELU>(v[r]) : act_f32<ACT_ELU>(v[r]);      // (each engine's own ELU)
                         const int ru = 2 * n + py, uc = 2 * lp + px;
                         const bool in = (unsigned)(y0 - 2 + ru) < (unsigned)H && (unsigned)(x0 - 2 + uc) < (unsigned)W;
                         if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
                         uint2 hh, mm, ll;
-                        split4_x3(v, hh, mm, ll);
                         uint2* const up = reinterpret_cast<uint2*>(Ub) + ((ru * DT_UC + uc) * 2 + ((lg >> 1) ^ ((uc >> 2) & 1))) * 2 + (lg & 1);
-                        up[0] = hh; up[2 * DT_UPL] = mm; up[4 * DT_UPL] = ll;
+                        if constexpr (HS) {
+                            split4_hs(v, hh, mm, (sat_ptr_t) nullptr);
+                            up[0] = hh; up[2 * DT_UPL] = mm;
+                        } else {
+                            split4_x3(v, hh, mm, ll);
+                            up[0] = hh; up[2 * DT_UPL] = mm; up[4 * DT_UPL] = ll;
+                        }
                     }
                 }
             }
@@ -263,9 +283,11 @@ __global__ __launch_bounds__(512, 1) void dec_tail1_x3_kernel(const DecTailParam
         // =====================================================================================================================
         u32x4 w2[6][3];                                                        // [row block dy, half][plane], resident for the whole launch
 #pragma unroll
-        for (int ks = 0; ks < 6; ++ks)
+        for (int ks = 0; ks < 6; ++ks) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) w2[ks][pl] = p.w2[(ks * 3 + pl) * 64 + lane];
+            for (int pl = 0; pl < NPL; ++pl) w2[ks][pl] = p.w2[(ks * 3 + pl) * 64 + lane];
+            if constexpr (HS) w2[ks][2] = hs_wscaled(w2[ks][0]);
+        }
         const f32x4 bias2 = *reinterpret_cast<const f32x4*>(p.b2 + 4 * lg);
         const int strip = wv & 1, ri0 = (DT_IR / 2) * (wv >> 1);
         const int c = 16 * strip + lp;
@@ -281,9 +303,9 @@ __global__ __launch_bounds__(512, 1) void dec_tail1_x3_kernel(const DecTailParam
                 u32x4 G[3][2][3];                                             // [u row slot][half][plane]
                 auto gload = [&](int slot, int ru) {
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
+                    for (int pl = 0; pl < NPL; ++pl) {
                         G[slot][0][pl] = Ub[pl * DT_UPL + ru * (DT_UC * 2) + offA];
-                        G[slot][1][pl] = Ub[lg < 2 ? pl * DT_UPL + ru * (DT_UC * 2) + offB : 3 * DT_UPL + pl * DT_EPL + (ru >> 1) * DT_UC + c + 1];
+                        G[slot][1][pl] = Ub[lg < 2 ? pl * DT_UPL + ru * (DT_UC * 2) + offB : NPL * DT_UPL + pl * DT_EPL + (ru >> 1) * DT_UC + c + 1];
                     }
                 };
                 gload(0, ri0); gload(1, ri0 + 1);
@@ -296,12 +318,12 @@ __global__ __launch_bounds__(512, 1) void dec_tail1_x3_kernel(const DecTailParam
                     for (int dy = 0; dy < 3; ++dy) {
                         acc[dy] = f32x4{0.f, 0.f, 0.f, 0.f};
                         const int sl = (it + dy) % 3;
-                        acc[dy] = mac6(w2[2 * dy], G[sl][0][0], G[sl][0][1], G[sl][0][2], acc[dy]);
-                        acc[dy] = mac6(w2[2 * dy + 1], G[sl][1][0], G[sl][1][1], G[sl][1][2], acc[dy]);
+                        acc[dy] = mac6(w2[2 * dy], G[sl][0][0], G[sl][0][1], G[sl][0][HS ? 1 : 2], acc[dy]);
+                        acc[dy] = mac6(w2[2 * dy + 1], G[sl][1][0], G[sl][1][1], G[sl][1][HS ? 1 : 2], acc[dy]);
                     }
-                    f32x4 v = (acc[0] + acc[1]) + acc[2] + bias2;
+                    f32x4 v = HS ? ((acc[0] + acc[1]) + acc[2]) * p.alpha + bias2 : (acc[0] + acc[1]) + acc[2] + bias2;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = act_f32<ACT_ELU>(v[r]);
+                    for (int r = 0; r < 4; ++r) v[r] = HS ? act_split<ACT_ELU>(v[r]) : act_f32<ACT_ELU>(v[r]);
                     const bool in = (unsigned)(cur.y0 - 1 + ri) < (unsigned)H && (unsigned)(cur.x0 - 1 + c) < (unsigned)W;
                     if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
                     *reinterpret_cast<f32x4*>(I + (ri * DT_IC + c) * DT_IPIX + 16 * lg) = v;
@@ -328,7 +350,8 @@ hipError_t launch_dec_tail1(const DecTailParams& p, hipStream_t s) {
         cus = prop.multiProcessorCount;
     }
     const int tiles = ((p.W + DT_TW - 1) / DT_TW) * (p.H / DT_TH) * p.N;
-    hipLaunchKernelGGL(dec_tail1_x3_kernel, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(512), 0, s, p);
+    if (p.hs) hipLaunchKernelGGL(dec_tail1_kernel<true>, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL(dec_tail1_kernel<false>, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(512), 0, s, p);
     return hipGetLastError();
 }
 

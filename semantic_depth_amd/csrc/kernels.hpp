@@ -193,6 +193,8 @@ struct DecTailParams {
     const float* bd;       // [1]
     float* out;            // [N, H, W] f32
     unsigned sw;
+    int hs;                // 1 (SD_PREC_F16X2): a / d2 are fp16 hi + scaled lo planes, w1 / w2 hold fp16 hi + lo of w * 2^12 in planes 0 and 1 (split_fmt.hpp "HS")
+    float alpha;           // hs: 2^-12, applied to the accumulators of stages 1 and 2
 };
 bool dec_tail1_eligible(int H, int W);
 hipError_t launch_dec_tail1(const DecTailParams& p, hipStream_t s);

@@ -68,6 +68,7 @@ struct Builder {
         s.bytes = n * sizeof(float);
         if (p.x3 && (layout == WL_IGEMM_SPLIT || layout == WL_DIRECT_SPLIT)) { s.x3 = 1; s.bytes = n * 6; }      // three bf16 planes
         if (p.h2 && (layout == WL_IGEMM_SPLIT || layout == WL_DIRECT_SPLIT)) { s.f16 = 1; s.hs = 1; }            // two fp16 planes of w * 2^12
+        if (p.h2 && (layout == WL_TAIL_UP || layout == WL_TAIL_ICONV)) s.hs = 1;                                 // the same in planes 0 and 1 of the fragments
         p.weights.push_back(s);
         p.weight_by_name[name] = (int)p.weights.size() - 1;
         return (int)p.weights.size() - 1;
@@ -119,8 +120,8 @@ struct Builder {
             if (p.tensors[op.src[i]].C % 8 || op.sstride[i] != 1) direct = false;
         // bf16 x 3: an upconv layer (3x3 on a x2 nearest-neighbour upsampled source) with a wide output runs as four 2x2 convs on the source
         // itself, one per output parity, on the 256 x 256 GEMM block (OpDesc::fold).  The choice depends on the layer alone, never on the batch.
-        // SD_PREC_F16X2: the same on the H2 form of conv_dma.hip, for outputs of 128 channels and more (upconv6 / 5 / 4)
-        if (((p.x3 && Cout % 256 == 0) || (p.h2 && Cout % 128 == 0)) && k == 3 && stride == 1 && op.nsrc == 1 && op.up[0] && p.tensors[op.src[0]].C % 32 == 0 &&
+        // SD_PREC_F16X2: the same on the H2 form of conv_dma.hip, for outputs of 64 channels and more (upconv6 / 5 / 4 / 3)
+        if (((p.x3 && Cout % 256 == 0) || (p.h2 && Cout % 64 == 0)) && k == 3 && stride == 1 && op.nsrc == 1 && op.up[0] && p.tensors[op.src[0]].C % 32 == 0 &&
             residual < 0 && !(latch_switches() & (SW_NO_FOLD | SW_NO_DMA))) {        // (the folded GEMM form exists on conv_dma3 only: SEMDEPTH_NO_DMA implies no fold)
             const TensorDesc& t = p.tensors[op.src[0]];
             op.fold = 1; op.vec = 1;
@@ -618,7 +619,7 @@ NetPlan build_monodepth(int encoder, int frames, int H, int W, int prec, const c
     int disp_prev = -1;
     for (int lvl = top; lvl >= 1; --lvl) {
         const std::string L = std::to_string(lvl);
-        if (lvl == 1 && b.p.x3 && dec_tail1_eligible(H, W) && !(latch_switches() & SW_NO_TAIL1)) {
+        if (lvl == 1 && (b.p.x3 || b.p.h2) && dec_tail1_eligible(H, W) && !(latch_switches() & SW_NO_TAIL1)) {
             disp_prev = b.dec_tail1(x, disp_prev);
             break;
         }
@@ -832,6 +833,13 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
         auto bf16_to_f = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; };
         uint16_t* const o16 = reinterpret_cast<uint16_t*>(out.data());
         auto put = [&](int frag, int lane, int e, float v) {             // element e of the lane's eight, all three planes
+            if (s.hs) {              // SD_PREC_F16X2: fp16 hi + lo of w * 2^12 in planes 0 and 1 (the kernel forms w_hi * 2^-11 in the third slot)
+                uint16_t h16, l16;
+                f16_split(v * HS_WSCALE, h16, l16);
+                o16[(((size_t)frag * 3 + 0) * 64 + lane) * 8 + e] = h16;
+                o16[(((size_t)frag * 3 + 1) * 64 + lane) * 8 + e] = l16;
+                return;
+            }
             const uint16_t h = bf16(v);
             const float r1 = v - bf16_to_f(h);
             const uint16_t m = bf16(r1);

@@ -258,7 +258,7 @@ def test_precomputed_gather_offsets_of_conv_dma3_are_bit_identical_to_the_genera
 # (the small shapes, ADVICE r4: W % 28 == 0 -- no inward-shifted last tile column --, the narrowest width the networks take -- three tile columns
 # that overlap almost entirely --, and grids with fewer tiles than CUs -- one tile per workgroup, the u / e double buffer never swaps)
 @pytest.mark.parametrize("H,W,B,enc", [(512, 1024, 2, "resnet50"), (128, 256, 3, "resnet50"), (256, 512, 1, "vgg"),
-                                       (64, 448, 1, "resnet50"), (64, 64, 1, "resnet50"), (64, 128, 2, "resnet50"), (128, 64, 1, "vgg")])
+                                       (64, 448, 1, "resnet50"), (64, 64, 1, "resnet50"), (64, 128, 2, "resnet50"), (128, 128, 1, "vgg")])
 def test_folded_upconvs_and_fused_decoder_tail_against_the_layer_by_layer_form(H, W, B, enc):
     """bf16x3 runs the wide upconv layers upsample-FOLDED (four 2x2 convs on the source instead of a 3x3 conv on the upsampled source:
     the taps that read the same source pixel are added, 4/9 of the multiplications) and upconv1 -> iconv1 -> disp1 as ONE kernel
@@ -304,7 +304,7 @@ def test_folded_upconvs_and_fused_decoder_tail_against_the_layer_by_layer_form(H
 def test_folded_upconvs_of_the_three_product_fp16_engine(H, W, B, enc):
     """f16x2 runs the upconv layers with >= 128 output channels upsample-FOLDED as four parity GEMMs on the H2 form of conv_dma (the algebra of the
     bf16x3 engine's fold: 4 / 9 of the multiplications; the folded weight summed in double, rounded once to f32, then split into its two fp16
-    planes of w * 2^12).  Against the layer-by-layer form (SEMDEPTH_NO_FOLD) the raw disparities agree to a few f32 roundings; at the small size
+    planes of w * 2^12), and level 1 of the decoder (upconv1 -> iconv1 -> disp1) as ONE launch (the HS form of dec_tail.hip).  Against the layer-by-layer form (SEMDEPTH_NO_FOLD) the raw disparities agree to a few f32 roundings; at the small size
     both are held against the CPU oracle."""
     from semantic_depth_amd.engine import Engine
     from semantic_depth_amd import weights as Wt
@@ -312,7 +312,7 @@ def test_folded_upconvs_of_the_three_product_fp16_engine(H, W, B, enc):
     frn = _frames(B, H, W, seed=H + 3)
     fr = dev(frn)
     outs, kern = {}, {}
-    for mode, env in (("fold", {}), ("plain", {"SEMDEPTH_NO_FOLD": "1"})):
+    for mode, env in (("fold", {}), ("plain", {"SEMDEPTH_NO_FOLD": "1", "SEMDEPTH_NO_TAIL1": "1"})):
         os.environ.update(env)
         os.environ["SEMDEPTH_PROFILE_VERBOSE"] = "1"
         try:
@@ -331,6 +331,7 @@ def test_folded_upconvs_of_the_three_product_fp16_engine(H, W, B, enc):
         del eng
     n_direct = lambda d: sum(v for k, v in d.items() if k.startswith("conv_direct_hs"))
     assert n_direct(kern["fold"]) <= n_direct(kern["plain"]) - 3, kern     # upconv6 / 5 / 4 (vgg: 7 / 6 / 5 / 4) left the direct 3x3 kernel for the GEMM one
+    assert "dec_tail1_hs_kernel" in kern["fold"] and "dec_tail1_hs_kernel" not in kern["plain"], kern      # and level 1 of the decoder is one launch
     e1 = relerr(outs["fold"], outs["plain"])
     print(H, W, enc, "f16x2 folded vs layer by layer:", e1)
     assert e1 < 5e-6
