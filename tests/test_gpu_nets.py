@@ -300,6 +300,38 @@ def test_folded_upconvs_and_fused_decoder_tail_against_the_layer_by_layer_form(H
             assert ef < 1e-5 and ef < 2.0 * ep + 1e-6
 
 
+@pytest.mark.parametrize("gains", [(-6, -6, 4, 4, 4), (2, 2, -2, -2, 0)])
+def test_three_product_fp16_engine_needs_no_activation_scale(gains):
+    """The HS format (fp16 hi + 2^11-scaled lo) carries 22 significand bits for every |v| in [1.2e-4, 65504] WITHOUT a per-tensor scale: the scaled
+    residual is a normal fp16 number wherever hi is.  ReLU and max-pool are positively homogeneous, so multiplying the weights of conv1_1 .. conv3_1 by
+    2^g (biases by the cumulative factor) with the gains summing to zero leaves the network's function unchanged while the tensors in between move by
+    the cumulative gain: (-6, -12, -8, -4, 0) binades -- the full-resolution conv1_2 output then sits around 1e-2 .. 1e-1, where a plain hi + lo format has
+    its low plane in the subnormals -- or (+2, +4, +2, 0, 0), towards the top of the fp16 range.  The logits must stay as close to the oracle as unscaled, with
+    nothing saturated."""
+    from semantic_depth_amd.engine import Engine
+    from semantic_depth_amd import weights as Wt
+    H, W, B = 128, 256, 1
+    wf = Wt.make_fcn8s_weights(1, decoder_std=0.05, bias_std=0.1)
+    fr = _frames(B, H, W, seed=21)
+    ref = nets.fcn8s_forward(fr, wf)
+    ws, cum = dict(wf), 0
+    for layer, g in zip(("conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1"), gains):
+        cum += g
+        ws[f"vgg/{layer}/filter"] = wf[f"vgg/{layer}/filter"] * np.float32(2.0 ** g)
+        ws[f"vgg/{layer}/biases"] = wf[f"vgg/{layer}/biases"] * np.float32(2.0 ** cum)
+    assert cum == 0
+    errs = {}
+    for name, wts in (("unscaled", wf), ("scaled", ws)):
+        eng = Engine(H, W, B, "resnet50", precision="f16x2")
+        eng.load_weights(L.SD_NET_FCN8S, wts)
+        lg = eng.fcn8s_forward(dev(fr), want_logits=True)["logits"].cpu().numpy()
+        assert eng.saturation_count() == 0, (name, gains)
+        errs[name] = relerr(lg, ref)
+        del eng
+    print("f16x2 logits vs oracle with the early tensors moved by", gains, "binades:", errs)
+    assert errs["scaled"] < 1e-5 and errs["scaled"] < 3.0 * errs["unscaled"] + 1e-6, errs
+
+
 @pytest.mark.parametrize("H,W,B,enc", [(512, 1024, 2, "resnet50"), (128, 256, 3, "resnet50"), (256, 512, 1, "vgg"), (64, 128, 2, "resnet50")])
 def test_folded_upconvs_of_the_three_product_fp16_engine(H, W, B, enc):
     """f16x2 runs the upconv layers with >= 128 output channels upsample-FOLDED as four parity GEMMs on the H2 form of conv_dma (the algebra of the
