@@ -211,7 +211,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 const bool stem = split && !dma && !dma3 && conv_stem_eligible(c);
                 if (c.out_planar16 && !stem && !dma) return fail(h, SD_ERR_STATE, "sub-planar output needs the LDS-DMA or the stem conv kernel");
                 if (c.pool && !dma) return fail(h, SD_ERR_STATE, "fused pool needs the LDS-DMA conv kernel");
-                if (c.fold && !dma3 && !(dma && c.f16 == 4)) return fail(h, SD_ERR_STATE, "an upsample-folded conv needs the conv_dma3 kernel (bf16 x 3) or the H2 form of conv_dma");
+                if (c.fold && !dma3 && !(dma && !c.x3)) return fail(h, SD_ERR_STATE, "an upsample-folded conv needs the conv_dma3 kernel (bf16 x 3) or a two-plane form of conv_dma");
                 e = dma3 ? launch_conv_dma3(c, s) : dma ? launch_conv_dma(c, s) : stem ? launch_conv_stem(c, s) : split ? launch_conv_split(c, s) : launch_conv_igemm(c, s);
                 if (h->prof) {
                     hipEventRecord(eb, s);

@@ -22,7 +22,7 @@ int conv_dma_variant(const ConvParams& p) {
     // the other's k-loop, which wins below ~32 k-tiles (measured: K <= 640 +5..14 %, K = 768..1280 equal, K >= 1536 and fc6 -2..4 %)
     const bool shortk = p.f16 == 2 && p.Kpad < 1024;
     if (p.x3 && (p.pool || p.out_planar16)) return 0;         // (bf16 x 3: plain outputs only)
-    if (p.fold && p.f16 != 4) return 0;                       // (folded GEMMs: the H2 form only)
+    if (p.fold && p.x3) return 0;                             // (folded GEMMs of bf16 x 3: conv_dma3.hip)
     if (big && !p.x3 && !shortk && !p.pool && p.Cout % 256 == 0 && ((M + 255) / 256) * (p.Cout / 256) * (p.fold ? 4 : 1) >= 512) return 5;
     if (p.Cout % 256 == 0 && ((M + 127) / 128) * (p.Cout / 256) >= thr) return 1;     // 128 x 256
     if (p.Cout % 128 == 0 && ((M + 255) / 256) * (p.Cout / 128) >= thr) return 2;     // 256 x 128

@@ -100,13 +100,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
 
     int tid_;
     {
-        const int nwg = tilesM * tilesN * ((H2 && p.fold) ? 4 : 1), bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int nwg = tilesM * tilesN * ((!X3 && p.fold) ? 4 : 1), bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         tid_ = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    // upsample-folded conv (ConvParams::fold; the H2 form only -- bf16 x 3 folds on conv_dma3.hip): the parity is the outermost tile index; parity q
+    // upsample-folded conv (ConvParams::fold; every two-plane form -- bf16 x 3 folds on conv_dma3.hip): the parity is the outermost tile index; parity q
     // reads weight rows [q Kpad, (q + 1) Kpad) and its own gather table, and writes source pixel (i, j) to output pixel (2 i + py, 2 j + px)
     int par = 0;
-    if constexpr (H2) { if (p.fold) { par = tid_ / (tilesM * tilesN); tid_ -= par * (tilesM * tilesN); } }
+    if constexpr (!X3) { if (p.fold) { par = tid_ / (tilesM * tilesN); tid_ -= par * (tilesM * tilesN); } }
     const int tm = tid_ % tilesM, tn = tid_ / tilesM;
     const int bm0 = tm * BM, bn0 = tn * BN;
 
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
     const KEntry* __restrict__ const ktab = p.ktab + par * (p.Kpad / 32);
     const int CoutPad = p.CoutPad, Nmax = p.Nmax;
     const u32x4* __restrict__ const wt_hi = reinterpret_cast<const u32x4*>(p.wt) + (size_t)par * (p.Kpad / 8) * CoutPad;
-    const size_t wplane = (size_t)(p.Kpad / 8) * CoutPad * ((H2 && p.fold) ? 4 : 1);     // units
+    const size_t wplane = (size_t)(p.Kpad / 8) * CoutPad * ((!X3 && p.fold) ? 4 : 1);     // units
     const u32x4* const zero = reinterpret_cast<const u32x4*>(p.zero16);
     const int ktiles = p.Kpad / 32;
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ring;   // wave-uniform LDS address
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
                 const u32x4 h = *reinterpret_cast<const u32x4*>(sh + pix * ROW + seg * 16);
                 if (mo < M) {
                     size_t opix = (size_t)mo;
-                    if constexpr (H2) {
+                    if constexpr (!X3) {
                         if (p.fold) {            // source pixel (img, i, j) of parity (py, px) -> output pixel (2 i + py, 2 j + px)
                             const int hw = p.Hout * p.Wout, img = mo / hw, r = mo - img * hw, i = r / p.Wout, j = r - i * p.Wout;
                             opix = ((size_t)(img * 2 * p.Hout + 2 * i + (par >> 1))) * (2 * p.Wout) + 2 * j + (par & 1);
@@ -561,8 +561,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
 template <int WM, int WN, int MT, int NT, int S3, int S2, int S1>
 void launch_dma_variant(const ConvParams& p, long M, hipStream_t s) {
     const int tilesM = (int)((M + WM * MT * 32 - 1) / (WM * MT * 32)), tilesN = p.Cout / (WN * NT * 32);
-    const dim3 grid((unsigned)(tilesM * tilesN * ((p.fold && p.f16 == 4) ? 4 : 1))), block(64 * WM * WN);
-    if (p.fold && p.f16 != 4) return;                          // (folded GEMMs: the H2 form here, bf16 x 3 on conv_dma3.hip; the caller sees hipErrorInvalidValue)
+    const dim3 grid((unsigned)(tilesM * tilesN * ((p.fold && !p.x3) ? 4 : 1))), block(64 * WM * WN);
+    if (p.fold && p.x3) return;                                // (folded GEMMs: the two-plane forms here, bf16 x 3 on conv_dma3.hip; the caller sees hipErrorInvalidValue)
     const int mode = (p.dbg & 16) ? 0 : p.simple;
     constexpr bool x3_fits = 2 * 12 * (WM * MT * 32 + WN * NT * 32) * 16 <= 160 * 1024;
     if constexpr (x3_fits) if (p.x3) {               // bf16 x 3: two stages

@@ -120,9 +120,10 @@ struct Builder {
             if (p.tensors[op.src[i]].C % 8 || op.sstride[i] != 1) direct = false;
         // bf16 x 3: an upconv layer (3x3 on a x2 nearest-neighbour upsampled source) with a wide output runs as four 2x2 convs on the source
         // itself, one per output parity, on the 256 x 256 GEMM block (OpDesc::fold).  The choice depends on the layer alone, never on the batch.
-        // SD_PREC_F16X2: the same on the H2 form of conv_dma.hip, for outputs of 128 channels and more (upconv6 / 5 / 4; measured at 64: upconv3 0.74 ms as a
-        // direct 3x3 conv on the upsampled source, 0.89 ms folded on the 256 x 64 GEMM block)
-        if (((p.x3 && Cout % 256 == 0) || (p.h2 && Cout % 128 == 0)) && k == 3 && stride == 1 && op.nsrc == 1 && op.up[0] && p.tensors[op.src[0]].C % 32 == 0 &&
+        // The two-plane split engines (SD_PREC_F16X2, and bf16 x 2 / the precision plan: VERDICT r4 item 7): the same on conv_dma.hip, for outputs of 128
+        // channels and more (upconv6 / 5 / 4; measured at 64 on f16x2: upconv3 0.74 ms as a direct 3x3 conv on the upsampled source, 0.89 ms folded on the
+        // 256 x 64 GEMM block)
+        if (((p.x3 && Cout % 256 == 0) || (p.prec && !p.x3 && Cout % 128 == 0)) && k == 3 && stride == 1 && op.nsrc == 1 && op.up[0] && p.tensors[op.src[0]].C % 32 == 0 &&
             residual < 0 && !(latch_switches() & (SW_NO_FOLD | SW_NO_DMA))) {        // (the folded GEMM form exists on conv_dma3 only: SEMDEPTH_NO_DMA implies no fold)
             const TensorDesc& t = p.tensors[op.src[0]];
             op.fold = 1; op.vec = 1;
