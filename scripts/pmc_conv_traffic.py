@@ -43,16 +43,22 @@ def label(k):
         if len(args) > 4 and args[4] == "true":
             return f"conv_direct_x3_fold_kernel<{args[0]}>"
         return f"conv_direct_x3_kernel<{args[0]},2>"
-    if fam == "conv_direct":       # <NB, MT, F16, N16, UP, W1, X2>
+    if fam == "conv_direct":       # <NB, MT, F16, N16, UP, W1, X2, H2>
+        if len(args) > 7 and args[7] == "true":          # the three-product HS form (SD_PREC_F16X2)
+            return "conv_direct_hs_kernel" + ("<1,n16>" if args[3] == "true" else ("<1,2>" if args[0] == "1" else "<2,2>"))
         prec = "_f16w_x2" if (len(args) > 6 and args[6] == "true") else "_f16x1" if (len(args) > 5 and args[5] == "true") else ("_f16w" if args[2] == "true" else "")
         shape = "<1,n16>" if args[3] == "true" else ("<1,2>" if args[0] == "1" else "<2,2>")
         return f"conv_direct{prec}_kernel{shape}"
-    if fam == "conv_dma":          # <WM, WN, MT, NT, SIMPLE, STAGES, F16, W1, X3>
+    if fam == "conv_dma":          # <WM, WN, MT, NT, SIMPLE, STAGES, F16, W1, X3, H2>
+        if len(args) > 9 and args[9] == "true":
+            return f"conv_dma_hs_kernel<{args[0]},{args[1]},{args[2]},{args[3]}>"
         if len(args) > 8 and args[8] == "true":
             return f"conv_dma_x3_kernel<{args[0]},{args[1]},{args[2]},{args[3]}>"
         prec = "_f16x1" if (len(args) > 7 and args[7] == "true") else ("_f16w" if args[6] == "true" else "")
         return f"conv_dma{prec}_kernel<{args[0]},{args[1]},{args[2]},{args[3]}>"
-    if fam == "conv_stem":         # <NB, RW, F16, X3>
+    if fam == "conv_stem":         # <NB, RW, F16, X3, H2>
+        if len(args) > 4 and args[4] == "true":
+            return "conv_stem_hs_kernel"
         if len(args) > 3 and args[3] == "true":
             return "conv_stem_x3_kernel"
         return "conv_stem_f16w_kernel" if args[2] == "true" else "conv_stem_kernel"

@@ -28,7 +28,7 @@ def test_other_geometries_track_the_f32_engine(H, W, B):
     fr = _frames(B, H, W, seed=H + W)
     rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
     got = {}
-    for prec in ("f32", "plan", "bf16x2"):
+    for prec in ("f32", "plan", "bf16x2", "f16x2"):
         e = Engine(H, W, B, "resnet50", precision=prec)
         e.load_weights(L.SD_NET_FCN8S, wf)
         e.load_weights(L.SD_NET_MONODEPTH, wm)
@@ -39,7 +39,7 @@ def test_other_geometries_track_the_f32_engine(H, W, B):
         got[prec] = (lg, pp, rec["n_road"].astype(np.int64), rec["found"].copy(), rec["width"].copy())
         e.close()
     assert got["f32"][2].min() > 1000                      # the masks are not empty
-    for prec, tol in (("plan", TOL), ("bf16x2", 1e-4)):
+    for prec, tol in (("plan", TOL), ("bf16x2", 1e-4), ("f16x2", 1e-5)):       # (f16x2: fp32-grade, an order of magnitude inside bf16x2's budget)
         lg, pp, n, found, width = got[prec]
         print(H, W, B, prec, rel(lg, got["f32"][0]), rel(pp, got["f32"][1]))
         assert rel(lg, got["f32"][0]) < tol and rel(pp, got["f32"][1]) < tol

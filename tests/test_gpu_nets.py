@@ -156,11 +156,13 @@ def test_generic_kernels_behind_each_specialised_one(switch, precision="bf16x2")
     assert relerr(raw[1].cpu().numpy(), ref) < TOL
 
 
-@pytest.mark.parametrize("switch", ["SEMDEPTH_NO_DMA", "SEMDEPTH_NO_DMA3", "SEMDEPTH_NO_FOLD", "SEMDEPTH_NO_TAIL1", "SEMDEPTH_NO_STEM"])
-def test_generic_kernels_behind_the_specialised_ones_of_the_fp32_grade_engine(switch):
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
+@pytest.mark.parametrize("switch", ["SEMDEPTH_NO_DMA", "SEMDEPTH_NO_DMA3", "SEMDEPTH_NO_FOLD", "SEMDEPTH_NO_TAIL1", "SEMDEPTH_NO_STEM", "SEMDEPTH_NO_DIRECT",
+                                    "SEMDEPTH_NO_N16", "SEMDEPTH_NO_POOL_FUSE", "SEMDEPTH_NO_PLANAR"])
+def test_generic_kernels_behind_the_specialised_ones_of_the_fp32_grade_engines(switch, precision):
     """the same on bf16x3 (SEMDEPTH_NO_DMA made the folded upconvs fail with SD_ERR_STATE -- the folded GEMM form exists on
-    conv_dma3 only, so the switch now also keeps the plan from folding)"""
-    test_generic_kernels_behind_each_specialised_one(switch, precision="bf16x3")
+    conv_dma3 only, so the switch now also keeps the plan from folding) and on f16x2 (every H2 form has the generic H2 kernel behind it)"""
+    test_generic_kernels_behind_each_specialised_one(switch, precision=precision)
 
 
 def test_256x256_block_of_the_dma_pipeline_is_bit_identical_to_the_128x256_one():

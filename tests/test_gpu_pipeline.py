@@ -311,7 +311,7 @@ def test_split_engine_records_track_the_exact_f32_engine(prec, flip_tol, disp_to
 
 
 # ------------------------------------------------------------------------------------------------ the reference-shaped boundary
-@pytest.mark.parametrize("precision", ["bf16x3"])
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
 def test_process_frame_full_size_against_the_oracle(precision):
     """BASELINE configs[0]'s substitute at the size it names: ONE 512 x 1024 frame through api.FrameProcessor.process_frame (the
     reference's per-frame operator, semantic_depth.py:98-334) on the headline engine.  Networks against the CPU oracle (logits -> masks
