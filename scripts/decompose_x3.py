@@ -6,7 +6,7 @@ column of scripts/layer_times.py then mixes the store cost with a data effect (m
 Here engine A runs normally and fills its arenas; engines B1 / B2 (the switch set) are bound to A's arenas, so every layer of their
 profiled pass reads the real activations A left behind and writes nothing.
 
-    python scripts/decompose_x3.py [B] > table"""
+    python scripts/decompose_x3.py [B [bf16x3|f16x2]] 2> table"""
 import ctypes as C
 import os
 import sys
@@ -19,6 +19,8 @@ from semantic_depth_amd import _lib as L, weights as Wt
 from semantic_depth_amd.engine import Engine, _ptr
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+PREC = sys.argv[2] if len(sys.argv) > 2 else "bf16x3"       # "f16x2": SEMDEPTH_X3_DIAG=2 = the H2 direct kernel without its epilogue
+DIAGS = (1, 2) if PREC == "bf16x3" else (2,)
 H, W, enc = 512, 1024, "resnet50"
 wf = Wt.make_fcn8s_weights(1, decoder_std=0.05)
 wm = Wt.make_monodepth_weights(enc, 2)
@@ -29,7 +31,7 @@ def make(diag):
     if diag:
         os.environ["SEMDEPTH_X3_DIAG"] = str(diag)
     try:
-        e = Engine(H, W, B, enc, precision="bf16x3")
+        e = Engine(H, W, B, enc, precision=PREC)
     finally:
         os.environ.pop("SEMDEPTH_X3_DIAG", None)
     return e
@@ -59,7 +61,7 @@ for _ in range(2):
 torch.cuda.synchronize()
 print("=== diag 0 (engine A)", file=sys.stderr)
 layers(A, False)
-for d in (1, 2):
+for d in DIAGS:
     Bn = make(d)
     # bind B to A's arenas (same plan, same layout; the tables it uploads are the ones already there) and mark its weights loaded
     L.check(Bn.lib, Bn.h, Bn.lib.sd_bind_memory(Bn.h, _ptr(A._wf), _ptr(A._wm), _ptr(A._ws)), "sd_bind_memory")
