@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-5 GPU batch (rewritten per experiment; results under gpurun_out/<tag>/).
-tag=${1:-r05k}
+tag=${1:-r05n}
 o=gpurun_out/$tag
 mkdir -p $o
-timeout 600 python scripts/decompose_x3.py 32 f16x2 2> $o/decompose_f16x2.txt > /dev/null
-grep -c sd_profile $o/decompose_f16x2.txt
+timeout 300 python scripts/dma3_timed.py bf16x3 > $o/dma3_timed_bf16x3.txt 2>&1
+timeout 300 python scripts/dma3_timed.py f16x2 > $o/dma3_timed_f16x2.txt 2>&1
+grep -c timed $o/dma3_timed_bf16x3.txt $o/dma3_timed_f16x2.txt

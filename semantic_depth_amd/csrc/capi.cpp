@@ -187,11 +187,12 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.sat = reinterpret_cast<unsigned long long*>(h->ws + h->o_misc + SAT_OFF);
                 c.x3 = p.x3;
                 // conv_dma3.hip, k x k stride-1 layers on one source (fc6): one output row of 256 / Wout images per tile, taps on padding rows skipped
-                if (p.x3 && !op.fold && op.nsrc == 1 && op.vec && op.Kvec == op.Kpad && op.k >= 3 && op.sstride[0] == 1 && !op.up[0] && !c.pool &&
+                const bool ph3 = p.x3 || p.h2;          // the phased 256 x 256 GEMM block of conv_dma3.hip exists for these two engines
+                if (ph3 && !op.fold && op.nsrc == 1 && op.vec && op.Kvec == op.Kpad && op.k >= 3 && op.sstride[0] == 1 && !op.up[0] && !c.pool &&
                     op.Kpad == op.k * op.k * s0.C && c.Wout > 0 && 256 % c.Wout == 0 && N % (256 / c.Wout) == 0 && !(h->sw & SW_NO_ROWSKIP))
                     c.rowgrp = 256 / c.Wout;
-                c.flat = (p.x3 && op.k == 1 && !op.fold && !op.up[0] && !(op.nsrc > 1 && op.up[1]) && op.nsrc <= 2 && !(h->sw & SW_NO_FLAT)) ? 1 : 0;
-                c.noup = (p.x3 && op.nsrc <= 2 && !(h->sw & SW_NO_FLAT)) ? 1 : 0;
+                c.flat = (ph3 && op.k == 1 && !op.fold && !op.up[0] && !(op.nsrc > 1 && op.up[1]) && op.nsrc <= 2 && !(h->sw & SW_NO_FLAT)) ? 1 : 0;
+                c.noup = (ph3 && op.nsrc <= 2 && !(h->sw & SW_NO_FLAT)) ? 1 : 0;
                 for (int j = 0; j < op.nsrc; ++j) {      // (32-bit byte offsets inside a plane of every source; strides 1 or 2)
                     if (PL(op.src[j]) * 2 >= ((size_t)1 << 32)) c.flat = c.noup = 0;
                     // (a folded op keeps up[0] = 1 from the plan, but its table reads the source at its own resolution: tap layers without upsample)
@@ -217,8 +218,10 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                     hipEventRecord(eb, s);
                     h->prof_last = eb; conv_op = true;
                     static const char* const dma3_names[3] = {"conv_dma3_kernel<0>", "conv_dma3_kernel<1>", "conv_dma3_kernel<2>"};
+                    static const char* const dmah_names[3] = {"conv_dma_hs_phased_kernel<0>", "conv_dma_hs_phased_kernel<1>", "conv_dma_hs_phased_kernel<2>"};
                     // (one bucket for the bench line; the per-layer listing of SEMDEPTH_PROFILE_VERBOSE names the gather variant)
-                    const char* const dma3_name = (h->sw & SW_PROFILE_VERBOSE) ? dma3_names[conv_dma3_mode(c)] : "conv_dma3_kernel";
+                    const char* const dma3_name = (h->sw & SW_PROFILE_VERBOSE) ? (c.f16 == 4 ? dmah_names : dma3_names)[conv_dma3_mode(c)]
+                                                                               : (c.f16 == 4 ? "conv_dma_hs_phased_kernel" : "conv_dma3_kernel");
                     h->prof_recs.push_back({dma3 ? dma3_name : dma ? conv_dma_kernel_name(c) : stem ? (c.x3 ? "conv_stem_x3_kernel" : c.f16 == 4 ? "conv_stem_hs_kernel" : c.f16 ? "conv_stem_f16w_kernel" : "conv_stem_kernel") : split ? conv_split_kernel_name(c) : conv_igemm_kernel_name(c), op.flops * N / p.images, ea, eb,
                                             op.name.c_str(), N * c.Hout * c.Wout * (c.fold ? 4 : 1), d.C, op.K, op_bytes(op)});
                 }

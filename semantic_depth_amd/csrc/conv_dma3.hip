@@ -64,9 +64,21 @@ constexpr int G3_ROW = G3_NT * 64 + 16;
 // Rows past M fetch pixel 0 (finite values; their outputs are never stored).
 // MODE 2 (ConvParams::noup, not flat): any taps, no upsample, at most two source geometries -- the same precomputed pixel offset plus a
 // SCALAR tap offset and the in-image test (fc6, the folded upconvs, the strided 3x3 layers): ~10 VALU per piece, no multiplies.
-template <int MODE>
+// HS (round 5; SD_PREC_F16X2, split_fmt.hpp "HS"): the same ring for TWO planes per operand and three fp16 products -- two phases per k-tile,
+//        phase lo: W_lo x X_hi                       16 MFMAs per wave (the X_hi fragments stay in VGPRs for the k-tile)
+//        phase hi: W_hi x (X_lo [scaled], X_hi)      32                (the X_lo product against w_hi * 2^-11, formed in registers)
+// i.e. the lo and hi phases of the six-product form without its mid plane.  A pair is still 16 + 16 KB and phase q still issues the pair of phase
+// q + 3, which is now one and a half k-tiles ahead: the lo phase of k-tile kt issues (X_lo, W_hi) of kt + 1, the hi phase (X_hi, W_lo) of kt + 2.
+// 64 KB per k-tile against 48 MFMAs per wave: the L2 -> LDS path bounds it at 0.75 of the MFMA rate.  The accumulator times ConvParams::alpha,
+// HS output planes.
+// TIMED (SEMDEPTH_X3_DIAG=3; MODE 1 only, decomposition runs): s_memtime stamps around the counted wait, the barrier and the body of every phase, summed
+// per wave; waves 0 and 4 of the middle workgroup print their sums (the instrumentation itself costs ~10 % of the wave cycles: read the SPLIT, not the total)
+template <int MODE, bool HS = false, bool TIMED = false>
 __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
-    static_assert(G3_NW * 3 * 32 * G3_ROW <= G3_LDS * 16, "epilogue slabs fit in the ring");
+    long long tm_wait = 0, tm_bar = 0, tm_body = 0, tm_t0 = 0, tm_pro = 0;
+    if constexpr (TIMED) tm_t0 = __builtin_amdgcn_s_memtime();
+    constexpr int NPL = HS ? 2 : 3;                          // planes per operand
+    static_assert(G3_NW * NPL * 32 * G3_ROW <= G3_LDS * 16, "epilogue slabs fit in the ring");
     __shared__ __attribute__((aligned(16))) u32x4 lds[G3_LDS];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -192,11 +204,16 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
         const u32x4* base = wt_hi + (size_t)pl * wplane + (size_t)(kt * 4) * CoutPad + bn0;       // (wave-uniform: SGPRs)
         g3dma16s(base, woff[i], lds0 + (unsigned)((slot * G3_PAIR + G3_XPL + (wave + G3_NW * i) * 64) * 16));
     };
-    auto issue_pair = [&](int kt, int ph, int slot) {          // (prologue: all four instructions at once)
+    auto issue_pair = [&](int kt, int wpl, int xpl, int slot) {          // (prologue: all four instructions at once) weight plane wpl, X plane xpl of k-tile kt
         const KEntry e = g3load_kentry(ktab + kt);
-        issue_w1(kt, 2 - ph, slot, 0); issue_w1(kt, 2 - ph, slot, 1);
-        issue_x1(e, ph, slot, 0); issue_x1(e, ph, slot, 1);
+        issue_w1(kt, wpl, slot, 0); issue_w1(kt, wpl, slot, 1);
+        issue_x1(e, xpl, slot, 0); issue_x1(e, xpl, slot, 1);
     };
+    // plane indices in memory: X hi = 0 (bf16 x 3: mid = 1, lo = 2; HS: scaled lo = 1); W hi = 0 (bf16 x 3: mid = 1, lo = 2; HS: lo = 1).
+    // Phase tag PH (0 lo, 1 mid, 2 hi; HS runs 0 and 2) -> the weight plane it multiplies and the X plane it reads for the first time
+    auto wpl_of = [](int ph) { return HS ? (ph == 0 ? 1 : 0) : 2 - ph; };
+    auto xpl_of = [](int ph) { return HS ? (ph == 0 ? 0 : 1) : ph; };
+    constexpr int NPH = HS ? 2 : 3;                          // phases per k-tile
 
     f32x16 acc[G3_MT][G3_NT];
 #pragma unroll
@@ -208,11 +225,16 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
 
     // phase q = 3 kt + ph reads weight plane (2 - ph) and, for the first and only time, X plane ph of k-tile kt from ring slot q % 4
     // (ph 0: lo, 1: mid, 2: hi)
-    const int nphase = 3 * ktiles;
-    // prologue = the issues of the (virtual) phases -3 .. -1: the pairs of phases 0, 1, 2
-    issue_pair(t0, 0, 0);
-    issue_pair(t0, 1, 1);
-    issue_pair(t0, 2, 2);
+    const int nphase = NPH * ktiles;
+    // prologue = the issues of the (virtual) phases -3 .. -1: the pairs of phases 0, 1, 2 (HS: the third one is the lo pair of the SECOND k-tile)
+    issue_pair(t0, wpl_of(0), xpl_of(0), 0);
+    if constexpr (HS) {
+        issue_pair(t0, wpl_of(2), xpl_of(2), 1);
+        issue_pair(knext(KCur{t0, 0}).idx, wpl_of(0), xpl_of(0), 2);
+    } else {
+        issue_pair(t0, wpl_of(1), xpl_of(1), 1);
+        issue_pair(t0, wpl_of(2), xpl_of(2), 2);
+    }
     int prev1 = 4;                                            // DMA instructions this wave issued in the previous phase
     const int frow = lane & 31, fk = lane >> 5;
     // Fragment registers that live across phase boundaries: the LDS reads a phase starts with are issued in the TAIL of the phase before
@@ -233,23 +255,37 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
 #pragma unroll
     for (int a = 0; a < G3_MT; ++a) xk[0][0][a] = xfrag(0, 0, a);
     int q = 0;
+    if constexpr (TIMED) tm_pro = __builtin_amdgcn_s_memtime() - tm_t0;
     KCur k1 = knext(KCur{t0, 0});                             // the k-tile whose pairs are being issued (the one after the k-tile being multiplied)
     KEntry e3 = g3load_kentry(ktab + k1.idx);                 // (at least two k-tiles) its gather entry
+    // HS: the hi phase issues the lo pair of the k-tile after that one
+    KCur k2 = knext(k1);
+    KEntry e4 = e3;
+    if constexpr (HS) { if (ktiles > 2) e4 = g3load_kentry(ktab + k2.idx); }
     for (int kt = 0; kt < ktiles; ++kt) {
         auto phase = [&](auto ph_tag) {
             constexpr int PH = decltype(ph_tag)::value, NPX = PH + 1;
+            long long ts0 = 0, ts1 = 0, ts2 = 0;
+            if constexpr (TIMED) ts0 = __builtin_amdgcn_s_memtime();
             // pairs q and q + 1 have landed once at most the previous phase's DMAs are outstanding (pair q + 1 feeds the tail's prefetch)
             if (prev1 == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (TIMED) ts1 = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_barrier();
+            if constexpr (TIMED) ts2 = __builtin_amdgcn_s_memtime();
             // the pair of phase q + 3 goes into the slot phase q - 1 has just finished reading -- its four DMA instructions are spread
             // BEHIND the first four MFMA groups of this phase (at the top of the phase, with the MFMA pipe drained by the barrier, each
             // of them would cost its full issue latency)
             const bool doissue = q + 3 < nphase;               // = 3 (kt + 1) + ph
             auto piece = [&](int n) {
                 if (!doissue) return;
-                if (n < 2) issue_w1(k1.idx, 2 - PH, (q + 3) & 3, n);
-                else issue_x1(e3, PH, (q + 3) & 3, n - 2);
+                if constexpr (HS) {          // phase q + 3: from the lo phase the hi pair of the next k-tile, from the hi phase the lo pair of the one after it
+                    if constexpr (PH == 0) { if (n < 2) issue_w1(k1.idx, wpl_of(2), (q + 3) & 3, n); else issue_x1(e3, xpl_of(2), (q + 3) & 3, n - 2); }
+                    else { if (n < 2) issue_w1(k2.idx, wpl_of(0), (q + 3) & 3, n); else issue_x1(e4, xpl_of(0), (q + 3) & 3, n - 2); }
+                } else {
+                    if (n < 2) issue_w1(k1.idx, 2 - PH, (q + 3) & 3, n);
+                    else issue_x1(e3, PH, (q + 3) & 3, n - 2);
+                }
             };
             prev1 = doissue ? 4 : 0;
             const int sq = q & 3, sn = (q + 1) & 3;            // this phase's ring slot, the next one's
@@ -276,7 +312,7 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
                 for (int b = 0; b < G3_NT; ++b) wn[b] = wfrag(sn, 0, b);
 #pragma unroll
                 for (int a = 0; a < G3_MT; ++a) {
-                    if constexpr (PH == 0) xk[1][0][a] = xfrag(sn, 0, a);
+                    if constexpr (PH == 0) { if constexpr (HS) xl[a] = xfrag(sn, 0, a); else xk[1][0][a] = xfrag(sn, 0, a); }      // (HS: the next phase is the hi phase)
                     else if constexpr (PH == 1) xl[a] = xfrag(sn, 0, a);
                     else xk[0][0][a] = xfrag(sn, 0, a);
                 }
@@ -284,13 +320,13 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
 #pragma unroll
-                for (int pl = 0; pl < (PH < 2 ? NPX : 2); ++pl) {        // the kept planes
+                for (int pl = 0; pl < (PH < 2 ? NPX : (HS ? 1 : 2)); ++pl) {        // the kept planes
 #pragma unroll
                     for (int b = 0; b < G3_NT; ++b) {
 #pragma unroll
                         for (int a = 0; a < G3_MT; ++a)
-                            acc[a][b] = mfma_frag<false>(w[s][b], xk[pl][s][a], acc[a][b]);
-                        const int grp = (s * (PH < 2 ? NPX : 2) + pl) * G3_NT + b;      // MFMA groups of four so far (lo phase: 4 in all)
+                            acc[a][b] = mfma_frag<HS>(w[s][b], xk[pl][s][a], acc[a][b]);
+                        const int grp = (s * (PH < 2 ? NPX : (HS ? 1 : 2)) + pl) * G3_NT + b;      // MFMA groups of four so far (lo phase: 4 in all)
                         if (PH == 0 ? true : (s == 0 && grp < 4)) {
                             __builtin_amdgcn_sched_barrier(0);
                             if (grp == 0) second_step();
@@ -316,10 +352,19 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
-                    for (int b = 0; b < G3_NT; ++b)
+                    for (int b = 0; b < G3_NT; ++b) {
+                        const u32x4 wx = HS ? hs_wscaled(w[s][b]) : w[s][b];      // (HS: the scaled-lo plane multiplies w_hi * 2^-11)
 #pragma unroll
                         for (int a = 0; a < G3_MT; ++a)
-                            acc[a][b] = mfma_frag<false>(w[s][b], xl[a], acc[a][b]);
+                            acc[a][b] = mfma_frag<HS>(wx, xl[a], acc[a][b]);
+                        if constexpr (HS) {
+                            if (s == 0) {                                    // (HS: the hi phase has two kept-plane groups in its first k-step: pieces 2 and 3 go here)
+                                __builtin_amdgcn_sched_barrier(0);
+                                piece(2 + b);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
                     if (s == 0) {
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -331,24 +376,31 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
                 }
             }
             ++q;
+            if constexpr (TIMED) { const long long ts3 = __builtin_amdgcn_s_memtime(); tm_wait += ts1 - ts0; tm_bar += ts2 - ts1; tm_body += ts3 - ts2; }
         };
         phase(IntTag<0>{});
-        phase(IntTag<1>{});
+        if constexpr (!HS) phase(IntTag<1>{});
         phase(IntTag<2>{});
-        k1 = knext(k1);
-        if (kt + 2 < ktiles) e3 = g3load_kentry(ktab + k1.idx);       // (one scalar load per k-tile, behind the hi phase's MFMAs)
+        if constexpr (HS) {
+            k1 = k2; e3 = e4;
+            k2 = knext(k2);
+            if (kt + 3 < ktiles) e4 = g3load_kentry(ktab + k2.idx);
+        } else {
+            k1 = knext(k1);
+            if (kt + 2 < ktiles) e3 = g3load_kentry(ktab + k1.idx);       // (one scalar load per k-tile, behind the hi phase's MFMAs)
+        }
     }
 
     // ---- epilogue: bias + activation in f32, exact three-way split, LDS transpose (one slab per plane and wave), 16-byte runs ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // SEMDEPTH_X3_DIAG (decomposition runs, latched in the handle's switches; 0 in production): 1 = no output stores, 2 = no epilogue at all
-    const int diag = ((p.sw & SW_X3_DIAG_NOSTORE) ? 1 : 0) | ((p.sw & SW_X3_DIAG_NOMFMA) ? 2 : 0);
+    const int diag = TIMED ? 0 : (((p.sw & SW_X3_DIAG_NOSTORE) ? 1 : 0) | ((p.sw & SW_X3_DIAG_NOMFMA) ? 2 : 0));
     if (diag & 2) { if (acc[0][0][0] == 12345.678f) p.out[0] = acc[1][1][3]; return; }
     auto ep3 = [&](auto tag) {
         constexpr int ACT = decltype(tag)::value;
         constexpr int ROW = G3_ROW;
-        unsigned char* slab = reinterpret_cast<unsigned char*>(lds) + wave * (3 * 32 * ROW);
+        unsigned char* slab = reinterpret_cast<unsigned char*>(lds) + wave * (NPL * 32 * ROW);
         constexpr int SEGS = G3_NT * 4, PPP = 64 / SEGS;
         const int seg = lane % SEGS, prow = lane / SEGS;
         uint16_t* const out_hi = reinterpret_cast<uint16_t*>(p.out);
@@ -361,14 +413,23 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int nl = b * 32 + 8 * r4 + 4 * (lane >> 5);
                     f32x4 v = {acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
+                    uint2 h, m, l;
+                    if constexpr (HS) {
+                        v = v * p.alpha + *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
+                        split4_hs(v, h, m, p.sat);
+                        *reinterpret_cast<uint2*>(slab + (lane & 31) * ROW + nl * 2) = h;
+                        *reinterpret_cast<uint2*>(slab + 32 * ROW + (lane & 31) * ROW + nl * 2) = m;
+                    } else {
                     v += *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_f32<ACT>(v[r]);
-                    uint2 h, m, l;
                     split4_x3(v, h, m, l);
                     *reinterpret_cast<uint2*>(slab + (lane & 31) * ROW + nl * 2) = h;
                     *reinterpret_cast<uint2*>(slab + 32 * ROW + (lane & 31) * ROW + nl * 2) = m;
                     *reinterpret_cast<uint2*>(slab + 64 * ROW + (lane & 31) * ROW + nl * 2) = l;
+                    }
                 }
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -388,7 +449,7 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
                     }
                     uint16_t* o = out_hi + opix * p.Cout + n0 + seg * 8;
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
+                    for (int pl = 0; pl < NPL; ++pl)
                         *reinterpret_cast<u32x4*>(o + pl * p.out_plane) = *reinterpret_cast<const u32x4*>(slab + pl * 32 * ROW + pix * ROW + seg * 16);
                 }
             }
@@ -396,15 +457,28 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     };
+    long long tm_e0 = 0;
+    if constexpr (TIMED) tm_e0 = __builtin_amdgcn_s_memtime();
     if (p.act == ACT_RELU) ep3(ActTag<ACT_RELU>{});
     else if (p.act == ACT_ELU) ep3(ActTag<ACT_ELU>{});
     else ep3(ActTag<ACT_NONE>{});
+    if constexpr (TIMED) {
+        const long long te = __builtin_amdgcn_s_memtime();
+        if ((int)blockIdx.x == (int)gridDim.x / 2 && lane == 0 && (wave == 0 || wave == 4))
+            printf("[conv_dma3 timed] %s K=%d ktiles=%d wave %d: prologue %lld | per phase (%d phases): wait %.1f barrier %.1f body %.1f | loop %lld epilogue %lld total %lld ticks\n",
+                   HS ? "HS" : "x3", p.Kpad, ktiles, wave, tm_pro, nphase, (double)tm_wait / nphase, (double)tm_bar / nphase, (double)tm_body / nphase,
+                   tm_wait + tm_bar + tm_body, te - tm_e0, te - tm_t0);
+    }
 }
 
+int conv_dma3_mode(const ConvParams& p);
 // layers the 256 x 256 phased block takes: bf16 x 3, all-vec K axis, Cout a multiple of 256 and enough blocks to occupy the chip
 bool conv_dma3_eligible(const ConvParams& p) {
-    if (!p.x3 || !p.vec || !p.zero16 || p.pool || p.out_planar16 || p.residual || p.Cout % G3_BN || p.Kpad < 64 || p.CoutPad != p.Cout) return false;
-    if (p.fold) return true;                                   // (the folded form exists here only: its results must not depend on the batch)
+    if (!(p.x3 || p.f16 == 4) || !p.vec || !p.zero16 || p.pool || p.out_planar16 || p.residual || p.Cout % G3_BN || p.Kpad < 64 || p.CoutPad != p.Cout) return false;
+    // SD_PREC_F16X2: measured against the two-stage block of conv_dma.hip (profiles/r05_hs_phased_gemm_ab.txt), the two-phase ring wins on the 1x1 layers (fc7
+    // 1.50 -> 1.29 ms, the res2 / res5 block tails 3-12 %) and loses on the tap layers (fc6 6.94 -> 7.26, the strided 3x3 of res4_6): the 1x1 layers only
+    if (p.f16 == 4 && conv_dma3_mode(p) != 1) return false;
+    if (p.fold) return true;                                   // (a folded layer always runs here when it can: its results must not depend on the batch)
     if (p.sw & SW_NO_DMA3) return false;                       // (A/B switch of the handle)
     const long M = (long)p.N * p.Hout * p.Wout;
     return ((M + G3_BM - 1) / G3_BM) * (p.Cout / G3_BN) >= 128;
@@ -420,6 +494,17 @@ hipError_t launch_conv_dma3(const ConvParams& p, hipStream_t s) {
     const int tilesM = (int)((M + G3_BM - 1) / G3_BM), tilesN = p.Cout / G3_BN;
     const dim3 grid((unsigned)(tilesM * tilesN * (p.fold ? 4 : 1)));
     const int mode = conv_dma3_mode(p);
+    if (mode == 1 && (p.sw & SW_X3_DIAG_NOSTORE) && (p.sw & SW_X3_DIAG_NOMFMA)) {          // SEMDEPTH_X3_DIAG=3: the timed copy of the 1x1 form
+        if (p.f16 == 4) hipLaunchKernelGGL((conv_dma3_kernel<1, true, true>), grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
+        else hipLaunchKernelGGL((conv_dma3_kernel<1, false, true>), grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
+        return hipGetLastError();
+    }
+    if (p.f16 == 4) {           // SD_PREC_F16X2: the two-plane, two-phase form
+        if (mode == 1) hipLaunchKernelGGL((conv_dma3_kernel<1, true>), grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
+        else if (mode == 2) hipLaunchKernelGGL((conv_dma3_kernel<2, true>), grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
+        else hipLaunchKernelGGL((conv_dma3_kernel<0, true>), grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
+        return hipGetLastError();
+    }
     if (mode == 1) hipLaunchKernelGGL(conv_dma3_kernel<1>, grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
     else if (mode == 2) hipLaunchKernelGGL(conv_dma3_kernel<2>, grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
     else hipLaunchKernelGGL(conv_dma3_kernel<0>, grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
