@@ -449,7 +449,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
                     }
                     v += bias[r4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = act_f32<ACT>(v[r]);
+                    for (int r = 0; r < 4; ++r) v[r] = act_x3<ACT>(v[r]);
                     split4_x3(v, pp[0][r4], pp[1][r4], pp[2][r4]);
                 }
                 const int pq = frow >> 1;                    // pooled pixel of this lane pair
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
                     f32x4 v = {acc[a][nb][4 * q4], acc[a][nb][4 * q4 + 1], acc[a][nb][4 * q4 + 2], acc[a][nb][4 * q4 + 3]};
                     v += bias[r4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = act_f32<ACT>(v[r]);
+                    for (int r = 0; r < 4; ++r) v[r] = act_x3<ACT>(v[r]);
                     split4_x3(v, pp[0][r4], pp[1][r4], pp[2][r4]);
                 }
 #pragma unroll

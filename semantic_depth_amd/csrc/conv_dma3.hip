@@ -424,7 +424,7 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
                     } else {
                     v += *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = act_f32<ACT>(v[r]);
+                    for (int r = 0; r < 4; ++r) v[r] = act_x3<ACT>(v[r]);
                     split4_x3(v, h, m, l);
                     *reinterpret_cast<uint2*>(slab + (lane & 31) * ROW + nl * 2) = h;
                     *reinterpret_cast<uint2*>(slab + 32 * ROW + (lane & 31) * ROW + nl * 2) = m;

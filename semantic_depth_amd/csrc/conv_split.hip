@@ -97,7 +97,7 @@ __device__ __forceinline__ void split_epilogue_x3(f32x16 (&acc)[MT][NT], unsigne
                 f32x4 v = {acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
                 if (n < p.Cout) v += *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = act_f32<ACT>(v[r]);
+                for (int r = 0; r < 4; ++r) v[r] = act_x3<ACT>(v[r]);
                 uint2 h, m, l;
                 split4_x3(v, h, m, l);
                 *reinterpret_cast<uint2*>(slab + (lane & 31) * ROW + nl * 2) = h;

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
                     if constexpr (H2) v = v * p.alpha + bias[r4]; else v += bias[r4];
                     if constexpr (X3) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = act_f32<ACT>(v[r]);
+                        for (int r = 0; r < 4; ++r) v[r] = act_x3<ACT>(v[r]);
                         split4_x3(v, hh[r4], ll[r4], mm[r4]);          // hh = hi, ll = mid, mm = lo (memory order)
                     } else {
 #pragma unroll

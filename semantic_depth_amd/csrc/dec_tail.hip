@@ -256,7 +256,7 @@ __global__ __launch_bounds__(512, 1) void dec_tail1_kernel(const DecTailParams p
                         }
                         f32x4 v = HS ? (acc0 + acc1) * p.alpha + bias1 : acc0 + acc1 + bias1;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = HS ? act_split<ACT_ELU>(v[r]) : act_f32<ACT_ELU>(v[r]);      // (each engine's own ELU)
+                        for (int r = 0; r < 4; ++r) v[r] = HS ? act_split<ACT_ELU>(v[r]) : act_x3<ACT_ELU>(v[r]);      // (each engine's own ELU)
                         const int ru = 2 * n + py, uc = 2 * lp + px;
                         const bool in = (unsigned)(y0 - 2 + ru) < (unsigned)H && (unsigned)(x0 - 2 + uc) < (unsigned)W;
                         if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(512, 1) void dec_tail1_kernel(const DecTailParams p
                     }
                     f32x4 v = HS ? ((acc[0] + acc[1]) + acc[2]) * p.alpha + bias2 : (acc[0] + acc[1]) + acc[2] + bias2;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = HS ? act_split<ACT_ELU>(v[r]) : act_f32<ACT_ELU>(v[r]);
+                    for (int r = 0; r < 4; ++r) v[r] = HS ? act_split<ACT_ELU>(v[r]) : act_x3<ACT_ELU>(v[r]);
                     const bool in = (unsigned)(cur.y0 - 1 + ri) < (unsigned)H && (unsigned)(cur.x0 - 1 + c) < (unsigned)W;
                     if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
                     *reinterpret_cast<f32x4*>(I + (ri * DT_IC + c) * DT_IPIX + 16 * lg) = v;

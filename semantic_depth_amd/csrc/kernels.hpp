@@ -129,6 +129,16 @@ template <int ACT> __device__ __forceinline__ float act_split(float v) {
     if (ACT == 3) return 0.3f * (1.0f / (1.0f + expf(-v)));      // as smalln_act (ops_misc.hip)
     return v;
 }
+// the bf16 x 3 engine's activation (round 5): its ELU is the branch-free form of the split engines, max(v, 0) + (exp2(min(v, 0) log2 e) - 1) -- six VALU slots
+// instead of thirteen (exp2 AND a degree-5 polynomial AND two selects), which is ~35 % of the VALU work of an epilogue that the two waves of a SIMD execute one
+// after the other (profiles/r05_conv_dma3_timed_bf16x3.txt).  Its absolute error near zero (<= 1.3e-7: v_exp_f32 is good to an ulp of a value near 1) was the
+// reason round 4 kept the polynomial; the three-product engine has run this form since it exists and measures CLOSER to the float64 oracle than this engine did
+// (profiles/r05_f32_grade_check.txt), and the reference's own tf.nn.elu is exp(x) - 1 in f32.
+template <int ACT> __device__ __forceinline__ float act_x3(float v) {
+    if (ACT == 1) return fmaxf(v, 0.f);
+    if (ACT == 2) return fast_elu_split(v);
+    return v;
+}
 template <int ACT> __device__ __forceinline__ float act_f32(float v) {
     if (ACT == 1) return fmaxf(v, 0.f);
     if (ACT == 2) return fast_elu(v);
