@@ -1,8 +1,12 @@
 #!/bin/bash
-tag=${1:-r05o}
+tag=${1:-r05p}
 o=gpurun_out/$tag
 mkdir -p $o
-timeout 300 python scripts/layer_times.py 32 resnet50 bf16x3 2> $o/layer_times_bf16x3.txt > /dev/null; tail -n 3 $o/layer_times_bf16x3.txt
-timeout 900 python scripts/f32_grade_check.py > $o/f32_grade_check.txt 2> $o/f32_grade_check.log; cat $o/f32_grade_check.txt
-timeout 900 python bench.py --legs f16x2 --no-cpu-baseline > $o/bench_legs.json 2> $o/bench_legs.log; grep 'frames/s' $o/bench_legs.log | cut -c1-220
-timeout 3000 python -m pytest tests -q -m gpu -x > $o/pytest_gpu.txt 2>&1; tail -n 5 $o/pytest_gpu.txt
+for rep in 1 2; do
+  for v in 1 0; do
+    if [ $v = 1 ]; then export SEMDEPTH_EPI_DRAIN=1; else unset SEMDEPTH_EPI_DRAIN; fi
+    timeout 900 python bench.py --legs f16x2 --no-cpu-baseline --no-overlap > $o/bench_drain${v}_$rep.json 2> $o/bench_drain${v}_$rep.log; echo "epi_drain=$v rep $rep"; grep 'frames/s' $o/bench_drain${v}_$rep.log | cut -c1-120
+  done
+done
+unset SEMDEPTH_EPI_DRAIN
+timeout 1500 python -m pytest tests/test_gpu_nets.py tests/test_gpu_pipeline.py -x -q -m gpu -k "bf16x3 or f16x2 or plan or bf16x2" > $o/pytest.txt 2>&1; tail -n 4 $o/pytest.txt
