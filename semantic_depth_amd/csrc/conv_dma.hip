@@ -59,7 +59,7 @@ const char* conv_dma_kernel_name(const ConvParams& p) {
     const int v = conv_dma_variant(p);
     static const char* const namesh[5] = {"conv_dma_hs_kernel<2,4,2,2>", "conv_dma_hs_kernel<4,2,2,2>", "conv_dma_hs_kernel<4,2,2,1>", "conv_dma_hs_kernel<8,1,1,1>",
                                           "conv_dma_hs_kernel<2,4,4,2>"};
-    if (p.f16 == 4) return (v == 5 && !(p.sw & SW_NO_WREG)) ? "conv_dma_hs_wreg_kernel<2,4,4,2>" : namesh[v >= 1 && v <= 5 ? v - 1 : 2];
+    if (p.f16 == 4) return namesh[v >= 1 && v <= 5 ? v - 1 : 2];
     return names[p.f16 == 2 ? 2 : (p.f16 ? 1 : 0)][v >= 1 && v <= 5 ? v - 1 : 2];
 }
 

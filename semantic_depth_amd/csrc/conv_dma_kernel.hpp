@@ -73,28 +73,21 @@ __device__ __forceinline__ KEntry load_kentry(const KEntry* ptr) {
 // H2 (SD_PREC_F16X2): the stage of the bf16 x 2 form (two planes per operand, three products), but the planes are fp16 hi + SCALED lo
 // activations and fp16 hi + lo weights (split_fmt.hpp "HS"): fp16 MFMAs, the x_lo product against w_hi * 2^-11 formed in registers, the
 // accumulator times ConvParams::alpha, HS output planes
-// WREG (with H2, round 5): the WEIGHT operand does not pass through LDS.  A wave's weight fragment is a coalesced 1-KB run of the weight image
-// ([k/8][Cout][8]): it is loaded straight into the registers the MFMA reads (global_load_dwordx4, one k-tile ahead, two register sets in ping-pong -- the
-// k-loop is unrolled by two so that no copy of a register with a load in flight is ever needed), a stage holds X only (32 KB for the 256 x 256 block), and
-// the same 128 KB are a ring of FOUR k-tiles with three in flight -- the two-stage form has one k-tile of look-ahead, and a k-tile there costs its MFMAs
-// plus the part of a 64-KB round trip they do not cover (profiles/r05_probe_l2_paths.txt, r05_conv_dma3_timed_f16x2.txt).  Each fragment is fetched by the
-// two waves that share it: 64 + 32 KB per k-tile through a path that delivers 30 B / clk.  Same k order and product order per output: bit-identical.
-template <int WAVES_M, int WAVES_N, int MT, int NT, int SIMPLE, int STAGES, bool F16 = false, bool W1 = false, bool X3 = false, bool H2 = false, bool WREG = false>
+template <int WAVES_M, int WAVES_N, int MT, int NT, int SIMPLE, int STAGES, bool F16 = false, bool W1 = false, bool X3 = false, bool H2 = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 : 1) void conv_dma_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
     static_assert(!X3 || (!F16 && !W1), "bf16 x 3 is a form of its own");
     static_assert(!H2 || (!F16 && !W1 && !X3), "H2 stages like the bf16 x 2 form");
-    static_assert(!WREG || H2, "the weight-in-registers form exists for H2");
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
     constexpr int NPX = F16 ? 1 : X3 ? 3 : 2, NPW = W1 ? 1 : X3 ? 3 : 2;      // planes of a stage per operand
     // 16-B units of a stage: Xh [4][BM] | Xl [4][BM] | Wh [4][BN] | Wl [4][BN]; the fp16 forms drop the planes they do not read
     // (Xl; W1: Wl too), so the same LDS holds a deeper ring: more k-tiles in flight against the L2 -> LDS latency
-    constexpr int X_UNITS = NPX * 4 * BM, W_UNITS = WREG ? 0 : NPW * 4 * BN;
+    constexpr int X_UNITS = NPX * 4 * BM, W_UNITS = NPW * 4 * BN;
     constexpr int STAGE_UNITS = X_UNITS + W_UNITS;
     static_assert(STAGES * STAGE_UNITS * 16 <= 160 * 1024, "ring fits in the LDS of a CU");
     constexpr int XI = 8 * BM / 64 / NW;                      // activation DMA instructions per wave and tile for TWO planes (2 or 4)
-    constexpr int WI = WREG ? 0 : NPW * 4 * BN / 64;          // weight instructions of a tile, every plane the form reads
-    constexpr int WPW = WREG ? 0 : (WI + NW - 1) / NW;        // per wave (a short last round re-fetches earlier units: equal counts)
+    constexpr int WI = NPW * 4 * BN / 64;                     // weight instructions of a tile, every plane the form reads
+    constexpr int WPW = (WI + NW - 1) / NW;                   // per wave (a short last round re-fetches earlier units: equal counts)
     constexpr int NDMA = NPX * (XI / 2) + WPW;                // DMA instructions per wave per tile (6; fp16 activations have ONE plane: 4 or 5; bf16 x 3: 9)
     constexpr int EPI_ROW = NT * 64 + 16;
     static_assert(NW * (X3 ? 3 : 2) * 32 * EPI_ROW <= STAGES * STAGE_UNITS * 16, "epilogue slabs fit in the ring");
@@ -232,7 +225,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
         // ---- weights: the stage image is the global image ----
 #pragma unroll
         for (int i = 0; i < WPW; ++i) {
-            const int jw = (wave + NW * i) % (WI ? WI : 1);   // weight instruction (wraps when WI < 8: duplicate fetch)
+            const int jw = (wave + NW * i) % WI;              // weight instruction (wraps when WI < 8: duplicate fetch)
             const int wu = jw * 64 + lane;                    // unit inside the W region: [plane][kg][n]
             const int pl = wu / (4 * BN), r = wu % (4 * BN), kg = r / BN, n_l = r % BN;
             const u32x4* g = wt_hi + pl * wplane + (size_t)(kt * 4 + kg) * CoutPad + bn0 + n_l;
@@ -272,7 +265,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
             }
         } else {
             const int i = n - XH * NPX;
-            const int jw = (wave + NW * i) % (WI ? WI : 1);
+            const int jw = (wave + NW * i) % WI;
             const int wu = jw * 64 + lane;
             const int pl = wu / (4 * BN), r = wu % (4 * BN), kg = r / BN, n_l = r % BN;
             dma16(wt_hi + pl * wplane + (size_t)(kt * 4 + kg) * CoutPad + bn0 + n_l, sbyte + (unsigned)(X_UNITS * 16 + jw * 1024));
@@ -323,81 +316,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
         else if (later == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * NDMA) : "memory");
     };
-    if constexpr (WREG) {
-        // ---- the weight-in-registers k-loop ----
-        // per-lane byte offsets of this wave's four fragments (k-step s, column block b) inside a (plane, k-tile, N tile) block of the weight image
-        unsigned wofs[2][NT];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int b = 0; b < NT; ++b) wofs[s2][b] = (unsigned)((((2 * s2 + fk) * CoutPad) + wn0 + b * 32 + frow) * 16);
-        u32x4 wA[NPW][2][NT], wB[NPW][2][NT];
-        auto wload = [&](u32x4 (&wd)[NPW][2][NT], int kt) {          // the eight fragments of k-tile kt (NPW planes x two k-steps x NT blocks)
-#pragma unroll
-            for (int pl = 0; pl < NPW; ++pl) {
-                const u32x4* base = wt_hi + pl * wplane + (size_t)(kt * 4) * CoutPad + bn0;       // (wave-uniform: SGPRs)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int b = 0; b < NT; ++b)
-                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wd[pl][s2][b]) : "v"(wofs[s2][b]), "s"(base) : "memory");
-            }
-        };
-        constexpr int NWL = NPW * 2 * NT;                 // weight loads per wave and k-tile
-        // (the X issues of the prologue went out above, BEFORE these loads: k-tile 0 waits for everything)
-        wload(wA, 0);
-        auto ktile = [&](auto par_tag, int kt) {
-            constexpr int PAR = decltype(par_tag)::value;
-            u32x4 (&wc)[NPW][2][NT] = PAR ? wB : wA;
-            u32x4 (&wnx)[NPW][2][NT] = PAR ? wA : wB;
-            // Outstanding, in issue order: [X pieces of tile kt - 1 + AHEAD, issued during tile kt - 1] after [W(kt), issued at the top of tile kt - 1] after
-            // everything older (X(kt) among it).  Loads complete in order: once at most the X pieces of the previous tile are outstanding, W(kt) and X(kt) are there.
-            if (kt >= 1 && kt - 1 + AHEAD < ktiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (kt + 1 < ktiles) wload(wnx, kt + 1);           // (first thing: a whole k-tile to land)
-            const bool doissue = kt + AHEAD < ktiles;
-            constexpr int xp2[3] = {0, 1, 0}, wp2[3] = {1, 0, 0};
-            constexpr int NGROUPS = 2 * 3 * NT, PPG = (NDMA + NGROUPS - 1) / NGROUPS;
-            int gidx = 0;
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const u32x4* Xs = ring + (kt % STAGES) * STAGE_UNITS;
-                const int kg = 2 * s2 + fk;
-                u32x4 xf[NPX][MT];
-#pragma unroll
-                for (int a = 0; a < MT; ++a) {
-                    const int mrow = wm0 + a * 32 + frow;
-                    const int slot = mrow * 4 + (kg ^ ((mrow >> 2) & 3));
-#pragma unroll
-                    for (int pl = 0; pl < NPX; ++pl) xf[pl][a] = Xs[pl * 4 * BM + slot];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int pr = 0; pr < 3; ++pr) {               // x_hi * w_lo, x_lo * (w_hi 2^-11), x_hi * w_hi: the order of the two-stage form
-#pragma unroll
-                    for (int b = 0; b < NT; ++b) {
-                        const u32x4 wv = pr == 1 ? hs_wscaled(wc[0][s2][b]) : wc[wp2[pr]][s2][b];
-#pragma unroll
-                        for (int a = 0; a < MT; ++a) acc[a][b] = mfma_frag<true>(wv, xf[xp2[pr]][a], acc[a][b]);
-                        if (gidx * PPG < NDMA) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (doissue) {
-#pragma unroll
-                                for (int n = gidx * PPG; n < (gidx + 1) * PPG && n < NDMA; ++n) piece(kt + AHEAD, (kt + AHEAD) % STAGES, n);
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                        ++gidx;
-                    }
-                }
-            }
-        };
-        for (int kt = 0; kt < ktiles; kt += 2) {
-            ktile(IntTag<0>{}, kt);
-            if (kt + 1 < ktiles) ktile(IntTag<1>{}, kt + 1);
-        }
-    } else {
     if constexpr (PRE) {
         wait_later(min(AHEAD - 1, ktiles - 1));       // tile 0 has landed
         __builtin_amdgcn_s_barrier();
@@ -474,10 +392,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
         }
     }
 
-    }       // (!WREG)
-
     // ---- epilogue (as conv_split.hip): bias + activation, split once, LDS transpose, 16-byte runs per pixel ----
-    if constexpr (WREG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if constexpr (X3) {
         // bf16 x 3 output: the exact three-way split, one slab per plane and wave
@@ -657,14 +572,6 @@ void launch_dma_variant(const ConvParams& p, long M, hipStream_t s) {
         return;
     }
     if (p.f16 == 4) {                     // SD_PREC_F16X2: the three-product stage, fp16 HS planes
-        if constexpr (WM == 2 && WN == 4 && MT == 4 && NT == 2) {          // the 256 x 256 block: weights in registers, a ring of four X-only stages
-            if (!(p.sw & SW_NO_WREG)) {
-                if (mode == 2) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 2, 4, false, false, false, true, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
-                else if (mode == 1) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 1, 4, false, false, false, true, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
-                else hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 0, 4, false, false, false, true, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
-                return;
-            }
-        }
         if (mode == 2) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 2, S3, false, false, false, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
         else if (mode == 1) hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 1, S3, false, false, false, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);
         else hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 0, S3, false, false, false, true>), grid, block, 0, s, p, (int)M, tilesM, tilesN);

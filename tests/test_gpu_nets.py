@@ -302,43 +302,6 @@ def test_folded_upconvs_and_fused_decoder_tail_against_the_layer_by_layer_form(H
             assert ef < 1e-5 and ef < 2.0 * ep + 1e-6
 
 
-def test_weights_in_registers_gemm_block_is_bit_identical_to_the_lds_staged_one():
-    """f16x2: the 256 x 256 GEMM block loads its weight fragments straight into registers (conv_dma_kernel<..., WREG>: a ring of four X-only stages, the k-loop
-    unrolled into two register sets) instead of staging them through LDS (SEMDEPTH_NO_WREG: two 64-KB stages).  Same k order, same product order per output:
-    logits and raw disparities must not change by a bit.  SEMDEPTH_NO_DMA3 routes every GEMM layer to this block (the two-phase ring would take the 1x1 layers);
-    256 x 512 frames, 8 of them: the block tails from res2 on, fc6 and fc7 have >= 512 blocks of 256 x 256 there... fc6 / fc7 do not (64 pixels per frame): they
-    are covered at B = 32 by the bench's parity record."""
-    from semantic_depth_amd.engine import Engine
-    from semantic_depth_amd import weights as Wt
-    H, W, B = 256, 512, 8
-    wf = Wt.make_fcn8s_weights(6, decoder_std=0.05, bias_std=0.1)
-    wm = Wt.make_monodepth_weights("resnet50", 7, bias_std=0.05)
-    fr = dev(_frames(B, H, W, seed=33))
-    outs, kern = [], []
-    os.environ["SEMDEPTH_NO_DMA3"] = "1"
-    try:
-        for off in (False, True):
-            if off:
-                os.environ["SEMDEPTH_NO_WREG"] = "1"
-            try:
-                eng = Engine(H, W, B, "resnet50", precision="f16x2")
-                eng.load_weights(L.SD_NET_FCN8S, wf)
-                eng.load_weights(L.SD_NET_MONODEPTH, wm)
-                eng.profile(True)
-                lg = eng.fcn8s_forward(fr, want_logits=True)["logits"].clone()
-                _, raw = eng.monodepth_forward(fr, want_raw=True)
-                kern.append({b["kernel"]: b["launches"] for b in eng.profile_read()})
-                eng.profile(False)
-                outs.append((lg, raw.clone()))
-            finally:
-                os.environ.pop("SEMDEPTH_NO_WREG", None)
-            del eng
-    finally:
-        os.environ.pop("SEMDEPTH_NO_DMA3", None)
-    assert kern[0].get("conv_dma_hs_wreg_kernel<2,4,4,2>", 0) >= 2 and "conv_dma_hs_wreg_kernel<2,4,4,2>" not in kern[1], kern
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-
-
 @pytest.mark.parametrize("gains", [(-6, -6, 4, 4, 4), (2, 2, -2, -2, 0)])
 def test_three_product_fp16_engine_needs_no_activation_scale(gains):
     """The HS format (fp16 hi + 2^11-scaled lo) carries 22 significand bits for every |v| in [1.2e-4, 65504] WITHOUT a per-tensor scale: the scaled
