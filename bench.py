@@ -549,7 +549,8 @@ def main():
         "n_gpus": world, "ranks_seen": ranks_seen, **({"shared_gpu_plumbing_test": True} if share else {}), "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": head_rec["ms_per_step"], "repeats": head_rec["repeats"], "repeat_ms_per_step": head_rec["repeat_ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
-        "config": {"workload": workload + f"batch {B} per GPU, 512x1024, monodepth-{args.encoder} on frame+flip, seeded synthetic weights",
+        "config": {"library": L.load().sd_version().decode(),       # (ends in src=<hash of the sources the .so was built from>)
+                   "workload": workload + f"batch {B} per GPU, 512x1024, monodepth-{args.encoder} on frame+flip, seeded synthetic weights",
                    "survey_config": args.config, "frames_per_step": world * B, "gflop_per_frame": round(flops_frame / 1e9, 2),
                    # gflop_per_frame = what this engine executes (bf16x3: the upconv layers run upsample-folded, 4/9 of the multiplications of a
                    # 3x3 conv on the upsampled tensor); the reference graph as written: FCN-8s 443.19 + 2 x monodepth-resnet50 179.92
