@@ -147,7 +147,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
     struct ChunkCtx { const uint16_t* img; size_t plane; unsigned rowel, C, okm, xbyte; int up, gy0, gx0; const u32x4* w; };
     auto begin_chunk = [&](const DirectChunk& ch, const Tile& tl, int c, int buf) {
         ChunkCtx k;
-        k.plane = (size_t)p.Nmax * ch.H * ch.W * ch.C;      // elements
+        k.plane = (size_t)p.Nmax * ch.H * ch.W * (ch.pad ? ch.pad : ch.C);      // elements (pad: the channel count of a tensor stored as 16-channel sub-planes)
         k.img = reinterpret_cast<const uint16_t*>(ch.base) + (size_t)tl.img * ch.H * ch.W * ch.C;
         k.rowel = (unsigned)(ch.W * ch.C); k.C = (unsigned)ch.C; k.up = UP ? 0 : ch.up;
         k.okm = ch.nvalid >= 2 ? okA : okB;

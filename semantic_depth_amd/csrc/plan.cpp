@@ -313,7 +313,29 @@ struct Builder {
     // LDS-tiled few-channel heads is handed over as 16-channel sub-planes (TensorDesc::planar16): the reader's 16-channel
     // chunk of a pixel row is then one contiguous run instead of 32 bytes out of every pixel's line
     void mark_planar() {
-        if (!p.prec || p.x3 || std::getenv("SEMDEPTH_NO_PLANAR")) return;     // (bf16 x 3: plain NHWC planes everywhere)
+        if (!p.prec || std::getenv("SEMDEPTH_NO_PLANAR")) return;
+        if (p.x3) {
+            // bf16 x 3 (round 5): the one hand-off whose writer and reader both know the layout -- a stem conv (conv_stem.hip) whose output is read by direct 3x3
+            // convs only (FCN-8s conv1_1 -> conv1_2): a 16-channel chunk of conv1_2's halo is then a contiguous run of the sub-plane instead of 32 bytes out of
+            // every pixel's 128-byte line, which four chunk passes fetched four times (6.4 GB of input read as ~20)
+            for (size_t ti = 0; ti < p.tensors.size(); ++ti) {
+                TensorDesc& t = p.tensors[ti];
+                if (t.C % 16 || (t.C != 32 && t.C != 64) || t.W % 32 || (int)ti == p.t_output || (int)ti == p.t_input) continue;
+                bool made = false, ok = true;
+                int readers = 0;
+                for (const OpDesc& op : p.ops) {
+                    if (op.dst == (int)ti)
+                        made = op.kind == OP_CONV && op.nsrc == 1 && op.src[0] == p.t_input && (op.k & 1) && op.k <= 7 && !op.fold && !op.fuse_pool && op.residual < 0;
+                    bool reads = op.residual == (int)ti;
+                    for (int j = 0; j < op.nsrc; ++j) reads = reads || op.src[j] == (int)ti;
+                    if (!reads) continue;
+                    ++readers;
+                    ok = ok && op.kind == OP_CONV_DIRECT && op.residual != (int)ti;
+                }
+                if (made && ok && readers > 0 && !(latch_switches() & SW_NO_STEM)) t.planar16 = 1;
+            }
+            return;
+        }
         const bool wide = !std::getenv("SEMDEPTH_NO_PLANAR_WIDE");
         for (size_t ti = 0; ti < p.tensors.size(); ++ti) {
             TensorDesc& t = p.tensors[ti];

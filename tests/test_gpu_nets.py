@@ -302,6 +302,29 @@ def test_folded_upconvs_and_fused_decoder_tail_against_the_layer_by_layer_form(H
             assert ef < 1e-5 and ef < 2.0 * ep + 1e-6
 
 
+def test_sub_planar_stem_output_of_the_six_product_engine_is_bit_identical():
+    """bf16x3 (round 5): conv1_1's output goes to conv1_2 as 16-channel sub-planes (the stem kernel writes them, conv_direct3's chunk loader reads a contiguous
+    run per chunk instead of 32 bytes out of every pixel's line).  Addressing only: with SEMDEPTH_NO_PLANAR the logits must not change by a bit."""
+    from semantic_depth_amd.engine import Engine
+    from semantic_depth_amd import weights as Wt
+    H, W, B = 128, 256, 2
+    wf = Wt.make_fcn8s_weights(4, decoder_std=0.05, bias_std=0.1)
+    fr = dev(_frames(B, H, W, seed=17))
+    outs = []
+    for off in (False, True):
+        if off:
+            os.environ["SEMDEPTH_NO_PLANAR"] = "1"
+        try:
+            eng = Engine(H, W, B, "resnet50", precision="bf16x3")
+            eng.load_weights(L.SD_NET_FCN8S, wf)
+            outs.append(eng.fcn8s_forward(fr, want_logits=True)["logits"].clone())
+        finally:
+            os.environ.pop("SEMDEPTH_NO_PLANAR", None)
+        del eng
+    assert torch.equal(outs[0], outs[1])
+    assert relerr(outs[0].cpu().numpy(), nets.fcn8s_forward(fr.cpu().numpy(), wf)) < 1e-5
+
+
 @pytest.mark.parametrize("gains", [(-6, -6, 4, 4, 4), (2, 2, -2, -2, 0)])
 def test_three_product_fp16_engine_needs_no_activation_scale(gains):
     """The HS format (fp16 hi + 2^11-scaled lo) carries 22 significand bits for every |v| in [1.2e-4, 65504] WITHOUT a per-tensor scale: the scaled
