@@ -58,8 +58,14 @@ constexpr int T3_TW = 32, T3_HW = T3_TW + 2, T3_WAVES = 8, T3_TH = 16, T3_HH = T
 // source with the 3x3 taps that read the same source pixel added up (plan.hpp OpDesc::fold): 16 tap matrices per chunk instead of 9, but
 // 4 instead of 9 MFMAs per output pixel.  Wave w owns parity w & 3 and the source rows 4 (w >> 2) .. + 3 of the tile: its two 32-pixel MFMA
 // column groups are 2 source rows x 16 source columns each.
-template <int NB, bool UP, int KEEP, int WSLOTS, bool FOLD = false>
+// TIMED (SEMDEPTH_X3_DIAG=4; <2, false, 2, 2> only, decomposition runs): s_memtime stamps around every phase's wait + barrier, the barrier in front of the
+// epilogue and the epilogue itself, summed per wave over the items of a workgroup; waves 0 and 4 of the middle workgroup print their sums.
+template <int NB, bool UP, int KEEP, int WSLOTS, bool FOLD = false, bool TIMED = false>
 __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectParams p) {
+    int tm_loop = 0, tm_wb = 0, tm_wb0 = 0, tm_bar = 0, tm_ep = 0, tm_start = 0, tm_pro = 0, tm_epv = 0, tm_epw = 0, tm_eps = 0;      // (low 32 bits of s_memtime)
+    auto now = []() { return (int)__builtin_amdgcn_s_memtime(); };
+    int tm_items = 0;
+    if constexpr (TIMED) tm_start = now();
     static_assert(!FOLD || (UP && WSLOTS == 2 && KEEP == 2), "the folded form: upconv layers, two-slot ring, kept X fragments");
     constexpr int NTAP = FOLD ? 16 : 9;                        // tap matrices per chunk
     constexpr int S_HH = UP ? T3_HH / 2 + 1 : T3_HH, S_HW = UP ? T3_HW / 2 + 1 : T3_HW;      // stored tile
@@ -236,8 +242,11 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
         advance();
     }
     int g = 0, q = 0;                    // chunks / phases consumed so far
+    if constexpr (TIMED) tm_pro = now() - tm_start;
     for (; tid < items; tid += gridDim.x) {
         const int half = cur.half;
+        int tm_i0 = 0;
+        if constexpr (TIMED) { tm_i0 = now(); ++tm_items; }
         f32x16 acc[T3_MT][NB];
 #pragma unroll
         for (int a = 0; a < T3_MT; ++a)
@@ -392,15 +401,20 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
                 if (more) { kc = kn; }
             } else {
             // ---- phase lo: W_lo x X_hi (36 MFMAs per wave at NB = 2); brings W_mid of this chunk
+            int tm_a = 0;
+            if constexpr (TIMED) tm_a = now();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            if constexpr (TIMED) { const int d = now() - tm_a; tm_wb += d; if (c == 0) tm_wb0 += d; }
             SD_PHASE(0, [&](int grp) {
                 if (grp < WS) wslot(wcur, 1, grp, (q + 1) & 1);
             });
             ++q;
             // ---- phase mid: W_mid x (X_mid, X_hi) (72); brings W_hi of this chunk and X_hi of the cursor chunk
+            if constexpr (TIMED) tm_a = now();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            if constexpr (TIMED) tm_wb += now() - tm_a;
             if (more) kn = begin_chunk(d3load_chunk(p.chunks + ic), icur, ic, (g + 1) & 1);
             SD_PHASE(1, [&](int grp) {
                 if (grp < WS) wslot(wcur, 0, grp, (q + 1) & 1);
@@ -408,8 +422,10 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
             });
             ++q;
             // ---- phase hi: W_hi x (X_lo, X_mid, X_hi) (108); brings W_lo and X_mid, X_lo of the cursor chunk
+            if constexpr (TIMED) tm_a = now();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            if constexpr (TIMED) tm_wb += now() - tm_a;
             SD_PHASE(2, [&](int grp) {
                 if (!more) return;
                 if (grp < WS) wslot(kn.w, 2, grp, (q + 1) & 1);
@@ -422,7 +438,10 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
 
         // ---- epilogue: bias + activation, the exact three-way split, LDS transpose one plane at a time in the X buffer just consumed
         //      (the other one is being filled for the next item), 16-byte runs of 8 channels per pixel and plane ----
+        int tm_e0 = 0, tm_e1 = 0;
+        if constexpr (TIMED) tm_e0 = now();
         __builtin_amdgcn_s_barrier();
+        if constexpr (TIMED) { tm_e1 = now(); tm_loop += tm_e0 - tm_i0; tm_bar += tm_e1 - tm_e0; }
         auto epilogue = [&](auto tag) {
             constexpr int ACT = decltype(tag)::value;
             constexpr int SEGS = 4 * NB, PPP = 64 / SEGS;        // 16-byte segments per pixel, pixels per store pass
@@ -482,6 +501,8 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
             for (int a = 0; a < T3_MT; ++a) {
                 const int y = cur.ty0 + T3_MT * wave + a;
                 uint2 pp[3][4 * NB];
+                int tm_x = 0;
+                if constexpr (TIMED) tm_x = now();
 #pragma unroll
                 for (int r4 = 0; r4 < 4 * NB; ++r4) {
                     if (8 * r4 >= p.Cout) continue;         // rows past Cout are padding, never stored
@@ -492,6 +513,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
                     for (int r = 0; r < 4; ++r) v[r] = act_x3<ACT>(v[r]);
                     split4_x3(v, pp[0][r4], pp[1][r4], pp[2][r4]);
                 }
+                if constexpr (TIMED) { __builtin_amdgcn_sched_barrier(0); const int n = now(); tm_epv += n - tm_x; tm_x = n; }
 #pragma unroll
                 for (int pl0 = 0; pl0 < 3; pl0 += EPL) {
 #pragma unroll
@@ -503,6 +525,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
                         }
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if constexpr (TIMED) { const int n = now(); tm_epw += n - tm_x; tm_x = n; }
 #pragma unroll
                     for (int ps = 0; ps < 32 / PPP; ++ps) {
                         const int pix = ps * PPP + prow;
@@ -518,12 +541,14 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
                     }
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if constexpr (TIMED) { const int n = now(); tm_eps += n - tm_x; tm_x = n; }
                 }
             }
         };
         if (p.act == ACT_RELU) epilogue(ActTag<ACT_RELU>{});
         else if (p.act == ACT_ELU) epilogue(ActTag<ACT_ELU>{});
         else epilogue(ActTag<ACT_NONE>{});
+        if constexpr (TIMED) tm_ep += now() - tm_e1;
         if constexpr (WSLOTS == 3) {
             // gfx9 counts stores in vmcnt too and loads / stores may complete out of order with respect to each other: a COUNTED wait is
             // only sound over the DMA loads alone.  Drain the epilogue's stores (and the DMAs of the last phase with them) once per tile.
@@ -533,6 +558,14 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
         if (tid + (int)gridDim.x < items) cur = tile_of(tid + gridDim.x);
     }
 #undef SD_PHASE
+    if constexpr (TIMED) {
+        const int total = now() - tm_start;
+        if ((int)blockIdx.x == (int)gridDim.x / 2 && lane == 0 && (wave == 0 || wave == 4))
+            printf("[conv_direct3 timed] H=%d W=%d Cout=%d chunks=%d items=%d wave %d: prologue %d | per item: loop %.0f (wait+barrier of its %d phases %.0f, of the first one %.0f) "
+                   "barrier before the epilogue %.0f epilogue %.0f (bias + act + split %.0f, LDS writes + wait %.0f, LDS reads + stores + wait %.0f) | total %d ticks\n",
+                   p.H, p.W, p.Cout * p.nsplit, p.nchunks, tm_items, wave, tm_pro, (double)tm_loop / tm_items, 3 * p.nchunks, (double)tm_wb / tm_items, (double)tm_wb0 / tm_items,
+                   (double)tm_bar / tm_items, (double)tm_ep / tm_items, (double)tm_epv / tm_items, (double)tm_epw / tm_items, (double)tm_eps / tm_items, total);
+    }
 }
 
 hipError_t launch_conv_direct3(const ConvDirectParams& p, hipStream_t s) {
@@ -573,6 +606,10 @@ hipError_t launch_conv_direct3(const ConvDirectParams& p, hipStream_t s) {
     }
 #else
 #define SD_D3(NB_, UP_, WS_) hipLaunchKernelGGL((conv_direct3_kernel<NB_, UP_, 2, WS_>), grid, dim3(512), 0, s, pd)
+    if ((p.sw & SW_X3_DIAG_TIMED) && p.Cout > 32 && !up) {          // SEMDEPTH_X3_DIAG=4: the timed copy of the dominant form
+        hipLaunchKernelGGL((conv_direct3_kernel<2, false, 2, 2, false, true>), grid, dim3(512), 0, s, pd);
+        return hipGetLastError();
+    }
     if (p.Cout <= 32) { if (up) SD_D3(1, true, 2); else SD_D3(1, false, 2); }
     else { if (up) SD_D3(2, true, 2); else SD_D3(2, false, 2); }
 #endif

@@ -20,7 +20,8 @@ enum Switch : unsigned {
     SW_NO_FOLD = 1u << 17,       // SEMDEPTH_NO_FOLD: the upconv layers as 3x3 convs on the upsampled source (plan-time switch)
     SW_NO_TAIL1 = 1u << 18,      // SEMDEPTH_NO_TAIL1: upconv1 / iconv1 / disp1 of the bf16 x 3 monodepth as three launches (plan-time switch)
     SW_NO_ROWSKIP = 1u << 19,    // SEMDEPTH_NO_ROWSKIP: conv_dma3 without the row-grouped pixel order (ConvParams::rowgrp)
-    SW_NO_FLAT = 1u << 20        // SEMDEPTH_NO_FLAT: conv_dma3's 1x1 layers through the general gather
+    SW_NO_FLAT = 1u << 20,       // SEMDEPTH_NO_FLAT: conv_dma3's 1x1 layers through the general gather
+    SW_X3_DIAG_TIMED = 1u << 21  // SEMDEPTH_X3_DIAG=4: conv_direct3's timed copy (s_memtime stamps per item; decomposition runs)
 };
 unsigned latch_switches();      // plan.cpp
 

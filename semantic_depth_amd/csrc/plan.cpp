@@ -23,7 +23,7 @@ unsigned latch_switches() {
     if (const char* d = std::getenv("SEMDEPTH_DMA_DBG")) if (atoi(d) & 16) sw |= SW_DMA_DBG16;
     if (const char* v = std::getenv("SEMDEPTH_PROFILE_VERBOSE")) if (v[0] == '1') sw |= SW_PROFILE_VERBOSE;
     if (const char* v = std::getenv("SEMDEPTH_X3_KEEP")) if (atoi(v) == 0) sw |= SW_X3_NOKEEP;
-    if (const char* v = std::getenv("SEMDEPTH_X3_DIAG")) sw |= ((atoi(v) & 1) ? SW_X3_DIAG_NOSTORE : 0u) | ((atoi(v) & 2) ? SW_X3_DIAG_NOMFMA : 0u);
+    if (const char* v = std::getenv("SEMDEPTH_X3_DIAG")) sw |= ((atoi(v) & 1) ? SW_X3_DIAG_NOSTORE : 0u) | ((atoi(v) & 2) ? SW_X3_DIAG_NOMFMA : 0u) | ((atoi(v) & 4) ? SW_X3_DIAG_TIMED : 0u);
     return sw;
 }
 
