@@ -192,7 +192,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                     op.Kpad == op.k * op.k * s0.C && c.Wout > 0 && 256 % c.Wout == 0 && N % (256 / c.Wout) == 0 && !(h->sw & SW_NO_ROWSKIP))
                     c.rowgrp = 256 / c.Wout;
                 c.flat = (ph3 && op.k == 1 && !op.fold && !op.up[0] && !(op.nsrc > 1 && op.up[1]) && op.nsrc <= 2 && !(h->sw & SW_NO_FLAT)) ? 1 : 0;
-                c.noup = (ph3 && op.nsrc <= 2 && !(h->sw & SW_NO_FLAT)) ? 1 : 0;
+                c.noup = (ph3 && op.nsrc == 1 && !(h->sw & SW_NO_FLAT)) ? 1 : 0;       // (conv_dma3's precomputed gather: ONE source geometry)
                 for (int j = 0; j < op.nsrc; ++j) {      // (32-bit byte offsets inside a plane of every source; strides 1 or 2)
                     if (PL(op.src[j]) * 2 >= ((size_t)1 << 32)) c.flat = c.noup = 0;
                     // (a folded op keeps up[0] = 1 from the plan, but its table reads the source at its own resolution: tap layers without upsample)

@@ -73,7 +73,13 @@ constexpr int G3_ROW = G3_NT * 64 + 16;
 // HS output planes.
 // TIMED (SEMDEPTH_X3_DIAG=3; MODE 1 only, decomposition runs): s_memtime stamps around the counted wait, the barrier and the body of every phase, summed
 // per wave; waves 0 and 4 of the middle workgroup print their sums (the instrumentation itself costs ~10 % of the wave cycles: read the SPLIT, not the total)
-template <int MODE, bool HS = false, bool TIMED = false>
+// S16 (round 5; SEMDEPTH_MFMA16, not the default): the same ring and the same LDS traffic, multiplied by v_mfma_f32_16x16x32 instead of 32x32x16 -- a k-tile is ONE
+// k-step of 32, a wave's 128 x 64 tile 8 x 4 blocks of 16 x 16, the products grouped by X plane with the weight fragments kept.  In isolation the 16x16x32 form
+// sustains 15-17 % more products per second on plane data under the power cap (half the accumulator traffic per MAC; profiles/r05_probe_mfma_shapes.txt); in this
+// kernel the clock does rise by ~10 % but a phase takes 8 % more cycles (the DMA pieces / fragment prefetches between MFMA groups are covered by 16-clock instead of
+// 32-clock MFMAs): -1.4 % on the layers of this kernel, +1 % end to end (profiles/r05_mfma16_ab.txt).  Not the default because its sums differ in the last bits from
+// conv_dma.hip's 32x32x16 block, which takes the same layers at small batches: a frame's result would depend on the batch it was computed in.
+template <int MODE, bool HS = false, bool TIMED = false, bool S16 = false>
 __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
     long long tm_wait = 0, tm_bar = 0, tm_body = 0, tm_t0 = 0, tm_pro = 0;
     if constexpr (TIMED) tm_t0 = __builtin_amdgcn_s_memtime();
@@ -163,7 +169,12 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
             return ((ik >> 30) & 1) ? (unsigned)((((img * H_ + oy * st_) * W_ + ox * st_) * C_ + oct * 8) * 2) : (unsigned)(oct * 16);
         };
         offA0 = off_of(pyx[0], pik[0], ea.H, ea.W, ea.C, sa); offA1 = off_of(pyx[1], pik[1], ea.H, ea.W, ea.C, sa);
-        offB0 = off_of(pyx[0], pik[0], eb.H, eb.W, eb.C, sb); offB1 = off_of(pyx[1], pik[1], eb.H, eb.W, eb.C, sb);
+        if constexpr (FLAT) { offB0 = off_of(pyx[0], pik[0], eb.H, eb.W, eb.C, sb); offB1 = off_of(pyx[1], pik[1], eb.H, eb.W, eb.C, sb); }
+    }
+    int pyq[2] = {0, 0};                 // PRE: the only per-lane geometry the k-loop keeps beside the two offsets
+    if constexpr (PRE) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) pyq[i] = (pyx[i] & 0x7fff) | (((pik[i] >> 30) & 1) << 15) | (pyx[i] & (int)0xffff0000);
     }
     // one DMA instruction of a pair: piece 0, 1 = the weight plane's two instructions of this wave, 2, 3 = the X plane's
     auto issue_x1 = [&](const KEntry& e, int pl, int slot, int i) {     // X plane pl of the k-tile of entry e -> ring slot
@@ -176,14 +187,12 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
             g3dma16s(sbase, isA ? (i == 0 ? offA0 : offA1) : (i == 0 ? offB0 : offB1), dst + (unsigned)((wave + G3_NW * i) * 1024));
             return;
         }
-        if constexpr (PRE) {
-            const bool isA = e.W == geoA_W && e.C == geoA_C && st == geoA_st;          // (wave-uniform)
-            // scalar: plane base + the tap's offset; per lane: the pixel offset of tap (0, 0) and the in-image test
+        if constexpr (PRE) {             // (ONE source geometry: ConvParams::noup is set for single-source layers only)
+            // scalar: plane base + the tap's offset; per lane: the pixel offset of tap (0, 0) and the in-image test (pyq = oy | m < M << 15 | ox << 16)
             const uint16_t* sbase = reinterpret_cast<const uint16_t*>(e.base) + (ptrdiff_t)pl * (ptrdiff_t)plane + ((ptrdiff_t)e.dy * e.W + e.dx) * e.C;
-            const int iy = ((pyx[i] & 0xffff) << (st - 1)) + e.dy, ix = ((pyx[i] >> 16) << (st - 1)) + e.dx;      // (stride 1 or 2)
-            const bool ok = ((pik[i] >> 30) & 1) && (unsigned)iy < (unsigned)e.H && (unsigned)ix < (unsigned)e.W;
-            const unsigned voff = isA ? (i == 0 ? offA0 : offA1) : (i == 0 ? offB0 : offB1);
-            const unsigned char* px = reinterpret_cast<const unsigned char*>(sbase) + voff;
+            const int iy = ((pyq[i] & 0x7fff) << (st - 1)) + e.dy, ix = ((pyq[i] >> 16) << (st - 1)) + e.dx;      // (stride 1 or 2)
+            const bool ok = ((pyq[i] >> 15) & 1) && (unsigned)iy < (unsigned)e.H && (unsigned)ix < (unsigned)e.W;
+            const unsigned char* px = reinterpret_cast<const unsigned char*>(sbase) + (i == 0 ? offA0 : offA1);
             g3dma16(ok ? reinterpret_cast<const u32x4*>(px) : zero, dst + (unsigned)((wave + G3_NW * i) * 1024));
             return;
         }
@@ -194,15 +203,13 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
         g3dma16(ok ? reinterpret_cast<const u32x4*>(px) : zero, dst + (unsigned)((wave + G3_NW * i) * 1024));
     };
     // weight DMA: piece i of a plane covers units [(wave + 8 i) 64, + 64) of [k-octet][BN channels]; per-lane byte offset into the panel
-    unsigned woff[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int wu = (wave + G3_NW * i) * 64 + lane;         // unit inside the plane: [kg][n]
-        woff[i] = (unsigned)(((wu / G3_BN) * CoutPad + wu % G3_BN) * 16);
-    }
+    // (piece 1 is piece 0 two k-octets on: the same per-lane offset from a scalar base 2 CoutPad units further)
+    static_assert(G3_NW * 64 == 2 * G3_BN, "piece 1 of a weight plane starts two k-octets after piece 0");
+    const int wu0 = wave * 64 + lane;                          // unit inside the plane: [kg][n]
+    const unsigned woff0 = (unsigned)(((wu0 / G3_BN) * CoutPad + wu0 % G3_BN) * 16);
     auto issue_w1 = [&](int kt, int pl, int slot, int i) {              // weight plane pl of k-tile kt -> ring slot
-        const u32x4* base = wt_hi + (size_t)pl * wplane + (size_t)(kt * 4) * CoutPad + bn0;       // (wave-uniform: SGPRs)
-        g3dma16s(base, woff[i], lds0 + (unsigned)((slot * G3_PAIR + G3_XPL + (wave + G3_NW * i) * 64) * 16));
+        const u32x4* base = wt_hi + (size_t)pl * wplane + (size_t)(kt * 4 + 2 * i) * CoutPad + bn0;       // (wave-uniform: SGPRs)
+        g3dma16s(base, woff0, lds0 + (unsigned)((slot * G3_PAIR + G3_XPL + (wave + G3_NW * i) * 64) * 16));
     };
     auto issue_pair = [&](int kt, int wpl, int xpl, int slot) {          // (prologue: all four instructions at once) weight plane wpl, X plane xpl of k-tile kt
         const KEntry e = g3load_kentry(ktab + kt);
@@ -211,17 +218,26 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
     };
     // plane indices in memory: X hi = 0 (bf16 x 3: mid = 1, lo = 2; HS: scaled lo = 1); W hi = 0 (bf16 x 3: mid = 1, lo = 2; HS: lo = 1).
     // Phase tag PH (0 lo, 1 mid, 2 hi; HS runs 0 and 2) -> the weight plane it multiplies and the X plane it reads for the first time
-    auto wpl_of = [](int ph) { return HS ? (ph == 0 ? 1 : 0) : 2 - ph; };
-    auto xpl_of = [](int ph) { return HS ? (ph == 0 ? 0 : 1) : ph; };
+    // (S16 groups the products by X plane: phase lo reads X_lo and W_hi, mid X_mid and W_mid, hi X_hi and W_lo)
+    auto wpl_of = [](int ph) { return S16 ? (HS ? (ph == 0 ? 0 : 1) : ph) : (HS ? (ph == 0 ? 1 : 0) : 2 - ph); };
+    auto xpl_of = [](int ph) { return S16 ? (HS ? (ph == 0 ? 1 : 0) : 2 - ph) : (HS ? (ph == 0 ? 0 : 1) : ph); };
     constexpr int NPH = HS ? 2 : 3;                          // phases per k-tile
 
-    f32x16 acc[G3_MT][G3_NT];
+    f32x16 acc[S16 ? 1 : G3_MT][S16 ? 1 : G3_NT];
+    f32x4 acc16[S16 ? 2 * G3_MT : 1][S16 ? 2 * G3_NT : 1];    // S16: [16-pixel block][16-channel block]; lane l holds pixel l & 15, channels 4 (l >> 4) .. + 3
+    if constexpr (S16) {
+#pragma unroll
+        for (int a = 0; a < 2 * G3_MT; ++a)
+#pragma unroll
+            for (int b = 0; b < 2 * G3_NT; ++b) acc16[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
 #pragma unroll
     for (int a = 0; a < G3_MT; ++a)
 #pragma unroll
         for (int b = 0; b < G3_NT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    }
 
     // phase q = 3 kt + ph reads weight plane (2 - ph) and, for the first and only time, X plane ph of k-tile kt from ring slot q % 4
     // (ph 0: lo, 1: mid, 2: hi)
@@ -242,18 +258,27 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
     // directly instead of waiting out an LDS round trip with the MFMA pipes drained.
     u32x4 xk[2][2][G3_MT];                                    // X fragments of the hi and mid planes, kept for the k-tile: [plane][k-step][a]
     u32x4 wn[G3_NT], xl[G3_MT];                               // the next phase's first-k-step weight fragments; X_lo fragments of a k-step
+    u32x4 wk[2][2 * G3_NT], wl[2 * G3_NT], xa[G3_MT], xb[G3_MT];      // S16: kept W_hi / W_mid blocks, W_lo blocks, the two halves of the phase's X plane
     auto wfrag = [&](int slot, int s, int b) { return lds[slot * G3_PAIR + G3_XPL + (2 * s + fk) * G3_BN + wn0 + b * 32 + frow]; };
     auto xfrag = [&](int slot, int s, int a) {
         const int mrow = wm0 + a * 32 + frow;
         return lds[slot * G3_PAIR + mrow * 4 + ((2 * s + fk) ^ ((mrow >> 2) & 3))];
     };
+    // S16 fragments: lane l supplies row / column l & 15 and the k-octet l >> 4 of the k-tile.  Weights: 16-channel block b (0 .. 3); X: pixel half h (0, 1), 16-pixel
+    // block a4 (0 .. 3) of the half -- xk[plane][h][a4], xl[a4] and wn[0 .. 1] have the shapes of the 32x32x16 form's arrays
+    const int l16 = lane & 15, ko = lane >> 4;
+    auto wfrag16 = [&](int slot, int b) { return lds[slot * G3_PAIR + G3_XPL + ko * G3_BN + wn0 + b * 16 + l16]; };
+    auto xfrag16 = [&](int slot, int h, int a4) {
+        const int mrow = wm0 + (4 * h + a4) * 16 + l16;
+        return lds[slot * G3_PAIR + mrow * 4 + (ko ^ ((mrow >> 2) & 3))];
+    };
     // heads of phase 0: pairs 0 and 1 have landed once only the third prologue pair is outstanding
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int b = 0; b < G3_NT; ++b) wn[b] = wfrag(0, 0, b);
+    for (int b = 0; b < G3_NT; ++b) { if constexpr (S16) wk[0][b] = wfrag16(0, b); else wn[b] = wfrag(0, 0, b); }
 #pragma unroll
-    for (int a = 0; a < G3_MT; ++a) xk[0][0][a] = xfrag(0, 0, a);
+    for (int a = 0; a < G3_MT; ++a) { if constexpr (S16) xa[a] = xfrag16(0, 0, a); else xk[0][0][a] = xfrag(0, 0, a); }
     int q = 0;
     if constexpr (TIMED) tm_pro = __builtin_amdgcn_s_memtime() - tm_t0;
     KCur k1 = knext(KCur{t0, 0});                             // the k-tile whose pairs are being issued (the one after the k-tile being multiplied)
@@ -378,9 +403,116 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
             ++q;
             if constexpr (TIMED) { const long long ts3 = __builtin_amdgcn_s_memtime(); tm_wait += ts1 - ts0; tm_bar += ts2 - ts1; tm_body += ts3 - ts2; }
         };
-        phase(IntTag<0>{});
-        if constexpr (!HS) phase(IntTag<1>{});
-        phase(IntTag<2>{});
+        // S16: the phases on 16x16x32 MFMAs, grouped BY X PLANE: a wave's tile is 128 pixels x 64 channels, so the weight fragments are the smaller set to keep
+        // in registers (2 planes x 4 blocks = 32 VGPRs; the 32x32x16 form keeps 64 VGPRs of X fragments) -- with 32 accumulator tuples the kept-X form spills.
+        //        phase lo : X_lo  x W_hi                  32 MFMAs per wave      (HS: X_lo x W_hi 2^-11)
+        //        phase mid: X_mid x (W_hi, W_mid)         64
+        //        phase hi : X_hi  x (W_hi, W_mid, W_lo)   96                     (HS: X_hi x (W_hi, W_lo))
+        // A phase reads ONE new X plane (two halves of four 16-pixel blocks: xa prefetched by the tail of the phase before, xb behind the first MFMA group) and one
+        // new weight plane (W_hi in lo -- its first two blocks prefetched by the hi phase's tail, straight into the kept registers once the hi phase's W_hi products
+        // are done --, W_mid in mid, W_lo in hi: behind the first group, while the products of the kept planes run).  Groups of four MFMAs are half as long as the 32x32x16 form's: the DMA pieces go behind every other group.
+        auto phase16 = [&](auto ph_tag) {
+            constexpr int PH = decltype(ph_tag)::value;
+            constexpr int KP = HS ? (PH == 0 ? 1 : 2) : PH + 1;       // weight planes multiplied in this phase
+            // the six-product hi phase holds the most registers (accumulators + three weight planes + both X halves = 208) while its DMA pieces need their address
+            // temporaries: the second half's X fragments are read behind the LAST piece there (five groups before their first use) instead of the first
+            constexpr bool LATE_XB = KP == 3;
+            long long ts0 = 0, ts1 = 0, ts2 = 0;
+            if constexpr (TIMED) ts0 = __builtin_amdgcn_s_memtime();
+            if (prev1 == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (TIMED) ts1 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_barrier();
+            if constexpr (TIMED) ts2 = __builtin_amdgcn_s_memtime();
+            const bool doissue = q + 3 < nphase;
+            auto piece = [&](int n) {
+                if (!doissue) return;
+                if constexpr (HS) {
+                    if constexpr (PH == 0) { if (n < 2) issue_w1(k1.idx, wpl_of(2), (q + 3) & 3, n); else issue_x1(e3, xpl_of(2), (q + 3) & 3, n - 2); }
+                    else { if (n < 2) issue_w1(k2.idx, wpl_of(0), (q + 3) & 3, n); else issue_x1(e4, xpl_of(0), (q + 3) & 3, n - 2); }
+                } else {
+                    if (n < 2) issue_w1(k1.idx, wpl_of(PH), (q + 3) & 3, n);
+                    else issue_x1(e3, xpl_of(PH), (q + 3) & 3, n - 2);
+                }
+            };
+            prev1 = doissue ? 4 : 0;
+            const int sq = q & 3, sn = (q + 1) & 3;
+            const bool next = q + 1 < nphase;
+            auto second_step = [&]() {                         // (issued behind the phase's first MFMA group)
+                if constexpr (PH == 0) { wk[0][2] = wfrag16(sq, 2); wk[0][3] = wfrag16(sq, 3); }
+                else {
+#pragma unroll
+                    for (int b = 0; b < 2 * G3_NT; ++b) { if constexpr (PH == 1) wk[1][b] = wfrag16(sq, b); else wl[b] = wfrag16(sq, b); }
+                }
+                if constexpr (!LATE_XB) {
+#pragma unroll
+                    for (int a = 0; a < G3_MT; ++a) xb[a] = xfrag16(sq, 1, a);
+                }
+            };
+            auto tail = [&]() {                                // the next phase's first-half X fragments (+ from the hi phase: the first two blocks of the next W_hi)
+                if (!next) return;
+                if constexpr (PH == 2) { wk[0][0] = wfrag16(sn, 0); wk[0][1] = wfrag16(sn, 1); }      // (this k-tile's W_hi products are done)
+#pragma unroll
+                for (int a = 0; a < G3_MT; ++a) xa[a] = xfrag16(sn, 0, a);
+            };
+            // weight plane of product kp: the kept planes first in the first half (the new plane's fragments are still arriving), the new plane first in the
+            // second half (hi phase: W_lo is dead before the tail reuses registers)
+            auto wsel = [&](int h, int kp, int b) -> u32x4 {
+                // 0 = W_hi, 1 = W_mid (HS: W_lo), 2 = W_lo.  Second half of the hi phase: W_lo, W_hi, W_mid (HS: W_hi, W_lo) -- the tail follows the W_hi product
+                const int k = h == 0 ? kp : (PH == 2 ? (HS ? kp : (kp == 0 ? 2 : kp - 1)) : KP - 1 - kp);
+                if constexpr (HS) {
+                    if constexpr (PH == 0) return hs_wscaled(wk[0][b]);
+                    else return k == 0 ? wk[0][b] : wl[b];
+                } else return k == 0 ? wk[0][b] : k == 1 ? wk[1][b] : wl[b];
+            };
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int kp = 0; kp < KP; ++kp) {
+#pragma unroll
+                    for (int b = 0; b < 2 * G3_NT; ++b) {
+                        const u32x4 wv = wsel(h, kp, b);
+#pragma unroll
+                        for (int a = 0; a < G3_MT; ++a)
+                            acc16[4 * h + a][b] = mfma_frag16<HS>(wv, h == 0 ? xa[a] : xb[a], acc16[4 * h + a][b]);
+                        const int grp = (h * KP + kp) * (2 * G3_NT) + b;             // MFMA groups of four so far
+                        if (!(grp & 1) && grp < 8) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (grp == 0) second_step();
+                            piece(grp >> 1);
+                            if constexpr (LATE_XB) {
+                                if (grp == 6) {
+#pragma unroll
+                                    for (int a = 0; a < G3_MT; ++a) xb[a] = xfrag16(sq, 1, a);
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    if (KP > 1 && h == 1 && kp == (PH == 2 && !HS ? 1 : 0)) {      // second half, after its first product (hi phase: after the W_hi product)
+                        __builtin_amdgcn_sched_barrier(0);
+                        tail();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (KP == 1 && h == 0) {                                 // one product only: between the halves (xa is free from here on)
+                    __builtin_amdgcn_sched_barrier(0);
+                    tail();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            ++q;
+            if constexpr (TIMED) { const long long ts3 = __builtin_amdgcn_s_memtime(); tm_wait += ts1 - ts0; tm_bar += ts2 - ts1; tm_body += ts3 - ts2; }
+        };
+        if constexpr (S16) {
+            phase16(IntTag<0>{});
+            if constexpr (!HS) phase16(IntTag<1>{});
+            phase16(IntTag<2>{});
+        } else {
+            phase(IntTag<0>{});
+            if constexpr (!HS) phase(IntTag<1>{});
+            phase(IntTag<2>{});
+        }
         if constexpr (HS) {
             k1 = k2; e3 = e4;
             k2 = knext(k2);
@@ -396,13 +528,20 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
     __syncthreads();
     // SEMDEPTH_X3_DIAG (decomposition runs, latched in the handle's switches; 0 in production): 1 = no output stores, 2 = no epilogue at all
     const int diag = TIMED ? 0 : (((p.sw & SW_X3_DIAG_NOSTORE) ? 1 : 0) | ((p.sw & SW_X3_DIAG_NOMFMA) ? 2 : 0));
-    if (diag & 2) { if (acc[0][0][0] == 12345.678f) p.out[0] = acc[1][1][3]; return; }
+    if (diag & 2) {
+        if constexpr (S16) { if (acc16[0][0][0] == 12345.678f) p.out[0] = acc16[7][3][3]; }
+        else { if (acc[0][0][0] == 12345.678f) p.out[0] = acc[1][1][3]; }
+        return;
+    }
+    // (the epilogue's per-lane values are formed from an opaque copy of the lane id: nothing of it is hoisted above the k-loop, whose registers are all taken)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
     auto ep3 = [&](auto tag) {
         constexpr int ACT = decltype(tag)::value;
         constexpr int ROW = G3_ROW;
         unsigned char* slab = reinterpret_cast<unsigned char*>(lds) + wave * (NPL * 32 * ROW);
         constexpr int SEGS = G3_NT * 4, PPP = 64 / SEGS;
-        const int seg = lane % SEGS, prow = lane / SEGS;
+        const int seg = lane_e % SEGS, prow = lane_e / SEGS;
         uint16_t* const out_hi = reinterpret_cast<uint16_t*>(p.out);
         const int m0 = bm0 + wm0, n0 = bn0 + wn0;
 #pragma unroll
@@ -411,24 +550,29 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
             for (int b = 0; b < G3_NT; ++b)
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
-                    const int nl = b * 32 + 8 * r4 + 4 * (lane >> 5);
-                    f32x4 v = {acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
+                    // four consecutive channels of one pixel per lane.  32x32x16: pixel lane & 31 of the 32, channels b 32 + 8 r4 + 4 (lane_e >> 5);
+                    // S16: (b, r4) = (16-pixel block of the 32, 16-channel block): pixel 16 b + (lane_e & 15), channels 16 r4 + 4 (lane_e >> 4)
+                    const int nl = S16 ? r4 * 16 + 4 * (lane_e >> 4) : b * 32 + 8 * r4 + 4 * (lane_e >> 5);
+                    const int srow = S16 ? b * 16 + (lane_e & 15) : (lane_e & 31);
+                    f32x4 v;
+                    if constexpr (S16) v = acc16[2 * a + b][r4];
+                    else v = f32x4{acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
                     uint2 h, m, l;
                     if constexpr (HS) {
                         v = v * p.alpha + *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
                         split4_hs(v, h, m, p.sat);
-                        *reinterpret_cast<uint2*>(slab + (lane & 31) * ROW + nl * 2) = h;
-                        *reinterpret_cast<uint2*>(slab + 32 * ROW + (lane & 31) * ROW + nl * 2) = m;
+                        *reinterpret_cast<uint2*>(slab + srow * ROW + nl * 2) = h;
+                        *reinterpret_cast<uint2*>(slab + 32 * ROW + srow * ROW + nl * 2) = m;
                     } else {
                     v += *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_x3<ACT>(v[r]);
                     split4_x3(v, h, m, l);
-                    *reinterpret_cast<uint2*>(slab + (lane & 31) * ROW + nl * 2) = h;
-                    *reinterpret_cast<uint2*>(slab + 32 * ROW + (lane & 31) * ROW + nl * 2) = m;
-                    *reinterpret_cast<uint2*>(slab + 64 * ROW + (lane & 31) * ROW + nl * 2) = l;
+                    *reinterpret_cast<uint2*>(slab + srow * ROW + nl * 2) = h;
+                    *reinterpret_cast<uint2*>(slab + 32 * ROW + srow * ROW + nl * 2) = m;
+                    *reinterpret_cast<uint2*>(slab + 64 * ROW + srow * ROW + nl * 2) = l;
                     }
                 }
             __builtin_amdgcn_wave_barrier();
@@ -494,20 +638,19 @@ hipError_t launch_conv_dma3(const ConvParams& p, hipStream_t s) {
     const int tilesM = (int)((M + G3_BM - 1) / G3_BM), tilesN = p.Cout / G3_BN;
     const dim3 grid((unsigned)(tilesM * tilesN * (p.fold ? 4 : 1)));
     const int mode = conv_dma3_mode(p);
+    const bool s16 = (p.sw & SW_MFMA16) != 0;                  // SEMDEPTH_MFMA16: the 16x16x32 form (see the kernel's header)
+#define SD_G3(MODE_, HS_, TIMED_) do { if (s16) hipLaunchKernelGGL((conv_dma3_kernel<MODE_, HS_, TIMED_, true>), grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN); \
+                                       else hipLaunchKernelGGL((conv_dma3_kernel<MODE_, HS_, TIMED_, false>), grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN); } while (0)
     if (mode == 1 && (p.sw & SW_X3_DIAG_NOSTORE) && (p.sw & SW_X3_DIAG_NOMFMA)) {          // SEMDEPTH_X3_DIAG=3: the timed copy of the 1x1 form
-        if (p.f16 == 4) hipLaunchKernelGGL((conv_dma3_kernel<1, true, true>), grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
-        else hipLaunchKernelGGL((conv_dma3_kernel<1, false, true>), grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
+        if (p.f16 == 4) SD_G3(1, true, true); else SD_G3(1, false, true);
         return hipGetLastError();
     }
     if (p.f16 == 4) {           // SD_PREC_F16X2: the two-plane, two-phase form
-        if (mode == 1) hipLaunchKernelGGL((conv_dma3_kernel<1, true>), grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
-        else if (mode == 2) hipLaunchKernelGGL((conv_dma3_kernel<2, true>), grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
-        else hipLaunchKernelGGL((conv_dma3_kernel<0, true>), grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
+        if (mode == 1) SD_G3(1, true, false); else if (mode == 2) SD_G3(2, true, false); else SD_G3(0, true, false);
         return hipGetLastError();
     }
-    if (mode == 1) hipLaunchKernelGGL(conv_dma3_kernel<1>, grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
-    else if (mode == 2) hipLaunchKernelGGL(conv_dma3_kernel<2>, grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
-    else hipLaunchKernelGGL(conv_dma3_kernel<0>, grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN);
+    if (mode == 1) SD_G3(1, false, false); else if (mode == 2) SD_G3(2, false, false); else SD_G3(0, false, false);
+#undef SD_G3
     return hipGetLastError();
 }
 

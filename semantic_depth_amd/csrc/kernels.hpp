@@ -21,7 +21,8 @@ enum Switch : unsigned {
     SW_NO_TAIL1 = 1u << 18,      // SEMDEPTH_NO_TAIL1: upconv1 / iconv1 / disp1 of the bf16 x 3 monodepth as three launches (plan-time switch)
     SW_NO_ROWSKIP = 1u << 19,    // SEMDEPTH_NO_ROWSKIP: conv_dma3 without the row-grouped pixel order (ConvParams::rowgrp)
     SW_NO_FLAT = 1u << 20,       // SEMDEPTH_NO_FLAT: conv_dma3's 1x1 layers through the general gather
-    SW_X3_DIAG_TIMED = 1u << 21  // SEMDEPTH_X3_DIAG=4: conv_direct3's timed copy (s_memtime stamps per item; decomposition runs)
+    SW_X3_DIAG_TIMED = 1u << 21, // SEMDEPTH_X3_DIAG=4: conv_direct3's timed copy (s_memtime stamps per item; decomposition runs)
+    SW_MFMA16 = 1u << 22         // SEMDEPTH_MFMA16: conv_dma3's 16x16x32 MFMA form instead of 32x32x16 (round 5; conv_dma3.hip "S16")
 };
 unsigned latch_switches();      // plan.cpp
 
@@ -80,7 +81,7 @@ struct ConvParams {
     int x3;            // 1: bf16 x 3 planes in, out and in the weights (SD_PREC_BF16X3: six MFMA products per product, split_fmt.hpp)
     int flat;          // 1 (conv_dma3.hip): a 1x1 conv without upsample (every source read at tap (0, 0), per-source strides allowed): the gather
                        // offset of a lane is computed once per source geometry (conv_dma3_kernel<FLAT>); SEMDEPTH_NO_FLAT switches it off
-    int noup;          // 1 (conv_dma3.hip): no source is read through an upsample, <= 2 sources, strides 1 or 2, planes below 4 GB: the gather of a
+    int noup;          // 1 (conv_dma3.hip): the ONE source is not read through an upsample, stride 1 or 2, planes below 4 GB: the gather of a
                        // k-tile is a precomputed per-lane pixel offset + a scalar tap offset + the in-image test (conv_dma3_kernel<2>)
     int rowgrp;        // > 0 (conv_dma3.hip): the GEMM's pixels are ordered (image group of rowgrp images, row, image, column) with rowgrp * Wout = 256,
                        // so that a 256-pixel tile is ONE output row of rowgrp images and skips the k-tiles of the taps whose input row is zero

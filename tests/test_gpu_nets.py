@@ -257,6 +257,42 @@ def test_precomputed_gather_offsets_of_conv_dma3_are_bit_identical_to_the_genera
     assert set(variants[1]) == {"conv_dma3_kernel<0>"} and sum(variants[1].values()) == sum(variants[0].values()), variants
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
+def test_16x16x32_form_of_the_phased_gemm_block_agrees_with_the_32x32x16_form(precision):
+    """SEMDEPTH_MFMA16 (round 5): conv_dma3's layers on v_mfma_f32_16x16x32 -- one k-step of 32 per k-tile, products grouped by X plane with the
+    weight fragments kept -- instead of 32x32x16.  Same products, same LDS ring; the sums differ in the last bits (the hardware adds 32 k's
+    per instruction instead of 16), which is why the form is not the default: both forms must sit at fp32 grade from each other.  512 x 1024,
+    8 frames: fc6 (row-grouped, tap skipping), fc7, the block tails, the folded upconv6 / upconv5 all run on the block."""
+    from semantic_depth_amd.engine import Engine
+    from semantic_depth_amd import weights as Wt
+    H, W, B = 512, 1024, 8
+    wf = Wt.make_fcn8s_weights(6, decoder_std=0.05, bias_std=0.1)
+    wm = Wt.make_monodepth_weights("resnet50", 7, bias_std=0.05)
+    fr = dev(_frames(B, H, W, seed=33))
+    outs, launches = [], []
+    for on in (False, True):
+        if on:
+            os.environ["SEMDEPTH_MFMA16"] = "1"
+        try:
+            eng = Engine(H, W, B, "resnet50", precision=precision)
+            eng.load_weights(L.SD_NET_FCN8S, wf)
+            eng.load_weights(L.SD_NET_MONODEPTH, wm)
+            eng.profile(True)
+            lg = eng.fcn8s_forward(fr, want_logits=True)["logits"].clone()
+            _, raw = eng.monodepth_forward(fr, want_raw=True)
+            launches.append(sum(b["launches"] for b in eng.profile_read() if "phased" in b["kernel"] or b["kernel"].startswith("conv_dma3")))
+            eng.profile(False)
+            assert eng.saturation_count() == 0
+            outs.append((lg.cpu().numpy(), raw.cpu().numpy()))
+        finally:
+            os.environ.pop("SEMDEPTH_MFMA16", None)
+        del eng
+    assert launches[0] == launches[1] and launches[0] >= (20 if precision == "bf16x3" else 10), launches
+    el, ed = relerr(outs[1][0], outs[0][0]), relerr(outs[1][1], outs[0][1])
+    assert el < 5e-6 and ed < 5e-6, (el, ed)
+    assert not (np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]))      # (the switch did select another kernel)
+
+
 # (the small shapes, ADVICE r4: W % 28 == 0 -- no inward-shifted last tile column --, the narrowest width the networks take -- three tile columns
 # that overlap almost entirely --, and grids with fewer tiles than CUs -- one tile per workgroup, the u / e double buffer never swaps)
 @pytest.mark.parametrize("H,W,B,enc", [(512, 1024, 2, "resnet50"), (128, 256, 3, "resnet50"), (256, 512, 1, "vgg"),
