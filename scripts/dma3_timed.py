@@ -3,7 +3,7 @@ the counted s_waitcnt, the s_barrier and the body of every phase, printed by wav
     python scripts/dma3_timed.py [bf16x3|f16x2] [B]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["SEMDEPTH_X3_DIAG"] = "3"
+os.environ.setdefault("SEMDEPTH_X3_DIAG", "3")        # (7: the timed copies without their DMA pieces -- what the hooks cost)
 import numpy as np, torch
 from semantic_depth_amd import _lib as L, weights as Wt
 from semantic_depth_amd.engine import Engine

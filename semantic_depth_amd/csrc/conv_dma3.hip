@@ -176,20 +176,33 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
 #pragma unroll
         for (int i = 0; i < 2; ++i) pyq[i] = (pyx[i] & 0x7fff) | (((pik[i] >> 30) & 1) << 15) | (pyx[i] & (int)0xffff0000);
     }
-    // one DMA instruction of a pair: piece 0, 1 = the weight plane's two instructions of this wave, 2, 3 = the X plane's
-    auto issue_x1 = [&](const KEntry& e, int pl, int slot, int i) {     // X plane pl of the k-tile of entry e -> ring slot
+    // one DMA instruction of a pair: piece 0, 1 = the weight plane's two instructions of this wave, 2, 3 = the X plane's.
+    // Everything of a piece's address that depends on the k-tile only -- the weight panel's row, the source's plane stride (a 64-bit product of four table
+    // fields), the tap offset, the geometry test -- is formed ONCE per k-tile (KCtx, when the issue cursor moves on) instead of in every piece: a piece was
+    // 12-35 scalar instructions between two MFMA groups, four times per phase, and the timed copy without its pieces runs a phase in 175 clocks less
+    // (profiles/r05_conv_dma3_hooks.txt).
+    struct KCtx { const u32x4* wrow; const uint16_t* xb; size_t plane; int isA; KEntry e; };
+    auto make_ctx = [&](int kt, const KEntry& e) {
+        KCtx c;
+        c.e = e;
+        c.wrow = wt_hi + (size_t)(kt * 4) * CoutPad + bn0;
+        c.plane = (size_t)Nmax * e.H * e.W * e.C;
+        c.isA = (e.W == geoA_W && e.C == geoA_C && ((e.flags >> 4) & 3) == geoA_st) ? 1 : 0;          // (wave-uniform)
+        c.xb = reinterpret_cast<const uint16_t*>(e.base) + (PRE ? ((ptrdiff_t)e.dy * e.W + e.dx) * e.C : (ptrdiff_t)0);      // PRE: + the tap's offset
+        return c;
+    };
+    auto issue_x1 = [&](const KCtx& c, int pl, int slot, int i) {     // X plane pl of the k-tile of context c -> ring slot
+        const KEntry& e = c.e;
         const int st = (e.flags >> 4) & 3, up = e.flags & 1;
-        const size_t plane = (size_t)Nmax * e.H * e.W * e.C;
         const unsigned dst = lds0 + (unsigned)(slot * G3_PAIR * 16);
         if constexpr (FLAT) {
-            const bool isA = e.W == geoA_W && e.C == geoA_C && st == geoA_st;          // (wave-uniform)
-            const uint16_t* sbase = reinterpret_cast<const uint16_t*>(e.base) + (size_t)pl * plane;
-            g3dma16s(sbase, isA ? (i == 0 ? offA0 : offA1) : (i == 0 ? offB0 : offB1), dst + (unsigned)((wave + G3_NW * i) * 1024));
+            const uint16_t* sbase = c.xb + (size_t)pl * c.plane;
+            g3dma16s(sbase, c.isA ? (i == 0 ? offA0 : offA1) : (i == 0 ? offB0 : offB1), dst + (unsigned)((wave + G3_NW * i) * 1024));
             return;
         }
         if constexpr (PRE) {             // (ONE source geometry: ConvParams::noup is set for single-source layers only)
             // scalar: plane base + the tap's offset; per lane: the pixel offset of tap (0, 0) and the in-image test (pyq = oy | m < M << 15 | ox << 16)
-            const uint16_t* sbase = reinterpret_cast<const uint16_t*>(e.base) + (ptrdiff_t)pl * (ptrdiff_t)plane + ((ptrdiff_t)e.dy * e.W + e.dx) * e.C;
+            const uint16_t* sbase = c.xb + (ptrdiff_t)pl * (ptrdiff_t)c.plane;
             const int iy = ((pyq[i] & 0x7fff) << (st - 1)) + e.dy, ix = ((pyq[i] >> 16) << (st - 1)) + e.dx;      // (stride 1 or 2)
             const bool ok = ((pyq[i] >> 15) & 1) && (unsigned)iy < (unsigned)e.H && (unsigned)ix < (unsigned)e.W;
             const unsigned char* px = reinterpret_cast<const unsigned char*>(sbase) + (i == 0 ? offA0 : offA1);
@@ -199,7 +212,7 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
         int iy = (pyx[i] & 0xffff) * st + e.dy, ix = (pyx[i] >> 16) * st + e.dx;
         const bool ok = ((pik[i] >> 30) & 1) && iy >= 0 && ix >= 0 && iy < (e.H << up) && ix < (e.W << up);
         iy >>= up; ix >>= up;
-        const uint16_t* px = reinterpret_cast<const uint16_t*>(e.base) + ((size_t)((pik[i] & 0x3ffffff) * e.H + iy) * e.W + ix) * e.C + ((pik[i] >> 26) & 3) * 8 + (size_t)pl * plane;
+        const uint16_t* px = reinterpret_cast<const uint16_t*>(e.base) + ((size_t)((pik[i] & 0x3ffffff) * e.H + iy) * e.W + ix) * e.C + ((pik[i] >> 26) & 3) * 8 + (size_t)pl * c.plane;
         g3dma16(ok ? reinterpret_cast<const u32x4*>(px) : zero, dst + (unsigned)((wave + G3_NW * i) * 1024));
     };
     // weight DMA: piece i of a plane covers units [(wave + 8 i) 64, + 64) of [k-octet][BN channels]; per-lane byte offset into the panel
@@ -207,14 +220,14 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
     static_assert(G3_NW * 64 == 2 * G3_BN, "piece 1 of a weight plane starts two k-octets after piece 0");
     const int wu0 = wave * 64 + lane;                          // unit inside the plane: [kg][n]
     const unsigned woff0 = (unsigned)(((wu0 / G3_BN) * CoutPad + wu0 % G3_BN) * 16);
-    auto issue_w1 = [&](int kt, int pl, int slot, int i) {              // weight plane pl of k-tile kt -> ring slot
-        const u32x4* base = wt_hi + (size_t)pl * wplane + (size_t)(kt * 4 + 2 * i) * CoutPad + bn0;       // (wave-uniform: SGPRs)
+    auto issue_w1 = [&](const KCtx& c, int pl, int slot, int i) {       // weight plane pl of the k-tile of context c -> ring slot
+        const u32x4* base = c.wrow + (size_t)pl * wplane + (size_t)(2 * i) * CoutPad;       // (wave-uniform: SGPRs)
         g3dma16s(base, woff0, lds0 + (unsigned)((slot * G3_PAIR + G3_XPL + (wave + G3_NW * i) * 64) * 16));
     };
     auto issue_pair = [&](int kt, int wpl, int xpl, int slot) {          // (prologue: all four instructions at once) weight plane wpl, X plane xpl of k-tile kt
-        const KEntry e = g3load_kentry(ktab + kt);
-        issue_w1(kt, wpl, slot, 0); issue_w1(kt, wpl, slot, 1);
-        issue_x1(e, xpl, slot, 0); issue_x1(e, xpl, slot, 1);
+        const KCtx c = make_ctx(kt, g3load_kentry(ktab + kt));
+        issue_w1(c, wpl, slot, 0); issue_w1(c, wpl, slot, 1);
+        issue_x1(c, xpl, slot, 0); issue_x1(c, xpl, slot, 1);
     };
     // plane indices in memory: X hi = 0 (bf16 x 3: mid = 1, lo = 2; HS: scaled lo = 1); W hi = 0 (bf16 x 3: mid = 1, lo = 2; HS: lo = 1).
     // Phase tag PH (0 lo, 1 mid, 2 hi; HS runs 0 and 2) -> the weight plane it multiplies and the X plane it reads for the first time
@@ -282,11 +295,11 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
     int q = 0;
     if constexpr (TIMED) tm_pro = __builtin_amdgcn_s_memtime() - tm_t0;
     KCur k1 = knext(KCur{t0, 0});                             // the k-tile whose pairs are being issued (the one after the k-tile being multiplied)
-    KEntry e3 = g3load_kentry(ktab + k1.idx);                 // (at least two k-tiles) its gather entry
+    KCtx c3 = make_ctx(k1.idx, g3load_kentry(ktab + k1.idx)); // (at least two k-tiles) its gather entry and address context
     // HS: the hi phase issues the lo pair of the k-tile after that one
     KCur k2 = knext(k1);
-    KEntry e4 = e3;
-    if constexpr (HS) { if (ktiles > 2) e4 = g3load_kentry(ktab + k2.idx); }
+    KCtx c4 = c3;
+    if constexpr (HS) { if (ktiles > 2) c4 = make_ctx(k2.idx, g3load_kentry(ktab + k2.idx)); }
     for (int kt = 0; kt < ktiles; ++kt) {
         auto phase = [&](auto ph_tag) {
             constexpr int PH = decltype(ph_tag)::value, NPX = PH + 1;
@@ -301,15 +314,15 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
             // the pair of phase q + 3 goes into the slot phase q - 1 has just finished reading -- its four DMA instructions are spread
             // BEHIND the first four MFMA groups of this phase (at the top of the phase, with the MFMA pipe drained by the barrier, each
             // of them would cost its full issue latency)
-            const bool doissue = q + 3 < nphase;               // = 3 (kt + 1) + ph
+            const bool doissue = q + 3 < nphase && !(TIMED && (p.sw & SW_X3_DIAG_TIMED));      // = 3 (kt + 1) + ph  (SEMDEPTH_X3_DIAG=7: timed copy without DMA pieces)
             auto piece = [&](int n) {
                 if (!doissue) return;
                 if constexpr (HS) {          // phase q + 3: from the lo phase the hi pair of the next k-tile, from the hi phase the lo pair of the one after it
-                    if constexpr (PH == 0) { if (n < 2) issue_w1(k1.idx, wpl_of(2), (q + 3) & 3, n); else issue_x1(e3, xpl_of(2), (q + 3) & 3, n - 2); }
-                    else { if (n < 2) issue_w1(k2.idx, wpl_of(0), (q + 3) & 3, n); else issue_x1(e4, xpl_of(0), (q + 3) & 3, n - 2); }
+                    if constexpr (PH == 0) { if (n < 2) issue_w1(c3, wpl_of(2), (q + 3) & 3, n); else issue_x1(c3, xpl_of(2), (q + 3) & 3, n - 2); }
+                    else { if (n < 2) issue_w1(c4, wpl_of(0), (q + 3) & 3, n); else issue_x1(c4, xpl_of(0), (q + 3) & 3, n - 2); }
                 } else {
-                    if (n < 2) issue_w1(k1.idx, 2 - PH, (q + 3) & 3, n);
-                    else issue_x1(e3, PH, (q + 3) & 3, n - 2);
+                    if (n < 2) issue_w1(c3, 2 - PH, (q + 3) & 3, n);
+                    else issue_x1(c3, PH, (q + 3) & 3, n - 2);
                 }
             };
             prev1 = doissue ? 4 : 0;
@@ -424,15 +437,15 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
             if constexpr (TIMED) ts1 = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_barrier();
             if constexpr (TIMED) ts2 = __builtin_amdgcn_s_memtime();
-            const bool doissue = q + 3 < nphase;
+            const bool doissue = q + 3 < nphase && !(TIMED && (p.sw & SW_X3_DIAG_TIMED));      // (SEMDEPTH_X3_DIAG=7: the timed copy WITHOUT its DMA pieces -- what do the hooks cost?)
             auto piece = [&](int n) {
                 if (!doissue) return;
                 if constexpr (HS) {
-                    if constexpr (PH == 0) { if (n < 2) issue_w1(k1.idx, wpl_of(2), (q + 3) & 3, n); else issue_x1(e3, xpl_of(2), (q + 3) & 3, n - 2); }
-                    else { if (n < 2) issue_w1(k2.idx, wpl_of(0), (q + 3) & 3, n); else issue_x1(e4, xpl_of(0), (q + 3) & 3, n - 2); }
+                    if constexpr (PH == 0) { if (n < 2) issue_w1(c3, wpl_of(2), (q + 3) & 3, n); else issue_x1(c3, xpl_of(2), (q + 3) & 3, n - 2); }
+                    else { if (n < 2) issue_w1(c4, wpl_of(0), (q + 3) & 3, n); else issue_x1(c4, xpl_of(0), (q + 3) & 3, n - 2); }
                 } else {
-                    if (n < 2) issue_w1(k1.idx, wpl_of(PH), (q + 3) & 3, n);
-                    else issue_x1(e3, xpl_of(PH), (q + 3) & 3, n - 2);
+                    if (n < 2) issue_w1(c3, wpl_of(PH), (q + 3) & 3, n);
+                    else issue_x1(c3, xpl_of(PH), (q + 3) & 3, n - 2);
                 }
             };
             prev1 = doissue ? 4 : 0;
@@ -514,12 +527,12 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
             phase(IntTag<2>{});
         }
         if constexpr (HS) {
-            k1 = k2; e3 = e4;
+            k1 = k2; c3 = c4;
             k2 = knext(k2);
-            if (kt + 3 < ktiles) e4 = g3load_kentry(ktab + k2.idx);
+            if (kt + 3 < ktiles) c4 = make_ctx(k2.idx, g3load_kentry(ktab + k2.idx));
         } else {
             k1 = knext(k1);
-            if (kt + 2 < ktiles) e3 = g3load_kentry(ktab + k1.idx);       // (one scalar load per k-tile, behind the hi phase's MFMAs)
+            if (kt + 2 < ktiles) c3 = make_ctx(k1.idx, g3load_kentry(ktab + k1.idx));       // (one scalar load + the context per k-tile, behind the hi phase's MFMAs)
         }
     }
 
