@@ -150,14 +150,15 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
         }
     };
     // a chunk in flight: source image + plane stride, its X buffer, its weight block (hi plane; plane stride = nchunks * WUNITS)
-    struct ChunkCtx { const uint16_t* img; size_t plane; unsigned rowel, C, okm, xbyte; int up, gy0, gx0; const u32x4* w; };
+    // (tile0: the source element under halo pixel (0, 0) of the tile -- the 64-bit products of a slot's address are formed ONCE per chunk, not per DMA instruction)
+    struct ChunkCtx { const uint16_t* tile0; size_t plane; unsigned rowel, C, okm, xbyte; int up, gy0, gx0; const u32x4* w; };
     auto begin_chunk = [&](const DirectChunk& ch, const Tile& tl, int c, int buf) {
         ChunkCtx k;
         k.plane = (size_t)p.Nmax * ch.H * ch.W * (ch.pad ? ch.pad : ch.C);      // elements (pad: the channel count of a tensor stored as 16-channel sub-planes)
-        k.img = reinterpret_cast<const uint16_t*>(ch.base) + (size_t)tl.img * ch.H * ch.W * ch.C;
         k.rowel = (unsigned)(ch.W * ch.C); k.C = (unsigned)ch.C; k.up = UP ? 0 : ch.up;
         k.okm = ch.nvalid >= 2 ? okA : okB;
         k.gy0 = tgy; k.gx0 = tgx;                           // (the tile of the cursor at this moment: a chunk's X planes may be issued after the cursor moved on)
+        k.tile0 = reinterpret_cast<const uint16_t*>(ch.base) + (size_t)tl.img * ch.H * ch.W * ch.C + ((ptrdiff_t)k.gy0 * (ptrdiff_t)k.rowel + (ptrdiff_t)k.gx0 * (ptrdiff_t)k.C);
         k.xbyte = lds0 + (unsigned)(buf * XBUF * 16);
         k.w = p.wt + ((size_t)(3 * tl.half) * p.nchunks + c) * WUNITS;
         return k;
@@ -168,20 +169,22 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
         const uint16_t* src;
         if (k.up == 0) {        // (wave-uniform) scalar tile share + the lane's pixel share x C
             const unsigned off = __umul24(pshare[i], k.C) + (((octb >> i) & 1u) << 3);
-            src = k.img + (ptrdiff_t)pl * (ptrdiff_t)k.plane + ((ptrdiff_t)k.gy0 * (ptrdiff_t)k.rowel + (ptrdiff_t)k.gx0 * (ptrdiff_t)k.C) + off;
+            src = k.tile0 + (ptrdiff_t)pl * (ptrdiff_t)k.plane + off;
         } else {                // a x2-upsampled source of a mixed layer (up2(disp) of the iconv layers): halo coordinates halved per pixel
             int ry, rx, oct;
             slot_geo(i, ry, rx, oct);
             const int gy = k.gy0 + ry, gx = k.gx0 + rx;
             const unsigned off = (unsigned)(gy >> 1) * k.rowel + ((unsigned)(gx >> 1) * k.C + (unsigned)(oct << 3));
-            src = k.img + (size_t)pl * k.plane + off;
+            const uint16_t* img = k.tile0 - ((ptrdiff_t)k.gy0 * (ptrdiff_t)k.rowel + (ptrdiff_t)k.gx0 * (ptrdiff_t)k.C);
+            src = img + (size_t)pl * k.plane + off;
         }
         d3dma16(((k.okm >> i) & 1u) ? reinterpret_cast<const u32x4*>(src) : zero, k.xbyte + (unsigned)((pl * XUNITS + j * 64) * 16));
     };
+    const size_t wplane_u = (size_t)p.nchunks * WUNITS;      // units between the planes of a weight block
     auto wslot = [&](const u32x4* wbase, int pl, int i, int slot) {     // weight-DMA instruction wave + 8 i of plane pl into ring slot
         const int jw = wave + T3_WAVES * i;
         if (jw >= WI) return;
-        d3dma16(wbase + (size_t)pl * p.nchunks * WUNITS + jw * 64 + lane, lds0 + (unsigned)((2 * XBUF + slot * WUNITS + jw * 64) * 16));     // slot < WSLOTS
+        d3dma16(wbase + (size_t)pl * wplane_u + jw * 64 + lane, lds0 + (unsigned)((2 * XBUF + slot * WUNITS + jw * 64) * 16));     // slot < WSLOTS
     };
 
     sbias[threadIdx.x] = (int)threadIdx.x < p.nsplit * p.Cout ? p.bias[threadIdx.x] : 0.f;
