@@ -73,12 +73,13 @@ constexpr int G3_ROW = G3_NT * 64 + 16;
 // HS output planes.
 // TIMED (SEMDEPTH_X3_DIAG=3; MODE 1 only, decomposition runs): s_memtime stamps around the counted wait, the barrier and the body of every phase, summed
 // per wave; waves 0 and 4 of the middle workgroup print their sums (the instrumentation itself costs ~10 % of the wave cycles: read the SPLIT, not the total)
-// S16 (round 5; SEMDEPTH_MFMA16, not the default): the same ring and the same LDS traffic, multiplied by v_mfma_f32_16x16x32 instead of 32x32x16 -- a k-tile is ONE
+// S16 (round 5; the bf16 x 3 engine's production form): the same ring and the same LDS traffic, multiplied by v_mfma_f32_16x16x32 instead of 32x32x16 -- a k-tile is ONE
 // k-step of 32, a wave's 128 x 64 tile 8 x 4 blocks of 16 x 16, the products grouped by X plane with the weight fragments kept.  In isolation the 16x16x32 form
 // sustains 15-17 % more products per second on plane data under the power cap (half the accumulator traffic per MAC; profiles/r05_probe_mfma_shapes.txt); in this
-// kernel the clock does rise by ~10 % but a phase takes 8 % more cycles (the DMA pieces / fragment prefetches between MFMA groups are covered by 16-clock instead of
-// 32-clock MFMAs): -1.4 % on the layers of this kernel, +1 % end to end (profiles/r05_mfma16_ab.txt).  Not the default because its sums differ in the last bits from
-// conv_dma.hip's 32x32x16 block, which takes the same layers at small batches: a frame's result would depend on the batch it was computed in.
+// kernel the clock does rise by ~10 % but a phase takes 8-10 % more cycles (the DMA pieces / fragment prefetches between MFMA groups are covered by 16-clock instead of
+// 32-clock MFMAs): -3 % on the layers of this kernel, +1 % end to end (profiles/r05_mfma16_ab.txt, r05_conv_dma3_hooks.txt).  Its sums differ in the last bits from the
+// 32x32x16 form's (SEMDEPTH_MFMA32), as this block's always did from conv_dma.hip's: which of the two blocks a layer takes is decided per ENGINE, not per call
+// (conv_dma3_eligible).  The three-product (HS) form stays on 32x32x16: measured equal on the 1x1 layers and 2 % slower on fc6.
 template <int MODE, bool HS = false, bool TIMED = false, bool S16 = false>
 __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
     long long tm_wait = 0, tm_bar = 0, tm_body = 0, tm_t0 = 0, tm_pro = 0;
@@ -468,11 +469,11 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
 #pragma unroll
                 for (int a = 0; a < G3_MT; ++a) xa[a] = xfrag16(sn, 0, a);
             };
-            // weight plane of product kp: the kept planes first in the first half (the new plane's fragments are still arriving), the new plane first in the
-            // second half (hi phase: W_lo is dead before the tail reuses registers)
+            // weight plane of product kp: the kept planes first (in the first half the new plane's fragments are still arriving)
             auto wsel = [&](int h, int kp, int b) -> u32x4 {
-                // 0 = W_hi, 1 = W_mid (HS: W_lo), 2 = W_lo.  Second half of the hi phase: W_lo, W_hi, W_mid (HS: W_hi, W_lo) -- the tail follows the W_hi product
-                const int k = h == 0 ? kp : (PH == 2 ? (HS ? kp : (kp == 0 ? 2 : kp - 1)) : KP - 1 - kp);
+                // 0 = W_hi, 1 = W_mid (HS: W_lo), 2 = W_lo -- the SAME order in both halves: a pixel's sum must not depend on where in a tile it lands (a frame
+                // sits at different tile offsets in calls of different sizes); the new plane's fragments are still arriving during the first half's kept planes
+                const int k = kp; (void)h;
                 if constexpr (HS) {
                     if constexpr (PH == 0) return hs_wscaled(wk[0][b]);
                     else return k == 0 ? wk[0][b] : wl[b];
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
-                    if (KP > 1 && h == 1 && kp == (PH == 2 && !HS ? 1 : 0)) {      // second half, after its first product (hi phase: after the W_hi product)
+                    if (KP > 1 && h == 1 && kp == 0) {                   // second half, after its first product (W_hi's: in the hi phase the tail refills its registers)
                         __builtin_amdgcn_sched_barrier(0);
                         tail();
                         __builtin_amdgcn_sched_barrier(0);
@@ -633,11 +634,18 @@ int conv_dma3_mode(const ConvParams& p);
 bool conv_dma3_eligible(const ConvParams& p) {
     if (!(p.x3 || p.f16 == 4) || !p.vec || !p.zero16 || p.pool || p.out_planar16 || p.residual || p.Cout % G3_BN || p.Kpad < 64 || p.CoutPad != p.Cout) return false;
     // SD_PREC_F16X2: measured against the two-stage block of conv_dma.hip (profiles/r05_hs_phased_gemm_ab.txt), the two-phase ring wins on the 1x1 layers (fc7
-    // 1.50 -> 1.29 ms, the res2 / res5 block tails 3-12 %) and loses on the tap layers (fc6 6.94 -> 7.26, the strided 3x3 of res4_6): the 1x1 layers only
-    if (p.f16 == 4 && conv_dma3_mode(p) != 1) return false;
+    // 1.50 -> 1.29 ms, the res2 / res5 block tails 3-12 %) and -- since a piece's address arithmetic is formed once per k-tile -- on the row-grouped fc6
+    // (6.93 -> 6.50 ms: it also skips the taps on padding rows), and loses on the small strided 3x3 of res4_6 (0.135 -> 0.178): the 1x1 layers and fc6 only
+    // (SEMDEPTH_HS_PHASED_TAPS: every tap layer, the A/B switch of that measurement)
+    // (the rule must not look at the call: the k x k stride-1 single-source layers -- fc6 --, row-grouped or not)
+    if (p.f16 == 4 && conv_dma3_mode(p) != 1 && !(p.kh >= 3 && p.stride == 1 && !p.fold && p.noup) && !(p.sw & SW_HS_TAPS)) return false;
     if (p.fold) return true;                                   // (a folded layer always runs here when it can: its results must not depend on the batch)
     if (p.sw & SW_NO_DMA3) return false;                       // (A/B switch of the handle)
-    const long M = (long)p.N * p.Hout * p.Wout;
+    // enough tiles to occupy the chip -- counted on a FULL pass of the engine (ConvParams::Nmax), not on the frames of this call: this block and conv_dma.hip's
+    // two-stage block differ in the last bits of their sums, and a frame's result must not depend on how many frames the call carries (round 5: until then the
+    // rule read the call's own pixel count, and at 512 x 1024 frame 0 of a call of one differed from frame 0 of a call of eight by 3e-7;
+    // scripts/batch_independence_full_size.py)
+    const long M = (long)(p.Nmax > 0 ? p.Nmax : p.N) * p.Hout * p.Wout;
     return ((M + G3_BM - 1) / G3_BM) * (p.Cout / G3_BN) >= 128;
 }
 
@@ -651,8 +659,8 @@ hipError_t launch_conv_dma3(const ConvParams& p, hipStream_t s) {
     const int tilesM = (int)((M + G3_BM - 1) / G3_BM), tilesN = p.Cout / G3_BN;
     const dim3 grid((unsigned)(tilesM * tilesN * (p.fold ? 4 : 1)));
     const int mode = conv_dma3_mode(p);
-    const bool s16 = (p.sw & SW_MFMA16) != 0;                  // SEMDEPTH_MFMA16: the 16x16x32 form (see the kernel's header)
-#define SD_G3(MODE_, HS_, TIMED_) do { if (s16) hipLaunchKernelGGL((conv_dma3_kernel<MODE_, HS_, TIMED_, true>), grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN); \
+    const bool s16 = p.f16 != 4 && !(p.sw & SW_MFMA32);        // bf16 x 3: the 16x16x32 form (SEMDEPTH_MFMA32: the 32x32x16 form, same-box A/B); the HS form gains nothing from it
+#define SD_G3(MODE_, HS_, TIMED_) do { if (s16) hipLaunchKernelGGL((conv_dma3_kernel<MODE_, HS_, TIMED_, !(HS_)>), grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN); \
                                        else hipLaunchKernelGGL((conv_dma3_kernel<MODE_, HS_, TIMED_, false>), grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN); } while (0)
     if (mode == 1 && (p.sw & SW_X3_DIAG_NOSTORE) && (p.sw & SW_X3_DIAG_NOMFMA)) {          // SEMDEPTH_X3_DIAG=3: the timed copy of the 1x1 form
         if (p.f16 == 4) SD_G3(1, true, true); else SD_G3(1, false, true);

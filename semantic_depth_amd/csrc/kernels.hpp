@@ -22,7 +22,8 @@ enum Switch : unsigned {
     SW_NO_ROWSKIP = 1u << 19,    // SEMDEPTH_NO_ROWSKIP: conv_dma3 without the row-grouped pixel order (ConvParams::rowgrp)
     SW_NO_FLAT = 1u << 20,       // SEMDEPTH_NO_FLAT: conv_dma3's 1x1 layers through the general gather
     SW_X3_DIAG_TIMED = 1u << 21, // SEMDEPTH_X3_DIAG=4: conv_direct3's timed copy (s_memtime stamps per item; decomposition runs)
-    SW_MFMA16 = 1u << 22         // SEMDEPTH_MFMA16: conv_dma3's 16x16x32 MFMA form instead of 32x32x16 (round 5; conv_dma3.hip "S16")
+    SW_HS_TAPS = 1u << 23,       // SEMDEPTH_HS_PHASED_TAPS: the three-product engine's tap layers (fc6, folded upconvs, strided 3x3) on conv_dma3's two-phase ring too
+    SW_MFMA32 = 1u << 22         // SEMDEPTH_MFMA32: conv_dma3's bf16 x 3 layers on 32x32x16 MFMAs instead of 16x16x32 (round 5; conv_dma3.hip "S16")
 };
 unsigned latch_switches();      // plan.cpp
 

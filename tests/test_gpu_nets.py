@@ -193,8 +193,11 @@ def test_256x256_block_of_the_dma_pipeline_is_bit_identical_to_the_128x256_one()
     assert torch.equal(outs[0], outs[1])
 
 
-def test_row_grouped_fc6_tiles_skip_padding_taps_bit_identically():
-    """bf16x3, fc6 (7x7 on the 16 x 32 pool5 map): conv_dma3 orders the GEMM's pixels (image group, row, image, column) so that a
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
+def test_row_grouped_fc6_tiles_skip_padding_taps_bit_identically(precision):
+    """(f16x2, round 5: its fc6 runs on the two-phase ring of the same block when it is row-grouped and on conv_dma.hip's two-stage block otherwise -- a call
+    with fewer frames than a tile row group takes must give the same bits.)
+    bf16x3, fc6 (7x7 on the 16 x 32 pool5 map): conv_dma3 orders the GEMM's pixels (image group, row, image, column) so that a
     256-pixel tile is one output row of eight images, and skips the k-tiles of the taps whose input row is zero padding (10.7 % of them).
     Skipped terms are exact zeros: the logits must not change by a bit against the plain pixel order (SEMDEPTH_NO_ROWSKIP)."""
     from semantic_depth_amd.engine import Engine
@@ -207,7 +210,7 @@ def test_row_grouped_fc6_tiles_skip_padding_taps_bit_identically():
         if off:
             os.environ["SEMDEPTH_NO_ROWSKIP"] = "1"
         try:
-            eng = Engine(H, W, B, "resnet50", precision="bf16x3")
+            eng = Engine(H, W, B, "resnet50", precision=precision)
             eng.load_weights(L.SD_NET_FCN8S, wf)
             outs.append((eng.fcn8s_forward(fr, want_logits=True)["logits"].clone(), eng.net_tensor(L.SD_NET_FCN8S, "layer7_out").clone()))
         finally:
@@ -257,12 +260,11 @@ def test_precomputed_gather_offsets_of_conv_dma3_are_bit_identical_to_the_genera
     assert set(variants[1]) == {"conv_dma3_kernel<0>"} and sum(variants[1].values()) == sum(variants[0].values()), variants
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
-def test_16x16x32_form_of_the_phased_gemm_block_agrees_with_the_32x32x16_form(precision):
-    """SEMDEPTH_MFMA16 (round 5): conv_dma3's layers on v_mfma_f32_16x16x32 -- one k-step of 32 per k-tile, products grouped by X plane with the
-    weight fragments kept -- instead of 32x32x16.  Same products, same LDS ring; the sums differ in the last bits (the hardware adds 32 k's
-    per instruction instead of 16), which is why the form is not the default: both forms must sit at fp32 grade from each other.  512 x 1024,
-    8 frames: fc6 (row-grouped, tap skipping), fc7, the block tails, the folded upconv6 / upconv5 all run on the block."""
+def test_16x16x32_form_of_the_phased_gemm_block_agrees_with_the_32x32x16_form(precision="bf16x3"):
+    """bf16x3 runs conv_dma3's layers on v_mfma_f32_16x16x32 (round 5) -- one k-step of 32 per k-tile, products grouped by X plane with the weight
+    fragments kept; SEMDEPTH_MFMA32 selects the 32x32x16 form it replaced.  Same products, same LDS ring; the sums differ in the last bits (the
+    hardware adds 32 k's per instruction instead of 16): both forms must sit at fp32 grade from each other.  512 x 1024, 8 frames: fc6 (row-grouped,
+    tap skipping), fc7, the block tails, the folded upconv6 / upconv5 all run on the block."""
     from semantic_depth_amd.engine import Engine
     from semantic_depth_amd import weights as Wt
     H, W, B = 512, 1024, 8
@@ -270,9 +272,9 @@ def test_16x16x32_form_of_the_phased_gemm_block_agrees_with_the_32x32x16_form(pr
     wm = Wt.make_monodepth_weights("resnet50", 7, bias_std=0.05)
     fr = dev(_frames(B, H, W, seed=33))
     outs, launches = [], []
-    for on in (False, True):
-        if on:
-            os.environ["SEMDEPTH_MFMA16"] = "1"
+    for m32 in (False, True):
+        if m32:
+            os.environ["SEMDEPTH_MFMA32"] = "1"
         try:
             eng = Engine(H, W, B, "resnet50", precision=precision)
             eng.load_weights(L.SD_NET_FCN8S, wf)
@@ -280,17 +282,39 @@ def test_16x16x32_form_of_the_phased_gemm_block_agrees_with_the_32x32x16_form(pr
             eng.profile(True)
             lg = eng.fcn8s_forward(fr, want_logits=True)["logits"].clone()
             _, raw = eng.monodepth_forward(fr, want_raw=True)
-            launches.append(sum(b["launches"] for b in eng.profile_read() if "phased" in b["kernel"] or b["kernel"].startswith("conv_dma3")))
+            launches.append(sum(b["launches"] for b in eng.profile_read() if b["kernel"].startswith("conv_dma3")))
             eng.profile(False)
-            assert eng.saturation_count() == 0
             outs.append((lg.cpu().numpy(), raw.cpu().numpy()))
         finally:
-            os.environ.pop("SEMDEPTH_MFMA16", None)
+            os.environ.pop("SEMDEPTH_MFMA32", None)
         del eng
-    assert launches[0] == launches[1] and launches[0] >= (20 if precision == "bf16x3" else 10), launches
+    assert launches[0] == launches[1] and launches[0] >= 20, launches
     el, ed = relerr(outs[1][0], outs[0][0]), relerr(outs[1][1], outs[0][1])
     assert el < 5e-6 and ed < 5e-6, (el, ed)
     assert not (np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]))      # (the switch did select another kernel)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2", "f32"])
+def test_a_frames_result_does_not_depend_on_the_call_it_is_computed_in_at_full_size(precision):
+    """512 x 1024, an engine of 8: frame 0 alone, frames 0 .. 1 and frames 0 .. 7 -- the same bits every time.  Round 5: conv_dma3's 256 x 256 block and
+    conv_dma.hip's two-stage block differ in the last bits of their sums, and which one a layer took was decided on the CALL's pixel count (the 128 x 256
+    test above never reaches the big block): frame 0 of a call of one differed from frame 0 of a call of eight by 3e-7 on both fp32-grade split
+    engines.  The choice is now made on a full pass of the engine (conv_dma3_eligible)."""
+    from semantic_depth_amd.engine import Engine
+    from semantic_depth_amd import weights as Wt
+    H, W, B = 512, 1024, 8
+    wf = Wt.make_fcn8s_weights(1, decoder_std=0.05)
+    wm = Wt.make_monodepth_weights("resnet50", 2)
+    fr = dev(_frames(B, H, W, seed=41))
+    eng = Engine(H, W, B, "resnet50", precision=precision)
+    eng.load_weights(L.SD_NET_FCN8S, wf)
+    eng.load_weights(L.SD_NET_MONODEPTH, wm)
+    lg8 = eng.fcn8s_forward(fr, want_logits=True)["logits"].clone()
+    raw8 = eng.monodepth_forward(fr, want_raw=True)[1].clone()
+    for n in (1, 2):
+        lg = eng.fcn8s_forward(fr[:n].contiguous(), want_logits=True)["logits"]
+        raw = eng.monodepth_forward(fr[:n].contiguous(), want_raw=True)[1]
+        assert torch.equal(lg[0], lg8[0]) and torch.equal(raw[0], raw8[0]), n
 
 
 # (the small shapes, ADVICE r4: W % 28 == 0 -- no inward-shifted last tile column --, the narrowest width the networks take -- three tile columns
