@@ -2,7 +2,7 @@
 # The GPU batch behind profiles/r05_*: rocprofv3 kernel stats, HBM traffic (separate FETCH / WRITE passes), SQ counters, layer times, the float64 grade check and
 # the default bench line, for the headline engine (bf16x3) and for the three-product leg (f16x2), in ONE gpurun call:
 #     gpurun --timeout 3600 -- './scripts/gpu_batch.sh r05v'      (results under gpurun_out/<tag>/)
-# During the round this file is rewritten per experiment (A/B runs of a switch, decomposition runs, ...); this is the evidence form, run as r05f / r05g on the final tree.
+# During the round this file is rewritten per experiment (A/B runs of a switch, decomposition runs, ...); this is the evidence form, run on the final tree.
 tag=${1:-r05g}
 mkdir -p gpurun_out/$tag
 o=gpurun_out/$tag

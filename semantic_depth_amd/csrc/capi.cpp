@@ -305,7 +305,7 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
             }
             case OP_POOL3Z: {
                 const TensorDesc& s0 = p.tensors[op.src[0]];
-                e = launch_maxpool3z(T(op.src[0]), T(op.dst), N, s0.H, s0.W, s0.C, FMT(op.src[0]), PL(op.src[0]), PL(op.dst), s);
+                e = launch_maxpool3z(T(op.src[0]), T(op.dst), N, s0.H, s0.W, s0.C, FMT(op.src[0]), PL(op.src[0]), PL(op.dst), s0.planar16 ? p.images : 0, s);
                 break;
             }
             case OP_DECONV4_ADD: {

@@ -22,7 +22,7 @@ enum Switch : unsigned {
     SW_NO_ROWSKIP = 1u << 19,    // SEMDEPTH_NO_ROWSKIP: conv_dma3 without the row-grouped pixel order (ConvParams::rowgrp)
     SW_NO_FLAT = 1u << 20,       // SEMDEPTH_NO_FLAT: conv_dma3's 1x1 layers through the general gather
     SW_X3_DIAG_TIMED = 1u << 21, // SEMDEPTH_X3_DIAG=4: conv_direct3's timed copy (s_memtime stamps per item; decomposition runs)
-    SW_HS_TAPS = 1u << 23,       // SEMDEPTH_HS_PHASED_TAPS: the three-product engine's tap layers (fc6, folded upconvs, strided 3x3) on conv_dma3's two-phase ring too
+    SW_HS_TAPS = 1u << 23,       // SEMDEPTH_HS_PHASED_TAPS: ALL tap layers of the three-product engine (folded upconvs, strided 3x3; fc6 is there anyway) on conv_dma3's two-phase ring
     SW_MFMA32 = 1u << 22         // SEMDEPTH_MFMA32: conv_dma3's bf16 x 3 layers on 32x32x16 MFMAs instead of 16x16x32 (round 5; conv_dma3.hip "S16")
 };
 unsigned latch_switches();      // plan.cpp
@@ -243,7 +243,7 @@ bool conv_smalln_tiled(int in_split, int k, int W, int C, int nout, unsigned sw)
 hipError_t launch_pre_vgg(const uint8_t* frames, float* out, long npix, int split, size_t plane, hipStream_t s);                 // K1
 hipError_t launch_pre_mono(const uint8_t* frames, float* out, int B, int H, int W, int split, size_t plane, int raw, hipStream_t s);      // /255 (raw: not) + fliplr pair
 hipError_t launch_maxpool2(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s);
-hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s);
+hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, int sub_nmax, hipStream_t s);
 hipError_t launch_unsplit(const float* x, float* y, long npix, int C, int Ctf, size_t plane, size_t sub, int f16, hipStream_t s);  // split planes -> f32 [npix][Ctf]; f16 = TensorDesc::f16, or -1: bf16 x 3
 // y[n,2i+ky-1,2j+kx-1,o] += x[n,i,j,c]*w[ky,kx,o,c]; y += bias + skip   (3->3 channels; fcn8s/fcn.py:186-204)
 hipError_t launch_deconv4s2_add(const float* x, const float* w, const float* bias, const float* skip, float* y,

@@ -167,9 +167,10 @@ __global__ __launch_bounds__(256) void maxpool3z_kernel(const float* __restrict_
 // split planes with C % 8 == 0: one thread per (output pixel, channel octet), 16-byte loads per plane and tap.
 // NPL = planes: 1 ONE fp16 plane, 2 bf16 hi + lo, 3 bf16 hi + mid + lo (exact: the max of exact values, split exactly again)
 // HS (NPL = 2): the planes are fp16 hi + scaled lo (the max of 22-bit values, split again without loss)
+// sub_nmax > 0: the input is stored as 16-channel sub-planes [C / 16][sub_nmax][H][W][16] (TensorDesc::planar16; the output never is)
 template <int NPL, bool HS = false>
 __global__ __launch_bounds__(256) void maxpool3z_oct_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C8,
-                                                            size_t plane_in, size_t plane_out) {
+                                                            size_t plane_in, size_t plane_out, int sub_nmax) {
     constexpr bool F16 = NPL == 1;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256) void maxpool3z_oct_kernel(const float* __restr
             int iy = 2 * oy - 1 + dy, ix = 2 * ox - 1 + dx;
             f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;   // the padding is ZERO and takes part in the max (upstream quirk)
             if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-                const long q = (((long)n * H + iy) * W + ix) * C8 + c;
+                const long q = sub_nmax ? ((((long)(c >> 1) * sub_nmax + n) * H + iy) * W + ix) * 2 + (c & 1) : (((long)n * H + iy) * W + ix) * C8 + c;
                 const u32x4_t h = xh[q], l = F16 ? h : xl[q];
                 if constexpr (NPL == 3) {
                     const u32x4_t t = x3[q];
@@ -224,15 +225,16 @@ __global__ __launch_bounds__(256) void maxpool3z_oct_kernel(const float* __restr
     reinterpret_cast<u32x4_t*>(y)[i] = (u32x4_t){h0.x, h0.y, h1.x, h1.y};
     if (!F16) reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(y) + plane_out)[i] = (u32x4_t){l0.x, l0.y, l1.x, l1.y};
 }
-hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, hipStream_t s) {
+hipError_t launch_maxpool3z(const float* x, float* y, int N, int H, int W, int C, int split, size_t plane_in, size_t plane_out, int sub_nmax, hipStream_t s) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    if (sub_nmax && !(split && C % 16 == 0)) return hipErrorInvalidValue;      // (sub-planar inputs: the octet kernel only)
     if (split && C % 8 == 0) {
         const long tot8 = (long)N * Ho * Wo * (C / 8);
         const dim3 g8((unsigned)((tot8 + 255) / 256));
-        if (split == 5) hipLaunchKernelGGL((maxpool3z_oct_kernel<2, true>), g8, dim3(256), 0, s, x, y, N, H, W, C / 8, plane_in, plane_out);
-        else if (split == 4) hipLaunchKernelGGL(maxpool3z_oct_kernel<3>, g8, dim3(256), 0, s, x, y, N, H, W, C / 8, plane_in, plane_out);
-        else if (split == 2) hipLaunchKernelGGL(maxpool3z_oct_kernel<1>, g8, dim3(256), 0, s, x, y, N, H, W, C / 8, plane_in, plane_out);
-        else hipLaunchKernelGGL(maxpool3z_oct_kernel<2>, g8, dim3(256), 0, s, x, y, N, H, W, C / 8, plane_in, plane_out);
+        if (split == 5) hipLaunchKernelGGL((maxpool3z_oct_kernel<2, true>), g8, dim3(256), 0, s, x, y, N, H, W, C / 8, plane_in, plane_out, sub_nmax);
+        else if (split == 4) hipLaunchKernelGGL(maxpool3z_oct_kernel<3>, g8, dim3(256), 0, s, x, y, N, H, W, C / 8, plane_in, plane_out, sub_nmax);
+        else if (split == 2) hipLaunchKernelGGL(maxpool3z_oct_kernel<1>, g8, dim3(256), 0, s, x, y, N, H, W, C / 8, plane_in, plane_out, sub_nmax);
+        else hipLaunchKernelGGL(maxpool3z_oct_kernel<2>, g8, dim3(256), 0, s, x, y, N, H, W, C / 8, plane_in, plane_out, sub_nmax);
         return hipGetLastError();
     }
     long total = (long)N * Ho * Wo * (C / 4);

@@ -330,7 +330,8 @@ struct Builder {
                     for (int j = 0; j < op.nsrc; ++j) reads = reads || op.src[j] == (int)ti;
                     if (!reads) continue;
                     ++readers;
-                    ok = ok && op.kind == OP_CONV_DIRECT && op.residual != (int)ti;
+                    // (and, round 5, the 3x3 stride-2 pool: monodepth's enc/conv1 -> pool1 + the skip of iconv2, whose four chunk passes fetched 3.2 GB as 12.9)
+                    ok = ok && (op.kind == OP_CONV_DIRECT || (op.kind == OP_POOL3Z && t.C % 8 == 0)) && op.residual != (int)ti;
                 }
                 if (made && ok && readers > 0 && !(latch_switches() & SW_NO_STEM)) t.planar16 = 1;
             }
@@ -346,13 +347,16 @@ struct Builder {
                 if (op.dst == (int)ti)
                     made = op.kind == OP_CONV_DIRECT ||
                            (wide && op.kind == OP_CONV && op.vec && op.Kvec == op.Kpad && t.C % 64 == 0 && op.Kpad >= 64 &&
-                            !std::getenv("SEMDEPTH_NO_DMA"));
+                            !std::getenv("SEMDEPTH_NO_DMA")) ||
+                           // (three-product engine, round 5: a stem conv's output, as on bf16 x 3 above)
+                           (p.h2 && op.kind == OP_CONV && op.nsrc == 1 && op.src[0] == p.t_input && (op.k & 1) && op.k <= 7 && !op.fold && !op.fuse_pool &&
+                            op.residual < 0 && (t.C == 32 || t.C == 64) && t.W % 32 == 0 && !(latch_switches() & SW_NO_STEM));
                 bool reads = op.residual == (int)ti;
                 for (int j = 0; j < op.nsrc; ++j) reads = reads || op.src[j] == (int)ti;
                 if (!reads) continue;
                 ++readers;
                 const bool head = wide && op.kind == OP_SMALLN && conv_smalln_tiled(1, op.k, t.W, t.C, op.nout, latch_switches());
-                ok = ok && (op.kind == OP_CONV_DIRECT || head) && op.residual != (int)ti;
+                ok = ok && (op.kind == OP_CONV_DIRECT || head || (p.h2 && op.kind == OP_POOL3Z && t.C % 8 == 0)) && op.residual != (int)ti;
             }
             if (made && ok && readers > 0) t.planar16 = 1;
         }

@@ -362,27 +362,34 @@ def test_folded_upconvs_and_fused_decoder_tail_against_the_layer_by_layer_form(H
             assert ef < 1e-5 and ef < 2.0 * ep + 1e-6
 
 
-def test_sub_planar_stem_output_of_the_six_product_engine_is_bit_identical():
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
+def test_sub_planar_stem_output_of_the_six_product_engine_is_bit_identical(precision):
     """bf16x3 (round 5): conv1_1's output goes to conv1_2 as 16-channel sub-planes (the stem kernel writes them, conv_direct3's chunk loader reads a contiguous
-    run per chunk instead of 32 bytes out of every pixel's line).  Addressing only: with SEMDEPTH_NO_PLANAR the logits must not change by a bit."""
+    run per chunk instead of 32 bytes out of every pixel's line), and so does monodepth's enc/conv1 to its two readers -- the 3x3 stride-2 pool and the skip
+    input of iconv2 (whose four chunk passes fetched the skip four times) -- on bf16x3 and on f16x2 (where conv1_1 -> conv1_2 has been sub-planar like every
+    two-plane hand-off).  Addressing only: with SEMDEPTH_NO_PLANAR the logits and the raw disparities must not change by a bit.  256 x 512: the encoder's first
+    map is 128 x 256, four tile columns of the stem kernel."""
     from semantic_depth_amd.engine import Engine
     from semantic_depth_amd import weights as Wt
-    H, W, B = 128, 256, 2
+    H, W, B = 256, 512, 2
     wf = Wt.make_fcn8s_weights(4, decoder_std=0.05, bias_std=0.1)
+    wm = Wt.make_monodepth_weights("resnet50", 5, bias_std=0.05)
     fr = dev(_frames(B, H, W, seed=17))
     outs = []
     for off in (False, True):
         if off:
             os.environ["SEMDEPTH_NO_PLANAR"] = "1"
         try:
-            eng = Engine(H, W, B, "resnet50", precision="bf16x3")
+            eng = Engine(H, W, B, "resnet50", precision=precision)
             eng.load_weights(L.SD_NET_FCN8S, wf)
-            outs.append(eng.fcn8s_forward(fr, want_logits=True)["logits"].clone())
+            eng.load_weights(L.SD_NET_MONODEPTH, wm)
+            outs.append((eng.fcn8s_forward(fr, want_logits=True)["logits"].clone(), eng.monodepth_forward(fr, want_raw=True)[1].clone()))
         finally:
             os.environ.pop("SEMDEPTH_NO_PLANAR", None)
         del eng
-    assert torch.equal(outs[0], outs[1])
-    assert relerr(outs[0].cpu().numpy(), nets.fcn8s_forward(fr.cpu().numpy(), wf)) < 1e-5
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][1].abs().max()) > 0
+    assert relerr(outs[0][0].cpu().numpy(), nets.fcn8s_forward(fr.cpu().numpy(), wf)) < 1e-5
 
 
 @pytest.mark.parametrize("gains", [(-6, -6, 4, 4, 4), (2, 2, -2, -2, 0)])
