@@ -103,7 +103,9 @@ typedef struct {
 const char* sd_version(void);
 const char* sd_status_string(sd_status s);
 /* replaces DepthFrame.__init__ + SegmentFrame.__init__ (semantic_depth.py:464-469, :575-624):
- * fixes H, W, the largest batch a call may carry and the monodepth encoder; builds both layer plans. */
+ * fixes H, W, the largest batch a call may carry and the monodepth encoder; builds both layer plans.
+ * Every kernel choice that changes the order of a sum is made here, on a full network pass of the handle (sd_pass_frames), not on the frames of a
+ * call: on one handle a frame's outputs are the same bits whether it is submitted alone, with others, or at another batch position. */
 sd_status sd_create(sd_handle** out, int device, int H, int W, int max_batch, sd_encoder enc, sd_precision prec);
 /* the same with an explicit precision plan for the split engine: per network a comma-separated list of conv layer names
  * (sd_net_tensor names, e.g. "fc6,fc7" / "enc/res4*,dec/upconv6"; a trailing '*' matches a prefix, "*" = all, "" = none) that run
