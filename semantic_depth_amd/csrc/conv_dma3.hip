@@ -290,7 +290,7 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int b = 0; b < G3_NT; ++b) { if constexpr (S16) wk[0][b] = wfrag16(0, b); else wn[b] = wfrag(0, 0, b); }
+    for (int b = 0; b < G3_NT; ++b) { if constexpr (S16) { wk[0][b] = wfrag16(0, b); wk[0][b + G3_NT] = wfrag16(0, b + G3_NT); } else wn[b] = wfrag(0, 0, b); }
 #pragma unroll
     for (int a = 0; a < G3_MT; ++a) { if constexpr (S16) xa[a] = xfrag16(0, 0, a); else xk[0][0][a] = xfrag(0, 0, a); }
     int q = 0;
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
             const int sq = q & 3, sn = (q + 1) & 3;
             const bool next = q + 1 < nphase;
             auto second_step = [&]() {                         // (issued behind the phase's first MFMA group)
-                if constexpr (PH == 0) { wk[0][2] = wfrag16(sq, 2); wk[0][3] = wfrag16(sq, 3); }
+                if constexpr (PH == 0) { }                     // (all four W_hi blocks came with the hi phase's tail: the lo phase's third group is only 128 clocks away)
                 else {
 #pragma unroll
                     for (int b = 0; b < 2 * G3_NT; ++b) { if constexpr (PH == 1) wk[1][b] = wfrag16(sq, b); else wl[b] = wfrag16(sq, b); }
@@ -465,7 +465,10 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
             };
             auto tail = [&]() {                                // the next phase's first-half X fragments (+ from the hi phase: the first two blocks of the next W_hi)
                 if (!next) return;
-                if constexpr (PH == 2) { wk[0][0] = wfrag16(sn, 0); wk[0][1] = wfrag16(sn, 1); }      // (this k-tile's W_hi products are done)
+                if constexpr (PH == 2) {                       // (this k-tile's W_hi products are done: its four registers take the next k-tile's blocks)
+#pragma unroll
+                    for (int b = 0; b < 2 * G3_NT; ++b) wk[0][b] = wfrag16(sn, b);
+                }
 #pragma unroll
                 for (int a = 0; a < G3_MT; ++a) xa[a] = xfrag16(sn, 0, a);
             };
