@@ -79,7 +79,7 @@ constexpr int G3_ROW = G3_NT * 64 + 16;
 // kernel the clock does rise by ~10 % but a phase takes 8-10 % more cycles (the DMA pieces / fragment prefetches between MFMA groups are covered by 16-clock instead of
 // 32-clock MFMAs): -3 % on the layers of this kernel, +1 % end to end (profiles/r05_mfma16_ab.txt, r05_conv_dma3_hooks.txt).  Its sums differ in the last bits from the
 // 32x32x16 form's (SEMDEPTH_MFMA32), as this block's always did from conv_dma.hip's: which of the two blocks a layer takes is decided per ENGINE, not per call
-// (conv_dma3_eligible).  The three-product (HS) form stays on 32x32x16: measured equal on the 1x1 layers and 2 % slower on fc6.
+// (conv_dma3_eligible).  The three-product (HS) form takes it for its 1x1 layers (-1.9 %) and stays on 32x32x16 for fc6 (2 % slower there).
 template <int MODE, bool HS = false, bool TIMED = false, bool S16 = false>
 __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, int M, int tilesM, int tilesN) {
     long long tm_wait = 0, tm_bar = 0, tm_body = 0, tm_t0 = 0, tm_pro = 0;
@@ -662,8 +662,10 @@ hipError_t launch_conv_dma3(const ConvParams& p, hipStream_t s) {
     const int tilesM = (int)((M + G3_BM - 1) / G3_BM), tilesN = p.Cout / G3_BN;
     const dim3 grid((unsigned)(tilesM * tilesN * (p.fold ? 4 : 1)));
     const int mode = conv_dma3_mode(p);
-    const bool s16 = p.f16 != 4 && !(p.sw & SW_MFMA32);        // bf16 x 3: the 16x16x32 form (SEMDEPTH_MFMA32: the 32x32x16 form, same-box A/B); the HS form gains nothing from it
-#define SD_G3(MODE_, HS_, TIMED_) do { if (s16) hipLaunchKernelGGL((conv_dma3_kernel<MODE_, HS_, TIMED_, !(HS_)>), grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN); \
+    // the 16x16x32 form: every bf16 x 3 layer and the three-product engine's 1x1 layers (-1.9 % on them; its fc6 is 2 % faster on 32x32x16: r05_mfma16_ab.txt).
+    // SEMDEPTH_MFMA32: the 32x32x16 form everywhere (same-box A/B)
+    const bool s16 = !(p.sw & SW_MFMA32);
+#define SD_G3(MODE_, HS_, TIMED_) do { if (s16) hipLaunchKernelGGL((conv_dma3_kernel<MODE_, HS_, TIMED_, !(HS_) || (MODE_) == 1>), grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN); \
                                        else hipLaunchKernelGGL((conv_dma3_kernel<MODE_, HS_, TIMED_, false>), grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN); } while (0)
     if (mode == 1 && (p.sw & SW_X3_DIAG_NOSTORE) && (p.sw & SW_X3_DIAG_NOMFMA)) {          // SEMDEPTH_X3_DIAG=3: the timed copy of the 1x1 form
         if (p.f16 == 4) SD_G3(1, true, true); else SD_G3(1, false, true);
