@@ -57,8 +57,17 @@ PEAK_F32, PEAK_3P, PEAK_2P, PEAK_1P, PEAK_6P = 157.3, 2500.0 / 3.0, 2500.0 / 2.0
 # engine's by what two f32 summation orders differ by (`parity.vs_f32_engine`; against a float64 oracle both have the same error:
 # profiles/r03_f32_grade_check.txt).  The exact-f32 MFMA engine is timed beside it for the same --steps (`f32_exact`), and so is the
 # reduced-precision plan (within north_star's 1e-3: `legs.plan.parity_vs_f32_engine`).
-DEFAULT_PRECISION = "bf16x3"
+DEFAULT_PRECISION = "f16x2"
+# the stdout line carries the SHORT strings (it must stay a few KB: the driver parses it); the detail file carries DTYPE_LONG
 DTYPE = {
+    "f32": "f32 (exact, v_mfma_f32_16x16x4_f32)",
+    "bf16x3": "fp32-grade: f32 operands as 3 exact bf16 planes, 6 bf16 MFMA products, f32 accumulate",
+    "f16x2": "fp32-grade: f32 operands as fp16 hi + 2^11-scaled lo planes (22 bits), 3 fp16 MFMA products, f32 accumulate",
+    "bf16x2": "bf16 hi+lo operands (16 bits), 3 bf16 MFMA products, f32 accumulate",
+    "mixed": "FCN-8s bf16x2 (3 products); monodepth fp16 x fp16x2 weights (2 products); f32 accumulate",
+    "plan": "per-layer precision plan (1-3 MFMA products per product, 11-16 operand bits), f32 accumulate",
+}
+DTYPE_LONG = {
     "f32": "f32 (exact: v_mfma_f32_16x16x4_f32)",
     "bf16x3": "f32 operands carried EXACTLY as three bf16 planes each (v = hi + mid + lo, 8+8+8 significand bits), 6 bf16 MFMA products per "
               "product (the three dropped cross terms are below 2^-23 of the product), f32 accumulate",
@@ -111,6 +120,7 @@ def parse_args():
     ap.add_argument("--dump-cloud", default=None, help="dev: save the raw road cloud of frame 0 (before the road chain) as .npy and exit")
     ap.add_argument("--no-f32-leg", action="store_true", help="(kept for old command lines) same as --legs none")
     ap.add_argument("--no-colours", action="store_true", help="do not carry the RGB of the points through the road chain")
+    ap.add_argument("--detail", default=None, help="where the FULL record goes (default gpurun_out/bench_detail.json); stdout carries the compact line")
     return ap.parse_args()
 
 
@@ -226,7 +236,7 @@ def main():
     if custom_plan is not None and len(custom_plan) != 2:
         raise SystemExit("--plan needs the form 'fcn layers|monodepth layers'")
     if args.legs is None:
-        legs = [] if args.no_f32_leg else [p_ for p_ in ("f32", "f16x2", "plan") if p_ != args.precision]
+        legs = [] if args.no_f32_leg else [p_ for p_ in ("bf16x3", "f16x2", "f32", "plan") if p_ != args.precision]
     else:
         legs = [] if args.legs in ("", "none") else [p_ for p_ in args.legs.split(",") if p_ != args.precision]
     for p_ in legs:
@@ -495,7 +505,7 @@ def main():
     fuse_gbs = fuse_bytes / (stage_ms[3] * 1e-3) / 1e9 if stage_ms[3] > 0 else 0.0
     fuse_traffic, fuse_traffic_src = pmc_traffic("fuse_onepass_kernel", "*pmc_fuse_traffic.json")
     fusion_roofline = {"bound": "hbm", "achieved": round(fuse_gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(fuse_gbs / 8000.0, 4),
-                       "traffic": fuse_traffic, "traffic_source": fuse_traffic_src,
+                       "traffic": fuse_traffic, "traffic_source": fuse_traffic_src, "kernel_short": "fuse_onepass_kernel",
                        "kernel": "fuse_onepass_kernel (post-processing + back-projection + look-back gather; to3D stage of the last step, stream events)",
                        "algorithmic_bytes": round(fuse_bytes), "algorithmic_bytes_per_frame": round(fuse_bytes / B),
                        "stage_us_per_frame": round(stage_ms[3] * 1e3 / B, 2)}
@@ -570,9 +580,127 @@ def main():
         "roofline": roofline, "fusion_roofline": fusion_roofline, "f32_exact": f32_exact, "legs": leg_out or None, "parity": parity or None,
         "cpu_baseline": cpu,
     }
-    print(json.dumps(line), flush=True)
+    # The stdout line is the COMPACT record (a few KB: the driver parses it; round 5's 22.8-KB line was not parsed); everything else --
+    # per-kernel lists, the plan's layer list, strict statistics, the per-region times -- goes to the detail file and to stderr.
+    line["dtype_long"] = DTYPE_LONG[args.precision]
+    sat_total = sum(int(r_.get("fp16_saturated_values") or 0) for r_ in [head_rec] + list(leg_out.values()) + ([f32_exact] if f32_exact else []))
+    if head_rec.get("fp16_saturated_values"):
+        # a value left the fp16 range of the headline engine's planes: its outputs are not the network's -- no number
+        log(f"bench.py: {head_rec['fp16_saturated_values']} values left the fp16 range on the headline engine: value = null")
+        line["value"] = None
+    compact = compact_line(line)
+    detail_path = args.detail or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+    try:
+        os.makedirs(os.path.dirname(detail_path), exist_ok=True)
+        with open(detail_path, "w") as f_:
+            json.dump(line, f_, indent=1)
+        log(f"bench.py: full record ({len(json.dumps(line))} bytes) -> {detail_path}; stdout line {len(json.dumps(compact))} bytes; "
+            f"fp16-saturated values over all engines: {sat_total}")
+    except OSError as ex:
+        log(f"bench.py: could not write {detail_path}: {ex}")
+    print(json.dumps(compact), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+LINE_LIMIT = 8192       # bytes of the stdout JSON line (tests/test_bench_launcher.py asserts it on a full-size mocked record)
+
+
+def _r(x, n=4):
+    return None if x is None else (round(float(x), n) if isinstance(x, (int, float)) and not isinstance(x, bool) else x)
+
+
+def _sci(x):
+    """a small error figure with three significant digits (round() would print 1.4800000000000001e-06)"""
+    return None if x is None else float(f"{float(x):.3g}")
+
+
+def compact_parity(par):
+    """max-rel + mask figures of a parity section (err_stats dicts -> their max_rel)"""
+    if not par:
+        return None
+    out = {}
+    for k in ("frames",):
+        if k in par:
+            out[k] = par[k]
+    for k in ("logits", "disp_pp"):
+        if k in par:
+            out[k + "_max_rel"] = _sci(par[k]["max_rel"])
+    for k in ("road_mask_mismatch_frac", "argmax_mismatch_frac"):
+        if k in par:
+            out[k] = _sci(par[k])
+    if "records" in par:
+        out["width_max_abs_diff_m"] = _sci(par["records"].get("width_max_abs_diff_m"))
+        out["found_equal"] = par["records"].get("found_equal")
+    for k in ("records_given_same_masks_and_disparity_bit_equal", "tail_records_bit_equal_given_gpu_masks_and_disparity"):
+        if k in par:
+            out["tail_bit_equal"] = par[k]
+    return out
+
+
+def compact_roofline(rl):
+    if not rl:
+        return None
+    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_us", "algorithmic_gflop_per_launch",
+            "algorithmic_bytes_per_launch", "traffic_over_algorithmic")
+    out = {k: rl[k] for k in keep if k in rl}
+    if "engine" in rl:
+        out["engine_frac"] = rl["engine"]["frac"]
+        out["engine_achieved"] = rl["engine"]["achieved"]
+        out["conv_time_share_of_step"] = rl["engine"].get("conv_time_share_of_step")
+    return out
+
+
+def compact_leg(rec):
+    """{value, ms_per_step, dtype, roofline.frac (+ kernel), parity max-rels, fp16_saturated_values} of one leg"""
+    if not rec:
+        return None
+    out = {"value": rec["value"], "ms_per_step": rec["ms_per_step"], "dtype": rec["dtype"]}
+    if rec.get("roofline"):
+        out["roofline"] = {k: rec["roofline"][k] for k in ("kernel", "achieved", "peak", "frac") if k in rec["roofline"]}
+        if "engine" in rec["roofline"]:
+            out["roofline"]["engine_frac"] = rec["roofline"]["engine"]["frac"]
+    if "tail_overlap" in rec:
+        out["tail_ms_exposed"] = rec["tail_overlap"]["tail_ms_exposed"]
+    if "fp16_saturated_values" in rec:
+        out["fp16_saturated_values"] = rec["fp16_saturated_values"]
+    for k, short in (("parity_vs_f32_engine", "vs_f32_engine"), ("parity_vs_cpu_oracle", "vs_cpu_oracle")):
+        if rec.get(k):
+            out[short] = compact_parity(rec[k])
+    if rec.get("is_headline"):
+        out["is_headline"] = True
+    return out
+
+
+def compact_line(d: dict) -> dict:
+    """the stdout line from the full record: the contract's keys, `roofline` / `fusion_roofline` / `cpu_baseline`, `parity` as max-rel and mask
+    figures, `legs` (and `f32_exact`) as {value, ms_per_step, dtype, roofline.frac, parity max-rels, fp16_saturated_values}"""
+    cfg = d["config"]
+    ccfg = {k: cfg[k] for k in ("library", "workload", "survey_config", "frames_per_step", "gflop_per_frame", "gflop_per_frame_reference_graph", "engine",
+                                "approach", "overlap", "stage_ms_last_step", "fp16_saturated_values", "from_disk", "decode_threads_per_rank",
+                                "road_fraction", "n_road_mean", "n_after_chain_mean", "found", "built_in_plan") if k in cfg}
+    if "tail_overlap" in cfg:
+        ccfg["tail_overlap"] = {k: cfg["tail_overlap"][k] for k in ("on", "side_stream_priority", "ms_per_step_one_stream", "frames_per_s_one_stream",
+                                                                    "tail_ms_exposed") if k in cfg["tail_overlap"]}
+    if "precision_plan" in cfg:
+        ccfg["precision_plan_flop_share"] = {k: v["flop_share"] for k, v in cfg["precision_plan"].items()}
+    out = {k: d[k] for k in ("metric", "value", "unit", "n_gpus", "ranks_seen", "shared_gpu_plumbing_test", "steps", "warmup", "ms_per_step", "repeats",
+                             "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in d}
+    out["config"] = ccfg
+    out["roofline"] = compact_roofline(d.get("roofline"))
+    fr = d.get("fusion_roofline")
+    out["fusion_roofline"] = {k: fr[k] for k in ("bound", "kernel_short", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes",
+                                                 "stage_us_per_frame") if k in fr} if fr else None
+    cb = d.get("cpu_baseline")
+    out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "host_cpus", "kind", "value_1_thread", "sample") if k in cb} if cb else None
+    par = d.get("parity") or {}
+    out["parity"] = {k: compact_parity(par[k]) for k in ("vs_cpu_oracle", "vs_f32_engine") if par.get(k)} or None
+    if out["parity"]:
+        out["parity"]["tolerance"] = "north_star 1e-3: max|delta| / max|ref| per tensor; masks / argmax as mismatch fraction"
+    out["f32_exact"] = compact_leg(d.get("f32_exact"))
+    out["legs"] = {k: compact_leg(v) for k, v in (d.get("legs") or {}).items()} or None
+    out["detail"] = "gpurun_out/bench_detail.json (this run; copied per round to profiles/r0N_bench_detail.json): by_kernel lists, strict statistics, per-region times"
+    return out
 
 
 def pmc_traffic(label: str, pattern: str):
@@ -603,21 +731,6 @@ def peak_of(kernel: str, precision: str) -> float:
     return PEAK_2P if "f16w" in kernel else PEAK_3P
 
 
-def sustained_mfma_tflops():
-    """MFMA products per second the chip sustains under its power limit with operands that have the toggle statistics of the engine's planes
-    (scripts/probe_mfma_planes.hip, mode 2: hi / mid / lo planes of dense values in the six-product mix) -- read from the committed probe
-    output, profiles/r04_mfma_sustained_planes_probe.txt; (value, source)"""
-    import re
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_mfma_sustained_planes_probe.txt")
-    try:
-        vals = [float(m.group(1)) for m in re.finditer(r"mode 2 .*?: [0-9.]+ ms\s+([0-9.]+) TFLOP/s of MFMA products", open(path).read())]
-        if vals:
-            return sum(vals) / len(vals), "profiles/r04_mfma_sustained_planes_probe.txt (mode 2, mean of %d runs)" % len(vals)
-    except OSError:
-        pass
-    return 1812.0, "profiles/r01_mfma_sustained_probe.txt (random mantissas)"
-
-
 def conv_roofline(buckets, precision, dt):
     """`roofline` of the contract for the DOMINANT conv kernel (most time in this run) + the whole conv engine under `engine`.
     Durations are HIP events recorded by the library around every conv launch on the launch stream (sd_profile).  ``dt``: seconds of
@@ -637,15 +750,9 @@ def conv_roofline(buckets, precision, dt):
     if traffic_src is None:
         traffic, traffic_src = pmc_traffic(dom["kernel"], "*pmc_conv_traffic.json")
     dpk = peak_of(dom["kernel"], precision)
-    sus, sus_src = sustained_mfma_tflops()
-    prod = lambda k: 2500.0 / peak_of(k, precision) if "igemm" not in k else None       # MFMA products per algorithmic product
     return {
         "bound": "mfma", "kernel": dom["kernel"], "achieved": round(ach(dom), 2), "peak": round(dpk, 1), "unit": "TFLOP/s",
         "frac": round(ach(dom) / dpk, 4),
-        # the same against what the chip SUSTAINS under its power limit with plane-like operands (the nominal 2500 is reached with
-        # constant operands only): says whether the kernel's MFMA stream has anything left to tune
-        "frac_of_sustained": (round(ach(dom) * prod(dom["kernel"]) / sus, 4) if prod(dom["kernel"]) else None),
-        "sustained_mfma_tflops": round(sus, 1), "sustained_source": sus_src,
         "traffic": traffic, "traffic_source": traffic_src,
         "launches": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
         "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
@@ -659,8 +766,7 @@ def conv_roofline(buckets, precision, dt):
                    "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / eff_peak, 4), "launches": tot_n,
                    "conv_time_share_of_step": round(tot_ms * 1e-3 / dt, 4)},
         "by_kernel": [{"kernel": b["kernel"], "launches": b["launches"], "ms": round(b["ms"], 3), "tflops": round(ach(b), 2),
-                       "frac": round(ach(b) / peak_of(b["kernel"], precision), 4),
-                       **({"frac_of_sustained": round(ach(b) * prod(b["kernel"]) / sus, 4)} if prod(b["kernel"]) else {})}
+                       "frac": round(ach(b) / peak_of(b["kernel"], precision), 4)}
                       for b in sorted(buckets, key=lambda b: -b["ms"])],
     }
 
@@ -757,8 +863,8 @@ def cpu_baseline(frames_np, wf, wm, encoder, cam, planned, eng, prm, log):
     log(f"cpu baseline: 1 frame in {t1:.1f}s on 1 thread")
     cpu = {"value": round(n_done / t_used, 4), "unit": "frames/s", "cores": cores, "host_cpus": ncpu, "kind": "port",
            "value_1_thread": round(1.0 / t1, 5),
-           "sample": f"{n_done} of the bench's 512x1024 frames through the CPU oracle (torch-CPU f32 convs with TF semantics + numpy "
-                     f"fusion/pcl + cKDTree Open3D filters), whole path, {cores} threads of {ncpu} host CPUs; 1 frame on 1 thread"}
+           "sample": f"{n_done} of the bench's 512x1024 frames, whole path, through the CPU oracle ({t_used:.1f} s on {cores} threads of {ncpu} host CPUs); 1 frame on 1 thread",
+           "oracle": "torch-CPU f32 convs with TF semantics + numpy fusion/pcl + cKDTree Open3D filters (oracle/)"}
     cpu_baseline.last_ref = dict(n=n_done, logits=np.stack([o[0] for o in outs]), disp=np.stack([o[4]["disp_pp"] for o in outs]),
                                  road=np.stack([o[1] for o in outs]), argmax=np.stack([o[3] for o in outs]))
     par = None

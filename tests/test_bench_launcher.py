@@ -48,3 +48,46 @@ def test_a_rank_that_dies_takes_its_siblings_down():
     assert bench.wait_ranks([subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(3)]) == 0
     p = subprocess.Popen([sys.executable, "-c", "import os, signal; os.kill(os.getpid(), signal.SIGKILL)"])
     assert bench.wait_ranks([p]) == 128 + 9
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_the_stdout_line_of_a_full_size_record_stays_under_8_kb():
+    """VERDICT r5 item 1: round 5's 22.8-KB bench line was not parsed by the driver.  The stdout line is now `compact_line(full record)`;
+    the full record of round 5's default run (profiles/r05_bench_default.json: headline + f32_exact + two legs with their by_kernel lists
+    and the plan's 90-layer list), widened to the FOUR legs of the present default, must give a line under bench.LINE_LIMIT that still
+    carries every key of the contract."""
+    import json
+    bench = _bench_module()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")))
+    assert len(json.dumps(full)) > 20000                      # the mock is the real 22.8-KB record
+    full["legs"]["bf16x3"] = json.loads(json.dumps(full["legs"]["f16x2"]))
+    full["legs"]["mixed"] = json.loads(json.dumps(full["legs"]["plan"]))
+    full["dtype"] = bench.DTYPE["f16x2"]
+    for k, v in full["legs"].items():
+        v["dtype"] = bench.DTYPE.get(k, v["dtype"])
+    line = bench.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_LIMIT, len(text)
+    assert "\n" not in text
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert "workload" in line["config"] and "model" not in line["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
+    assert set(line["legs"]) == {"f16x2", "plan", "bf16x3", "mixed"}
+    for leg in line["legs"].values():
+        assert {"value", "ms_per_step", "dtype", "roofline", "fp16_saturated_values", "vs_f32_engine"} <= set(leg), leg.keys()
+    assert line["f32_exact"]["value"] == full["f32_exact"]["value"]
+    assert line["parity"]["vs_cpu_oracle"]["logits_max_rel"] < 1e-3
+    # every dtype string of the line is a short one
+    assert all(len(s_) < 160 for s_ in bench.DTYPE.values())
