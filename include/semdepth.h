@@ -55,11 +55,12 @@ typedef enum { SD_NET_FCN8S = 0, SD_NET_MONODEPTH = 1 } sd_net;
  *                  TFLOP/s of algorithmic work against 157.3 for the f32 MFMA;
  *   SD_PREC_F16X2  fp32-grade on THREE fp16 MFMA products (round 5): an activation is two fp16 planes, hi = RNE(v) and lo = RNE((v - hi) * 2^11)
  *                  -- the scaled residual stays in fp16's normal range wherever hi does, so v is carried to 22 significand bits for every
- *                  |v| in [1.2e-4, 65504] without any calibration (4 bytes per element); a weight is two fp16 planes of w * 2^12 (|w| < 16);
- *                  a product is x_hi*w_hi + x_hi*w_lo + x_lo*(w_hi * 2^-11) (the third weight operand formed in registers), f32 accumulate,
- *                  the accumulator times 2^-12 in the epilogue.  Dropped: x_lo*w_lo and the representation error of each operand, 2^-23 ..
+ *                  |v| in [1.2e-4, 65504] without any calibration (4 bytes per element); a weight is two fp16 planes of w * 2^k, the power of two k
+ *                  chosen PER LAYER by sd_load_weight from the tensor it is given (largest stored |w'| in [2^12, 2^13): any finite f32
+ *                  weight tensor loads); a product is x_hi*w_hi + x_hi*w_lo + x_lo*(w_hi * 2^-11) (the third weight operand formed in
+ *                  registers), f32 accumulate, the accumulator times 2^-k in the epilogue.  Dropped: x_lo*w_lo and the representation error of each operand, 2^-23 ..
  *                  2^-24 of the product (an f32 FMA chain commits 2^-24 of the ACCUMULATOR per step).  Activations beyond +-65504 are clamped
- *                  and counted (sd_saturation_count).  Ceiling 2500 / 3 = 833 TFLOP/s of algorithmic work. */
+ *                  and counted (sd_saturation_count; the host-side classes raise on a non-zero count).  Ceiling 2500 / 3 = 833 TFLOP/s of algorithmic work. */
 typedef enum { SD_PREC_F32 = 0, SD_PREC_BF16X2 = 1, SD_PREC_MIXED = 2, SD_PREC_PLAN = 3, SD_PREC_BF16X3 = 4, SD_PREC_F16X2 = 5 } sd_precision;
 
 typedef struct sd_handle sd_handle;
@@ -309,6 +310,16 @@ int sd_pass_frames(const sd_handle* h);
  * (synchronises the device); reset != 0 clears it.  A non-zero count means the plan does not fit these weights / inputs: run the
  * layer's producer with more products, or the exact engine (the reference has no such failure mode: it computes in f32). */
 sd_status sd_saturation_count(sd_handle* h, uint64_t* count_out, int reset);
+/* Tail overlap: the conv kernels of the 3x3 layers are persistent workgroups that fill every CU's register file, so work on a second stream
+ * (the per-frame tail of the previous batch: back-projection, road chain) finds no CU while they run.  n > 0 makes those launches use
+ * (CUs - n) workgroups; the n CUs left free take the side stream's kernels.  0 (default, or SEMDEPTH_RESERVE_CUS at sd_create) = every CU.
+ * Results do not depend on it (the tiles a workgroup walks change, not their arithmetic). */
+sd_status sd_set_reserved_cus(sd_handle* h, int n);
+
+/* the same count without a device synchronisation: an 8-byte device-to-host copy enqueued on `stream` behind the work already on it
+ * (host_dst = pinned host memory of the caller).  The host-side classes use it to turn a range violation into an ERROR of the call that
+ * produced it instead of a counter somebody has to poll (semantic_depth_amd/engine.py Engine.check_range). */
+sd_status sd_saturation_count_async(sd_handle* h, uint64_t* host_dst, void* stream);
 
 #ifdef __cplusplus
 }

@@ -93,6 +93,8 @@ SIGNATURES = {
     "sd_net_flops_per_image": (C.c_double, [_H, C.c_int]),
     "sd_pass_frames": (C.c_int, [_H]),
     "sd_saturation_count": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int]),
+    "sd_saturation_count_async": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    "sd_set_reserved_cus": (C.c_int, [_H, C.c_int]),
 }
 
 _lib = None

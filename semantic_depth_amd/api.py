@@ -121,6 +121,7 @@ class SegmentFrame:
         out = e.fcn8s_forward(fr)
         road = out["road"][0].cpu().numpy().astype(bool)[..., None]
         fence = out["fence"][0].cpu().numpy().astype(bool)[..., None]
+        e.check_range()                       # (engines with fp16 planes: a value beyond their range is an error of this call)
         return road, fence, self._overlay(frame, road, fence)
 
     @staticmethod
@@ -171,7 +172,9 @@ class DepthFrame:
         """semantic_depth.py:667-678 -> float32 (H,W), fraction of image width."""
         e = self.engine
         fr = torch.from_numpy(np.ascontiguousarray(frame, dtype=np.uint8))[None].to(e.device)
-        return e.monodepth_forward(fr)[0].cpu().numpy()
+        disp = e.monodepth_forward(fr)[0].cpu().numpy()
+        e.check_range()
+        return disp
 
     def disp_to_image(self, disp_pp: np.ndarray, output_name: str, original_height: int, original_width: int) -> str:
         """semantic_depth.py:681-683: ``scipy.misc.imresize(disp_pp.squeeze(), [h, w])`` + ``plt.imsave(name_disp.png, cmap='gray')``
@@ -253,6 +256,9 @@ class FrameProcessor:
                                       want_clouds=want_clouds)
                 out["f2f"], out["fence_final"] = f2 if want_clouds else (f2, None)
         rec = Engine.records(out["records"])[0]
+        e.check_range()
+        if es is not e:
+            es.check_range()
         n = int(out["fuse"]["n_road"][0].item())
         res = dict(record=rec, dist_rw=float(rec["width"]) if rec["found"] else None, dist_f2f=None, f2f_record=None,
                    road_mask=out["seg"]["road"][0].cpu().numpy().astype(bool),

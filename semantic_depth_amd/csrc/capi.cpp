@@ -36,8 +36,10 @@ struct sd_handle {
     int rsz_key[4] = {0, 0, 0, 0};
     size_t ws_bytes = 0;
     int last_fcn_images = 0, last_mono_images = 0;
+    int reserve_cus = 0;            // sd_set_reserved_cus: CUs the persistent conv launches leave free
     std::vector<CamDev> cams_stage;
     std::map<std::pair<int, int>, std::vector<float>> bias_host;   // (net, slot) -> host copy, for bias slots that are summed
+    std::map<std::pair<int, int>, std::vector<float>> w_host;      // (net, slot) -> f32 tensor of the SD_PREC_F16X2 slots that share a weight scale (sd_load_weight)
     std::string err;
     // profiling (sd_profile): event pairs around conv launches
     bool prof = false;
@@ -180,10 +182,10 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.out_plane = PL(op.dst); c.Nmax = p.images;
                 c.zero16 = h->ws + h->o_misc + 256;        // the arena is zero-filled and nothing writes here
                 const bool split = p.prec != 0;
-                c.f16 = op.f16; c.out_f16 = d.f16; c.alpha = op.f16 == 4 ? HS_ALPHA : 1.f;
+                c.f16 = op.f16; c.out_f16 = d.f16; c.alpha = op.f16 == 4 ? 1.f / p.weights[op.w].wscale : 1.f;
                 c.src0 = T(op.src[0]); c.src0_plane = PL(op.src[0]);
                 c.out_planar16 = d.planar16;
-                c.sw = h->sw;
+                c.sw = h->sw; c.reserve_cus = h->reserve_cus;
                 c.sat = reinterpret_cast<unsigned long long*>(h->ws + h->o_misc + SAT_OFF);
                 c.x3 = p.x3;
                 // conv_dma3.hip, k x k stride-1 layers on one source (fc6): one output row of 256 / Wout images per tile, taps on padding rows skipped
@@ -243,8 +245,8 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.out = T(op.dst); c.out_plane = PL(op.dst); c.act = op.act; c.Nmax = p.images;
                 c.zero16 = h->ws + h->o_misc + 256;
                 c.rows_per_wave = 2;
-                c.f16 = op.f16; c.out_f16 = d.f16; c.alpha = op.f16 == 4 ? HS_ALPHA : 1.f;
-                c.sw = h->sw;
+                c.f16 = op.f16; c.out_f16 = d.f16; c.alpha = op.f16 == 4 ? 1.f / p.weights[op.w].wscale : 1.f;
+                c.sw = h->sw; c.reserve_cus = h->reserve_cus;
                 c.sat = reinterpret_cast<unsigned long long*>(h->ws + h->o_misc + SAT_OFF);
                 hipEvent_t ea = nullptr, eb = nullptr;
                 if (h->prof) {
@@ -268,8 +270,8 @@ sd_status run_plan(sd_handle* h, sd_net net, const uint8_t* frames, int nframes,
                 c.w1 = reinterpret_cast<const u32x4_t*>(Wp(op.w)); c.b1 = Wp(op.b);
                 c.w2 = reinterpret_cast<const u32x4_t*>(Wp(op.w2)); c.b2 = Wp(op.b2);
                 c.wd = Wp(op.w3); c.bd = Wp(op.b3);
-                c.out = T(op.dst); c.sw = h->sw;
-                c.hs = p.h2; c.alpha = p.h2 ? HS_ALPHA : 1.f;
+                c.out = T(op.dst); c.sw = h->sw; c.reserve_cus = h->reserve_cus;
+                c.hs = p.h2; c.alpha = p.h2 ? 1.f / p.weights[op.w].wscale : 1.f; c.alpha2 = p.h2 ? 1.f / p.weights[op.w2].wscale : 1.f;
                 hipEvent_t ea = nullptr, eb = nullptr;
                 if (h->prof) {
                     ea = h->prof_last;
@@ -407,6 +409,7 @@ static sd_status create_impl(sd_handle** out, int device, int H, int W, int max_
     if (!out || H <= 0 || W <= 0 || max_batch <= 0) return SD_ERR_INVALID;
     sd_handle* h = new sd_handle();
     h->sw = latch_switches();
+    if (const char* e = std::getenv("SEMDEPTH_RESERVE_CUS")) h->reserve_cus = std::min(128, std::max(0, atoi(e)));
     h->device = device; h->H = H; h->W = W; h->max_batch = max_batch; h->enc = (int)enc; h->cap = H * W; h->prec = (int)prec;
     int chunk = 32;      // frames per network pass: the deep layers (M = 512 px per frame) need ~32 frames to fill 256 CUs;
                          // activations of a 32-frame chunk are ~17 GB at 512x1024, nothing on a 288 GB part
@@ -478,47 +481,90 @@ sd_status sd_load_weight(sd_handle* h, sd_net net, const char* name, const float
     if (rank != s.rank) return fail(h, SD_ERR_INVALID, std::string("rank mismatch for ") + name);
     for (int i = 0; i < rank; ++i)
         if (shape[i] != s.shape[i]) return fail(h, SD_ERR_INVALID, std::string("shape mismatch for ") + name);
-    std::vector<float> buf, scaled;
-    if (s.hs) {                         // SD_PREC_F16X2: the planes hold w * 2^12 in fp16
-        size_t n = 1;
-        for (int i = 0; i < rank; ++i) n *= (size_t)shape[i];
-        float mx = 0.f;
-        for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(data[i] * s.scale));
-        if (!(mx * HS_WSCALE * (s.fold ? 4.f : 1.f) <= 65504.f))
-            return fail(h, SD_ERR_INVALID, std::string("weight ") + name + ": |w| beyond the range of the fp16 weight planes of SD_PREC_F16X2 (max 15.99)");
-    }
+    std::vector<float> scaled;
+    size_t nel = 1;
+    for (int i = 0; i < rank; ++i) nel *= (size_t)shape[i];
     if (s.scale != 1.f) {               // (monodepth stem with integer input: the weights carry the 1/255)
-        size_t n = 1;
-        for (int i = 0; i < rank; ++i) n *= (size_t)shape[i];
-        scaled.resize(n);
-        for (size_t i = 0; i < n; ++i) scaled[i] = data[i] * s.scale;
+        scaled.resize(nel);
+        for (size_t i = 0; i < nel; ++i) scaled[i] = data[i] * s.scale;
         data = scaled.data();
     }
-    relayout_weight(s, data, buf);
-    char* base = warena(h, net) + s.offset;
-    if (s.layout == WL_IGEMM) {                     // rows [k_off, k_off+Kpad) of a [Ktotal/4][CoutPad][4] matrix
-        HIPCHK(h, hipMemcpy(base + (size_t)s.k_off * s.CoutPad * 4, buf.data(), s.bytes, hipMemcpyHostToDevice));
-    } else if (s.layout == WL_IGEMM_SPLIT) {        // the same rows in the hi plane and in the lo plane
-        const size_t plane = (size_t)s.Ktotal * s.CoutPad * 2, rows = (size_t)s.Kpad * s.CoutPad * 2, ro = (size_t)s.k_off * s.CoutPad * 2;
-        HIPCHK(h, hipMemcpy(base + ro, buf.data(), rows, hipMemcpyHostToDevice));
-        HIPCHK(h, hipMemcpy(base + plane + ro, reinterpret_cast<char*>(buf.data()) + rows, rows, hipMemcpyHostToDevice));
-        if (s.x3) HIPCHK(h, hipMemcpy(base + 2 * plane + ro, reinterpret_cast<char*>(buf.data()) + 2 * rows, rows, hipMemcpyHostToDevice));
-    } else {
-        const int root = s.owner >= 0 ? s.owner : it->second;
-        bool grouped = s.owner >= 0;
-        for (const WeightSlot& o : p.weights) grouped = grouped || (o.owner == root && o.layout == WL_RAW && &o != &s);
-        if (grouped && s.layout == WL_RAW && s.rank == 1) {      // summed bias group (ResNet conv3 + projection)
-            h->bias_host[{(int)net, it->second}] = buf;
-            std::vector<float> sum(buf.size(), 0.f);
-            for (int j = 0; j < (int)p.weights.size(); ++j)
-                if (j == root || p.weights[j].owner == root) {
-                    auto f = h->bias_host.find({(int)net, j});
-                    if (f != h->bias_host.end()) for (size_t i = 0; i < sum.size(); ++i) sum[i] += f->second[i];
-                }
-            HIPCHK(h, hipMemcpy(base, sum.data(), s.bytes, hipMemcpyHostToDevice));
+    const int idx = it->second;
+    // re-layout + upload of one slot from its TensorFlow-layout tensor
+    auto upload = [&](int j, const float* w) -> sd_status {
+        WeightSlot& t = p.weights[j];
+        std::vector<float> buf;
+        relayout_weight(t, w, buf);
+        char* base = warena(h, net) + t.offset;
+        if (t.layout == WL_IGEMM) {                     // rows [k_off, k_off+Kpad) of a [Ktotal/4][CoutPad][4] matrix
+            HIPCHK(h, hipMemcpy(base + (size_t)t.k_off * t.CoutPad * 4, buf.data(), t.bytes, hipMemcpyHostToDevice));
+        } else if (t.layout == WL_IGEMM_SPLIT) {        // the same rows in the hi plane and in the lo plane
+            const size_t plane = (size_t)t.Ktotal * t.CoutPad * 2, rows = (size_t)t.Kpad * t.CoutPad * 2, ro = (size_t)t.k_off * t.CoutPad * 2;
+            HIPCHK(h, hipMemcpy(base + ro, buf.data(), rows, hipMemcpyHostToDevice));
+            HIPCHK(h, hipMemcpy(base + plane + ro, reinterpret_cast<char*>(buf.data()) + rows, rows, hipMemcpyHostToDevice));
+            if (t.x3) HIPCHK(h, hipMemcpy(base + 2 * plane + ro, reinterpret_cast<char*>(buf.data()) + 2 * rows, rows, hipMemcpyHostToDevice));
         } else {
-            HIPCHK(h, hipMemcpy(base, buf.data(), s.bytes, hipMemcpyHostToDevice));
+            const int root = t.owner >= 0 ? t.owner : j;
+            bool grouped = t.owner >= 0;
+            for (const WeightSlot& o : p.weights) grouped = grouped || (o.owner == root && o.layout == WL_RAW && &o != &t);
+            if (grouped && t.layout == WL_RAW && t.rank == 1) {      // summed bias group (ResNet conv3 + projection)
+                h->bias_host[{(int)net, j}] = buf;
+                std::vector<float> sum(buf.size(), 0.f);
+                for (int q = 0; q < (int)p.weights.size(); ++q)
+                    if (q == root || p.weights[q].owner == root) {
+                        auto f = h->bias_host.find({(int)net, q});
+                        if (f != h->bias_host.end()) for (size_t i = 0; i < sum.size(); ++i) sum[i] += f->second[i];
+                    }
+                HIPCHK(h, hipMemcpy(base, sum.data(), t.bytes, hipMemcpyHostToDevice));
+            } else {
+                HIPCHK(h, hipMemcpy(base, buf.data(), t.bytes, hipMemcpyHostToDevice));
+            }
         }
+        return SD_OK;
+    };
+    if (s.hs) {
+        // SD_PREC_F16X2: the planes hold w' = w * 2^k in fp16 (hi + lo), k chosen HERE per layer so that the largest stored |w'| lies in
+        // [2^12, 2^13) -- any finite f32 weight tensor loads (round 5 used a fixed 2^12 and refused |w| >= 16), and a layer of tiny weights
+        // keeps the low plane's bits.  A stored value of an upsample-folded layer is a sum of up to four taps: bounded by 4 max |w|.  Slots
+        // that feed ONE accumulator (ResNet conv3 + projection shortcut) share the scale: the members' tensors are kept on the host and the
+        // ones already loaded are laid out again when a later member moves the group's exponent.
+        const int root = s.owner >= 0 ? s.owner : idx;
+        std::vector<int> members;
+        for (int j = 0; j < (int)p.weights.size(); ++j)
+            if ((j == root || p.weights[j].owner == root) && p.weights[j].hs) members.push_back(j);
+        const bool grouped = members.size() > 1;
+        for (size_t i = 0; i < nel; ++i)
+            if (!std::isfinite(data[i])) return fail(h, SD_ERR_INVALID, std::string("weight ") + name + ": non-finite value");
+        if (grouped) h->w_host[{(int)net, idx}].assign(data, data + nel);
+        float mx = 0.f;
+        auto amax = [&](const float* w, size_t n, const WeightSlot& t) {
+            float m = 0.f;
+            for (size_t i = 0; i < n; ++i) m = std::max(m, std::fabs(w[i]));
+            return m * ((t.fold || t.layout == WL_TAIL_UP) ? 4.f : 1.f);
+        };
+        mx = amax(data, nel, s);
+        if (grouped)
+            for (int j : members) {
+                auto f = h->w_host.find({(int)net, j});
+                if (j != idx && f != h->w_host.end()) mx = std::max(mx, amax(f->second.data(), f->second.size(), p.weights[j]));
+            }
+        int k = 12;
+        if (mx > 0.f) k = std::min(100, std::max(-100, 12 - std::ilogb(mx)));
+        const float wscale = std::ldexp(1.f, k);
+        const bool moved = wscale != p.weights[root].wscale;
+        for (int j : members) p.weights[j].wscale = wscale;
+        if (grouped && moved)
+            for (int j : members) {
+                auto f = h->w_host.find({(int)net, j});
+                if (j != idx && p.weights[j].loaded && f != h->w_host.end()) {
+                    sd_status st = upload(j, f->second.data());
+                    if (st != SD_OK) return st;
+                }
+            }
+    }
+    {
+        sd_status st = upload(idx, data);
+        if (st != SD_OK) return st;
     }
     s.loaded = true;
     return SD_OK;
@@ -913,6 +959,21 @@ sd_status sd_saturation_count(sd_handle* h, uint64_t* count_out, int reset) {
         *count_out = (uint64_t)v;
     }
     if (reset) HIPCHK(h, hipMemset(h->ws + h->o_misc + SAT_OFF, 0, sizeof(v)));
+    return SD_OK;
+}
+
+sd_status sd_set_reserved_cus(sd_handle* h, int n) {
+    if (!h || n < 0 || n > 128) return SD_ERR_INVALID;
+    h->reserve_cus = n;
+    return SD_OK;
+}
+
+// the same counter without a device synchronisation: an 8-byte device-to-host copy enqueued on `stream` (host_dst: pinned memory of the caller; it
+// holds the count once the work enqueued on the stream before this call has finished)
+sd_status sd_saturation_count_async(sd_handle* h, uint64_t* host_dst, void* stream) {
+    if (!h || !host_dst) return SD_ERR_INVALID;
+    if (!h->bound) return fail(h, SD_ERR_STATE, "sd_bind_memory first");
+    HIPCHK(h, hipMemcpyAsync(host_dst, h->ws + h->o_misc + SAT_OFF, sizeof(uint64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     return SD_OK;
 }
 

@@ -554,7 +554,7 @@ hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
 #define SD_DIRECT_(NB_, MT_, F16_, N16_, UP_, W1_, X2_, ...) \
     do { static int per_cu = 0; \
          if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_direct_kernel<NB_, MT_, F16_, N16_, UP_, W1_, X2_, ##__VA_ARGS__>, 512, 0) != hipSuccess || per_cu < 1)) per_cu = 1; \
-         const int slots = cus * per_cu; \
+         const int slots = (cus - p.reserve_cus > 0 ? cus - p.reserve_cus : 1) * per_cu; \
          const dim3 grid((unsigned)(tiles < slots ? tiles : slots)); \
          hipLaunchKernelGGL((conv_direct_kernel<NB_, MT_, F16_, N16_, UP_, W1_, X2_, ##__VA_ARGS__>), grid, dim3(512), 0, s, q); } while (0)
 #define SD_DIRECT_H2(NB_, MT_, N16_) do { if (up) SD_DIRECT_(NB_, MT_, true, N16_, true, false, true, true); else SD_DIRECT_(NB_, MT_, true, N16_, false, false, true, true); } while (0)

@@ -584,7 +584,8 @@ hipError_t launch_conv_direct3(const ConvDirectParams& p, hipStream_t s) {
     }
     const bool up = p.all_up && !(p.H & 1) && !(p.W & 1) && !(p.sw & SW_NO_UPTILE);
     const int tiles = (p.W / T3_TW) * ((p.H + T3_TH - 1) / T3_TH) * p.N * p.nsplit;
-    const dim3 grid((unsigned)(tiles < cus ? tiles : cus));        // persistent: one workgroup per CU (158 KB of LDS)
+    const int wgs = cus - p.reserve_cus > 0 ? cus - p.reserve_cus : 1;
+    const dim3 grid((unsigned)(tiles < wgs ? tiles : wgs));        // persistent: one workgroup per CU (158 KB of LDS)
     if (p.fold) {             // upsample-folded upconv layers: source-resolution tiles, two-slot ring, kept fragments
         if (!up || p.pool) return hipErrorInvalidValue;
         if (p.Cout <= 32) hipLaunchKernelGGL((conv_direct3_kernel<1, true, 2, 2, true>), grid, dim3(512), 0, s, p);

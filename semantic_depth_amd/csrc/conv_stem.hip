@@ -261,7 +261,8 @@ hipError_t launch_conv_stem(const ConvParams& p, hipStream_t s) {
     const size_t wbytes = (size_t)(p.Kpad / 8) * p.Cout * 16 * npl;
     const size_t lds = (size_t)npl * ST_MAXPIX * 8 + wbytes + (size_t)8 * 32 * (64 * nb + 16);
     if (lds + 512 > 160 * 1024) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)(tiles < cus ? tiles : cus));
+    const int wgs = cus - p.reserve_cus > 0 ? cus - p.reserve_cus : 1;
+    const dim3 grid((unsigned)(tiles < wgs ? tiles : wgs));
 #define SD_STEM(NB_, RW_, F_, ...)                                                                                     \
     do {                                                                                                               \
         static bool attr = false;                                                                                      \

@@ -43,7 +43,7 @@ constexpr int DT_NPIX = DT_TH * DT_TW;
 // HS = false: SD_PREC_BF16X3 (three bf16 planes per operand, six products per product).  HS = true: SD_PREC_F16X2 -- two planes per operand (fp16 hi +
 // scaled lo activations, fp16 hi + lo of w * 2^12: split_fmt.hpp "HS"), THREE fp16 products per product, the x_lo one against w_hi * 2^-11, which is
 // formed ONCE per launch here (the weight fragments are resident: it sits in the register slot of the bf16 form's third plane), the accumulators
-// times DecTailParams::alpha; the same tiles, stages and wave groups.
+// times DecTailParams::alpha (stage 1) / alpha2 (stage 2); the same tiles, stages and wave groups.
 template <bool HS>
 __global__ __launch_bounds__(512, 1) void dec_tail1_kernel(const DecTailParams p) {
     constexpr int NPL = HS ? 2 : 3;                                                 // planes per tensor
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(512, 1) void dec_tail1_kernel(const DecTailParams p
                         acc[dy] = mac6(w2[2 * dy], G[sl][0][0], G[sl][0][1], G[sl][0][HS ? 1 : 2], acc[dy]);
                         acc[dy] = mac6(w2[2 * dy + 1], G[sl][1][0], G[sl][1][1], G[sl][1][HS ? 1 : 2], acc[dy]);
                     }
-                    f32x4 v = HS ? ((acc[0] + acc[1]) + acc[2]) * p.alpha + bias2 : (acc[0] + acc[1]) + acc[2] + bias2;
+                    f32x4 v = HS ? ((acc[0] + acc[1]) + acc[2]) * p.alpha2 + bias2 : (acc[0] + acc[1]) + acc[2] + bias2;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = HS ? act_split<ACT_ELU>(v[r]) : act_x3<ACT_ELU>(v[r]);
                     const bool in = (unsigned)(cur.y0 - 1 + ri) < (unsigned)H && (unsigned)(cur.x0 - 1 + c) < (unsigned)W;
@@ -350,8 +350,9 @@ hipError_t launch_dec_tail1(const DecTailParams& p, hipStream_t s) {
         cus = prop.multiProcessorCount;
     }
     const int tiles = ((p.W + DT_TW - 1) / DT_TW) * (p.H / DT_TH) * p.N;
-    if (p.hs) hipLaunchKernelGGL(dec_tail1_kernel<true>, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(512), 0, s, p);
-    else hipLaunchKernelGGL(dec_tail1_kernel<false>, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(512), 0, s, p);
+    const int wgs = cus - p.reserve_cus > 0 ? cus - p.reserve_cus : 1;
+    if (p.hs) hipLaunchKernelGGL(dec_tail1_kernel<true>, dim3((unsigned)(tiles < wgs ? tiles : wgs)), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL(dec_tail1_kernel<false>, dim3((unsigned)(tiles < wgs ? tiles : wgs)), dim3(512), 0, s, p);
     return hipGetLastError();
 }
 

@@ -69,7 +69,7 @@ struct ConvParams {
                        // input and w_hi only (1 MFMA product: plain fp16 x fp16; conv_dma / conv_direct, the others run the 2-product form)
                        // 4 (SD_PREC_F16X2): fp16 hi + SCALED lo input planes x fp16 hi + lo weights, THREE products, `alpha` applied (split_fmt.hpp "HS")
     int out_f16;       // OUTPUT split planes are fp16 (the format the consumers of the output tensor compute in); 3 = fp16 hi + scaled lo (HS)
-    float alpha;       // f16 == 4: 2^-k of the layer's weight scale (WeightSlot::wscale): out = act(acc * alpha + bias)
+    float alpha;       // f16 == 4: 1 / WeightSlot::wscale = 2^-k of the layer's weight scale: out = act(acc * alpha + bias)
     int out_planar16;  // conv_stem.hip: write the output as Cout/16 sub-planes of 16 channels (TensorDesc::planar16)
     int pool;          // conv_dma.hip: output pixels are walked in 2x2-window-major order and the epilogue max-pools each
                        // window: out is [N,Hout/2,Wout/2,Cout]
@@ -78,6 +78,8 @@ struct ConvParams {
     int dbg;           // SEMDEPTH_DMA_DBG=16: general gather path on SIMPLE layers too (A/B switch; 0 in production)
     int m_fastest;     // block order: 1 = consecutive blocks walk M (share a weight panel), 0 = walk N
     unsigned sw;       // Switch bits of the handle
+    int reserve_cus;   // persistent launches use (CUs - reserve_cus) workgroups: the CUs left free take the per-frame tail of the previous step
+                       // that runs beside the networks on a side stream (sd_set_reserved_cus; 0 = every CU)
     unsigned long long* sat;   // DEVICE counter of fp16-saturated output values (split_fmt.hpp sat_report; sd_saturation_count)
     int x3;            // 1: bf16 x 3 planes in, out and in the weights (SD_PREC_BF16X3: six MFMA products per product, split_fmt.hpp)
     int flat;          // 1 (conv_dma3.hip): a 1x1 conv without upsample (every source read at tap (0, 0), per-source strides allowed): the gather
@@ -184,6 +186,7 @@ struct ConvDirectParams {
     float alpha;                 // f16 == 4: 2^-k of the layer's weight scale: out = act(acc * alpha + bias)
     int pool;                    // 1: fused 2x2 stride-2 max pool, out is [N,H/2,W/2,Cout] (needs rows_per_wave == 2)
     unsigned sw;                 // Switch bits of the handle
+    int reserve_cus;             // the persistent grid is (CUs - reserve_cus) workgroups (ConvParams::reserve_cus)
     unsigned long long* sat;     // DEVICE counter of fp16-saturated output values (split_fmt.hpp sat_report; sd_saturation_count)
 };
 hipError_t launch_conv_direct3(const ConvDirectParams& p, hipStream_t s);       // conv_direct3.hip: the bf16 x 3 form (SD_PREC_BF16X3)
@@ -206,8 +209,9 @@ struct DecTailParams {
     const float* bd;       // [1]
     float* out;            // [N, H, W] f32
     unsigned sw;
-    int hs;                // 1 (SD_PREC_F16X2): a / d2 are fp16 hi + scaled lo planes, w1 / w2 hold fp16 hi + lo of w * 2^12 in planes 0 and 1 (split_fmt.hpp "HS")
-    float alpha;           // hs: 2^-12, applied to the accumulators of stages 1 and 2
+    int hs;                // 1 (SD_PREC_F16X2): a / d2 are fp16 hi + scaled lo planes, w1 / w2 hold fp16 hi + lo of w * 2^k in planes 0 and 1 (split_fmt.hpp "HS")
+    int reserve_cus;       // the persistent grid is (CUs - reserve_cus) workgroups (ConvParams::reserve_cus)
+    float alpha, alpha2;   // hs: 2^-k of upconv1's / iconv1's weight scale, applied to the accumulators of stage 1 / stage 2
 };
 bool dec_tail1_eligible(int H, int W);
 hipError_t launch_dec_tail1(const DecTailParams& p, hipStream_t s);

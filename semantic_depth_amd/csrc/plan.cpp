@@ -67,7 +67,7 @@ struct Builder {
         }
         s.bytes = n * sizeof(float);
         if (p.x3 && (layout == WL_IGEMM_SPLIT || layout == WL_DIRECT_SPLIT)) { s.x3 = 1; s.bytes = n * 6; }      // three bf16 planes
-        if (p.h2 && (layout == WL_IGEMM_SPLIT || layout == WL_DIRECT_SPLIT)) { s.f16 = 1; s.hs = 1; }            // two fp16 planes of w * 2^12
+        if (p.h2 && (layout == WL_IGEMM_SPLIT || layout == WL_DIRECT_SPLIT)) { s.f16 = 1; s.hs = 1; }            // two fp16 planes of w * 2^k (WeightSlot::wscale)
         if (p.h2 && (layout == WL_TAIL_UP || layout == WL_TAIL_ICONV)) s.hs = 1;                                 // the same in planes 0 and 1 of the fragments
         p.weights.push_back(s);
         p.weight_by_name[name] = (int)p.weights.size() - 1;
@@ -750,7 +750,7 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
                             for (int iy = 0; iy < ny; ++iy)
                                 for (int ix = 0; ix < nx; ++ix) acc += (double)w[((int64_t)(dys[iy] * 3 + dxs[ix]) * C + c) * Cout + n];
                             const float wf = (float)acc;
-                            if (f16) { f16_split(s.hs ? wf * HS_WSCALE : wf, hi[base + n * 8], lo[base + n * 8]); continue; }      // (SD_PREC_F16X2: planes of w * 2^12)
+                            if (f16) { f16_split(s.hs ? wf * s.wscale : wf, hi[base + n * 8], lo[base + n * 8]); continue; }      // (SD_PREC_F16X2: planes of w * 2^k)
                             const uint16_t h = bf16(wf);
                             hi[base + n * 8] = h;
                             const float r1 = wf - bf16_to_f(h);
@@ -784,7 +784,7 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
                     } else {                          // two bf16 planes [k/8][n][8]
                         const size_t base = (size_t)(k / 8) * s.CoutPad * 8 + (k % 8);
                         for (int64_t n = 0; n < Cout; ++n) {
-                            if (f16) { f16_split(s.hs ? src[n] * HS_WSCALE : src[n], hi[base + n * 8], lo[base + n * 8]); continue; }      // (hs: planes of w * 2^12)
+                            if (f16) { f16_split(s.hs ? src[n] * s.wscale : src[n], hi[base + n * 8], lo[base + n * 8]); continue; }      // (hs: planes of w * 2^k)
                             const uint16_t h = bf16(src[n]);
                             hi[base + n * 8] = h;
                             const float r1 = src[n] - bf16_to_f(h);
@@ -844,7 +844,7 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
                         const size_t base = (((size_t)chunk * 9 + tap) * 2 + oct) * s.CoutPad * 8 + e;
                         for (int64_t n = 0; n < Cout; ++n) {
                             uint16_t* hi = hi0 + (size_t)(n / s.CoutPad) * (s.x3 ? 3 : 2) * plane + base + (n % s.CoutPad) * 8;
-                            if (s.f16) { f16_split(s.hs ? src[n] * HS_WSCALE : src[n], *hi, hi[plane]); continue; }
+                            if (s.f16) { f16_split(s.hs ? src[n] * s.wscale : src[n], *hi, hi[plane]); continue; }
                             const uint16_t h = bf16(src[n]);
                             *hi = h;
                             const float r1 = src[n] - bf16_to_f(h);
@@ -861,9 +861,9 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
         auto bf16_to_f = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; };
         uint16_t* const o16 = reinterpret_cast<uint16_t*>(out.data());
         auto put = [&](int frag, int lane, int e, float v) {             // element e of the lane's eight, all three planes
-            if (s.hs) {              // SD_PREC_F16X2: fp16 hi + lo of w * 2^12 in planes 0 and 1 (the kernel forms w_hi * 2^-11 in the third slot)
+            if (s.hs) {              // SD_PREC_F16X2: fp16 hi + lo of w * 2^k in planes 0 and 1 (the kernel forms w_hi * 2^-11 in the third slot)
                 uint16_t h16, l16;
-                f16_split(v * HS_WSCALE, h16, l16);
+                f16_split(v * s.wscale, h16, l16);
                 o16[(((size_t)frag * 3 + 0) * 64 + lane) * 8 + e] = h16;
                 o16[(((size_t)frag * 3 + 1) * 64 + lane) * 8 + e] = l16;
                 return;

@@ -44,8 +44,11 @@ struct WeightSlot {
     int vec = 0;           // 1: K axis is ordered (32-channel block, tap, channel) instead of (tap, channel)
     int f16 = 0;           // split layouts: two fp16 planes, hi = fp16(w), lo = fp16(w - hi) (the 2-product scheme of split_fmt.hpp)
     int x3 = 0;            // split layouts: THREE bf16 planes hi, mid, lo (exact: w = hi + mid + lo), SD_PREC_BF16X3
-    int hs = 0;            // split layouts (with f16): the two fp16 planes hold w * 2^12 (SD_PREC_F16X2: hi = fp16(w'), lo = fp16(w' - hi); the conv epilogues
-                           // multiply the accumulator by 2^-12 = HS_ALPHA); a weight beyond +-15.99 does not fit and sd_load_weight refuses it
+    int hs = 0;            // split layouts (with f16): the two fp16 planes hold w' = w * wscale (SD_PREC_F16X2: hi = fp16(w'), lo = fp16(w' - hi); the conv
+                           // epilogues multiply the accumulator by 1 / wscale)
+    float wscale = 4096.f; // hs: the layer's power-of-two weight scale 2^k, chosen by sd_load_weight from the tensor it is given so that the largest
+                           // stored |w'| lies in [2^12, 2^13) (folded layers: the bound 4 max|w| on a sum of four taps); slots that share an
+                           // accumulator (ResNet conv3 + projection: `owner`) share one scale
     float scale = 1.f;     // the tensor is multiplied by this while it is loaded (monodepth stem with integer input: 1/255, see NetPlan::input_scale)
     // a slot may be a VIEW of rows [k_off, k_off+Kpad) of a larger device matrix of Ktotal rows owned by slot `owner`
     // (ResNet block: conv3 and the projection shortcut are one GEMM over the concatenated K axis); a bias view is ADDED
@@ -118,7 +121,6 @@ struct NetPlan {
 
 // prec: 0 exact f32 MFMA, 1 split engine (bf16 x 2 + the fp16 forms of f16_layers), 2 split engine with bf16 x 3 planes (f16_layers ignored),
 // 3 split engine with fp16 hi + scaled lo planes (f16_layers ignored)
-constexpr float HS_WSCALE = 4096.f, HS_ALPHA = 1.f / 4096.f;
 NetPlan build_fcn8s(int frames, int H, int W, int prec, const char* f16_layers = nullptr);
 NetPlan build_monodepth(int encoder /*0 vgg, 1 resnet50*/, int frames, int H, int W, int prec, const char* f16_layers = nullptr);
 

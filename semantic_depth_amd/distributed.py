@@ -88,7 +88,10 @@ def run_sequence(load_frames, n_frames: int, step, batch: int = 32, group=None, 
         local = torch.cat(parts, 0)
     else:
         local = torch.zeros((0, RECORD_BYTES), dtype=torch.uint8, device=device or "cpu")
-    return gather_records(local, n_frames, group)
+    out = gather_records(local, n_frames, group)
+    if getattr(step, "finish", None) is not None:
+        step.finish()              # (make_engine_step: the engine's fp16 range check -- a violation is an error of the sequence)
+    return out
 
 
 def run_sequence_files(paths, step, batch: int = 32, group=None, device="cuda", workers: int = 0) -> torch.Tensor:
@@ -110,7 +113,10 @@ def run_sequence_files(paths, step, batch: int = 32, group=None, device="cuda", 
                 assert rec.dtype == torch.uint8 and tuple(rec.shape) == (frames.shape[0], RECORD_BYTES), (rec.dtype, rec.shape)
                 parts.append(rec)
     local = torch.cat(parts, 0) if parts else torch.zeros((0, RECORD_BYTES), dtype=torch.uint8, device=device)
-    return gather_records(local, n_frames, group)
+    out = gather_records(local, n_frames, group)
+    if getattr(step, "finish", None) is not None:
+        step.finish()
+    return out
 
 
 def make_engine_step(engine, camera_of, params=None, approach: str = "rw"):
@@ -129,4 +135,5 @@ def make_engine_step(engine, camera_of, params=None, approach: str = "rw"):
         cams = [camera_of(lo + i) for i in range(fr.shape[0])]
         return engine.process_batch(fr, cams, prm, approach=approach)["records"]
 
+    step.finish = getattr(engine, "check_range", None)
     return step

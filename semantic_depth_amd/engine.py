@@ -73,13 +73,25 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+class RangeError(L.SdError):
+    """an activation left the range of the fp16 planes of a reduced-plane engine (|v| > 65504, or NaN): the outputs of the call are not the
+    network's.  The fp32 reference has no such failure mode; run these weights with precision='bf16x3' or 'f32'."""
+
+
+# engines whose activation planes are fp16: their conv epilogues clamp at +-65504 and count what they clamped
+FP16_PLANE_ENGINES = ("f16x2", "f16x2x2", "mixed", "plan")
+
+
 class Engine:
     def __init__(self, H: int, W: int, max_batch: int = 1, encoder: str = "resnet50", device: int = 0, precision: str = "f32",
-                 plan: tuple[str, str] | None = None):
+                 plan: tuple[str, str] | None = None, range_check: bool = True):
         """precision: 'f32' (exact f32 MFMA), 'bf16x3' (fp32-grade on the bf16 MFMA: every f32 operand as three bf16 planes that sum to it
         exactly, 6 MFMA products), 'f16x2' (fp32-grade on 3 fp16 MFMA products: activations as fp16 hi + 2^11-scaled lo planes, weights as fp16 hi + lo of
-        w * 2^12), 'bf16x2' (3 bf16 MFMA products, ~1e-5), 'mixed' (monodepth on 2 fp16 products), 'plan' (per-layer
-        choice; ``plan`` = (fcn8s layers, monodepth layers) that run the 2-product scheme, default = the calibrated built-in)"""
+        w * 2^k, k per layer), 'bf16x2' (3 bf16 MFMA products, ~1e-5), 'mixed' (monodepth on 2 fp16 products), 'plan' (per-layer
+        choice; ``plan`` = (fcn8s layers, monodepth layers) that run the 2-product scheme, default = the calibrated built-in).
+        range_check (engines with fp16 planes): a value beyond the fp16 range is an ERROR -- every network call enqueues an 8-byte read of
+        the device's saturation counter behind its launches and the next call / ``check_range()`` raises RangeError on a non-zero count
+        (no device synchronisation on the launch path)."""
         if not torch.cuda.is_available():
             raise RuntimeError("semantic_depth_amd.Engine needs a GPU (MI355X); there is no CPU fallback")
         self.lib = L.load()
@@ -109,6 +121,8 @@ class Engine:
         L.check(self.lib, h, self.lib.sd_bind_memory(h, _ptr(self._wf), _ptr(self._wm), _ptr(self._ws)), "sd_bind_memory")
         self.cap = H * W
         self.pass_frames = int(self.lib.sd_pass_frames(h))        # frames per network pass, as the handle latched it at sd_create
+        self._sat_host = torch.zeros(1, dtype=torch.int64).pin_memory() if (range_check and precision in FP16_PLANE_ENGINES) else None
+        self._sat_pending = None                                  # event behind the counter read in flight
 
     def close(self):
         if getattr(self, "h", None):
@@ -140,6 +154,42 @@ class Engine:
             st = self.lib.sd_load_weight(self.h, net, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim)
             L.check(self.lib, self.h, st, f"sd_load_weight({name})")
 
+    # ------------------------------------------------------------------ fp16 range guard
+    def _resolve_range(self, block: bool):
+        ev = self._sat_pending
+        if ev is None:
+            return
+        if block:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        self._sat_pending = None
+        n = int(self._sat_host[0])
+        if n:
+            raise RangeError(f"{n} activation values left the fp16 range (+-65504) of the '{self.precision}' engine's planes since the arenas were bound: "
+                             "the outputs are not the network's.  Use precision='bf16x3' or 'f32' for these weights (Engine.saturation_count(reset=True) clears the count)")
+
+    def _post_range_check(self):
+        """behind the launches of a network call: raise for a finished counter read, then (if none is in flight) enqueue the next one"""
+        if self._sat_host is None:
+            return
+        self._resolve_range(block=False)
+        if self._sat_pending is None:
+            L.check(self.lib, self.h, self.lib.sd_saturation_count_async(self.h, C.c_void_p(self._sat_host.data_ptr()), self._stream()),
+                    "sd_saturation_count_async")
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._sat_pending = ev
+
+    def check_range(self):
+        """wait for the work enqueued so far and raise RangeError if any conv epilogue had to clamp a value to the fp16 range (no-op for the
+        engines without fp16 planes).  The api classes call it where they bring results to the host."""
+        if self._sat_host is None:
+            return
+        self._sat_pending = None
+        self._post_range_check()
+        self._resolve_range(block=True)
+
     # ------------------------------------------------------------------ operators
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -158,6 +208,7 @@ class Engine:
         amax = torch.empty_like(road)
         st = self.lib.sd_fcn8s_forward(self.h, _ptr(frames), B, _ptr(logits), _ptr(road), _ptr(fence), _ptr(amax), self._stream())
         L.check(self.lib, self.h, st, "sd_fcn8s_forward")
+        self._post_range_check()
         return dict(logits=logits, road=road, fence=fence, argmax=amax)
 
     def monodepth_forward(self, frames: torch.Tensor, want_raw: bool = False, post_process: bool = True):
@@ -166,11 +217,13 @@ class Engine:
         if not post_process:
             st = self.lib.sd_monodepth_forward(self.h, _ptr(frames), B, None, None, self._stream())
             L.check(self.lib, self.h, st, "sd_monodepth_forward")
+            self._post_range_check()
             return None
         pp = torch.empty((B, self.H, self.W), dtype=torch.float32, device=self.device)
         raw = torch.empty((B, 2, self.H, self.W), dtype=torch.float32, device=self.device) if want_raw else None
         st = self.lib.sd_monodepth_forward(self.h, _ptr(frames), B, _ptr(pp), _ptr(raw), self._stream())
         L.check(self.lib, self.h, st, "sd_monodepth_forward")
+        self._post_range_check()
         return (pp, raw) if want_raw else pp
 
     def resize_cubic(self, frames: torch.Tensor, out_h: int | None = None, out_w: int | None = None) -> torch.Tensor:
@@ -348,7 +401,14 @@ class Engine:
         bound / the last reset (synchronises).  Non-zero = the plan does not fit these weights: use more products or precision='f32'."""
         n = C.c_uint64()
         L.check(self.lib, self.h, self.lib.sd_saturation_count(self.h, C.byref(n), int(reset)), "sd_saturation_count")
+        if reset:
+            self._sat_pending = None
         return int(n.value)
+
+    def reserve_cus(self, n: int):
+        """persistent conv launches leave ``n`` CUs free for work on another stream (the tail of the previous batch under the networks of this
+        one: sd_set_reserved_cus); 0 = use every CU"""
+        L.check(self.lib, self.h, self.lib.sd_set_reserved_cus(self.h, int(n)), "sd_set_reserved_cus")
 
     def flops_per_image(self, net: int) -> float:
         return float(self.lib.sd_net_flops_per_image(self.h, net))
