@@ -340,8 +340,9 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
         //      filled for the next tile), 16-byte runs of 8 channels per pixel and plane ----
         // REGEP (the three-product engine's 32 / 64-channel forms; round 6): the epilogue stores straight from the accumulator registers -- no LDS
         // transposition, so no barrier in front of it either (the slabs of the other forms live in the stage the slowest wave may still be reading)
-        constexpr bool REGEP = H2 && !N16;
-        if constexpr (!REGEP) __builtin_amdgcn_s_barrier();
+        constexpr bool REGEP_T = H2 && !N16;
+        const bool REGEP = REGEP_T && !(p.sw & SW_LDS_EP);
+        if (!REGEP) __builtin_amdgcn_s_barrier();
         auto epilogue = [&](auto tag, auto otag) {
             constexpr int ACT = decltype(tag)::value;
             constexpr int OF = decltype(otag)::value;          // output planes (the consumers' format): 0 bf16 hi+lo, 1 ONE fp16, 2 fp16 hi+lo
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                 }
                 return;
             }
-            if constexpr (REGEP) {
+            if constexpr (REGEP_T) if (REGEP) {
                 // A lane of the 32x32 accumulator holds, for ONE pixel (lane & 31), the channel groups 8 r4 + 4 fk .. + 3 (fk = lane >> 5): the two half-waves
                 // hold the two halves of every 8-channel (16-byte) run.  v_permlane32_swap on the packed planes of a PAIR of groups (r4, r4 + 1) leaves lanes
                 // 0-31 with channels 8 r4 .. + 7 and lanes 32-63 with channels 8 (r4 + 1) .. + 7 of their pixel: one 16-byte store per pair, plane and lane, the

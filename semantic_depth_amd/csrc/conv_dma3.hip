@@ -542,7 +542,8 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
 
     // ---- epilogue: bias + activation in f32, exact three-way split, LDS transpose (one slab per plane and wave), 16-byte runs ----
     // (HS: the epilogue stores straight from the accumulator registers -- nothing of it touches the ring, so no drain and no barrier in front of it)
-    if constexpr (!HS) {
+    const bool regep = HS && !(p.sw & SW_LDS_EP);
+    if (!regep) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -701,11 +702,16 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
     };
     long long tm_e0 = 0;
     if constexpr (TIMED) tm_e0 = __builtin_amdgcn_s_memtime();
+    bool done_regs = false;
     if constexpr (HS) {
-        if (p.act == ACT_RELU) ep_hs(ActTag<ACT_RELU>{});
-        else if (p.act == ACT_ELU) ep_hs(ActTag<ACT_ELU>{});
-        else ep_hs(ActTag<ACT_NONE>{});
-    } else {
+        if (regep) {
+            if (p.act == ACT_RELU) ep_hs(ActTag<ACT_RELU>{});
+            else if (p.act == ACT_ELU) ep_hs(ActTag<ACT_ELU>{});
+            else ep_hs(ActTag<ACT_NONE>{});
+            done_regs = true;
+        }
+    }
+    if (!done_regs) {
         if (p.act == ACT_RELU) ep3(ActTag<ACT_RELU>{});
         else if (p.act == ACT_ELU) ep3(ActTag<ACT_ELU>{});
         else ep3(ActTag<ACT_NONE>{});

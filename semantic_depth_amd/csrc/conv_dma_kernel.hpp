@@ -394,7 +394,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
 
     // ---- epilogue (as conv_split.hip): bias + activation, split once, LDS transpose, 16-byte runs per pixel ----
     // (H2, round 6: the register epilogue below touches no LDS -- no barrier in front of it)
-    if constexpr (!H2) __syncthreads();
+    const bool regep = H2 && !(p.sw & SW_LDS_EP);
+    if (!regep) __syncthreads();
     if constexpr (X3) {
         // bf16 x 3 output: the exact three-way split, one slab per plane and wave
         auto ep3 = [&](auto tag) {
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
             return p.out_planar16 ? out_hi + (size_t)(ch >> 4) * osub + px * 16 + (ch & 8) : out_hi + px * p.Cout + ch;
         };
         const int m0 = bm0 + wm0, n0 = bn0 + wn0;
-        if constexpr (H2) {
+        if constexpr (H2) if (regep) {
             // register epilogue (conv_dma3.hip ep_hs / conv_direct.hip REGEP): lanes l and l + 32 hold the two halves of every 8-channel run of pixel l & 31;
             // v_permlane32_swap on the packed planes of a PAIR of channel groups gives every lane a whole 16-byte run -- no LDS transposition
             const int fk_e = lane >> 5;
