@@ -338,11 +338,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
 
         // ---- epilogue: bias + activation, split once, LDS transpose (in the stage just consumed; the other one is being
         //      filled for the next tile), 16-byte runs of 8 channels per pixel and plane ----
-        // REGEP (the three-product engine's 32 / 64-channel forms; round 6): the epilogue stores straight from the accumulator registers -- no LDS
-        // transposition, so no barrier in front of it either (the slabs of the other forms live in the stage the slowest wave may still be reading)
-        constexpr bool REGEP_T = H2 && !N16;
-        const bool REGEP = REGEP_T && !(p.sw & SW_LDS_EP);
-        if (!REGEP) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
         auto epilogue = [&](auto tag, auto otag) {
             constexpr int ACT = decltype(tag)::value;
             constexpr int OF = decltype(otag)::value;          // output planes (the consumers' format): 0 bf16 hi+lo, 1 ONE fp16, 2 fp16 hi+lo
@@ -402,67 +398,6 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                     }
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-                return;
-            }
-            if constexpr (REGEP_T) if (REGEP) {
-                // A lane of the 32x32 accumulator holds, for ONE pixel (lane & 31), the channel groups 8 r4 + 4 fk .. + 3 (fk = lane >> 5): the two half-waves
-                // hold the two halves of every 8-channel (16-byte) run.  v_permlane32_swap on the packed planes of a PAIR of groups (r4, r4 + 1) leaves lanes
-                // 0-31 with channels 8 r4 .. + 7 and lanes 32-63 with channels 8 (r4 + 1) .. + 7 of their pixel: one 16-byte store per pair, plane and lane, the
-                // same bytes at the same addresses as the LDS-transposed form (MI355X guide T21).
-                auto store_pairs = [&](uint2* hh, uint2* ll, size_t px, size_t npix, bool ok) {
-#pragma unroll
-                    for (int k = 0; k < 4 * NB; k += 2) {
-                        if (8 * k >= p.Cout) continue;
-                        const auto hx = __builtin_amdgcn_permlane32_swap(hh[k].x, hh[k + 1].x, false, false);
-                        const auto hy = __builtin_amdgcn_permlane32_swap(hh[k].y, hh[k + 1].y, false, false);
-                        const auto lx = __builtin_amdgcn_permlane32_swap(ll[k].x, ll[k + 1].x, false, false);
-                        const auto ly = __builtin_amdgcn_permlane32_swap(ll[k].y, ll[k + 1].y, false, false);
-                        if (ok && 8 * (k + fk) < p.Cout) {
-                            uint16_t* o = oaddr(px, npix, k + fk);
-                            *reinterpret_cast<u32x4*>(o) = u32x4{hx[0], hy[0], hx[1], hy[1]};
-                            *reinterpret_cast<u32x4*>(o + p.out_plane) = u32x4{lx[0], ly[0], lx[1], ly[1]};
-                        }
-                    }
-                };
-                if (MT == 2 && p.pool) {
-                    uint2 hh[4 * NB], ll[4 * NB];
-#pragma unroll
-                    for (int r4 = 0; r4 < 4 * NB; ++r4) {
-                        hh[r4] = ll[r4] = uint2{0u, 0u};
-                        if (8 * r4 >= p.Cout) continue;
-                        const int nb = r4 >> 2, q = r4 & 3;
-                        f32x4 v;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float m = fmaxf(acc[0][nb][4 * q + r], acc[MT - 1][nb][4 * q + r]);
-                            v[r] = fmaxf(m, __shfl_xor(m, 1));
-                        }
-                        v = v * p.alpha + bias[r4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
-                        split4_fmt<OF>(v, hh[r4], ll[r4], p.sat);
-                    }
-                    const int yp = (cur.ty0 >> 1) + wave, Hp = p.H >> 1, Wp = p.W >> 1;
-                    store_pairs(hh, ll, (size_t)(cur.img * Hp + yp) * Wp + (cur.tx0 >> 1) + (frow >> 1), (size_t)Hp * Wp, !(lane & 1) && yp < Hp);
-                    return;
-                }
-#pragma unroll
-                for (int a = 0; a < MT; ++a) {
-                    const int y = cur.ty0 + MT * wave + a;
-                    uint2 hh[4 * NB], ll[4 * NB];
-#pragma unroll
-                    for (int r4 = 0; r4 < 4 * NB; ++r4) {
-                        hh[r4] = ll[r4] = uint2{0u, 0u};
-                        if (8 * r4 >= p.Cout) continue;
-                        const int nb = r4 >> 2, q = r4 & 3;
-                        f32x4 v = {acc[a][nb][4 * q], acc[a][nb][4 * q + 1], acc[a][nb][4 * q + 2], acc[a][nb][4 * q + 3]};
-                        v = v * p.alpha + bias[r4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
-                        split4_fmt<OF>(v, hh[r4], ll[r4], p.sat);
-                    }
-                    store_pairs(hh, ll, (size_t)(cur.img * p.H + y) * p.W + cur.tx0 + frow, (size_t)p.H * p.W, y < p.H);
                 }
                 return;
             }

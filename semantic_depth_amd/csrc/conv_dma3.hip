@@ -541,12 +541,8 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
     }
 
     // ---- epilogue: bias + activation in f32, exact three-way split, LDS transpose (one slab per plane and wave), 16-byte runs ----
-    // (HS: the epilogue stores straight from the accumulator registers -- nothing of it touches the ring, so no drain and no barrier in front of it)
-    const bool regep = HS && !(p.sw & SW_LDS_EP);
-    if (!regep) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     // SEMDEPTH_X3_DIAG (decomposition runs, latched in the handle's switches; 0 in production): 1 = no output stores, 2 = no epilogue at all
     const int diag = TIMED ? 0 : (((p.sw & SW_X3_DIAG_NOSTORE) ? 1 : 0) | ((p.sw & SW_X3_DIAG_NOMFMA) ? 2 : 0));
     if (diag & 2) {
@@ -557,84 +553,6 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
     // (the epilogue's per-lane values are formed from an opaque copy of the lane id: nothing of it is hoisted above the k-loop, whose registers are all taken)
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
-    // HS (round 6): the register epilogue.  A lane holds four consecutive channels of one pixel per accumulator tuple; the lanes that hold the neighbouring
-    // four are 32 lanes away (32x32x16: channels 8 r4 + 4 (lane >> 5)) or 16 lanes away (16x16x32: channels 16 r4 + 4 (lane >> 4)).  One v_permlane32_swap /
-    // v_permlane16_swap per packed dword of a PAIR of tuples leaves every lane with a whole 16-byte run of eight channels of its pixel: the same bytes at the same
-    // addresses as the LDS-transposed form, without the two LDS round trips per 32 pixels and the barrier in front of them (MI355X guide T21).
-    auto ep_hs = [&](auto tag) {
-        constexpr int ACT = decltype(tag)::value;
-        uint16_t* const out_hi = reinterpret_cast<uint16_t*>(p.out);
-        const int m0 = bm0 + wm0, n0 = bn0 + wn0;
-        auto out_pixel = [&](int mo) -> size_t {
-            size_t opix = (size_t)mo;
-            if (p.rowgrp) {              // (image group, row, image of the group, column) -> (image, row, column)
-                const int q1 = mo / p.Wout, q2 = q1 / p.rowgrp, g = q2 / p.Hout;
-                opix = ((size_t)((g * p.rowgrp + (q1 - q2 * p.rowgrp)) * p.Hout + (q2 - g * p.Hout))) * p.Wout + (mo - q1 * p.Wout);
-            }
-            if (p.fold) {                // source pixel (img, i, j) of parity (py, px) -> output pixel (2 i + py, 2 j + px)
-                const int hw = p.Hout * p.Wout, img = mo / hw, r = mo - img * hw, i = r / p.Wout, j = r - i * p.Wout;
-                opix = ((size_t)(img * 2 * p.Hout + 2 * i + (par >> 1))) * (2 * p.Wout) + 2 * j + (par & 1);
-            }
-            return opix;
-        };
-        auto value = [&](f32x4 v, int nl, uint2& h, uint2& l) {
-            v = v * p.alpha + *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
-            split4_hs(v, h, l, p.sat);
-        };
-#pragma unroll
-        for (int a = 0; a < G3_MT; ++a) {
-            if constexpr (S16) {
-                const int qd = lane_e >> 4;
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {                 // 16-pixel block of the 32
-                    const int mo = m0 + a * 32 + b * 16 + (lane_e & 15);
-                    const bool ok = mo < M && !(diag & 1);
-                    uint16_t* const o = out_hi + out_pixel(ok ? mo : 0) * p.Cout + n0;
-                    uint2 h[4], l[4];
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) value(acc16[2 * a + b][r4], r4 * 16 + 4 * qd, h[r4], l[r4]);
-#pragma unroll
-                    for (int k = 0; k < 4; k += 2) {
-                        const auto hx = __builtin_amdgcn_permlane16_swap(h[k].x, h[k + 1].x, false, false);
-                        const auto hy = __builtin_amdgcn_permlane16_swap(h[k].y, h[k + 1].y, false, false);
-                        const auto lx = __builtin_amdgcn_permlane16_swap(l[k].x, l[k + 1].x, false, false);
-                        const auto ly = __builtin_amdgcn_permlane16_swap(l[k].y, l[k + 1].y, false, false);
-                        if (ok) {
-                            uint16_t* oc = o + 16 * (k + (qd & 1)) + 8 * (qd >> 1);
-                            *reinterpret_cast<u32x4*>(oc) = u32x4{hx[0], hy[0], hx[1], hy[1]};
-                            *reinterpret_cast<u32x4*>(oc + p.out_plane) = u32x4{lx[0], ly[0], lx[1], ly[1]};
-                        }
-                    }
-                }
-            } else {
-                const int fk_e = lane_e >> 5;
-                const int mo = m0 + a * 32 + (lane_e & 31);
-                const bool ok = mo < M && !(diag & 1);
-                uint16_t* const o = out_hi + out_pixel(ok ? mo : 0) * p.Cout + n0;
-#pragma unroll
-                for (int b = 0; b < G3_NT; ++b) {
-                    uint2 h[4], l[4];
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4)
-                        value(f32x4{acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]}, b * 32 + 8 * r4 + 4 * fk_e, h[r4], l[r4]);
-#pragma unroll
-                    for (int k = 0; k < 4; k += 2) {
-                        const auto hx = __builtin_amdgcn_permlane32_swap(h[k].x, h[k + 1].x, false, false);
-                        const auto hy = __builtin_amdgcn_permlane32_swap(h[k].y, h[k + 1].y, false, false);
-                        const auto lx = __builtin_amdgcn_permlane32_swap(l[k].x, l[k + 1].x, false, false);
-                        const auto ly = __builtin_amdgcn_permlane32_swap(l[k].y, l[k + 1].y, false, false);
-                        if (ok) {
-                            uint16_t* oc = o + b * 32 + 8 * (k + fk_e);
-                            *reinterpret_cast<u32x4*>(oc) = u32x4{hx[0], hy[0], hx[1], hy[1]};
-                            *reinterpret_cast<u32x4*>(oc + p.out_plane) = u32x4{lx[0], ly[0], lx[1], ly[1]};
-                        }
-                    }
-                }
-            }
-        }
-    };
     auto ep3 = [&](auto tag) {
         constexpr int ACT = decltype(tag)::value;
         constexpr int ROW = G3_ROW;
@@ -702,20 +620,9 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
     };
     long long tm_e0 = 0;
     if constexpr (TIMED) tm_e0 = __builtin_amdgcn_s_memtime();
-    bool done_regs = false;
-    if constexpr (HS) {
-        if (regep) {
-            if (p.act == ACT_RELU) ep_hs(ActTag<ACT_RELU>{});
-            else if (p.act == ACT_ELU) ep_hs(ActTag<ACT_ELU>{});
-            else ep_hs(ActTag<ACT_NONE>{});
-            done_regs = true;
-        }
-    }
-    if (!done_regs) {
-        if (p.act == ACT_RELU) ep3(ActTag<ACT_RELU>{});
-        else if (p.act == ACT_ELU) ep3(ActTag<ACT_ELU>{});
-        else ep3(ActTag<ACT_NONE>{});
-    }
+    if (p.act == ACT_RELU) ep3(ActTag<ACT_RELU>{});
+    else if (p.act == ACT_ELU) ep3(ActTag<ACT_ELU>{});
+    else ep3(ActTag<ACT_NONE>{});
     if constexpr (TIMED) {
         const long long te = __builtin_amdgcn_s_memtime();
         if ((int)blockIdx.x == (int)gridDim.x / 2 && lane == 0 && (wave == 0 || wave == 4))

@@ -393,9 +393,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
     }
 
     // ---- epilogue (as conv_split.hip): bias + activation, split once, LDS transpose, 16-byte runs per pixel ----
-    // (H2, round 6: the register epilogue below touches no LDS -- no barrier in front of it)
-    const bool regep = H2 && !(p.sw & SW_LDS_EP);
-    if (!regep) __syncthreads();
+    __syncthreads();
     if constexpr (X3) {
         // bf16 x 3 output: the exact three-way split, one slab per plane and wave
         auto ep3 = [&](auto tag) {
@@ -461,58 +459,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
             return p.out_planar16 ? out_hi + (size_t)(ch >> 4) * osub + px * 16 + (ch & 8) : out_hi + px * p.Cout + ch;
         };
         const int m0 = bm0 + wm0, n0 = bn0 + wn0;
-        if constexpr (H2) if (regep) {
-            // register epilogue (conv_dma3.hip ep_hs / conv_direct.hip REGEP): lanes l and l + 32 hold the two halves of every 8-channel run of pixel l & 31;
-            // v_permlane32_swap on the packed planes of a PAIR of channel groups gives every lane a whole 16-byte run -- no LDS transposition
-            const int fk_e = lane >> 5;
-#pragma unroll
-            for (int a = 0; a < MT; ++a) {
-                // plain: pixel lane & 31 of the 32; pool: the window's four pixels are lanes 4 j .. 4 j + 3, lane 4 j stores pooled pixel j
-                const int mo = m0 + a * 32 + (lane & 31);
-                bool ok = mo < M;
-                size_t opix = (size_t)(ok ? mo : 0);
-                if (p.pool) { ok = ok && (lane & 3) == 0; opix >>= 2; }
-                else if (p.fold) {            // source pixel (img, i, j) of parity (py, px) -> output pixel (2 i + py, 2 j + px)
-                    const int mm = (int)opix, hw = p.Hout * p.Wout, img = mm / hw, r = mm - img * hw, i = r / p.Wout, j = r - i * p.Wout;
-                    opix = ((size_t)(img * 2 * p.Hout + 2 * i + (par >> 1))) * (2 * p.Wout) + 2 * j + (par & 1);
-                }
-#pragma unroll
-                for (int b = 0; b < NT; ++b) {
-                    uint2 h[4], l[4];
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        const int nl = b * 32 + 8 * r4 + 4 * fk_e;
-                        f32x4 v = {acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
-                        if (p.pool) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                float mx = v[r];
-                                mx = fmaxf(mx, __shfl_xor(mx, 1));
-                                mx = fmaxf(mx, __shfl_xor(mx, 2));
-                                v[r] = mx;
-                            }
-                        }
-                        v = v * p.alpha + *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
-                        split4_fmt<OF>(v, h[r4], l[r4], p.sat);
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; k += 2) {
-                        const auto hx = __builtin_amdgcn_permlane32_swap(h[k].x, h[k + 1].x, false, false);
-                        const auto hy = __builtin_amdgcn_permlane32_swap(h[k].y, h[k + 1].y, false, false);
-                        const auto lx = __builtin_amdgcn_permlane32_swap(l[k].x, l[k + 1].x, false, false);
-                        const auto ly = __builtin_amdgcn_permlane32_swap(l[k].y, l[k + 1].y, false, false);
-                        if (ok) {
-                            uint16_t* o = oaddr(opix, n0 + b * 32 + 8 * (k + fk_e));
-                            *reinterpret_cast<u32x4*>(o) = u32x4{hx[0], hy[0], hx[1], hy[1]};
-                            *reinterpret_cast<u32x4*>(o + p.out_plane) = u32x4{lx[0], ly[0], lx[1], ly[1]};
-                        }
-                    }
-                }
-            }
-            return;
-        }
         if (p.pool) {
             // fused 2x2 max pool: the four pixels of a window are four consecutive accumulator columns = lanes 4j..4j+3;
             // max over the lane quad, THEN bias + activation (monotonic), one pooled pixel per quad

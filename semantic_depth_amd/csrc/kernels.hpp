@@ -23,7 +23,6 @@ enum Switch : unsigned {
     SW_NO_FLAT = 1u << 20,       // SEMDEPTH_NO_FLAT: conv_dma3's 1x1 layers through the general gather
     SW_X3_DIAG_TIMED = 1u << 21, // SEMDEPTH_X3_DIAG=4: conv_direct3's timed copy (s_memtime stamps per item; decomposition runs)
     SW_HS_TAPS = 1u << 23,       // SEMDEPTH_HS_PHASED_TAPS: ALL tap layers of the three-product engine (folded upconvs, strided 3x3; fc6 is there anyway) on conv_dma3's two-phase ring
-    SW_LDS_EP = 1u << 24,        // SEMDEPTH_LDS_EPILOGUE: the three-product engine's epilogues through the LDS transposition instead of v_permlane*_swap (round 6 A/B)
     SW_MFMA32 = 1u << 22         // SEMDEPTH_MFMA32: conv_dma3's bf16 x 3 layers on 32x32x16 MFMAs instead of 16x16x32 (round 5; conv_dma3.hip "S16")
 };
 unsigned latch_switches();      // plan.cpp

@@ -1178,87 +1178,40 @@ __device__ __forceinline__ void shell_row(const GridMeta& g, const int* st, int 
 //  d32 > kth (1 + 2e-6) rejects without the nine half-rate f64 operations, exactness untouched -- made the statistical filter SLOWER,
 //  2.15 -> 2.42 ms per 32 frames (2.96 with the bound converted per candidate), and left the radius filter at 1.50: the search waits
 //  for its gathers, not for its arithmetic; the extra compare + branch per candidate only lengthens the dependent chain.)
-template <class L, class F>
-__device__ __forceinline__ void visit_loaded(L&& load, double qx, double qy, double qz, int t0, int t1, F&& push) {
+template <class F>
+__device__ __forceinline__ void visit_points(const float* __restrict__ pts, double qx, double qy, double qz, int t0, int t1, F&& push) {
     for (int t = t0; t < t1; t += 4) {
         float c[4][3];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int tt = min(t + u, t1 - 1);
-            { const float4 v4 = load(tt); c[u][0] = v4.x; c[u][1] = v4.y; c[u][2] = v4.z; }
+            { const float4 v4 = reinterpret_cast<const float4*>(pts)[tt]; c[u][0] = v4.x; c[u][1] = v4.y; c[u][2] = v4.z; }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (t + u < t1) push(dist2(qx, qy, qz, c[u]));
     }
 }
-template <class F>
-__device__ __forceinline__ void visit_points(const float* __restrict__ pts, double qx, double qy, double qz, int t0, int t1, F&& push) {
-    visit_loaded([&](int tt) { return reinterpret_cast<const float4*>(pts)[tt]; }, qx, qy, qz, t0, t1, push);
-}
 
 // one thread per query for the first SOR_RSOFT shells (99 % of a dense cloud); a query whose k-th neighbour is still
 // farther than the searched shells is appended to the frame's hard list (one slow lane would stall its whole wave)
-// Round 6: the candidates of shells 0 and 1 come out of LDS.  The queries of a workgroup are 256 CONSECUTIVE points of the cell-sorted array, i.e. the cells
-// [c_first, c_last] of a few grid rows; for each of the nine (dz, dy) row offsets the cells [c_first + off - 1, c_last + off + 1] (off = (dz gy + dy) gx) hold
-// every shell-0/1 candidate of every query of the workgroup, and they are ONE contiguous range of the cell-sorted points.  The nine ranges (~2-3 k points) are
-// copied into LDS once, coalesced, and the per-thread search reads them there: before, every thread gathered its ~100-200 candidates from L2 / HBM on its own
-// (14 GB of 16-byte gathers per 32 frames; the kernel waited for them, not for its arithmetic -- the note on visit_loaded above).  Same candidates, same
-// canonical d2, same k smallest: bit-identical results.  A workgroup whose ranges do not fit (a very dense or very scattered neighbourhood) reads global memory as before.
-constexpr int KNN_LDS_PTS = 3584;      // float4 slots (56 KB: two workgroups per CU)
 template <int CAPK>
 __global__ __launch_bounds__(256) void sor_knn_kernel(CloudView in, int cap, const GridMeta* meta, const int* cell_start,
                                                       const int* sidx, const float* sxyz, int k, double* mean_d, int* hard_n, int* hard_idx,
                                                       double* hard_best) {
-    __shared__ float4 spts[KNN_LDS_PTS];
-    __shared__ int s_start[9], s_len[9], s_delta[9], s_fit;
     const int b = blockIdx.y;
-    const int j0 = blockIdx.x * 256, j = j0 + threadIdx.x;
+    const int j = blockIdx.x * 256 + threadIdx.x;
     const int n = min(in.n[b], cap);
-    if (j0 >= n) return;                                  // (uniform over the workgroup)
+    if (j >= n) return;
     const GridMeta g = meta[b];
     const int* st = cell_start + (size_t)b * (GRID_CELLS + 1);
     const float* pts = sxyz + (size_t)b * cap * 4;      // float4 per point
-    if (threadIdx.x < 9) {
-        const float* qa = pts + (size_t)j0 * 4;
-        const float* qb = pts + (size_t)min(j0 + 255, n - 1) * 4;
-        const int ca = (cell_coord((double)qa[2], g.oz, g.inv, g.gz) * g.gy + cell_coord((double)qa[1], g.oy, g.inv, g.gy)) * g.gx + cell_coord((double)qa[0], g.ox, g.inv, g.gx);
-        const int cb = (cell_coord((double)qb[2], g.oz, g.inv, g.gz) * g.gy + cell_coord((double)qb[1], g.oy, g.inv, g.gy)) * g.gx + cell_coord((double)qb[0], g.ox, g.inv, g.gx);
-        const int off = (((int)threadIdx.x / 3 - 1) * g.gy + ((int)threadIdx.x % 3 - 1)) * g.gx;
-        const int lo = max(min(ca, cb) + off - 1, 0), hi = min(max(ca, cb) + off + 1, GRID_CELLS - 1);
-        int s0 = 0, s1 = 0;
-        if (lo <= hi) { s0 = st[lo]; s1 = st[hi + 1]; }
-        s_start[threadIdx.x] = s0; s_len[threadIdx.x] = s1 - s0;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int acc = 0;
-#pragma unroll
-        for (int r = 0; r < 9; ++r) { s_delta[r] = acc - s_start[r]; acc += s_len[r]; }
-        s_fit = acc <= KNN_LDS_PTS ? 1 : 0;
-    }
-    __syncthreads();
-    const bool fit = s_fit != 0;
-    if (fit) {
-#pragma unroll 1
-        for (int r = 0; r < 9; ++r) {
-            const int len = s_len[r], src = s_start[r], dst = src + s_delta[r];
-            for (int t = threadIdx.x; t < len; t += 256) spts[dst + t] = reinterpret_cast<const float4*>(pts)[src + t];
-        }
-    }
-    __syncthreads();
-    if (j >= n) return;
     const float* q = pts + (size_t)j * 4;
     const double qx = q[0], qy = q[1], qz = q[2];
     const int cx = cell_coord(qx, g.ox, g.inv, g.gx), cy = cell_coord(qy, g.oy, g.inv, g.gy), cz = cell_coord(qz, g.oz, g.inv, g.gz);
     const int kk = k < n ? k : n;
     TopK<CAPK> top;
     top.init(kk);
-    // candidates [t0, t1) of grid row r = 3 (dz + 1) + (dy + 1): out of LDS when the workgroup's ranges fit
-    auto visit01 = [&](int r, int t0, int t1) {
-        if (fit) { const int d = s_delta[r]; visit_loaded([&](int tt) { return spts[tt + d]; }, qx, qy, qz, t0, t1, [&](double dd) { top.push(dd); }); }
-        else visit_points(pts, qx, qy, qz, t0, t1, [&](double dd) { top.push(dd); });
-    };
     const int rall = max(g.gx, max(g.gy, g.gz));
     bool done = false;
     // shells 0 and 1 (every query visits them: the bound of shell 0 is zero): the cell ranges of all ten runs -- the own cell,
@@ -1284,18 +1237,18 @@ __global__ __launch_bounds__(256) void sor_knn_kernel(CloudView in, int cap, con
             const int slot = i < 4 ? i + 1 : i;
             t0[slot] = st[rb + x0]; t1[slot] = st[rb + x1 + 1];
         }
-        visit01(4, t0[0], t1[0]);                           // shell 0
+        visit_points(pts, qx, qy, qz, t0[0], t1[0], [&](double d) { top.push(d); });       // shell 0
         if (top.kth <= 0.0 || rall == 0) done = true;      // (the bound of shell 0 is zero)
         if (!done) {
             // shell 1 in the order of the generic walk below: (dz, dy) rows ascending, centre row = its two end cells
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
                 if (i == 4) {
-                    visit01(4, t0[9], t1[9]);
-                    visit01(4, t0[10], t1[10]);
+                    visit_points(pts, qx, qy, qz, t0[9], t1[9], [&](double d) { top.push(d); });
+                    visit_points(pts, qx, qy, qz, t0[10], t1[10], [&](double d) { top.push(d); });
                 } else {
                     const int slot = i < 4 ? i + 1 : i;
-                    visit01(i, t0[slot], t1[slot]);
+                    visit_points(pts, qx, qy, qz, t0[slot], t1[slot], [&](double d) { top.push(d); });
                 }
             }
             const double bound = g.cell * (1.0 - 1e-9);

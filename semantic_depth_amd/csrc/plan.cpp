@@ -16,7 +16,7 @@ unsigned latch_switches() {
         {"SEMDEPTH_NO_FUSE4", SW_NO_FUSE4}, {"SEMDEPTH_NO_SMALLN_TILE", SW_NO_SMALLN_TILE}, {"SEMDEPTH_NO_DMA", SW_NO_DMA},
         {"SEMDEPTH_NO_FUSE1", SW_NO_FUSE1}, {"SEMDEPTH_X3_RING3", SW_X3_RING3}, {"SEMDEPTH_NO_DMA3", SW_NO_DMA3}, {"SEMDEPTH_NO_FOLD", SW_NO_FOLD},
         {"SEMDEPTH_NO_TAIL1", SW_NO_TAIL1}, {"SEMDEPTH_NO_ROWSKIP", SW_NO_ROWSKIP},
-        {"SEMDEPTH_NO_FLAT", SW_NO_FLAT}, {"SEMDEPTH_MFMA32", SW_MFMA32}, {"SEMDEPTH_HS_PHASED_TAPS", SW_HS_TAPS}, {"SEMDEPTH_LDS_EPILOGUE", SW_LDS_EP}};
+        {"SEMDEPTH_NO_FLAT", SW_NO_FLAT}, {"SEMDEPTH_MFMA32", SW_MFMA32}, {"SEMDEPTH_HS_PHASED_TAPS", SW_HS_TAPS}};
     unsigned sw = 0;
     for (const auto& e : tab)
         if (std::getenv(e.name)) sw |= e.bit;
