@@ -12,8 +12,8 @@ fence = torch.from_numpy(np.repeat(np.repeat((blob > 0.4) & (blob < 0.73), 16, 1
 frames = torch.from_numpy(rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)).cuda()
 cams = [Camera(W / 2, H / 2, 1000.0, 1.0, float(W))] * B
 res = {}
-for name, env in (("onepass", {}), ("three_launch", {"SEMDEPTH_NO_FUSE1": "1"})):
-    os.environ.pop("SEMDEPTH_NO_FUSE1", None)
+for name, env in (("onepass", {}), ("three_launch", {"SEMDEPTH_DISABLE": "fuse1"})):
+    os.environ.pop("SEMDEPTH_DISABLE", None)
     os.environ.update(env)
     e = Engine(H, W, B, "resnet50", precision="bf16x2")
     for mode in ("from_raw", "from_pp"):

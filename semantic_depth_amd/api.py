@@ -24,10 +24,11 @@ from .engine import Camera, Engine, FenceParams, RoadWidthParams
 # live in one process / on one GPU; here they share the handle, the activation workspace and the stream
 # ---------------------------------------------------------------------------------------------------------------------
 _engines: dict = {}
-# The reference computes in float32 (semantic_depth.py:550-552, 675).  Two engines here do, to the same measured error against a float64
-# oracle: "bf16x3" (every f32 operand carried exactly as three bf16 planes, six MFMA products, f32 accumulation: the engine bench.py
-# headlines) and "f32" (the f32 MFMA, about half the speed).  The classes below default to the faster one; precision="f32" selects the other.
-DEFAULT_PRECISION = "bf16x3"
+# The reference computes in float32 (semantic_depth.py:550-552, 675).  Three engines here do, to the same measured error against a float64
+# oracle (profiles/r06_f32_grade_check.txt): "f16x2" (every f32 operand carried to 22 bits as fp16 hi + scaled lo planes, three fp16 MFMA products, f32
+# accumulation: the engine bench.py headlines; a value beyond the fp16 range of its planes raises engine.RangeError), "bf16x3" (three exact bf16 planes,
+# six products, no range limit) and "f32" (the f32 MFMA, a third of the speed).  The classes below default to the fastest; precision= selects the others.
+DEFAULT_PRECISION = "f16x2"
 
 
 def shared_engine(H: int, W: int, device: int = 0, precision: str = DEFAULT_PRECISION, encoder: str | None = None, max_batch: int = 1) -> Engine:

@@ -61,11 +61,14 @@ def source_hash() -> str:
         h.update(f.encode() + b"\0")
         h.update(open(os.path.join(CSRC, f), "rb").read())
     h.update(open(os.path.join(HERE, "..", "include", "semdepth.h"), "rb").read())
-    h.update(repr(SOURCES).encode() + ARCH.encode() + repr(LINK_FLAGS).encode())
+    h.update(repr(SOURCES).encode() + ARCH.encode() + repr(LINK_FLAGS).encode() + (repr(DEV_FLAGS).encode() if DEV_FLAGS else b""))
     return h.hexdigest()[:16]
 
 
 LINK_FLAGS = ["-lz", "-lpthread"]      # zlib: host_png.cpp inflates PNG streams natively
+# SEMDEPTH_DEV_BUILD=1: -DSD_DEV_VARIANTS -- the closed A/B variants and the s_memtime / no-store / no-MFMA decomposition copies of the kernels
+# (scripts/decompose_x3.py, dma3_timed.py, direct3_timed.py).  The shipped library carries none of them; the flag is part of the source hash.
+DEV_FLAGS = ["-DSD_DEV_VARIANTS"] if os.environ.get("SEMDEPTH_DEV_BUILD") == "1" else []
 
 
 def _deps(path: str, seen=None) -> list:
@@ -108,7 +111,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         op = os.path.join(OBJ, src + ".o")
         objs.append(op)
         if force or _stale(op, _deps(sp)) or (src.endswith(".hip") and not os.path.exists(op + ".remarks")) or (src == "capi.cpp" and hash_changed):
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", sp, "-o", op] + extra
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", sp, "-o", op] + extra + DEV_FLAGS
             if src.endswith(".hip"):
                 cmd.append("-Rpass-analysis=kernel-resource-usage")      # registers / spills / LDS per kernel -> <obj>.remarks
             if src == "capi.cpp":

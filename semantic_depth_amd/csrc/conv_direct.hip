@@ -518,7 +518,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
             }
         };
         // SEMDEPTH_X3_DIAG=2 on the H2 form (decomposition runs, scripts/decompose_x3.py f16x2; 0 in production): no epilogue at all
-        if (H2 && !N16 && (p.sw & SW_X3_DIAG_NOMFMA)) { if (acc[0][0][0] == 12345.678f) p.out[0] = acc[MT - 1][NB - 1][3]; }
+        if (H2 && !N16 && (SD_DIAG_BITS(p.sw) & 2)) { if (acc[0][0][0] == 12345.678f) p.out[0] = acc[MT - 1][NB - 1][3]; }
         else if (p.act == ACT_RELU) ep(ActTag<ACT_RELU>{});
         else if (p.act == ACT_ELU) ep(ActTag<ACT_ELU>{});
         else if (N16 && p.act == ACT_SIGMOID03) ep(ActTag<ACT_SIGMOID03>{});

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct3_kernel(const ConvDirectPa
     const int frow = lane & 31, fk = lane >> 5;
     const int fpar = wave & 3, fpy = fpar >> 1, fpx = fpar & 1, fhh = wave >> 2;     // FOLD: this wave's parity and half of the tile's source rows
     // SEMDEPTH_X3_DIAG (decomposition runs, latched in the handle's switches): 1 no output stores, 2 no MFMAs; 0 in production
-    const int diag = ((p.sw & SW_X3_DIAG_NOSTORE) ? 1 : 0) | ((p.sw & SW_X3_DIAG_NOMFMA) ? 2 : 0);
+    const int diag = SD_DIAG_BITS(p.sw);
 
     // work item = (tile, pass of <= 64 output channels); the passes of a tile are neighbouring items
     const int items = total * p.nsplit;
@@ -598,6 +598,10 @@ hipError_t launch_conv_direct3(const ConvDirectParams& p, hipStream_t s) {
     // SEMDEPTH_X3_RING3 then select them); the default build carries six instantiations of this kernel instead of sixteen.
     const ConvDirectParams& pd = p;
 #ifdef SD_DEV_VARIANTS
+    if ((p.sw & SW_X3_DIAG_TIMED) && p.Cout > 32 && !up) {          // SEMDEPTH_X3_DIAG=4: the timed copy of the dominant form
+        hipLaunchKernelGGL((conv_direct3_kernel<2, false, 2, 2, false, true>), grid, dim3(512), 0, s, pd);
+        return hipGetLastError();
+    }
     const int keep = (p.sw & SW_X3_NOKEEP) ? 0 : 2;
     const bool ring3 = (p.sw & SW_X3_RING3) != 0;
 #define SD_D3(NB_, UP_, WS_) do { if (keep >= 2) hipLaunchKernelGGL((conv_direct3_kernel<NB_, UP_, 2, WS_>), grid, dim3(512), 0, s, pd); \
@@ -610,10 +614,6 @@ hipError_t launch_conv_direct3(const ConvDirectParams& p, hipStream_t s) {
     }
 #else
 #define SD_D3(NB_, UP_, WS_) hipLaunchKernelGGL((conv_direct3_kernel<NB_, UP_, 2, WS_>), grid, dim3(512), 0, s, pd)
-    if ((p.sw & SW_X3_DIAG_TIMED) && p.Cout > 32 && !up) {          // SEMDEPTH_X3_DIAG=4: the timed copy of the dominant form
-        hipLaunchKernelGGL((conv_direct3_kernel<2, false, 2, 2, false, true>), grid, dim3(512), 0, s, pd);
-        return hipGetLastError();
-    }
     if (p.Cout <= 32) { if (up) SD_D3(1, true, 2); else SD_D3(1, false, 2); }
     else { if (up) SD_D3(2, true, 2); else SD_D3(2, false, 2); }
 #endif

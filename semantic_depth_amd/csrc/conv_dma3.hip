@@ -544,7 +544,7 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // SEMDEPTH_X3_DIAG (decomposition runs, latched in the handle's switches; 0 in production): 1 = no output stores, 2 = no epilogue at all
-    const int diag = TIMED ? 0 : (((p.sw & SW_X3_DIAG_NOSTORE) ? 1 : 0) | ((p.sw & SW_X3_DIAG_NOMFMA) ? 2 : 0));
+    const int diag = TIMED ? 0 : SD_DIAG_BITS(p.sw);
     if (diag & 2) {
         if constexpr (S16) { if (acc16[0][0][0] == 12345.678f) p.out[0] = acc16[7][3][3]; }
         else { if (acc[0][0][0] == 12345.678f) p.out[0] = acc[1][1][3]; }
@@ -667,10 +667,12 @@ hipError_t launch_conv_dma3(const ConvParams& p, hipStream_t s) {
     const bool s16 = !(p.sw & SW_MFMA32);
 #define SD_G3(MODE_, HS_, TIMED_) do { if (s16) hipLaunchKernelGGL((conv_dma3_kernel<MODE_, HS_, TIMED_, !(HS_) || (MODE_) == 1>), grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN); \
                                        else hipLaunchKernelGGL((conv_dma3_kernel<MODE_, HS_, TIMED_, false>), grid, dim3(512), 0, s, p, (int)M, tilesM, tilesN); } while (0)
+#ifdef SD_DEV_VARIANTS
     if (mode == 1 && (p.sw & SW_X3_DIAG_NOSTORE) && (p.sw & SW_X3_DIAG_NOMFMA)) {          // SEMDEPTH_X3_DIAG=3: the timed copy of the 1x1 form
         if (p.f16 == 4) SD_G3(1, true, true); else SD_G3(1, false, true);
         return hipGetLastError();
     }
+#endif
     if (p.f16 == 4) {           // SD_PREC_F16X2: the two-plane, two-phase form
         if (mode == 1) SD_G3(1, true, false); else if (mode == 2) SD_G3(2, true, false); else SD_G3(0, true, false);
         return hipGetLastError();

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(512, 1) void dec_tail1_kernel(const DecTailParams p
     const int ntiles = ntx * nty * p.N;
     const int lp = lane & 15, lg = lane >> 4;            // MFMA fragment: pixel / output channel (lane & 15), k group (lane >> 4)
     // SEMDEPTH_X3_DIAG (decomposition runs; 0 in production): 1 / 2 / 3 = without stage 1 / 2 / 3
-    const int diag = ((p.sw & SW_X3_DIAG_NOSTORE) ? 1 : 0) | ((p.sw & SW_X3_DIAG_NOMFMA) ? 2 : 0);
+    const int diag = SD_DIAG_BITS(p.sw);
 
     struct Tile { int img, y0, x0; };
     auto tile_of = [&](int it) {

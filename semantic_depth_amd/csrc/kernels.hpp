@@ -7,8 +7,8 @@ namespace sd {
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
-// run-time A/B switches (SEMDEPTH_* environment variables), latched ONCE per handle in sd_create (capi.cpp latch_switches)
-// and handed to the launchers in their parameter structs: nothing on the launch path calls getenv
+// run-time switches (SEMDEPTH_DISABLE=name,... -- plan.cpp sd_disabled; the closed A/Bs and the decomposition runs of earlier rounds in -DSD_DEV_VARIANTS builds
+// only), latched ONCE per handle in sd_create (plan.cpp latch_switches) and handed to the launchers in their parameter structs: nothing on the launch path calls getenv
 enum Switch : unsigned {
     SW_NO_N16 = 1u << 0, SW_NO_UPTILE = 1u << 1, SW_NO_N16_MT1 = 1u << 2, SW_NO_DMA_BIG = 1u << 3, SW_NO_DMA32 = 1u << 4,
     SW_NO_STEM = 1u << 5, SW_NO_FUSE4 = 1u << 6, SW_NO_SMALLN_TILE = 1u << 7, SW_NO_DMA = 1u << 8, SW_DMA_DBG16 = 1u << 9,
@@ -26,6 +26,14 @@ enum Switch : unsigned {
     SW_MFMA32 = 1u << 22         // SEMDEPTH_MFMA32: conv_dma3's bf16 x 3 layers on 32x32x16 MFMAs instead of 16x16x32 (round 5; conv_dma3.hip "S16")
 };
 unsigned latch_switches();      // plan.cpp
+bool sd_disabled(const char* what);   // plan.cpp: is `what` in SEMDEPTH_DISABLE?
+// decomposition runs (SEMDEPTH_X3_DIAG: 1 no output stores, 2 no MFMAs / no epilogue): compiled into -DSD_DEV_VARIANTS builds only -- in the shipped library
+// the expression is the constant 0 and every branch on it folds away
+#ifdef SD_DEV_VARIANTS
+#define SD_DIAG_BITS(sw) ((((sw) & sd::SW_X3_DIAG_NOSTORE) ? 1 : 0) | (((sw) & sd::SW_X3_DIAG_NOMFMA) ? 2 : 0))
+#else
+#define SD_DIAG_BITS(sw) 0
+#endif
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_SIGMOID03 = 3 /* 0.3*sigmoid, monodepth get_disp */ };
 

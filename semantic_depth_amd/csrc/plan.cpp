@@ -9,21 +9,48 @@
 
 namespace sd {
 
+// SEMDEPTH_DISABLE=name[,name...]: the ONE run-time variable that switches specialised kernels off in favour of the generic ones behind them (parity tests, A/B
+// runs).  Names: dma dma3 direct stem fold tail1 pool_fuse planar n16 fuse1 fuse4 flat rowskip dma_big mfma16.  Read when a handle is created (plan + switches).
+// Closed A/Bs of earlier rounds (SEMDEPTH_NO_UPTILE, _NO_N16_MT1, _NO_DMA32, _NO_SMALLN_TILE, _X3_RING3, _X3_KEEP, _HS_PHASED_TAPS, _DMA_DBG, _NO_PLANAR_WIDE,
+// _NO_DIRECT128, _DIRECT_MINPIX, _NO_MFMA_HEADS, _X3_NO_POOL_FUSE) and the decomposition runs (SEMDEPTH_X3_DIAG) exist in -DSD_DEV_VARIANTS builds only
+// (SEMDEPTH_DEV_BUILD=1 python -m semantic_depth_amd.build --force).
+bool sd_disabled(const char* what) {
+    const char* e = std::getenv("SEMDEPTH_DISABLE");
+    if (!e) return false;
+    const size_t n = std::strlen(what);
+    for (const char* p = e; *p;) {
+        const char* q = std::strchr(p, ',');
+        const size_t len = q ? (size_t)(q - p) : std::strlen(p);
+        if (len == n && !std::strncmp(p, what, n)) return true;
+        p += len + (q ? 1 : 0);
+    }
+    return false;
+}
+static const char* dev_env(const char* name) {
+#ifdef SD_DEV_VARIANTS
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 unsigned latch_switches() {
     static const struct { const char* name; unsigned bit; } tab[] = {
-        {"SEMDEPTH_NO_N16", SW_NO_N16}, {"SEMDEPTH_NO_UPTILE", SW_NO_UPTILE}, {"SEMDEPTH_NO_N16_MT1", SW_NO_N16_MT1},
-        {"SEMDEPTH_NO_DMA_BIG", SW_NO_DMA_BIG}, {"SEMDEPTH_NO_DMA32", SW_NO_DMA32}, {"SEMDEPTH_NO_STEM", SW_NO_STEM},
-        {"SEMDEPTH_NO_FUSE4", SW_NO_FUSE4}, {"SEMDEPTH_NO_SMALLN_TILE", SW_NO_SMALLN_TILE}, {"SEMDEPTH_NO_DMA", SW_NO_DMA},
-        {"SEMDEPTH_NO_FUSE1", SW_NO_FUSE1}, {"SEMDEPTH_X3_RING3", SW_X3_RING3}, {"SEMDEPTH_NO_DMA3", SW_NO_DMA3}, {"SEMDEPTH_NO_FOLD", SW_NO_FOLD},
-        {"SEMDEPTH_NO_TAIL1", SW_NO_TAIL1}, {"SEMDEPTH_NO_ROWSKIP", SW_NO_ROWSKIP},
-        {"SEMDEPTH_NO_FLAT", SW_NO_FLAT}, {"SEMDEPTH_MFMA32", SW_MFMA32}, {"SEMDEPTH_HS_PHASED_TAPS", SW_HS_TAPS}};
+        {"n16", SW_NO_N16}, {"dma_big", SW_NO_DMA_BIG}, {"stem", SW_NO_STEM}, {"fuse4", SW_NO_FUSE4}, {"dma", SW_NO_DMA}, {"fuse1", SW_NO_FUSE1},
+        {"dma3", SW_NO_DMA3}, {"fold", SW_NO_FOLD}, {"tail1", SW_NO_TAIL1}, {"rowskip", SW_NO_ROWSKIP}, {"flat", SW_NO_FLAT}, {"mfma16", SW_MFMA32}};
+    static const struct { const char* name; unsigned bit; } dev[] = {
+        {"SEMDEPTH_NO_UPTILE", SW_NO_UPTILE}, {"SEMDEPTH_NO_N16_MT1", SW_NO_N16_MT1}, {"SEMDEPTH_NO_DMA32", SW_NO_DMA32}, {"SEMDEPTH_NO_SMALLN_TILE", SW_NO_SMALLN_TILE},
+        {"SEMDEPTH_X3_RING3", SW_X3_RING3}, {"SEMDEPTH_HS_PHASED_TAPS", SW_HS_TAPS}};
     unsigned sw = 0;
     for (const auto& e : tab)
-        if (std::getenv(e.name)) sw |= e.bit;
-    if (const char* d = std::getenv("SEMDEPTH_DMA_DBG")) if (atoi(d) & 16) sw |= SW_DMA_DBG16;
+        if (sd_disabled(e.name)) sw |= e.bit;
+    for (const auto& e : dev)
+        if (dev_env(e.name)) sw |= e.bit;
+    if (const char* d = dev_env("SEMDEPTH_DMA_DBG")) if (atoi(d) & 16) sw |= SW_DMA_DBG16;
     if (const char* v = std::getenv("SEMDEPTH_PROFILE_VERBOSE")) if (v[0] == '1') sw |= SW_PROFILE_VERBOSE;
-    if (const char* v = std::getenv("SEMDEPTH_X3_KEEP")) if (atoi(v) == 0) sw |= SW_X3_NOKEEP;
-    if (const char* v = std::getenv("SEMDEPTH_X3_DIAG")) sw |= ((atoi(v) & 1) ? SW_X3_DIAG_NOSTORE : 0u) | ((atoi(v) & 2) ? SW_X3_DIAG_NOMFMA : 0u) | ((atoi(v) & 4) ? SW_X3_DIAG_TIMED : 0u);
+    if (const char* v = dev_env("SEMDEPTH_X3_KEEP")) if (atoi(v) == 0) sw |= SW_X3_NOKEEP;
+    if (const char* v = dev_env("SEMDEPTH_X3_DIAG")) sw |= ((atoi(v) & 1) ? SW_X3_DIAG_NOSTORE : 0u) | ((atoi(v) & 2) ? SW_X3_DIAG_NOMFMA : 0u) | ((atoi(v) & 4) ? SW_X3_DIAG_TIMED : 0u);
     return sw;
 }
 
@@ -110,12 +137,12 @@ struct Builder {
         // full-resolution few-channel 3x3 layers of the split engine go to the direct (halo-tile) kernel
         // 128 .. 512 output channels: 2 .. 8 passes of 64 per tile (256 and more only where an image has enough tiles: the
         // choice must not depend on the batch)
-        const char* mp = std::getenv("SEMDEPTH_DIRECT_MINPIX");
+        const char* mp = dev_env("SEMDEPTH_DIRECT_MINPIX");
         const int64_t minpix = mp ? std::atoll(mp) : 512;
-        const bool split128 = (Cout == 128 && !std::getenv("SEMDEPTH_NO_DIRECT128")) ||
+        const bool split128 = (Cout == 128 && !dev_env("SEMDEPTH_NO_DIRECT128")) ||
                               ((Cout == 256 || Cout == 512) && (int64_t)Hin * Win >= minpix);
         bool direct = p.prec && k == 3 && stride == 1 && (Cout <= 32 || Cout == 64 || split128) && Cout % 8 == 0 && Win % 32 == 0 && residual < 0 &&
-                      !std::getenv("SEMDEPTH_NO_DIRECT");
+                      !sd_disabled("direct");
         for (int i = 0; i < op.nsrc; ++i)
             if (p.tensors[op.src[i]].C % 8 || op.sstride[i] != 1) direct = false;
         // bf16 x 3: an upconv layer (3x3 on a x2 nearest-neighbour upsampled source) with a wide output runs as four 2x2 convs on the source
@@ -224,7 +251,7 @@ struct Builder {
         // a 3x3 head whose output feeds the next iconv (disp4..disp2, written as one zero-padded octet per pixel) is a direct
         // conv on the 16-wide MFMA: its two real output channels ride in a 16-column weight image
         if (feeds_conv && p.prec && !p.x3 && k == 3 && t.W % 32 == 0 && t.C % 8 == 0 && nout <= 8 && nout == cout_tf &&
-            !std::getenv("SEMDEPTH_NO_DIRECT") && !std::getenv("SEMDEPTH_NO_N16") && !std::getenv("SEMDEPTH_NO_MFMA_HEADS")) {
+            !sd_disabled("direct") && !sd_disabled("n16") && !dev_env("SEMDEPTH_NO_MFMA_HEADS")) {
             op.kind = OP_CONV_DIRECT; op.stride = 1;
             op.nchunks = (t.C + 15) / 16;
             op.nsplit = 1;
@@ -282,8 +309,8 @@ struct Builder {
         const int Ho = zero3 ? (t.H - 1) / 2 + 1 : t.H / 2, Wo = zero3 ? (t.W - 1) / 2 + 1 : t.W / 2;
         // a direct conv whose only consumer is this pool applies it in its epilogue (max commutes with bias + ReLU/ELU);
         // the full-resolution tensor is then never written
-        if (!zero3 && !(p.x3 && std::getenv("SEMDEPTH_X3_NO_POOL_FUSE")) && !p.ops.empty() && p.ops.back().kind == OP_CONV_DIRECT && p.ops.back().dst == src && t.H % 2 == 0 && t.W % 2 == 0 &&
-            (p.ops.back().act == ACT_RELU || p.ops.back().act == ACT_ELU || p.ops.back().act == ACT_NONE) && !std::getenv("SEMDEPTH_NO_POOL_FUSE")) {
+        if (!zero3 && !(p.x3 && dev_env("SEMDEPTH_X3_NO_POOL_FUSE")) && !p.ops.empty() && p.ops.back().kind == OP_CONV_DIRECT && p.ops.back().dst == src && t.H % 2 == 0 && t.W % 2 == 0 &&
+            (p.ops.back().act == ACT_RELU || p.ops.back().act == ACT_ELU || p.ops.back().act == ACT_NONE) && !sd_disabled("pool_fuse")) {
             OpDesc& prod = p.ops.back();
             prod.fuse_pool = 1;
             for (auto it = p.tensor_by_name.begin(); it != p.tensor_by_name.end();)
@@ -295,8 +322,8 @@ struct Builder {
         if (!zero3 && p.prec && !p.x3 && !p.ops.empty() && p.ops.back().kind == OP_CONV && p.ops.back().dst == src && p.ops.back().vec &&
             p.ops.back().nsrc == 1 && p.ops.back().Kvec == p.ops.back().Kpad && p.ops.back().Kpad >= 64 && t.C % 64 == 0 &&
             p.ops.back().residual < 0 && t.H % 2 == 0 && t.W % 2 == 0 &&
-            (p.ops.back().act == ACT_RELU || p.ops.back().act == ACT_ELU || p.ops.back().act == ACT_NONE) && !std::getenv("SEMDEPTH_NO_POOL_FUSE") &&
-            !std::getenv("SEMDEPTH_NO_DMA")) {
+            (p.ops.back().act == ACT_RELU || p.ops.back().act == ACT_ELU || p.ops.back().act == ACT_NONE) && !sd_disabled("pool_fuse") &&
+            !sd_disabled("dma")) {
             OpDesc& prod = p.ops.back();
             prod.fuse_pool = 1;
             for (auto it = p.tensor_by_name.begin(); it != p.tensor_by_name.end();)
@@ -313,7 +340,7 @@ struct Builder {
     // LDS-tiled few-channel heads is handed over as 16-channel sub-planes (TensorDesc::planar16): the reader's 16-channel
     // chunk of a pixel row is then one contiguous run instead of 32 bytes out of every pixel's line
     void mark_planar() {
-        if (!p.prec || std::getenv("SEMDEPTH_NO_PLANAR")) return;
+        if (!p.prec || sd_disabled("planar")) return;
         if (p.x3) {
             // bf16 x 3 (round 5): the one hand-off whose writer and reader both know the layout -- a stem conv (conv_stem.hip) whose output is read by direct 3x3
             // convs only (FCN-8s conv1_1 -> conv1_2): a 16-channel chunk of conv1_2's halo is then a contiguous run of the sub-plane instead of 32 bytes out of
@@ -337,7 +364,7 @@ struct Builder {
             }
             return;
         }
-        const bool wide = !std::getenv("SEMDEPTH_NO_PLANAR_WIDE");
+        const bool wide = !dev_env("SEMDEPTH_NO_PLANAR_WIDE");
         for (size_t ti = 0; ti < p.tensors.size(); ++ti) {
             TensorDesc& t = p.tensors[ti];
             if (t.C % 16 || (int)ti == p.t_output || (int)ti == p.t_input) continue;
@@ -347,7 +374,7 @@ struct Builder {
                 if (op.dst == (int)ti)
                     made = op.kind == OP_CONV_DIRECT ||
                            (wide && op.kind == OP_CONV && op.vec && op.Kvec == op.Kpad && t.C % 64 == 0 && op.Kpad >= 64 &&
-                            !std::getenv("SEMDEPTH_NO_DMA")) ||
+                            !sd_disabled("dma")) ||
                            // (three-product engine, round 5: a stem conv's output, as on bf16 x 3 above)
                            (p.h2 && op.kind == OP_CONV && op.nsrc == 1 && op.src[0] == p.t_input && (op.k & 1) && op.k <= 7 && !op.fold && !op.fuse_pool &&
                             op.residual < 0 && (t.C == 32 || t.C == 64) && t.W % 32 == 0 && !(latch_switches() & SW_NO_STEM));
@@ -548,7 +575,7 @@ NetPlan build_fcn8s(int frames, int H, int W, int prec, const char* f16_layers) 
             x = b.conv(n, {{x, 0}}, ch[s], 3, 1, ACT_RELU, "vgg/" + n + "/filter", "vgg/" + n + "/biases");
             // conv1_1 (stem kernel) -> conv1_2 (direct kernel): hand the 64 channels over as four 16-channel sub-planes
             if (s == 0 && j == 1 && prec == 1 && b.p.ops.back().kind == OP_CONV_DIRECT && b.p.tensors[xin].C == 64 && W % 32 == 0 &&
-                !std::getenv("SEMDEPTH_NO_PLANAR") && !std::getenv("SEMDEPTH_NO_STEM")) {
+                !sd_disabled("planar") && !sd_disabled("stem")) {
                 b.p.tensors[xin].planar16 = 1;
             }
         }

@@ -141,8 +141,8 @@ def test_no_conv_kernel_spills_vector_registers():
     if not res:
         pytest.skip("no resource remarks next to the library (object directory absent)")
     conv = {k: v for k, v in res.items() if v["file"].startswith("conv_") or v["file"].startswith("dec_tail")}
-    # (the s_memtime-instrumented copy of conv_direct3 -- SEMDEPTH_X3_DIAG=4, decomposition runs only -- carries ten counters more than the kernel it times)
-    conv = {k: v for k, v in conv.items() if "conv_direct3_kernelILi2ELb0ELi2ELi2ELb0ELb1E" not in k}
+    # (the s_memtime-instrumented decomposition copies exist in -DSD_DEV_VARIANTS builds only: the shipped library has none of them)
+    assert not any("conv_direct3_kernelILi2ELb0ELi2ELi2ELb0ELb1E" in k for k in conv) or os.environ.get("SEMDEPTH_DEV_BUILD") == "1"
     assert len(conv) > 50
     bad = {k: (v.get("VGPRs Spill"), v.get("ScratchSize [bytes/lane]")) for k, v in conv.items()
            if v.get("VGPRs Spill", 0) or v.get("ScratchSize [bytes/lane]", 0)}

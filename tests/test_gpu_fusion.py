@@ -45,7 +45,7 @@ def test_fuse_matches_oracle_small(eng_small, one_pixel_per_thread, monkeypatch)
     """both forms of the gather: four pixels per thread (widths that are multiples of 4) and the generic one behind it"""
     e = eng_small
     if one_pixel_per_thread:
-        monkeypatch.setenv("SEMDEPTH_NO_FUSE4", "1")            # switches are latched when the handle is created
+        monkeypatch.setenv("SEMDEPTH_DISABLE", "fuse4")            # switches are latched when the handle is created
         from semantic_depth_amd.engine import Engine
         e = Engine(128, 256, 4, "resnet50")
     scenes = [pipeline.synthetic_scene(128, 256, seed=s, f=250.0, fences=True) for s in (3, 4, 5)]
@@ -155,15 +155,13 @@ def _assert_fuse_equals_oracle(out, scenes, cams, pp=None):
         assert np.array_equal(out["fence_rgb"][b, :nf].cpu().numpy(), ref["fence_rgb"])
 
 
-@pytest.mark.parametrize("switch", [None, "SEMDEPTH_NO_FUSE1", "SEMDEPTH_NO_FUSE4"])
+@pytest.mark.parametrize("switch", [None, "fuse1", "fuse1,fuse4"])
 def test_one_pass_and_three_launch_forms_agree_with_the_oracle(switch, monkeypatch):
     """sd_fuse_backproject (post-processed map in) and sd_postprocess_fuse_backproject (raw pair in, post-processing folded into
     the same pass) in the one-pass look-back form (default) and the three-launch forms behind it: all bit-exact vs the oracle"""
     from semantic_depth_amd.engine import Engine
     if switch:
-        monkeypatch.setenv(switch, "1")
-        if switch == "SEMDEPTH_NO_FUSE4":
-            monkeypatch.setenv("SEMDEPTH_NO_FUSE1", "1")
+        monkeypatch.setenv("SEMDEPTH_DISABLE", switch)
     e = Engine(128, 256, 4, "resnet50")
     scenes, cams, raw, road, fence, frames = _scene_batch(128, 256, (3, 4, 5), 250.0)
     cams[1] = Camera(cams[1].cx + 2.25, cams[1].cy - 1.5, 300.0, 0.6, 3800.0)

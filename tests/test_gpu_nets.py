@@ -127,18 +127,15 @@ def test_flipped_frame_symmetry_of_post_processing():
     assert relerr(b[:, ::-1], a) < 1e-5
 
 
-@pytest.mark.parametrize("switch", ["SEMDEPTH_NO_DMA", "SEMDEPTH_NO_DIRECT", "SEMDEPTH_NO_STEM", "SEMDEPTH_NO_POOL_FUSE", "SEMDEPTH_NO_PLANAR",
-                                    "SEMDEPTH_NO_N16", "SEMDEPTH_NO_SMALLN_TILE", "SEMDEPTH_NO_DIRECT128", "SEMDEPTH_NO_N16_MT1",
-                                    "SEMDEPTH_NO_PLANAR_WIDE", "SEMDEPTH_NO_UPTILE", "SEMDEPTH_DIRECT_MINPIX=1000000000"])
+@pytest.mark.parametrize("switch", ["dma", "direct", "stem", "pool_fuse", "planar", "n16"])
 def test_generic_kernels_behind_each_specialised_one(switch, precision="bf16x2"):
-    """every specialised kernel (LDS-DMA pipeline, direct conv and its multi-pass form for 128..512 output channels, stem
-    conv, fused pools, sub-plane hand-off, 16-wide MFMA and its 8-row tiles, tiled heads) has a generic one behind it; with
-    the specialised one switched off the networks still meet the budget."""
+    """every specialised kernel (LDS-DMA pipeline, direct conv, stem conv, fused pools, sub-plane hand-off, 16-wide MFMA) has a generic one
+    behind it; with the specialised one switched off (SEMDEPTH_DISABLE=<name>) the networks still meet the budget."""
     from semantic_depth_amd.engine import Engine
     from semantic_depth_amd import weights as Wt
     H, W, B = 64, 128, 2
-    switch, _, val = switch.partition("=")
-    os.environ[switch] = val or "1"
+    os.environ["SEMDEPTH_DISABLE"] = switch
+    switch = "SEMDEPTH_DISABLE"
     try:
         eng = Engine(H, W, B, "resnet50", precision=precision)      # the switches are read when the plan is built / at launch
         wf = Wt.make_fcn8s_weights(1, decoder_std=0.05, bias_std=0.1)
@@ -157,10 +154,9 @@ def test_generic_kernels_behind_each_specialised_one(switch, precision="bf16x2")
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
-@pytest.mark.parametrize("switch", ["SEMDEPTH_NO_DMA", "SEMDEPTH_NO_DMA3", "SEMDEPTH_NO_FOLD", "SEMDEPTH_NO_TAIL1", "SEMDEPTH_NO_STEM", "SEMDEPTH_NO_DIRECT",
-                                    "SEMDEPTH_NO_N16", "SEMDEPTH_NO_POOL_FUSE", "SEMDEPTH_NO_PLANAR"])
+@pytest.mark.parametrize("switch", ["dma", "dma3", "fold", "tail1", "stem", "direct", "n16", "pool_fuse", "planar"])
 def test_generic_kernels_behind_the_specialised_ones_of_the_fp32_grade_engines(switch, precision):
-    """the same on bf16x3 (SEMDEPTH_NO_DMA made the folded upconvs fail with SD_ERR_STATE -- the folded GEMM form exists on
+    """the same on bf16x3 (SEMDEPTH_DISABLE=dma made the folded upconvs fail with SD_ERR_STATE -- the folded GEMM form exists on
     conv_dma3 only, so the switch now also keeps the plan from folding) and on f16x2 (every H2 form has the generic H2 kernel behind it)"""
     test_generic_kernels_behind_each_specialised_one(switch, precision=precision)
 
@@ -177,7 +173,7 @@ def test_256x256_block_of_the_dma_pipeline_is_bit_identical_to_the_128x256_one()
     outs = []
     for off in (False, True):
         if off:
-            os.environ["SEMDEPTH_NO_DMA_BIG"] = "1"
+            os.environ["SEMDEPTH_DISABLE"] = "dma_big"
         try:
             eng = Engine(H, W, B, "resnet50", precision="bf16x2")
             eng.load_weights(L.SD_NET_MONODEPTH, wm)
@@ -186,7 +182,7 @@ def test_256x256_block_of_the_dma_pipeline_is_bit_identical_to_the_128x256_one()
             kernels = {b["kernel"] for b in eng.profile_read()}
             eng.profile(False)
         finally:
-            os.environ.pop("SEMDEPTH_NO_DMA_BIG", None)
+            os.environ.pop("SEMDEPTH_DISABLE", None)
         assert any("<2,4,4,2>" in k for k in kernels) == (not off), kernels
         outs.append(raw.clone())
         del eng
@@ -199,7 +195,7 @@ def test_row_grouped_fc6_tiles_skip_padding_taps_bit_identically(precision):
     with fewer frames than a tile row group takes must give the same bits.)
     bf16x3, fc6 (7x7 on the 16 x 32 pool5 map): conv_dma3 orders the GEMM's pixels (image group, row, image, column) so that a
     256-pixel tile is one output row of eight images, and skips the k-tiles of the taps whose input row is zero padding (10.7 % of them).
-    Skipped terms are exact zeros: the logits must not change by a bit against the plain pixel order (SEMDEPTH_NO_ROWSKIP)."""
+    Skipped terms are exact zeros: the logits must not change by a bit against the plain pixel order (SEMDEPTH_DISABLE=rowskip)."""
     from semantic_depth_amd.engine import Engine
     from semantic_depth_amd import weights as Wt
     H, W, B = 512, 1024, 8
@@ -208,13 +204,13 @@ def test_row_grouped_fc6_tiles_skip_padding_taps_bit_identically(precision):
     outs = []
     for off in (False, True):
         if off:
-            os.environ["SEMDEPTH_NO_ROWSKIP"] = "1"
+            os.environ["SEMDEPTH_DISABLE"] = "rowskip"
         try:
             eng = Engine(H, W, B, "resnet50", precision=precision)
             eng.load_weights(L.SD_NET_FCN8S, wf)
             outs.append((eng.fcn8s_forward(fr, want_logits=True)["logits"].clone(), eng.net_tensor(L.SD_NET_FCN8S, "layer7_out").clone()))
         finally:
-            os.environ.pop("SEMDEPTH_NO_ROWSKIP", None)
+            os.environ.pop("SEMDEPTH_DISABLE", None)
         del eng
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0])
     assert float(outs[0][0].abs().max()) > 0
@@ -223,7 +219,7 @@ def test_row_grouped_fc6_tiles_skip_padding_taps_bit_identically(precision):
 def test_precomputed_gather_offsets_of_conv_dma3_are_bit_identical_to_the_general_gather():
     """conv_dma3 computes a lane's gather offset once per source geometry (kernel<1>: the 1x1 layers -- block tails with their strided
     shortcut source, conv1 of res4 / res5, fc7; kernel<2>: tap layers without upsample -- fc6, the folded upconvs, strided 3x3) instead of
-    per DMA piece and phase (kernel<0>, SEMDEPTH_NO_FLAT).  Same k order, same products: raw disparities and logits must not change by a
+    per DMA piece and phase (kernel<0>, SEMDEPTH_DISABLE=flat).  Same k order, same products: raw disparities and logits must not change by a
     bit.  256 x 512 frames, 8 of them (the block tails have >= 128 tiles of 256 x 256 there).  The per-layer profile labels
     (SEMDEPTH_PROFILE_VERBOSE) name the variant that ran: no layer of either network is left on the general gather -- the folded
     upconv6 / upconv5 included -- and with the switch every one of them is."""
@@ -238,7 +234,7 @@ def test_precomputed_gather_offsets_of_conv_dma3_are_bit_identical_to_the_genera
     try:
         for off in (False, True):
             if off:
-                os.environ["SEMDEPTH_NO_FLAT"] = "1"
+                os.environ["SEMDEPTH_DISABLE"] = "flat"
             try:
                 eng = Engine(H, W, B, "resnet50", precision="bf16x3")
                 eng.load_weights(L.SD_NET_FCN8S, wf)
@@ -250,7 +246,7 @@ def test_precomputed_gather_offsets_of_conv_dma3_are_bit_identical_to_the_genera
                 eng.profile(False)
                 outs.append((lg, raw.clone()))
             finally:
-                os.environ.pop("SEMDEPTH_NO_FLAT", None)
+                os.environ.pop("SEMDEPTH_DISABLE", None)
             del eng
     finally:
         os.environ.pop("SEMDEPTH_PROFILE_VERBOSE", None)
@@ -264,7 +260,7 @@ def test_precomputed_gather_offsets_of_conv_dma3_are_bit_identical_to_the_genera
 def test_16x16x32_form_of_the_phased_gemm_block_agrees_with_the_32x32x16_form(precision):
     """(f16x2: the 1x1 layers of its two-phase ring run the 16x16x32 form too, its fc6 the 32x32x16 one either way.)
     bf16x3 runs conv_dma3's layers on v_mfma_f32_16x16x32 (round 5) -- one k-step of 32 per k-tile, products grouped by X plane with the weight
-    fragments kept; SEMDEPTH_MFMA32 selects the 32x32x16 form it replaced.  Same products, same LDS ring; the sums differ in the last bits (the
+    fragments kept; SEMDEPTH_DISABLE=mfma16 selects the 32x32x16 form it replaced.  Same products, same LDS ring; the sums differ in the last bits (the
     hardware adds 32 k's per instruction instead of 16): both forms must sit at fp32 grade from each other.  512 x 1024, 8 frames: fc6 (row-grouped,
     tap skipping), fc7, the block tails, the folded upconv6 / upconv5 all run on the block."""
     from semantic_depth_amd.engine import Engine
@@ -276,7 +272,7 @@ def test_16x16x32_form_of_the_phased_gemm_block_agrees_with_the_32x32x16_form(pr
     outs, launches = [], []
     for m32 in (False, True):
         if m32:
-            os.environ["SEMDEPTH_MFMA32"] = "1"
+            os.environ["SEMDEPTH_DISABLE"] = "mfma16"
         try:
             eng = Engine(H, W, B, "resnet50", precision=precision)
             eng.load_weights(L.SD_NET_FCN8S, wf)
@@ -288,7 +284,7 @@ def test_16x16x32_form_of_the_phased_gemm_block_agrees_with_the_32x32x16_form(pr
             eng.profile(False)
             outs.append((lg.cpu().numpy(), raw.cpu().numpy()))
         finally:
-            os.environ.pop("SEMDEPTH_MFMA32", None)
+            os.environ.pop("SEMDEPTH_DISABLE", None)
         del eng
     assert launches[0] == launches[1] and launches[0] >= (20 if precision == "bf16x3" else 10), launches
     el, ed = relerr(outs[1][0], outs[0][0]), relerr(outs[1][1], outs[0][1])
@@ -326,8 +322,8 @@ def test_a_frames_result_does_not_depend_on_the_call_it_is_computed_in_at_full_s
 def test_folded_upconvs_and_fused_decoder_tail_against_the_layer_by_layer_form(H, W, B, enc):
     """bf16x3 runs the wide upconv layers upsample-FOLDED (four 2x2 convs on the source instead of a 3x3 conv on the upsampled source:
     the taps that read the same source pixel are added, 4/9 of the multiplications) and upconv1 -> iconv1 -> disp1 as ONE kernel
-    (dec_tail.hip).  Both are the same function in another summation order: against the layer-by-layer form (SEMDEPTH_NO_FOLD,
-    SEMDEPTH_NO_TAIL1: 3x3 convs on the upsampled source, three launches) the raw disparities and every intermediate scale agree to a
+    (dec_tail.hip).  Both are the same function in another summation order: against the layer-by-layer form (SEMDEPTH_DISABLE=fold,tail1:
+    3x3 convs on the upsampled source, three launches) the raw disparities and every intermediate scale agree to a
     few f32 roundings, and against the CPU oracle both are equally far away.  Matches upconv / iconv / get_disp of oracle/nets.py:138-160."""
     from semantic_depth_amd.engine import Engine
     from semantic_depth_amd import weights as Wt
@@ -335,7 +331,7 @@ def test_folded_upconvs_and_fused_decoder_tail_against_the_layer_by_layer_form(H
     frn = _frames(B, H, W, seed=H + 3)
     fr = dev(frn)
     outs, kern = {}, {}
-    for mode, env in (("fused", {}), ("plain", {"SEMDEPTH_NO_FOLD": "1", "SEMDEPTH_NO_TAIL1": "1"})):
+    for mode, env in (("fused", {}), ("plain", {"SEMDEPTH_DISABLE": "fold,tail1"})):
         os.environ.update(env)
         try:
             eng = Engine(H, W, B, enc, precision="bf16x3")
@@ -369,7 +365,7 @@ def test_sub_planar_stem_output_of_the_six_product_engine_is_bit_identical(preci
     """bf16x3 (round 5): conv1_1's output goes to conv1_2 as 16-channel sub-planes (the stem kernel writes them, conv_direct3's chunk loader reads a contiguous
     run per chunk instead of 32 bytes out of every pixel's line), and so does monodepth's enc/conv1 to its two readers -- the 3x3 stride-2 pool and the skip
     input of iconv2 (whose four chunk passes fetched the skip four times) -- on bf16x3 and on f16x2 (where conv1_1 -> conv1_2 has been sub-planar like every
-    two-plane hand-off).  Addressing only: with SEMDEPTH_NO_PLANAR the logits and the raw disparities must not change by a bit.  256 x 512: the encoder's first
+    two-plane hand-off).  Addressing only: with SEMDEPTH_DISABLE=planar the logits and the raw disparities must not change by a bit.  256 x 512: the encoder's first
     map is 128 x 256, four tile columns of the stem kernel."""
     from semantic_depth_amd.engine import Engine
     from semantic_depth_amd import weights as Wt
@@ -380,14 +376,14 @@ def test_sub_planar_stem_output_of_the_six_product_engine_is_bit_identical(preci
     outs = []
     for off in (False, True):
         if off:
-            os.environ["SEMDEPTH_NO_PLANAR"] = "1"
+            os.environ["SEMDEPTH_DISABLE"] = "planar"
         try:
             eng = Engine(H, W, B, "resnet50", precision=precision)
             eng.load_weights(L.SD_NET_FCN8S, wf)
             eng.load_weights(L.SD_NET_MONODEPTH, wm)
             outs.append((eng.fcn8s_forward(fr, want_logits=True)["logits"].clone(), eng.monodepth_forward(fr, want_raw=True)[1].clone()))
         finally:
-            os.environ.pop("SEMDEPTH_NO_PLANAR", None)
+            os.environ.pop("SEMDEPTH_DISABLE", None)
         del eng
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert float(outs[0][1].abs().max()) > 0
@@ -430,7 +426,7 @@ def test_three_product_fp16_engine_needs_no_activation_scale(gains):
 def test_folded_upconvs_of_the_three_product_fp16_engine(H, W, B, enc):
     """f16x2 runs the upconv layers with >= 128 output channels upsample-FOLDED as four parity GEMMs on the H2 form of conv_dma (the algebra of the
     bf16x3 engine's fold: 4 / 9 of the multiplications; the folded weight summed in double, rounded once to f32, then split into its two fp16
-    planes of w * 2^12), and level 1 of the decoder (upconv1 -> iconv1 -> disp1) as ONE launch (the HS form of dec_tail.hip).  Against the layer-by-layer form (SEMDEPTH_NO_FOLD) the raw disparities agree to a few f32 roundings; at the small size
+    planes of w * 2^12), and level 1 of the decoder (upconv1 -> iconv1 -> disp1) as ONE launch (the HS form of dec_tail.hip).  Against the layer-by-layer form (SEMDEPTH_DISABLE=fold) the raw disparities agree to a few f32 roundings; at the small size
     both are held against the CPU oracle."""
     from semantic_depth_amd.engine import Engine
     from semantic_depth_amd import weights as Wt
@@ -438,7 +434,7 @@ def test_folded_upconvs_of_the_three_product_fp16_engine(H, W, B, enc):
     frn = _frames(B, H, W, seed=H + 3)
     fr = dev(frn)
     outs, kern = {}, {}
-    for mode, env in (("fold", {}), ("plain", {"SEMDEPTH_NO_FOLD": "1", "SEMDEPTH_NO_TAIL1": "1"})):
+    for mode, env in (("fold", {}), ("plain", {"SEMDEPTH_DISABLE": "fold,tail1"})):
         os.environ.update(env)
         os.environ["SEMDEPTH_PROFILE_VERBOSE"] = "1"
         try:

@@ -224,7 +224,7 @@ def _check_records_against_oracle(eng, frames_np, out, raw, cam, prm, colours=Tr
 
 # (the benchmarked batch of 32 on the headline engine and on the plan leg; the other engines on 8: the CPU oracle tail costs ~1 s per frame,
 #  and the tail kernels are the same whatever engine produced the masks and the disparity)
-@pytest.mark.parametrize("B,precision", [(8, "bf16x2"), (8, "f32"), (32, "plan"), (32, "bf16x3"), (8, "f16x2")])
+@pytest.mark.parametrize("B,precision", [(8, "bf16x2"), (8, "f32"), (32, "plan"), (8, "bf16x3"), (32, "f16x2")])
 def test_process_batch_records_equal_oracle_tail(B, precision):
     """configs[3] (B = 32: the benchmarked configuration, on the engines bench.py times -- f32 headline, plan leg) and the B = 8 batch
     of configs[1]/[2] through Engine.process_batch"""
