@@ -1,14 +1,14 @@
 #!/bin/bash
-# The GPU batch behind profiles/r05_*: rocprofv3 kernel stats, HBM traffic (separate FETCH / WRITE passes), SQ counters, layer times, the float64 grade check and
-# the default bench line, for the headline engine (bf16x3) and for the three-product leg (f16x2), in ONE gpurun call:
-#     gpurun --timeout 3600 -- './scripts/gpu_batch.sh r05v'      (results under gpurun_out/<tag>/)
-# During the round this file is rewritten per experiment (A/B runs of a switch, decomposition runs, ...); this is the evidence form, run on the final tree.
-tag=${1:-r05g}
+# The GPU batch behind profiles/r06_*: rocprofv3 kernel stats, HBM traffic (separate FETCH / WRITE passes), SQ counters, layer times, the float64 grade check and
+# the default bench line, for the headline engine (f16x2) and for the six-product leg (bf16x3), in ONE gpurun call of ~15 min:
+#     gpurun --timeout 2400 -- './scripts/gpu_batch.sh r06v'      (results under gpurun_out/<tag>/)
+# The test suite is its own call (one outer timeout must not have to cover both):  gpurun --timeout 1500 -- 'python -m pytest tests -q -m gpu'
+tag=${1:-r06v}
+cd "${GRAFT_REPO_ROOT:?}"
 mkdir -p gpurun_out/$tag
 o=gpurun_out/$tag
-timeout 3000 python -m pytest tests -q -m gpu --durations=15 > $o/pytest_gpu.txt 2>&1; tail -n 25 $o/pytest_gpu.txt
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for prec in bf16x3 f16x2; do
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+for prec in f16x2 bf16x3; do
   B="bench.py --no-overlap --legs none --no-cpu-baseline --precision $prec"
   rocprofv3 --kernel-trace --stats -d $o/stats_$prec -o t --output-format csv -- python3 $B --steps 5 --warmup 2 --repeats 1 > $o/bench_stats_$prec.json 2> $o/bench_stats_$prec.log
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $o/fetch_$prec -o t --output-format csv -- python3 $B --steps 1 --warmup 1 --repeats 1 > /dev/null 2> $o/fetch_$prec.log
@@ -22,6 +22,6 @@ for prec in bf16x3 f16x2; do
   rm -rf $o/fetch_$prec $o/write_$prec $o/sq_$prec $o/stats_$prec
   timeout 300 python scripts/layer_times.py 32 resnet50 $prec 2> $o/layer_times_$prec.txt >/dev/null
 done
-timeout 900 python scripts/f32_grade_check.py > $o/f32_grade_check.txt 2> $o/f32_grade_check.log
-timeout 1200 python bench.py > $o/bench_default.json 2> $o/bench_default.log
+timeout 900 python scripts/f32_grade_check.py --pairs 8 --extra > $o/f32_grade_check.txt 2> $o/f32_grade_check.log
+timeout 1200 python bench.py --steps 20 --detail $o/bench_detail.json > $o/bench_default.json 2> $o/bench_default.log
 grep 'frames/s' $o/bench_default.log | cut -c1-200

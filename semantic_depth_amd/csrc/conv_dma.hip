@@ -13,7 +13,10 @@ void launch_dma_v5(const ConvParams& p, long M, hipStream_t s);      // 256 x 25
 
 int conv_dma_variant(const ConvParams& p) {
     if (!p.vec || !p.zero16 || p.Cout % 32 || p.Kpad < 64) return 0;
-    const long M = (long)p.N * p.Hout * p.Wout;
+    // the block shape is chosen on a FULL pass of the engine (ConvParams::Nmax), not on the frames of this call: a call with fewer frames runs the same
+    // kernels on fewer tiles, so a frame's result cannot depend on the call it is computed in even where two block shapes round differently (ADVICE r5 #3;
+    // conv_dma3_eligible has counted this way since round 5)
+    const long M = (long)(p.Nmax > 0 ? p.Nmax : p.N) * p.Hout * p.Wout;
     const long thr = (p.pool || p.out_planar16 || p.fold) ? 0 : 96;     // (a folded layer runs here whatever the batch: its results must not depend on it) tiles needed: the DMA pipeline at half occupancy still beats the register-staged
                                           // kernel (a fused pool exists only here: such layers always take this kernel)
     const bool big = !(p.sw & SW_NO_DMA_BIG);

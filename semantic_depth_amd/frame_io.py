@@ -100,10 +100,12 @@ def _cgroup_cpu_quota():
 
 
 def _local_ranks() -> int:
-    """ranks that share this node: LOCAL_WORLD_SIZE (torch.distributed.run, bench.py's launcher), Open MPI's / Slurm's per-node counts,
-    else WORLD_SIZE (a single-node job started by hand with RANK / WORLD_SIZE), else 1"""
+    """ranks that share this node: LOCAL_WORLD_SIZE (torch.distributed.run, bench.py's launcher), Open MPI's / MPICH's / Slurm's per-node counts
+    (SLURM_TASKS_PER_NODE is always set by srun, SLURM_NTASKS_PER_NODE only with --ntasks-per-node), else WORLD_SIZE -- the conservative single-node
+    assumption for a job started by hand with RANK / WORLD_SIZE: on several nodes it UNDER-subscribes the decode threads (affinity / WORLD_SIZE each),
+    never over-subscribes them --, else 1"""
     import os
-    for k in ("LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "SLURM_NTASKS_PER_NODE", "WORLD_SIZE"):
+    for k in ("LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS", "SLURM_NTASKS_PER_NODE", "SLURM_TASKS_PER_NODE", "WORLD_SIZE"):
         v = os.environ.get(k, "")
         try:
             n = int(v.split("(")[0])           # (Slurm writes "8(x2)" for heterogeneous jobs)
