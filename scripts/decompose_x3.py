@@ -1,4 +1,5 @@
-"""Decomposition of the bf16x3 conv kernels WITHOUT disturbing their inputs (dev tool, round 5).
+"""[needs a dev build of the library: SEMDEPTH_DEV_BUILD=1 python -m semantic_depth_amd.build --force -- the shipped library carries no decomposition copies]
+Decomposition of the bf16x3 conv kernels WITHOUT disturbing their inputs (dev tool, round 5).
 
 SEMDEPTH_X3_DIAG (1 = no output stores, 2 = conv_dma3: no epilogue at all / conv_direct3: no MFMAs) is latched per handle, and a handle
 that does not store its outputs feeds zeros to every later layer -- zeros draw less MFMA power, the chip clocks up, and the "no stores"

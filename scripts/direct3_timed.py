@@ -1,4 +1,5 @@
-"""Where does a (tile, pass) item of conv_direct3 go?  SEMDEPTH_X3_DIAG=4 launches the TIMED copy of the dominant form (conv_direct3_kernel<2, false, 2, 2, false, true>):
+"""[needs a dev build of the library: SEMDEPTH_DEV_BUILD=1 python -m semantic_depth_amd.build --force -- the shipped library carries no decomposition copies]
+Where does a (tile, pass) item of conv_direct3 go?  SEMDEPTH_X3_DIAG=4 launches the TIMED copy of the dominant form (conv_direct3_kernel<2, false, 2, 2, false, true>):
 s_memtime stamps around every phase's wait + barrier, the barrier in front of the epilogue and the three parts of the epilogue, summed per wave over the items of a
 workgroup and printed by waves 0 and 4 (the older and the younger wave of SIMD 0) of the middle workgroup of every launch (dev tool, round 5).
     python scripts/direct3_timed.py [B]"""

@@ -1,4 +1,5 @@
-"""Where does a phase of conv_dma3 go?  SEMDEPTH_X3_DIAG=3 launches the TIMED copy of the 1x1 form (conv_dma3_kernel<1, HS, true>): s_memtime stamps around
+"""[needs a dev build of the library: SEMDEPTH_DEV_BUILD=1 python -m semantic_depth_amd.build --force -- the shipped library carries no decomposition copies]
+Where does a phase of conv_dma3 go?  SEMDEPTH_X3_DIAG=3 launches the TIMED copy of the 1x1 form (conv_dma3_kernel<1, HS, true>): s_memtime stamps around
 the counted s_waitcnt, the s_barrier and the body of every phase, printed by waves 0 and 4 of the middle workgroup of every launch (dev tool, round 5).
     python scripts/dma3_timed.py [bf16x3|f16x2] [B]"""
 import os, sys

@@ -71,10 +71,17 @@ __device__ __forceinline__ DirectChunk load_chunk(const DirectChunk* ptr) {
 // X2 (with F16): the input is fp16 hi + lo planes and only w_hi is used: TWO products x_hi*w_hi + x_lo*w_hi (split_fmt.hpp)
 // H2 (with F16 and X2; SD_PREC_F16X2): fp16 hi + SCALED lo input planes x fp16 hi + lo weight planes, THREE products
 // x_hi*w_hi + x_hi*w_lo + x_lo*(w_hi * 2^-11), the accumulator times ConvDirectParams::alpha, HS output planes (split_fmt.hpp "HS")
-template <int NB, int MT, bool F16, bool N16 = false, bool UP = false, bool W1 = false, bool X2 = false, bool H2 = false>
+// FOLD (with H2 and UP; round 6: the upconv layers of SD_PREC_F16X2 that stay on this kernel -- upconv3 / upconv2): the upsample-folded form -- per output parity
+// (y & 1, x & 1) a 2x2 conv on the SOURCE with the 3x3 taps that read the same source pixel added up (plan.hpp OpDesc::fold): 16 tap matrices per chunk instead of
+// 9, but 4 instead of 9 MFMA groups per output pixel.  Wave w owns parity w & 3 and the source rows 4 (w >> 2) .. + 3 of the tile: its two 32-pixel MFMA column groups
+// are 2 source rows x 16 source columns each (the fragment scheme of conv_direct3.hip's fold).  The X fragments of a chunk (2 column shifts x 4 row offsets x 2 planes)
+// are read once and stay in registers; a chunk is 4 NB MFMA groups, so the DMA slots go out two per group.
+template <int NB, int MT, bool F16, bool N16 = false, bool UP = false, bool W1 = false, bool X2 = false, bool H2 = false, bool FOLD = false>
 __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_kernel(const ConvDirectParams p) {
     static_assert(!N16 || NB == 1, "N16 is a variant of the 32-channel kernel");
     static_assert(!H2 || (F16 && X2 && !W1), "H2 is the fp16 form with both planes of both operands");
+    static_assert(!FOLD || (H2 && UP && !N16 && MT == 2), "the folded form: three-product engine, source-resolution tiles");
+    constexpr int NTAP = FOLD ? 16 : 9;                  // tap matrices per chunk
     constexpr bool ONEW = W1 || (X2 && !H2);           // only the w_hi plane is fetched and multiplied
     using Cfg = DirectCfg<NB, MT, UP>;
     constexpr int S_HH = Cfg::SH, S_HW = Cfg::SW;
@@ -82,8 +89,8 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
     auto hpix = [](int hy, int hx) { return UP ? ((hy + 1) >> 1) * S_HW + ((hx + 1) >> 1) : hy * S_HW + hx; };
     // weights: a (plane, chunk) block in memory is [tap][octet][32 NB][8]; the LDS image is the same, except N16, which keeps
     // only the 16 output channels it multiplies ([tap][octet][16][8], 288 units in 5 DMA instructions)
-    constexpr int D_GW = Cfg::WUNITS;
-    constexpr int D_WI = N16 ? 5 : Cfg::WI, D_WUNITS = N16 ? 320 : Cfg::WUNITS;
+    constexpr int D_GW = NTAP * 2 * 32 * NB;             // ([tap][octet][32 NB channels]; FOLD: [parity 4][2x2 tap 4][octet][32 NB])
+    constexpr int D_WI = N16 ? 5 : NTAP * NB, D_WUNITS = N16 ? 320 : D_GW;
     // a stage holds the planes the form reads -- X hi [+ lo] | W hi [+ lo] -- and is at least as large as the epilogue's transposition
     // slabs, which live in a consumed stage.  (The fp16 forms of the 16-channel kernels thereby fit THREE workgroups per CU instead of
     // two: these layers -- two chunks of little arithmetic per tile -- are bound by the latency of the two-stage ring.)
@@ -269,6 +276,55 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                                 acc16[a][pb] = mfma_frag16<F16>(pr == 0 ? wl : pr == 1 ? whs : wh, pr == 1 ? xl : xh, acc16[a][pb]);
                             }
                         }
+                }
+            } else if constexpr (FOLD) {
+                constexpr int NGRPF = 4 * NB, SPG = (NSLOT + NGRPF - 1) / NGRPF;       // MFMA groups of a chunk (2x2 tap, 32-channel block); DMA slots per group
+                const int fpar = wave & 3, fpy = fpar >> 1, fpx = fpar & 1, fhh = wave >> 2;
+                // fragment (column shift tb, row offset ro = 2 a + ta): lane = (source row frow >> 4, source column frow & 15) -> pixel (4 hh + ro + row + py, column + tb + px)
+                // of the stored source tile
+                u32x4 xh[2][4], xl[2][4];
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                    for (int ro = 0; ro < 4; ++ro) {
+                        const int lp = (4 * fhh + ro + (frow >> 4) + fpy) * S_HW + (frow & 15) + tb + fpx;
+                        const int idx = lp * 2 + (fk ^ ((lp >> 3) & 1));
+                        xh[tb][ro] = Xh[idx];
+                        xl[tb][ro] = Xl[idx];
+                    }
+                u32x4 wqh[3], wql[3];
+                auto wloadf = [&](int grp) {
+                    const int tp = grp / NB, nb = grp % NB;
+                    const int wi = ((fpar * 4 + tp) * 2 + fk) * (32 * NB) + nb * 32 + frow;
+                    wqh[grp % 3] = Wh[wi];
+                    wql[grp % 3] = Wl[wi];
+                };
+                wloadf(0);
+                wloadf(1);
+#pragma unroll
+                for (int grp = 0; grp < NGRPF; ++grp) {
+                    const int tp = grp / NB, ta = tp >> 1, tb = tp & 1, nb = grp % NB;
+                    if (grp + 2 < NGRPF) wloadf(grp + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    {
+                        const u32x4 wh = wqh[grp % 3], wl = wql[grp % 3];
+                        const u32x4 whs = hs_wscaled(wh);
+#pragma unroll
+                        for (int pr = 0; pr < 3; ++pr)            // x_hi*w_lo, x_lo*w_hi, x_hi*w_hi: the product order of the plain form
+#pragma unroll
+                            for (int a = 0; a < MT; ++a)
+                                acc[a][nb] = mfma_frag<true>(pr == 0 ? wl : pr == 1 ? whs : wh, pr == 1 ? xl[tb][2 * a + ta] : xh[tb][2 * a + ta], acc[a][nb]);
+                    }
+                    if (grp == 0 && more) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        k = begin_chunk(load_chunk(p.chunks + ic), icur, ic, (g + 1) & 1);
+                    }
+                    if (more) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int sidx = grp * SPG; sidx < (grp + 1) * SPG; ++sidx) slot(k, sidx);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             } else {
             constexpr int NGRP = 9 * NB;               // MFMA groups of a chunk; the DMA slots follow groups 1 .. NSLOT
@@ -495,8 +551,11 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                         const u32x4 h = *reinterpret_cast<const u32x4*>(sh + pix * ROW + seg * 16);
                         u32x4 l = h;
                         if (TWO && !O16) l = *reinterpret_cast<const u32x4*>(sl + pix * ROW + seg * 16);
-                        if (y < p.H && seg * 8 < p.Cout) {
-                            uint16_t* o = oaddr((size_t)(cur.img * p.H + y) * p.W + cur.tx0 + pix, (size_t)p.H * p.W, seg);
+                        // FOLD: pixel pix of column group a = source (row 4 hh + 2 a + (pix >> 4), column pix & 15) of this wave's parity
+                        const int yo = FOLD ? cur.ty0 + 2 * (4 * (wave >> 2) + 2 * a + (pix >> 4)) + ((wave & 3) >> 1) : y;
+                        const int xo = FOLD ? cur.tx0 + 2 * (pix & 15) + (wave & 1) : cur.tx0 + pix;
+                        if (yo < p.H && seg * 8 < p.Cout) {
+                            uint16_t* o = oaddr((size_t)(cur.img * p.H + yo) * p.W + xo, (size_t)p.H * p.W, seg);
                             if (TWO) {
                                 *reinterpret_cast<u32x4*>(o) = h;
                                 if constexpr (!O16) *reinterpret_cast<u32x4*>(o + p.out_plane) = l;
@@ -558,6 +617,11 @@ hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
          const dim3 grid((unsigned)(tiles < slots ? tiles : slots)); \
          hipLaunchKernelGGL((conv_direct_kernel<NB_, MT_, F16_, N16_, UP_, W1_, X2_, ##__VA_ARGS__>), grid, dim3(512), 0, s, q); } while (0)
 #define SD_DIRECT_H2(NB_, MT_, N16_) do { if (up) SD_DIRECT_(NB_, MT_, true, N16_, true, false, true, true); else SD_DIRECT_(NB_, MT_, true, N16_, false, false, true, true); } while (0)
+    if (p.fold) {               // upsample-folded upconv layers of SD_PREC_F16X2: source-resolution tiles, 16 tap matrices per chunk
+        if (p.f16 != 4 || p.out_f16 != 3 || !up || p.pool || n16) return hipErrorInvalidValue;
+        if (nb == 1) SD_DIRECT_(1, 2, true, false, true, false, true, true, true); else SD_DIRECT_(2, 2, true, false, true, false, true, true, true);
+        return hipGetLastError();
+    }
 #define SD_DIRECT(NB_, MT_, F16_, N16_, W1_) do { if (up) SD_DIRECT_(NB_, MT_, F16_, N16_, true, W1_, false); else SD_DIRECT_(NB_, MT_, F16_, N16_, false, W1_, false); } while (0)
     if (p.f16 == 4) {           // SD_PREC_F16X2: fp16 hi + scaled lo x fp16 hi + lo weights, three products (every tile shape of the bf16 form)
         if (p.out_f16 != 3) return hipErrorInvalidValue;
@@ -595,6 +659,7 @@ hipError_t launch_conv_direct(const ConvDirectParams& p, hipStream_t s) {
 const char* conv_direct_kernel_name(const ConvDirectParams& p) {
     const bool n16 = p.Cout <= 16 && p.nsplit == 1 && !p.pool && !(p.sw & SW_NO_N16);
     // f16w: fp16 activations x two fp16 weight planes (2 products); f16x1: fp16 x fp16 (1 product); f16w_x2: fp16 hi+lo x w_hi (2 products)
+    if (p.f16 == 4 && p.fold) return p.Cout <= 32 ? "conv_direct_hs_fold_kernel<1>" : "conv_direct_hs_fold_kernel<2>";
     if (p.f16 == 4) return n16 ? "conv_direct_hs_kernel<1,n16>" : p.Cout <= 32 ? "conv_direct_hs_kernel<1,2>" : "conv_direct_hs_kernel<2,2>";
     if (p.f16 == 3) return "conv_direct_f16w_x2_kernel<2,2>";
     if (n16) return p.f16 == 2 ? "conv_direct_f16x1_kernel<1,n16>" : p.f16 ? "conv_direct_f16w_kernel<1,n16>" : "conv_direct_kernel<1,n16>";

@@ -172,8 +172,8 @@ struct Builder {
             for (int i = 0; i < op.nsrc; ++i) nch += (p.tensors[op.src[i]].C + 15) / 16;
             op.nchunks = nch;
             op.nsplit = Cout > 64 ? Cout / 64 : 1;
-            // bf16 x 3, an upconv layer (one x2-upsampled source): the upsample-folded form of the direct kernel (OpDesc::fold)
-            op.fold = (p.x3 && op.nsrc == 1 && op.up[0] && p.tensors[op.src[0]].C % 16 == 0 && Hout % 2 == 0 && !(latch_switches() & (SW_NO_FOLD | SW_NO_UPTILE))) ? 1 : 0;
+            // bf16 x 3 and (round 6) SD_PREC_F16X2, an upconv layer (one x2-upsampled source): the upsample-folded form of the direct kernel (OpDesc::fold)
+            op.fold = ((p.x3 || p.h2) && op.nsrc == 1 && op.up[0] && p.tensors[op.src[0]].C % 16 == 0 && Hout % 2 == 0 && !(latch_switches() & (SW_NO_FOLD | SW_NO_UPTILE))) ? 1 : 0;
             op.w = wslot(wname, {k, k, Ctf, Cout}, WL_DIRECT_SPLIT, nch * (op.fold ? 16 : 9) * 16, Cout <= 32 ? 32 : 64, 0, op.nsplit);
             WeightSlot& ws = p.weights[op.w];
             ws.nsrc = op.nsrc; ws.fold = op.fold;
@@ -850,7 +850,8 @@ void relayout_weight(const WeightSlot& s, const float* w, std::vector<float>& ou
                                 for (int iy = 0; iy < ny; ++iy)
                                     for (int ix = 0; ix < nx; ++ix) acc += (double)w[((int64_t)(dys[iy] * 3 + dxs[ix]) * Ctf + c) * Cout + n];
                                 const float wf = (float)acc;
-                                uint16_t* hi = hi0 + (size_t)(n / s.CoutPad) * 3 * plane + base + (n % s.CoutPad) * 8;
+                                uint16_t* hi = hi0 + (size_t)(n / s.CoutPad) * (s.x3 ? 3 : 2) * plane + base + (n % s.CoutPad) * 8;
+                                if (s.f16) { f16_split(s.hs ? wf * s.wscale : wf, *hi, hi[plane]); continue; }       // (SD_PREC_F16X2: two fp16 planes of w * 2^k)
                                 const uint16_t h = bf16(wf);
                                 *hi = h;
                                 const float r1 = wf - bf16_to_f(h);

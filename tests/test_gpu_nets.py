@@ -455,6 +455,8 @@ def test_folded_upconvs_of_the_three_product_fp16_engine(H, W, B, enc):
     if H * W >= 128 * 256:       # (below that the deep upconv layers are too narrow for the direct 3x3 kernel in either form)
         assert n_direct(kern["fold"]) <= n_direct(kern["plain"]) - 3, kern     # upconv6 / 5 / 4 (vgg: 7 / 6 / 5 / 4) left the direct 3x3 kernel for the GEMM one
     assert "dec_tail1_hs_kernel" in kern["fold"] and "dec_tail1_hs_kernel" not in kern["plain"], kern      # and level 1 of the decoder is one launch
+    if H * W >= 128 * 256:       # (round 6) upconv3 / upconv2 stay on the direct kernel, in its folded form
+        assert any(k.startswith("conv_direct_hs_fold_kernel") for k in kern["fold"]) and not any(k.startswith("conv_direct_hs_fold_kernel") for k in kern["plain"]), kern
     e1 = relerr(outs["fold"], outs["plain"])
     print(H, W, enc, "f16x2 folded vs layer by layer:", e1)
     assert e1 < 5e-6
