@@ -561,6 +561,12 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
         const int seg = lane_e % SEGS, prow = lane_e / SEGS;
         uint16_t* const out_hi = reinterpret_cast<uint16_t*>(p.out);
         const int m0 = bm0 + wm0, n0 = bn0 + wn0;
+        // the bias of this lane's channels, loaded ONCE (round 6: the loads sat inside the loop below, one L1 round trip in front of every group of four values and
+        // not merged across the asm waits: 32 dependent loads per wave and tile): S16 four vectors (channels 16 r4 + 4 (lane >> 4)), 32x32x16 eight (32 b + 8 r4 + 4 (lane >> 5))
+        f32x4 bias_v[S16 ? 4 : 4 * G3_NT];
+#pragma unroll
+        for (int i = 0; i < (S16 ? 4 : 4 * G3_NT); ++i)
+            bias_v[i] = *reinterpret_cast<const f32x4*>(p.bias + n0 + (S16 ? i * 16 + 4 * (lane_e >> 4) : (i >> 2) * 32 + 8 * (i & 3) + 4 * (lane_e >> 5)));
 #pragma unroll
         for (int a = 0; a < G3_MT; ++a) {
 #pragma unroll
@@ -576,14 +582,14 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
                     else v = f32x4{acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
                     uint2 h, m, l;
                     if constexpr (HS) {
-                        v = v * p.alpha + *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+                        v = v * p.alpha + bias_v[S16 ? r4 : b * 4 + r4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
                         split4_hs(v, h, m, p.sat);
                         *reinterpret_cast<uint2*>(slab + srow * ROW + nl * 2) = h;
                         *reinterpret_cast<uint2*>(slab + 32 * ROW + srow * ROW + nl * 2) = m;
                     } else {
-                    v += *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+                    v += bias_v[S16 ? r4 : b * 4 + r4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_x3<ACT>(v[r]);
                     split4_x3(v, h, m, l);

@@ -459,6 +459,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
             return p.out_planar16 ? out_hi + (size_t)(ch >> 4) * osub + px * 16 + (ch & 8) : out_hi + px * p.Cout + ch;
         };
         const int m0 = bm0 + wm0, n0 = bn0 + wn0;
+        // the bias of this lane's channels (32 b + 8 r4 + 4 (lane >> 5)), loaded once per tile instead of once per group of four values (conv_dma3.hip ep3)
+        // (formed from an opaque copy of the lane id: the loads must not be hoisted above the k-loop, whose registers are all taken)
+        int lane_b = lane;
+        asm volatile("" : "+v"(lane_b));
+        f32x4 bias_v[4 * NT];
+#pragma unroll
+        for (int i = 0; i < 4 * NT; ++i) bias_v[i] = *reinterpret_cast<const f32x4*>(p.bias + n0 + (i >> 2) * 32 + 8 * (i & 3) + 4 * (lane_b >> 5));
         if (p.pool) {
             // fused 2x2 max pool: the four pixels of a window are four consecutive accumulator columns = lanes 4j..4j+3;
             // max over the lane quad, THEN bias + activation (monotonic), one pooled pixel per quad
@@ -477,8 +484,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
                             mx = fmaxf(mx, __shfl_xor(mx, 2));
                             v[r] = mx;
                         }
-                        if constexpr (H2) v = v * p.alpha + *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
-                        else v += *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+                        if constexpr (H2) v = v * p.alpha + bias_v[b * 4 + r4];
+                        else v += bias_v[b * 4 + r4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
                         uint2 h, l;
@@ -514,8 +521,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int nl = b * 32 + 8 * r4 + 4 * (lane >> 5);
                     f32x4 v = {acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
-                    if constexpr (H2) v = v * p.alpha + *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
-                    else v += *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+                    if constexpr (H2) v = v * p.alpha + bias_v[b * 4 + r4];
+                    else v += bias_v[b * 4 + r4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
                     uint2 h, l;

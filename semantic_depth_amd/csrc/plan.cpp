@@ -172,8 +172,9 @@ struct Builder {
             for (int i = 0; i < op.nsrc; ++i) nch += (p.tensors[op.src[i]].C + 15) / 16;
             op.nchunks = nch;
             op.nsplit = Cout > 64 ? Cout / 64 : 1;
-            // bf16 x 3 and (round 6) SD_PREC_F16X2, an upconv layer (one x2-upsampled source): the upsample-folded form of the direct kernel (OpDesc::fold)
-            op.fold = ((p.x3 || p.h2) && op.nsrc == 1 && op.up[0] && p.tensors[op.src[0]].C % 16 == 0 && Hout % 2 == 0 && !(latch_switches() & (SW_NO_FOLD | SW_NO_UPTILE))) ? 1 : 0;
+            // bf16 x 3 and (round 6) SD_PREC_F16X2, an upconv layer (one x2-upsampled source): the upsample-folded form of the direct kernel (OpDesc::fold;
+            // f16x2: the 32 / 64-channel forms -- a 16-channel upconv1 outside the fused decoder tail runs the 16-wide MFMA kernel unfolded)
+            op.fold = ((p.x3 || (p.h2 && Cout >= 32)) && op.nsrc == 1 && op.up[0] && p.tensors[op.src[0]].C % 16 == 0 && Hout % 2 == 0 && !(latch_switches() & (SW_NO_FOLD | SW_NO_UPTILE))) ? 1 : 0;
             op.w = wslot(wname, {k, k, Ctf, Cout}, WL_DIRECT_SPLIT, nch * (op.fold ? 16 : 9) * 16, Cout <= 32 ? 32 : 64, 0, op.nsplit);
             WeightSlot& ws = p.weights[op.w];
             ws.nsrc = op.nsrc; ws.fold = op.fold;
