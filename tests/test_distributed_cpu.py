@@ -135,6 +135,37 @@ def test_run_sequence_single_process_equals_the_serial_loop():
     assert np.array_equal(got, serial)
 
 
+def test_run_sequence_calls_the_steps_finish_hook_once_after_the_gather():
+    """round 6: make_engine_step hangs Engine.check_range on the step as `finish` -- the fp16 range guard of the three-product engine is an ERROR of the
+    sequence, raised once where its results reach the host (after the all_gather), not a counter somebody has to poll; a failing hook propagates"""
+    from semantic_depth_amd.distributed import run_sequence
+    frames = _sequence(6)
+    calls = []
+
+    def step(fr, lo):
+        calls.append(("step", lo))
+        return _stub_step(fr, lo)
+    step.finish = lambda: calls.append(("finish",))
+    run_sequence(lambda lo, hi: frames[lo:hi], 6, step, batch=4)
+    assert calls == [("step", 0), ("step", 4), ("finish",)]
+
+    class Boom(RuntimeError):
+        pass
+
+    def bad():
+        raise Boom("range")
+    step.finish = bad
+    with pytest.raises(Boom):
+        run_sequence(lambda lo, hi: frames[lo:hi], 6, step, batch=4)
+
+
+def test_range_error_is_an_sd_error_and_names_the_engines_with_fp16_planes():
+    from semantic_depth_amd import _lib
+    from semantic_depth_amd.engine import FP16_PLANE_ENGINES, RangeError
+    assert issubclass(RangeError, _lib.SdError)
+    assert "f16x2" in FP16_PLANE_ENGINES and "bf16x3" not in FP16_PLANE_ENGINES and "f32" not in FP16_PLANE_ENGINES
+
+
 # ------------------------------------------------------------------------------------------------ files on disk -> FrameFeeder -> run_sequence_files
 def _files_worker(rank, world, port, paths, batch, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
