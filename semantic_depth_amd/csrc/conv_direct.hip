@@ -428,8 +428,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
 #pragma unroll
                     for (int pb = 0; pb < 2; ++pb) {
                         f32x4 v = H2 ? acc16[a][pb] * p.alpha + bias16 : acc16[a][pb] + bias16;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
+                        v = act_split4<ACT>(v);
                         if (p.nreal) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = 4 * kg16 + r < p.nreal ? v[r] : 0.f;
@@ -472,8 +471,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                         v[r] = fmaxf(m, __shfl_xor(m, 1));
                     }
                     if constexpr (H2) v = v * p.alpha + bias[r4]; else v += bias[r4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
+                    v = act_split4<ACT>(v);
                     split4_fmt<OF>(v, hh[r4], ll[r4], p.sat);
                 }
                 const int pp = frow >> 1;                    // pooled pixel of this lane pair
@@ -525,8 +523,7 @@ __global__ __launch_bounds__(512, (N16 && MT == 1) ? 2 : 1) void conv_direct_ker
                     const int nb = r4 >> 2, q = r4 & 3;
                     f32x4 v = {acc[a][nb][4 * q], acc[a][nb][4 * q + 1], acc[a][nb][4 * q + 2], acc[a][nb][4 * q + 3]};
                     if constexpr (H2) v = v * p.alpha + bias[r4]; else v += bias[r4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
+                    v = act_split4<ACT>(v);
                     split4_fmt<OF>(v, hh[r4], ll[r4], p.sat);
                 }
 #pragma unroll

@@ -583,8 +583,7 @@ __global__ __launch_bounds__(512, 1) void conv_dma3_kernel(const ConvParams p, i
                     uint2 h, m, l;
                     if constexpr (HS) {
                         v = v * p.alpha + bias_v[S16 ? r4 : b * 4 + r4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
+                        v = act_split4<ACT>(v);
                         split4_hs(v, h, m, p.sat);
                         *reinterpret_cast<uint2*>(slab + srow * ROW + nl * 2) = h;
                         *reinterpret_cast<uint2*>(slab + 32 * ROW + srow * ROW + nl * 2) = m;

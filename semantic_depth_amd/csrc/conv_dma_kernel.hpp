@@ -486,8 +486,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
                         }
                         if constexpr (H2) v = v * p.alpha + bias_v[b * 4 + r4];
                         else v += bias_v[b * 4 + r4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
+                        v = act_split4<ACT>(v);
                         uint2 h, l;
                         split4_fmt<OF>(v, h, l, p.sat);
                         if ((lane & 3) == 0) {
@@ -523,8 +522,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (F16 && MT * NT <= 4) ? 4 :
                     f32x4 v = {acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
                     if constexpr (H2) v = v * p.alpha + bias_v[b * 4 + r4];
                     else v += bias_v[b * 4 + r4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
+                    v = act_split4<ACT>(v);
                     uint2 h, l;
                     split4_fmt<OF>(v, h, l, p.sat);
                     *reinterpret_cast<uint2*>(sh + (lane & 31) * ROW + nl * 2) = h;

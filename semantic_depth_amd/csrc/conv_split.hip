@@ -53,8 +53,7 @@ __device__ __forceinline__ void split_epilogue_act(f32x16 (&acc)[MT][NT], unsign
                 f32x4 v = {acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
                 if constexpr (OF == 3) v *= p.alpha;
                 if (n < p.Cout) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
+                v = act_split4<ACT>(v);
                 uint2 h, l;
                 split4_fmt<OF>(v, h, l, p.sat);
                 *reinterpret_cast<uint2*>(sh + (lane & 31) * ROW + nl * 2) = h;

@@ -194,8 +194,7 @@ __global__ __launch_bounds__(512, 1) void conv_stem_kernel(const ConvParams p) {
                         for (int r = 0; r < 4; ++r) v[r] = act_x3<ACT>(v[r]);
                         split4_x3(v, hh[r4], ll[r4], mm[r4]);          // hh = hi, ll = mid, mm = lo (memory order)
                     } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = act_split<ACT>(v[r]);
+                        v = act_split4<ACT>(v);
                         split4_fmt<OF>(v, hh[r4], ll[r4], p.sat);
                         mm[r4] = ll[r4];
                     }

@@ -255,8 +255,7 @@ __global__ __launch_bounds__(512, 1) void dec_tail1_kernel(const DecTailParams p
                             acc1 = mac6(w1[2 + b], F[s1_][b][0], F[s1_][b][1], F[s1_][b][HS ? 1 : 2], acc1);
                         }
                         f32x4 v = HS ? (acc0 + acc1) * p.alpha + bias1 : acc0 + acc1 + bias1;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = HS ? act_split<ACT_ELU>(v[r]) : act_x3<ACT_ELU>(v[r]);      // (each engine's own ELU)
+                        v = act_split4<ACT_ELU>(v);      // (act_x3<ELU> and act_split<ELU> are the same function)
                         const int ru = 2 * n + py, uc = 2 * lp + px;
                         const bool in = (unsigned)(y0 - 2 + ru) < (unsigned)H && (unsigned)(x0 - 2 + uc) < (unsigned)W;
                         if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -322,8 +321,7 @@ __global__ __launch_bounds__(512, 1) void dec_tail1_kernel(const DecTailParams p
                         acc[dy] = mac6(w2[2 * dy + 1], G[sl][1][0], G[sl][1][1], G[sl][1][HS ? 1 : 2], acc[dy]);
                     }
                     f32x4 v = HS ? ((acc[0] + acc[1]) + acc[2]) * p.alpha2 + bias2 : (acc[0] + acc[1]) + acc[2] + bias2;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = HS ? act_split<ACT_ELU>(v[r]) : act_x3<ACT_ELU>(v[r]);
+                    v = act_split4<ACT_ELU>(v);      // (act_x3<ELU> and act_split<ELU> are the same function)
                     const bool in = (unsigned)(cur.y0 - 1 + ri) < (unsigned)H && (unsigned)(cur.x0 - 1 + c) < (unsigned)W;
                     if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
                     *reinterpret_cast<f32x4*>(I + (ri * DT_IC + c) * DT_IPIX + 16 * lg) = v;
