@@ -106,7 +106,11 @@ const char* sd_status_string(sd_status s);
 /* replaces DepthFrame.__init__ + SegmentFrame.__init__ (semantic_depth.py:464-469, :575-624):
  * fixes H, W, the largest batch a call may carry and the monodepth encoder; builds both layer plans.
  * Every kernel choice that changes the order of a sum is made here, on a full network pass of the handle (sd_pass_frames), not on the frames of a
- * call: on one handle a frame's outputs are the same bits whether it is submitted alone, with others, or at another batch position. */
+ * call: on one handle a frame's outputs are the same bits whether it is submitted alone, with others, or at another batch position.
+ * Environment read HERE and nowhere later: SEMDEPTH_DISABLE=name[,name...] (dma dma3 direct stem fold tail1 pool_fuse planar n16 fuse1 fuse4 flat rowskip
+ * dma_big mfma16: the generic kernel instead of the named specialised one -- parity tests and A/B runs; an unknown name fails with SD_ERR_INVALID),
+ * SEMDEPTH_CHUNK (frames per network pass, default 32), SEMDEPTH_RESERVE_CUS (sd_set_reserved_cus), SEMDEPTH_PROFILE_VERBOSE=1 (per-layer sd_profile labels),
+ * SEMDEPTH_KEEP_ACTIVATIONS (no arena reuse: every intermediate tensor stays readable by sd_net_tensor). */
 sd_status sd_create(sd_handle** out, int device, int H, int W, int max_batch, sd_encoder enc, sd_precision prec);
 /* the same with an explicit precision plan for the split engine: per network a comma-separated list of conv layer names
  * (sd_net_tensor names, e.g. "fc6,fc7" / "enc/res4*,dec/upconv6"; a trailing '*' matches a prefix, "*" = all, "" = none) that run

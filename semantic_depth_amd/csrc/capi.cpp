@@ -407,6 +407,13 @@ sd_status sd_precision_plan(const sd_handle* h, sd_net net, char* layers_out, si
 static sd_status create_impl(sd_handle** out, int device, int H, int W, int max_batch, sd_encoder enc, sd_precision prec,
                              const char* fcn_f16, const char* mono_f16) {
     if (!out || H <= 0 || W <= 0 || max_batch <= 0) return SD_ERR_INVALID;
+    {
+        const std::string bad = sd_disable_unknown();
+        if (!bad.empty()) {
+            std::fprintf(stderr, "sd_create: SEMDEPTH_DISABLE names no switch '%s' (dma dma3 direct stem fold tail1 pool_fuse planar n16 fuse1 fuse4 flat rowskip dma_big mfma16)\n", bad.c_str());
+            return SD_ERR_INVALID;
+        }
+    }
     sd_handle* h = new sd_handle();
     h->sw = latch_switches();
     if (const char* e = std::getenv("SEMDEPTH_RESERVE_CUS")) h->reserve_cus = std::min(128, std::max(0, atoi(e)));

@@ -26,6 +26,21 @@ bool sd_disabled(const char* what) {
     }
     return false;
 }
+// the first token of SEMDEPTH_DISABLE that names nothing (a typo must not silently leave the specialised kernel on): sd_create refuses the handle
+std::string sd_disable_unknown() {
+    static const char* const known[] = {"dma", "dma3", "direct", "stem", "fold", "tail1", "pool_fuse", "planar", "n16", "fuse1", "fuse4", "flat", "rowskip", "dma_big", "mfma16"};
+    const char* e = std::getenv("SEMDEPTH_DISABLE");
+    if (!e) return "";
+    for (const char* p = e; *p;) {
+        const char* q = std::strchr(p, ',');
+        const size_t len = q ? (size_t)(q - p) : std::strlen(p);
+        bool ok = len == 0;
+        for (const char* k : known) ok = ok || (std::strlen(k) == len && !std::strncmp(p, k, len));
+        if (!ok) return std::string(p, len);
+        p += len + (q ? 1 : 0);
+    }
+    return "";
+}
 static const char* dev_env(const char* name) {
 #ifdef SD_DEV_VARIANTS
     return std::getenv(name);

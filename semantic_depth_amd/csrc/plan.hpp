@@ -131,5 +131,6 @@ void build_conv_tables(const NetPlan& p, const OpDesc& op, const char* act_base,
 void build_direct_chunks(const NetPlan& p, const OpDesc& op, const char* act_base, std::vector<DirectChunk>& chunks);
 
 int conv_tile_n(int Cout);   // conv_igemm.hip
+std::string sd_disable_unknown();   // plan.cpp: first token of SEMDEPTH_DISABLE that is not a switch name ("" = all known)
 
 }  // namespace sd

@@ -147,3 +147,26 @@ def test_no_conv_kernel_spills_vector_registers():
     bad = {k: (v.get("VGPRs Spill"), v.get("ScratchSize [bytes/lane]")) for k, v in conv.items()
            if v.get("VGPRs Spill", 0) or v.get("ScratchSize [bytes/lane]", 0)}
     assert not bad, bad
+
+
+def test_semdepth_disable_names_are_checked_and_change_the_plan(lib, monkeypatch):
+    """round 6: the run-time switches are ONE variable, SEMDEPTH_DISABLE=name[,name...], read when a handle is created.  A token that names no
+    switch refuses the handle (a typo must not silently leave the specialised kernel on); a known one changes the plan: with `fold` the f16x2
+    monodepth keeps its upconv layers as 3x3 convs on the upsampled source (K = 9 C instead of the folded 4 C: more FLOPs per image)."""
+    def flops(env):
+        if env is None:
+            monkeypatch.delenv("SEMDEPTH_DISABLE", raising=False)
+        else:
+            monkeypatch.setenv("SEMDEPTH_DISABLE", env)
+        h = C.c_void_p()
+        st = lib.sd_create(C.byref(h), 0, 256, 512, 2, L.SD_ENC_RESNET50, L.SD_PREC_F16X2)
+        if st != 0:
+            return None
+        f = lib.sd_net_flops_per_image(h, L.SD_NET_MONODEPTH)
+        lib.sd_destroy(h)
+        return f
+    base = flops(None)
+    assert base and flops("bogus") is None and flops("fold,bogus") is None
+    assert flops("") == base and flops("rowskip") == base          # (a launch-time switch: the plan does not change)
+    nofold = flops("fold,tail1")
+    assert nofold is not None and nofold > base * 1.05, (nofold, base)
