@@ -292,15 +292,17 @@ def test_16x16x32_form_of_the_phased_gemm_block_agrees_with_the_32x32x16_form(pr
     assert not (np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]))      # (the switch did select another kernel)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "f16x2", "f32"])
-def test_a_frames_result_does_not_depend_on_the_call_it_is_computed_in_at_full_size(precision):
+@pytest.mark.parametrize("precision,H,W", [("bf16x3", 512, 1024), ("f16x2", 512, 1024), ("f32", 512, 1024), ("plan", 512, 1024), ("bf16x2", 512, 1024),
+                                           ("f16x2", 256, 512), ("mixed", 256, 512)])
+def test_a_frames_result_does_not_depend_on_the_call_it_is_computed_in_at_full_size(precision, H, W):
     """512 x 1024, an engine of 8: frame 0 alone, frames 0 .. 1 and frames 0 .. 7 -- the same bits every time.  Round 5: conv_dma3's 256 x 256 block and
     conv_dma.hip's two-stage block differ in the last bits of their sums, and which one a layer took was decided on the CALL's pixel count (the 128 x 256
     test above never reaches the big block): frame 0 of a call of one differed from frame 0 of a call of eight by 3e-7 on both fp32-grade split
-    engines.  The choice is now made on a full pass of the engine (conv_dma3_eligible)."""
+    engines.  The choice is now made on a full pass of the engine (conv_dma3_eligible) -- and, round 6, so is conv_dma.hip's choice among its own
+    block shapes and the generic kernel (conv_dma_variant): the two-plane engines (plan, bf16x2, mixed) and an intermediate geometry are held to the same bits."""
     from semantic_depth_amd.engine import Engine
     from semantic_depth_amd import weights as Wt
-    H, W, B = 512, 1024, 8
+    B = 8
     wf = Wt.make_fcn8s_weights(1, decoder_std=0.05)
     wm = Wt.make_monodepth_weights("resnet50", 2)
     fr = dev(_frames(B, H, W, seed=41))
